@@ -1,0 +1,657 @@
+/*
+ * oracle.c -- CPU ORACLE (test infrastructure only; see oracle.h).
+ *
+ * Plain-C restatement of the reference's single-threaded kernels.  The restatement is
+ * semantic, element at a time: where the reference walks 64-bit BitBlockCounter blocks
+ * with fast paths (all-set / none-set), every path computes the same per-element
+ * function, which is what is written here.  Line citations are to
+ * /root/reference/cpp/src/arrow/compute/kernels/ unless a directory is given.
+ */
+#include "oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static __thread char g_err[256];
+const char* orc_last_error(void) { return g_err; }
+static int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof g_err, "%s", msg);
+  return code;
+}
+
+/* ---- util/bit_util.h ---------------------------------------------------------- */
+static inline int get_bit(const uint8_t* b, int64_t i) { return (b[i >> 3] >> (i & 7)) & 1; }
+static inline void set_bit(uint8_t* b, int64_t i) { b[i >> 3] |= (uint8_t)(1u << (i & 7)); }
+static inline void clear_bit(uint8_t* b, int64_t i) { b[i >> 3] &= (uint8_t)~(1u << (i & 7)); }
+static inline void set_bit_to(uint8_t* b, int64_t i, int v) { if (v) set_bit(b, i); else clear_bit(b, i); }
+static inline int64_t bytes_for_bits(int64_t n) { return (n + 7) >> 3; }
+
+int orc_bit_width(int t) {
+  switch (t) {
+    case ORC_BOOL: return 1;
+    case ORC_UINT8: case ORC_INT8: return 8;
+    case ORC_UINT16: case ORC_INT16: return 16;
+    case ORC_UINT32: case ORC_INT32: case ORC_FLOAT: return 32;
+    case ORC_UINT64: case ORC_INT64: case ORC_DOUBLE: return 64;
+    default: return -1;
+  }
+}
+static int is_signed_int(int t) { return t == ORC_INT8 || t == ORC_INT16 || t == ORC_INT32 || t == ORC_INT64; }
+static int is_unsigned_int(int t) { return t == ORC_UINT8 || t == ORC_UINT16 || t == ORC_UINT32 || t == ORC_UINT64; }
+static int is_float(int t) { return t == ORC_FLOAT || t == ORC_DOUBLE; }
+
+/* util/bitmap_ops.cc CountSetBits */
+int64_t orc_count_set_bits(const uint8_t* bm, int64_t off, int64_t len) {
+  int64_t n = 0;
+  for (int64_t i = 0; i < len; ++i) n += get_bit(bm, off + i);
+  return n;
+}
+
+/* GetPrimitiveArg (util_internal.cc:45-58): null_count is 0 when there is no validity
+ * buffer, otherwise the STORED count (possibly -1 = unknown). */
+static inline int64_t arg_null_count(const orc_array* a) { return a->validity ? a->null_count : 0; }
+/* ArrayData::MayHaveNulls (array/data.h): null_count != 0 && buffers[0] != nullptr */
+static inline int may_have_nulls(const orc_array* a) { return a->validity && a->null_count != 0; }
+static inline int slot_valid(const orc_array* a, int64_t i) {
+  return a->validity ? get_bit(a->validity, a->offset + i) : 1;
+}
+static inline int bool_at(const orc_array* a, int64_t i) {
+  return get_bit((const uint8_t*)a->values, a->offset + i);
+}
+
+/* ---- a1: GetFilterOutputSize, vector_selection.cc:61-88 ------------------------- */
+int64_t orc_filter_output_size(const orc_array* f, int null_selection) {
+  int64_t n = 0;
+  if (may_have_nulls(f)) {
+    for (int64_t i = 0; i < f->length; ++i) {
+      int v = get_bit(f->validity, f->offset + i), d = bool_at(f, i);
+      n += (null_selection == ORC_EMIT_NULL) ? (d | !v) /* NextOrNotWord :70-75 */
+                                             : (d & v); /* NextAndWord   :77-81 */
+    }
+  } else {
+    n = orc_count_set_bits((const uint8_t*)f->values, f->offset, f->length); /* :85 */
+  }
+  return n;
+}
+
+/* copy element `src_i` of values (bit width bw, element offset applied) to out[dst_i] */
+static inline void copy_elem(const orc_array* v, int bw, int64_t src_i, void* out, int64_t dst_i) {
+  if (bw == 1) {
+    set_bit_to((uint8_t*)out, dst_i, bool_at(v, src_i));
+  } else {
+    int w = bw / 8;
+    memcpy((uint8_t*)out + dst_i * w, (const uint8_t*)v->values + (v->offset + src_i) * w, w);
+  }
+}
+static inline void zero_elem(int bw, void* out, int64_t dst_i) {
+  if (bw == 1) clear_bit((uint8_t*)out, dst_i);
+  else memset((uint8_t*)out + dst_i * (bw / 8), 0, bw / 8);
+}
+
+/* ---- a2: PrimitiveFilter + PrimitiveFilterImpl, vector_selection.cc:569-835 ------- */
+int orc_filter(const orc_array* values, const orc_array* filter, int null_selection,
+               void* out_values, uint8_t* out_validity, orc_out* out) {
+  const int bw = orc_bit_width(values->type_id);
+  if (bw < 0) return fail(ORC_NOT_IMPLEMENTED, "filter: unsupported value type");
+  if (filter->type_id != ORC_BOOL) return fail(ORC_NOT_IMPLEMENTED, "filter must be boolean");
+  if (values->length != filter->length)
+    return fail(ORC_INVALID, "Array arguments must all be the same length"); /* exec.cc:190-192 */
+  const int64_t v_nc = arg_null_count(values), f_nc = arg_null_count(filter);
+  const int64_t out_len = orc_filter_output_size(filter, null_selection); /* :792 */
+  /* :799-804 */
+  out->null_count = (v_nc == 0 && (null_selection == ORC_DROP || f_nc == 0)) ? 0 : -1;
+  out->has_validity = (v_nc != 0 || f_nc != 0); /* :809 */
+  out->length = out_len;
+  if (bw == 1) memset(out_values, 0, bytes_for_bits(out_len)); /* AllocateBitmap zero-fills */
+  if (out->has_validity) memset(out_validity, 0, bytes_for_bits(out_len));
+
+  int64_t pos = 0;
+  if (f_nc == 0 && v_nc == 0) {
+    /* ExecNonNull :625-630: only the filter's data bits are consulted */
+    for (int64_t i = 0; i < values->length; ++i)
+      if (bool_at(filter, i)) copy_elem(values, bw, i, out_values, pos++);
+    return ORC_OK;
+  }
+  /* Exec :632-744.  DropNullCounter keys on the PRESENCE of the filter validity buffer
+   * (:540-552), as does the per-slot code below it. */
+  for (int64_t i = 0; i < values->length; ++i) {
+    const int fv = filter->validity ? get_bit(filter->validity, filter->offset + i) : 1;
+    const int fd = bool_at(filter, i);
+    if (fv && fd) {
+      /* WriteNotNull / WriteMaybeNull :646-657: validity follows the value's validity,
+       * the value bytes are copied even when the value is null */
+      set_bit_to(out_validity, pos, slot_valid(values, i));
+      copy_elem(values, bw, i, out_values, pos++);
+    } else if (!fv && null_selection == ORC_EMIT_NULL) {
+      /* :706-709 / :733-736: emitted null -> validity 0, zeroed value (:743-746) */
+      clear_bit(out_validity, pos);
+      zero_elem(bw, out_values, pos++);
+    }
+  }
+  return ORC_OK;
+}
+
+/* ---- a3: GetTakeIndices[Impl], vector_selection.cc:92-237 ------------------------ */
+int orc_take_indices(const orc_array* f, int null_selection, void* out_idx,
+                     uint8_t* out_validity, int* out_width, orc_out* out) {
+  if (f->length > 0xFFFFFFFFLL)
+    return fail(ORC_NOT_IMPLEMENTED, "Filter length exceeds UINT32_MAX, consider a different strategy for selecting elements");
+  const int w = (f->length <= 65535) ? 16 : 32; /* :224-229 */
+  *out_width = w;
+  int64_t n = 0, nulls = 0;
+  const int have_nulls = may_have_nulls(f);
+#define PUT(v) do { if (w == 16) ((uint16_t*)out_idx)[n] = (uint16_t)(v); else ((uint32_t*)out_idx)[n] = (uint32_t)(v); } while (0)
+  if (have_nulls && null_selection == ORC_EMIT_NULL) {
+    /* :103-160: builder with validity; null slot value is T{} (UnsafeAppendNull) */
+    const int64_t total = orc_filter_output_size(f, null_selection);
+    memset(out_validity, 0, bytes_for_bits(total));
+    for (int64_t i = 0; i < f->length; ++i) {
+      if (get_bit(f->validity, f->offset + i)) {
+        if (bool_at(f, i)) { PUT(i); set_bit(out_validity, n); ++n; }
+      } else { PUT(0); ++n; ++nulls; }
+    }
+    out->length = n; out->null_count = nulls; out->has_validity = 1;
+    return ORC_OK;
+  }
+  for (int64_t i = 0; i < f->length; ++i) {
+    const int sel = have_nulls ? (get_bit(f->validity, f->offset + i) && bool_at(f, i)) /* :165-197 */
+                               : bool_at(f, i);                                          /* :198-209 */
+    if (sel) { PUT(i); ++n; }
+  }
+#undef PUT
+  out->length = n; out->null_count = 0; out->has_validity = 0; /* :214-216 */
+  return ORC_OK;
+}
+
+static inline int64_t load_index(const orc_array* idx, int64_t i, int* negative) {
+  const int64_t k = idx->offset + i;
+  *negative = 0;
+  switch (idx->type_id) {
+    case ORC_INT8: { int8_t v = ((const int8_t*)idx->values)[k]; *negative = v < 0; return v; }
+    case ORC_INT16: { int16_t v = ((const int16_t*)idx->values)[k]; *negative = v < 0; return v; }
+    case ORC_INT32: { int32_t v = ((const int32_t*)idx->values)[k]; *negative = v < 0; return v; }
+    case ORC_INT64: { int64_t v = ((const int64_t*)idx->values)[k]; *negative = v < 0; return v; }
+    case ORC_UINT8: return ((const uint8_t*)idx->values)[k];
+    case ORC_UINT16: return ((const uint16_t*)idx->values)[k];
+    case ORC_UINT32: return ((const uint32_t*)idx->values)[k];
+    default: return (int64_t)((const uint64_t*)idx->values)[k]; /* u64 >= 2^63 shows as negative */
+  }
+}
+
+/* ---- a4: PrimitiveTake, vector_selection.cc:273-530 -------------------------------- */
+int orc_take(const orc_array* values, const orc_array* idx, int boundscheck, void* out_values,
+             uint8_t* out_validity, orc_out* out) {
+  const int bw = orc_bit_width(values->type_id);
+  if (bw < 0) return fail(ORC_NOT_IMPLEMENTED, "take: unsupported value type");
+  if (!is_signed_int(idx->type_id) && !is_unsigned_int(idx->type_id))
+    return fail(ORC_NOT_IMPLEMENTED, "take: indices must be integers");
+  if (boundscheck) {
+    /* CheckIndexBounds, util/int_util.cc:534-561: only VALID index slots are checked */
+    for (int64_t i = 0; i < idx->length; ++i) {
+      if (!slot_valid(idx, i)) continue;
+      int neg; int64_t v = load_index(idx, i, &neg);
+      const int oob = idx->type_id == ORC_UINT64 ? ((uint64_t)v >= (uint64_t)values->length)
+                                                 : (neg || v >= values->length);
+      if (oob) {
+        char m[96];
+        if (idx->type_id == ORC_UINT64) snprintf(m, sizeof m, "Index %llu out of bounds", (unsigned long long)v);
+        else snprintf(m, sizeof m, "Index %lld out of bounds", (long long)v);
+        return fail(ORC_INDEX_ERROR, m);
+      }
+    }
+  }
+  const int64_t n = idx->length;
+  memset(out_validity, 0, bytes_for_bits(n));
+  if (bw == 1) memset(out_values, 0, bytes_for_bits(n)); /* :387-388 */
+  const int64_t v_nc = arg_null_count(values);
+  int64_t valid = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    int ok = slot_valid(idx, i);
+    int64_t j = 0;
+    if (ok) {
+      int neg; j = load_index(idx, i, &neg);
+      /* values' validity is consulted only when values.null_count != 0 (:306, :338) */
+      if (v_nc != 0 && !get_bit(values->validity, values->offset + j)) ok = 0;
+    }
+    if (ok) { copy_elem(values, bw, j, out_values, i); set_bit(out_validity, i); ++valid; }
+    else zero_elem(bw, out_values, i); /* out[position] = ValueCType{} */
+  }
+  out->length = n; out->null_count = n - valid; out->has_validity = 1; /* :367, :505-510 */
+  return ORC_OK;
+}
+
+/* ---- b: sort_indices, vector_sort.cc:224-575, 657-832 ------------------------------ */
+typedef struct { uint64_t key; uint64_t idx; } sort_rec;
+static int cmp_rec(const void* a, const void* b) {
+  const sort_rec* x = (const sort_rec*)a; const sort_rec* y = (const sort_rec*)b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+/* Order-preserving map value -> uint64 such that (a < b) <=> key(a) < key(b) and values
+ * that compare equal under `<` (incl. -0.0 vs +0.0) get the SAME key, so that a sort on
+ * (key, index) reproduces std::stable_sort with `lhs < rhs` (:386-401). */
+static uint64_t sort_key(int t, const void* base, int64_t k) {
+  switch (t) {
+    case ORC_BOOL: return get_bit((const uint8_t*)base, k);
+    case ORC_UINT8: return ((const uint8_t*)base)[k];
+    case ORC_UINT16: return ((const uint16_t*)base)[k];
+    case ORC_UINT32: return ((const uint32_t*)base)[k];
+    case ORC_UINT64: return ((const uint64_t*)base)[k];
+    case ORC_INT8: return (uint64_t)((int64_t)((const int8_t*)base)[k]) ^ 0x8000000000000000ULL;
+    case ORC_INT16: return (uint64_t)((int64_t)((const int16_t*)base)[k]) ^ 0x8000000000000000ULL;
+    case ORC_INT32: return (uint64_t)((int64_t)((const int32_t*)base)[k]) ^ 0x8000000000000000ULL;
+    case ORC_INT64: return (uint64_t)(((const int64_t*)base)[k]) ^ 0x8000000000000000ULL;
+    case ORC_FLOAT: case ORC_DOUBLE: {
+      double d = (t == ORC_FLOAT) ? (double)((const float*)base)[k] : ((const double*)base)[k];
+      if (d == 0.0) d = 0.0; /* -0.0 ties with +0.0 under `<` */
+      uint64_t u; memcpy(&u, &d, 8);
+      return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
+    }
+  }
+  return 0;
+}
+int orc_sort_indices(const orc_array* chunks, int nchunks, int order, uint64_t* out) {
+  int64_t total = 0;
+  for (int c = 0; c < nchunks; ++c) total += chunks[c].length;
+  if (nchunks > 0 && orc_bit_width(chunks[0].type_id) < 0) return fail(ORC_NOT_IMPLEMENTED, "sort: type");
+  sort_rec* recs = (sort_rec*)malloc(sizeof(sort_rec) * (size_t)(total ? total : 1));
+  uint64_t* nans = (uint64_t*)malloc(8 * (size_t)(total ? total : 1));
+  uint64_t* nulls = (uint64_t*)malloc(8 * (size_t)(total ? total : 1));
+  int64_t nr = 0, nn = 0, nz = 0, base = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    const orc_array* a = &chunks[c];
+    for (int64_t i = 0; i < a->length; ++i) {
+      const uint64_t gi = (uint64_t)(base + i); /* logical index = concat order (:95-160) */
+      if (!slot_valid(a, i)) { nulls[nz++] = gi; continue; } /* PartitionNullsOnly :224-234 */
+      if (is_float(a->type_id)) {
+        double d = a->type_id == ORC_FLOAT ? (double)((const float*)a->values)[a->offset + i]
+                                           : ((const double*)a->values)[a->offset + i];
+        if (isnan(d)) { nans[nn++] = gi; continue; } /* PartitionNullLikes :275-283 */
+      }
+      uint64_t k = sort_key(a->type_id, a->values, a->offset + i);
+      /* Descending = complement the key; ties still resolve by ascending index (:393-401,
+       * counting sort :466-475, golden vector_sort_test.cc:455-458) */
+      recs[nr].key = (order == ORC_DESCENDING) ? ~k : k;
+      recs[nr].idx = gi; ++nr;
+    }
+    base += a->length;
+  }
+  qsort(recs, (size_t)nr, sizeof(sort_rec), cmp_rec);
+  int64_t p = 0;
+  for (int64_t i = 0; i < nr; ++i) out[p++] = recs[i].idx;
+  for (int64_t i = 0; i < nn; ++i) out[p++] = nans[i];  /* NaNs, index order, before nulls */
+  for (int64_t i = 0; i < nz; ++i) out[p++] = nulls[i]; /* nulls last, index order */
+  free(recs); free(nans); free(nulls);
+  return ORC_OK;
+}
+
+/* ---- c1: GrouperImpl, hash_aggregate.cc:313-437 ------------------------------------- */
+struct orc_grouper {
+  int nkeys; int types[8]; int widths[8]; /* value byte width per key column */
+  int key_len;                             /* sum(1 + width) */
+  uint8_t* key_bytes; int64_t key_cap;     /* key_bytes_ (:434) */
+  uint32_t num_groups;                     /* num_groups_ (:435) */
+  uint32_t* table; uint64_t table_size;    /* open addressing; stands in for map_ (:432) */
+};
+static uint64_t hash_bytes(const uint8_t* p, int n) {
+  uint64_t h = 1469598103934665603ULL;
+  for (int i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ULL; }
+  return h ^ (h >> 29);
+}
+orc_grouper* orc_grouper_new(int nkeys, const int* types) {
+  if (nkeys < 1 || nkeys > 8) return NULL;
+  orc_grouper* g = (orc_grouper*)calloc(1, sizeof *g);
+  g->nkeys = nkeys;
+  for (int k = 0; k < nkeys; ++k) {
+    int bw = orc_bit_width(types[k]);
+    if (bw < 0) { free(g); return NULL; }
+    g->types[k] = types[k];
+    g->widths[k] = bw == 1 ? 1 : bw / 8; /* BooleanKeyEncoder kByteWidth=1 (:96), FixedWidth :145 */
+    g->key_len += 1 + g->widths[k];      /* kExtraByteForNull (:50) */
+  }
+  g->table_size = 1024;
+  g->table = (uint32_t*)malloc(4 * g->table_size);
+  memset(g->table, 0xFF, 4 * g->table_size);
+  g->key_cap = 1024 * g->key_len;
+  g->key_bytes = (uint8_t*)malloc((size_t)g->key_cap);
+  return g;
+}
+void orc_grouper_free(orc_grouper* g) { if (g) { free(g->table); free(g->key_bytes); free(g); } }
+uint32_t orc_grouper_num_groups(const orc_grouper* g) { return g->num_groups; }
+static void grouper_rehash(orc_grouper* g) {
+  uint64_t ns = g->table_size * 2;
+  uint32_t* nt = (uint32_t*)malloc(4 * ns);
+  memset(nt, 0xFF, 4 * ns);
+  for (uint32_t id = 0; id < g->num_groups; ++id) {
+    uint64_t h = hash_bytes(g->key_bytes + (int64_t)id * g->key_len, g->key_len) & (ns - 1);
+    while (nt[h] != 0xFFFFFFFFu) h = (h + 1) & (ns - 1);
+    nt[h] = id;
+  }
+  free(g->table); g->table = nt; g->table_size = ns;
+}
+int orc_grouper_consume(orc_grouper* g, const orc_array* keys, uint32_t* out_ids) {
+  const int64_t n = keys[0].length;
+  uint8_t enc[8 * 9];
+  for (int64_t i = 0; i < n; ++i) {
+    /* Encode :142-168 / :98-113: [null byte][value bytes, zeros when null] per column */
+    uint8_t* p = enc;
+    for (int k = 0; k < g->nkeys; ++k) {
+      const orc_array* a = &keys[k];
+      const int w = g->widths[k];
+      if (slot_valid(a, i)) {
+        *p++ = 0; /* kValidByte */
+        if (g->types[k] == ORC_BOOL) *p++ = (uint8_t)bool_at(a, i);
+        else { memcpy(p, (const uint8_t*)a->values + (a->offset + i) * w, w); p += w; }
+      } else {
+        *p++ = 1; /* kNullByte */
+        memset(p, 0, w); p += w;
+      }
+    }
+    /* map_.emplace(key, num_groups_) :391-401: new key <=> next dense id, in row order */
+    uint64_t h = hash_bytes(enc, g->key_len) & (g->table_size - 1);
+    uint32_t id;
+    for (;;) {
+      id = g->table[h];
+      if (id == 0xFFFFFFFFu) break;
+      if (memcmp(g->key_bytes + (int64_t)id * g->key_len, enc, g->key_len) == 0) break;
+      h = (h + 1) & (g->table_size - 1);
+    }
+    if (id == 0xFFFFFFFFu) {
+      id = g->num_groups++;
+      if ((int64_t)(id + 1) * g->key_len > g->key_cap) {
+        g->key_cap *= 2; g->key_bytes = (uint8_t*)realloc(g->key_bytes, (size_t)g->key_cap);
+      }
+      memcpy(g->key_bytes + (int64_t)id * g->key_len, enc, g->key_len);
+      g->table[h] = id;
+      if ((uint64_t)g->num_groups * 2 > g->table_size) grouper_rehash(g);
+    }
+    out_ids[i] = id;
+  }
+  return ORC_OK;
+}
+int orc_grouper_uniques(const orc_grouper* g, int k, void* out_values, uint8_t* out_validity,
+                        int64_t* out_null_count) {
+  int off = 0;
+  for (int j = 0; j < k; ++j) off += 1 + g->widths[j];
+  const int w = g->widths[k];
+  int64_t nulls = 0;
+  const int64_t n = g->num_groups;
+  memset(out_validity, 0, bytes_for_bits(n));
+  if (g->types[k] == ORC_BOOL) memset(out_values, 0, bytes_for_bits(n));
+  for (int64_t i = 0; i < n; ++i) {
+    const uint8_t* e = g->key_bytes + i * g->key_len + off;
+    if (e[0] == 1) ++nulls; else set_bit(out_validity, i); /* DecodeNulls :64-92 */
+    if (g->types[k] == ORC_BOOL) set_bit_to((uint8_t*)out_values, i, e[1] != 0); /* :127-131 */
+    else memcpy((uint8_t*)out_values + i * w, e + 1, w);                        /* :178-184 */
+  }
+  *out_null_count = nulls;
+  return ORC_OK;
+}
+
+/* ---- c2/c3: GroupedSumImpl / GroupedCountImpl, hash_aggregate.cc:466-622 ------------ */
+int orc_hash_sum(const orc_array* v, const uint32_t* ids, void* sums, int64_t* counts) {
+  const int t = v->type_id;
+  if (orc_bit_width(t) < 0) return fail(ORC_NOT_IMPLEMENTED, "Summing data of this type");
+  for (int64_t i = 0; i < v->length; ++i) {
+    if (!slot_valid(v, i)) continue; /* [&] { ++group; } :545 */
+    const uint32_t g = ids[i];
+    const int64_t k = v->offset + i;
+    /* sums[*group] += value; counts[*group] += 1 (:539-543); accumulator per
+     * FindAccumulatorType (aggregate_internal.h:29-50); integer adds wrap mod 2^64 */
+    switch (t) {
+      case ORC_BOOL: ((uint64_t*)sums)[g] += (uint64_t)get_bit((const uint8_t*)v->values, k); break;
+      case ORC_UINT8: ((uint64_t*)sums)[g] += ((const uint8_t*)v->values)[k]; break;
+      case ORC_UINT16: ((uint64_t*)sums)[g] += ((const uint16_t*)v->values)[k]; break;
+      case ORC_UINT32: ((uint64_t*)sums)[g] += ((const uint32_t*)v->values)[k]; break;
+      case ORC_UINT64: ((uint64_t*)sums)[g] += ((const uint64_t*)v->values)[k]; break;
+      case ORC_INT8: ((uint64_t*)sums)[g] += (uint64_t)(int64_t)((const int8_t*)v->values)[k]; break;
+      case ORC_INT16: ((uint64_t*)sums)[g] += (uint64_t)(int64_t)((const int16_t*)v->values)[k]; break;
+      case ORC_INT32: ((uint64_t*)sums)[g] += (uint64_t)(int64_t)((const int32_t*)v->values)[k]; break;
+      case ORC_INT64: ((uint64_t*)sums)[g] += (uint64_t)((const int64_t*)v->values)[k]; break;
+      case ORC_FLOAT: ((double*)sums)[g] += (double)((const float*)v->values)[k]; break;
+      case ORC_DOUBLE: ((double*)sums)[g] += ((const double*)v->values)[k]; break;
+    }
+    counts[g] += 1;
+  }
+  return ORC_OK;
+}
+/* NOTE (reference defect, not replicated): for COUNT_NON_NULL the reference indexes
+ * group_ids with `begin - input->offset` (:497-499) although VisitSetBitRunsVoid already
+ * reports run positions relative to the offset (util/bit_run_reader.h:484-499), so on a
+ * SLICED input (offset != 0) it reads ids out of bounds.  The restatement uses the
+ * logical row index; parity for hash_count is pinned on offset == 0 inputs only. */
+int orc_hash_count(const orc_array* v, const uint32_t* ids, int mode, int64_t* counts) {
+  for (int64_t i = 0; i < v->length; ++i) {
+    const int valid = slot_valid(v, i);
+    if (mode == ORC_COUNT_NULL) counts[ids[i]] += !valid; /* :485-492 */
+    else if (valid) counts[ids[i]] += 1;                  /* :495-503 */
+  }
+  return ORC_OK;
+}
+int orc_hash_mean_finalize(int t, const void* sums, const int64_t* counts, int64_t n,
+                           double* out, uint8_t* out_validity) {
+  memset(out_validity, 0, bytes_for_bits(n));
+  for (int64_t g = 0; g < n; ++g) {
+    if (counts[g] <= 0) { out[g] = 0.0; continue; }
+    double s = is_float(t) ? ((const double*)sums)[g]
+             : is_signed_int(t) ? (double)((const int64_t*)sums)[g] : (double)((const uint64_t*)sums)[g];
+    out[g] = s / (double)counts[g]; /* aggregate_basic_internal.h:94-103 */
+    set_bit(out_validity, g);
+  }
+  return ORC_OK;
+}
+int orc_hash_aggregate(int func, const orc_array* v, const uint32_t* ids, int64_t ng, int mode,
+                       void* out_values, uint8_t* out_validity, orc_out* out) {
+  out->length = ng;
+  memset(out_values, 0, (size_t)ng * 8); /* sums_.Append(added*8, 0) :568-569 */
+  memset(out_validity, 0xFF, bytes_for_bits(ng));
+  if (ng & 7) out_validity[bytes_for_bits(ng) - 1] = (uint8_t)((1u << (ng & 7)) - 1);
+  if (func == 1) {
+    out->has_validity = 0; out->null_count = 0; /* Int64Array(num_groups_, counts) :505-508 */
+    return orc_hash_count(v, ids, mode, (int64_t*)out_values);
+  }
+  int64_t* counts = (int64_t*)calloc((size_t)(ng ? ng : 1), 8);
+  int rc = orc_hash_sum(v, ids, out_values, counts);
+  if (rc == ORC_OK) {
+    /* Finalize :581-604: bitmap allocated only when some group saw no valid value */
+    int64_t nulls = 0;
+    for (int64_t g = 0; g < ng; ++g) if (counts[g] <= 0) { ++nulls; clear_bit(out_validity, g); }
+    out->null_count = nulls; out->has_validity = nulls > 0;
+    if (func == 2) {
+      double* m = (double*)malloc((size_t)(ng ? ng : 1) * 8);
+      orc_hash_mean_finalize(v->type_id, out_values, counts, ng, m, out_validity);
+      memcpy(out_values, m, (size_t)ng * 8); free(m);
+    }
+  }
+  free(counts);
+  return rc;
+}
+
+/* ---- f1: NullPropagator with a preallocated bitmap, exec.cc:255-461 ------------------ */
+static int generalization(const orc_array* a) { /* NullGeneralization::Get :258-281 */
+  if (!a) return 1;                              /* valid scalar: ALL_VALID */
+  if (a->null_count == 0 || a->validity == NULL) return 1;
+  if (a->null_count == a->length) return 2;      /* ALL_NULL */
+  return 0;                                      /* PERHAPS_NULL */
+}
+static void propagate(const orc_array* a, const orc_array* b, int64_t len, uint8_t* out_validity,
+                      orc_out* out) {
+  const orc_array* with_nulls[2]; int nw = 0; int all_null = 0;
+  const orc_array* in[2] = {a, b};
+  for (int k = 0; k < 2; ++k) {
+    int g = generalization(in[k]);
+    if (g == 2) all_null = 1;
+    if (g != 1 && in[k]) with_nulls[nw++] = in[k];
+  }
+  out->length = len; out->has_validity = 1; /* validity_preallocated_ :690-693 */
+  memset(out_validity, 0, bytes_for_bits(len));
+  if (all_null) { out->null_count = len; return; }                     /* :326-348 */
+  if (nw == 0) {                                                       /* :433-439 */
+    out->null_count = 0;
+    for (int64_t i = 0; i < len; ++i) set_bit(out_validity, i);
+    return;
+  }
+  if (nw == 1) {                                                       /* PropagateSingle :350-380 */
+    out->null_count = with_nulls[0]->null_count;
+    for (int64_t i = 0; i < len; ++i) if (slot_valid(with_nulls[0], i)) set_bit(out_validity, i);
+    return;
+  }
+  out->null_count = -1;                                                /* PropagateMultiple :382-408 */
+  for (int64_t i = 0; i < len; ++i)
+    if (slot_valid(with_nulls[0], i) && slot_valid(with_nulls[1], i)) set_bit(out_validity, i);
+}
+int orc_propagate_nulls(const orc_array* a, const orc_array* b, uint8_t* out_validity, orc_out* out) {
+  propagate(a, b, a ? a->length : b->length, out_validity, out);
+  return ORC_OK;
+}
+
+/* ---- d: compare, scalar_compare.cc:31-57 -------------------------------------------- */
+#define LOAD_AS(T, arr, scal, i) ((arr) ? ((const T*)(arr)->values)[(arr)->offset + (i)] : *(const T*)(scal))
+#define CMP_LOOP(T)                                                                       \
+  for (int64_t i = 0; i < n; ++i) {                                                       \
+    const T l = LOAD_AS(T, lhs, ls, i), r = LOAD_AS(T, rhs, rs, i);                       \
+    int v = 0;                                                                            \
+    switch (op) {                                                                         \
+      case ORC_EQ: v = l == r; break; case ORC_NE: v = l != r; break;                     \
+      case ORC_GT: v = l > r; break;  case ORC_GE: v = l >= r; break;                     \
+      case ORC_LT: v = r > l; break;  /* less = flipped greater, :161-171 */               \
+      case ORC_LE: v = r >= l; break;                                                     \
+    }                                                                                     \
+    if (v) set_bit(out_bits, i);                                                          \
+  }
+int orc_compare(int op, const orc_array* lhs, const void* ls, const orc_array* rhs, const void* rs,
+                uint8_t* out_bits, uint8_t* out_validity, orc_out* out) {
+  if (!lhs && !rhs) return fail(ORC_INVALID, "compare: need at least one array operand");
+  if (lhs && rhs && lhs->length != rhs->length)
+    return fail(ORC_INVALID, "Array arguments must all be the same length");
+  const int64_t n = lhs ? lhs->length : rhs->length;
+  const int t = lhs ? lhs->type_id : rhs->type_id;
+  if (lhs && rhs && lhs->type_id != rhs->type_id) return fail(ORC_NOT_IMPLEMENTED, "compare: implicit casts are out of scope");
+  propagate(lhs, rhs, n, out_validity, out);
+  memset(out_bits, 0, bytes_for_bits(n)); /* GenerateBitsUnrolled leaves trailing bits 0 */
+  switch (t) {
+    case ORC_BOOL:
+      for (int64_t i = 0; i < n; ++i) {
+        const int l = lhs ? bool_at(lhs, i) : (*(const uint8_t*)ls != 0);
+        const int r = rhs ? bool_at(rhs, i) : (*(const uint8_t*)rs != 0);
+        int v = 0;
+        switch (op) { case ORC_EQ: v = l == r; break; case ORC_NE: v = l != r; break;
+          case ORC_GT: v = l > r; break; case ORC_GE: v = l >= r; break;
+          case ORC_LT: v = r > l; break; case ORC_LE: v = r >= l; break; }
+        if (v) set_bit(out_bits, i);
+      }
+      break;
+    case ORC_UINT8: CMP_LOOP(uint8_t) break;   case ORC_INT8: CMP_LOOP(int8_t) break;
+    case ORC_UINT16: CMP_LOOP(uint16_t) break; case ORC_INT16: CMP_LOOP(int16_t) break;
+    case ORC_UINT32: CMP_LOOP(uint32_t) break; case ORC_INT32: CMP_LOOP(int32_t) break;
+    case ORC_UINT64: CMP_LOOP(uint64_t) break; case ORC_INT64: CMP_LOOP(int64_t) break;
+    case ORC_FLOAT: CMP_LOOP(float) break;     case ORC_DOUBLE: CMP_LOOP(double) break;
+    default: return fail(ORC_NOT_IMPLEMENTED, "compare: type");
+  }
+  return ORC_OK;
+}
+
+/* ---- e: arithmetic, scalar_arithmetic.cc:69-251 ------------------------------------- */
+/* INT: T signed?, U = unsigned twin.  Unchecked signed ops go through the unsigned type
+ * (SafeSignedAdd etc., util/int_util_internal.h). */
+#define ARITH_INT(T, U, SIGNED, TMIN)                                                     \
+  for (int64_t i = 0; i < n; ++i) {                                                       \
+    const int valid = get_bit(out_validity, i);                                           \
+    const T l = LOAD_AS(T, lhs, ls, i), r = LOAD_AS(T, rhs, rs, i);                       \
+    T res = 0;                                                                            \
+    switch (op) {                                                                         \
+      case ORC_ADD: res = (T)((U)l + (U)r); break;                                        \
+      case ORC_SUB: res = (T)((U)l - (U)r); break;                                        \
+      case ORC_MUL: res = (T)((uint64_t)(U)l * (uint64_t)(U)r); break; /* :145-185 */      \
+      case ORC_ADD_CHECKED: if (!valid) break;                                            \
+        if (__builtin_add_overflow(l, r, &res)) err = "overflow"; break;                  \
+      case ORC_SUB_CHECKED: if (!valid) break;                                            \
+        if (__builtin_sub_overflow(l, r, &res)) err = "overflow"; break;                  \
+      case ORC_MUL_CHECKED: if (!valid) break;                                            \
+        if (__builtin_mul_overflow(l, r, &res)) err = "overflow"; break;                  \
+      case ORC_DIV: case ORC_DIV_CHECKED: if (!valid) break;                              \
+        /* DivideWithOverflow: r == 0 or (MIN / -1) */                                    \
+        if (r == 0) { err = "divide by zero"; res = 0; }                                  \
+        else if (SIGNED && l == (T)TMIN && r == (T)-1) {                                  \
+          if (op == ORC_DIV_CHECKED) err = "overflow"; res = 0; } /* :222-228, :239-243 */ \
+        else res = (T)(l / r);                                                            \
+        break;                                                                            \
+    }                                                                                     \
+    ((T*)out_values)[i] = res;                                                            \
+  }
+#define ARITH_FLT(T)                                                                      \
+  for (int64_t i = 0; i < n; ++i) {                                                       \
+    const int valid = get_bit(out_validity, i);                                           \
+    const T l = LOAD_AS(T, lhs, ls, i), r = LOAD_AS(T, rhs, rs, i);                       \
+    T res = 0;                                                                            \
+    switch (op) {                                                                         \
+      case ORC_ADD: res = l + r; break; case ORC_SUB: res = l - r; break;                 \
+      case ORC_MUL: res = l * r; break;                                                   \
+      case ORC_ADD_CHECKED: if (valid) res = l + r; break;                                \
+      case ORC_SUB_CHECKED: if (valid) res = l - r; break;                                \
+      case ORC_MUL_CHECKED: if (valid) res = l * r; break;                                \
+      case ORC_DIV: if (valid) res = l / r; break;                          /* :206-210 */ \
+      case ORC_DIV_CHECKED: if (!valid) break;                                            \
+        if (r == 0) { err = "divide by zero"; res = 0; } else res = l / r; break; /* :244-250 */ \
+    }                                                                                     \
+    ((T*)out_values)[i] = res;                                                            \
+  }
+int orc_arith(int op, const orc_array* lhs, const void* ls, const orc_array* rhs, const void* rs,
+              void* out_values, uint8_t* out_validity, orc_out* out) {
+  if (!lhs && !rhs) return fail(ORC_INVALID, "arith: need at least one array operand");
+  if (lhs && rhs && lhs->length != rhs->length)
+    return fail(ORC_INVALID, "Array arguments must all be the same length");
+  if (lhs && rhs && lhs->type_id != rhs->type_id) return fail(ORC_NOT_IMPLEMENTED, "arith: implicit casts are out of scope");
+  const int64_t n = lhs ? lhs->length : rhs->length;
+  const int t = lhs ? lhs->type_id : rhs->type_id;
+  propagate(lhs, rhs, n, out_validity, out);
+  const char* err = NULL; /* *st is overwritten per failing element: the LAST one wins */
+  switch (t) {
+    case ORC_UINT8: ARITH_INT(uint8_t, uint8_t, 0, 0) break;
+    case ORC_INT8: ARITH_INT(int8_t, uint8_t, 1, INT8_MIN) break;
+    case ORC_UINT16: ARITH_INT(uint16_t, uint16_t, 0, 0) break;
+    case ORC_INT16: ARITH_INT(int16_t, uint16_t, 1, INT16_MIN) break;
+    case ORC_UINT32: ARITH_INT(uint32_t, uint32_t, 0, 0) break;
+    case ORC_INT32: ARITH_INT(int32_t, uint32_t, 1, INT32_MIN) break;
+    case ORC_UINT64: ARITH_INT(uint64_t, uint64_t, 0, 0) break;
+    case ORC_INT64: ARITH_INT(int64_t, uint64_t, 1, INT64_MIN) break;
+    case ORC_FLOAT: ARITH_FLT(float) break;
+    case ORC_DOUBLE: ARITH_FLT(double) break;
+    default: return fail(ORC_NOT_IMPLEMENTED, "arith: type");
+  }
+  if (err) return fail(ORC_INVALID, err);
+  return ORC_OK;
+}
+
+/* ---- headline composition: Filter -> GroupBy{hash_sum} ------------------------------- */
+int64_t orc_filter_groupby_sum(const orc_array* values, const orc_array* keys, const orc_array* mask,
+                               void* out_sums, int64_t* out_counts, void* out_keys,
+                               uint8_t* out_key_validity) {
+  const int64_t n = values->length;
+  const int vw = orc_bit_width(values->type_id) / 8, kw = orc_bit_width(keys->type_id) / 8;
+  orc_out o1, o2;
+  const int64_t m = orc_filter_output_size(mask, ORC_DROP);
+  uint8_t* fv = (uint8_t*)malloc((size_t)(m ? m : 1) * vw);
+  uint8_t* fk = (uint8_t*)malloc((size_t)(m ? m : 1) * kw);
+  uint8_t* fvv = (uint8_t*)malloc((size_t)bytes_for_bits(m) + 1);
+  uint8_t* fkv = (uint8_t*)malloc((size_t)bytes_for_bits(m) + 1);
+  (void)n;
+  orc_filter(values, mask, ORC_DROP, fv, fvv, &o1); /* FilterRecordBatch-style: same mask on each column */
+  orc_filter(keys, mask, ORC_DROP, fk, fkv, &o2);
+  orc_array V = {fv, o1.has_validity ? fvv : NULL, m, 0, values->type_id, o1.null_count};
+  orc_array K = {fk, o2.has_validity ? fkv : NULL, m, 0, keys->type_id, o2.null_count};
+  uint32_t* ids = (uint32_t*)malloc((size_t)(m ? m : 1) * 4);
+  orc_grouper* g = orc_grouper_new(1, &keys->type_id);
+  orc_grouper_consume(g, &K, ids);
+  const int64_t ng = orc_grouper_num_groups(g);
+  memset(out_sums, 0, (size_t)ng * 8);
+  memset(out_counts, 0, (size_t)ng * 8);
+  orc_hash_sum(&V, ids, out_sums, out_counts);
+  int64_t knc;
+  orc_grouper_uniques(g, 0, out_keys, out_key_validity, &knc);
+  orc_grouper_free(g);
+  free(fv); free(fk); free(fvv); free(fkv); free(ids);
+  return ng;
+}

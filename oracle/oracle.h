@@ -1,0 +1,164 @@
+/*
+ * oracle.h -- CPU ORACLE for the Arrow compute hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C, single-threaded restatement of the reference algorithms in
+ * /root/reference/cpp/src/arrow/compute/kernels/{vector_selection,vector_sort,
+ * hash_aggregate,scalar_compare,scalar_arithmetic}.cc.  Every function cites the
+ * reference file:line it follows.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this; the product (arrow-1_amd/) never does.
+ *
+ * Parity status: PINNED.  The restatement is checked (tests/test_oracle_golden.py)
+ * against (1) the known-answer vectors of the reference's own tests, restated as
+ * data in tests/golden/reference_literals.json, and (2) outputs of the reference
+ * itself, built from its own sources by oracle/ref_build.mk and driven through
+ * oracle/ref_driver.cc, stored in tests/golden/ref_random_*.npz by
+ * tests/golden/make_golden.py.
+ *
+ * The SAME entry-point signatures are exported twice:
+ *   orc_*  by liboracle.so      (this restatement)
+ *   ref_*  by libref_driver.so  (the real reference behind CallFunction / GroupBy)
+ */
+#ifndef ORACLE_H_
+#define ORACLE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Arrow Type::type ids (arrow/type_fwd.h:277-313) for the primitive types on the path. */
+enum {
+  ORC_BOOL = 1, ORC_UINT8 = 2, ORC_INT8 = 3, ORC_UINT16 = 4, ORC_INT16 = 5,
+  ORC_UINT32 = 6, ORC_INT32 = 7, ORC_UINT64 = 8, ORC_INT64 = 9,
+  ORC_FLOAT = 11, ORC_DOUBLE = 12
+};
+
+/* One primitive Arrow array: ArrayData{buffers[0]=validity, buffers[1]=values, offset,
+ * length, null_count} (arrow/array/data.h:234-244).  `values` is the BASE of buffers[1];
+ * `offset` (elements) applies to both buffers, as in PrimitiveArg
+ * (kernels/util_internal.h:35-47) before GetPrimitiveArg pre-offsets the data. */
+typedef struct {
+  const void* values;
+  const uint8_t* validity; /* NULL => no validity buffer (all valid) */
+  int64_t length;
+  int64_t offset;
+  int32_t type_id;         /* ORC_* */
+  int64_t null_count;      /* as stored: -1 = unknown; ignored when validity == NULL */
+} orc_array;
+
+/* Shape of a produced array. */
+typedef struct {
+  int64_t length;
+  int64_t null_count;   /* -1 = kUnknownNullCount */
+  int32_t has_validity; /* 0 => buffers[0] absent */
+} orc_out;
+
+/* status codes = arrow::StatusCode (arrow/status.h) */
+enum {
+  ORC_OK = 0, ORC_KEY_ERROR = 2, ORC_TYPE_ERROR = 3, ORC_INVALID = 4,
+  ORC_INDEX_ERROR = 7, ORC_NOT_IMPLEMENTED = 10
+};
+
+enum { ORC_DROP = 0, ORC_EMIT_NULL = 1 };             /* FilterOptions::NullSelectionBehavior */
+enum { ORC_ASCENDING = 0, ORC_DESCENDING = 1 };       /* SortOrder */
+enum { ORC_COUNT_NON_NULL = 0, ORC_COUNT_NULL = 1 };  /* CountOptions::Mode */
+enum { ORC_EQ = 0, ORC_NE, ORC_GT, ORC_GE, ORC_LT, ORC_LE };
+enum {
+  ORC_ADD = 0, ORC_SUB, ORC_MUL, ORC_DIV,
+  ORC_ADD_CHECKED, ORC_SUB_CHECKED, ORC_MUL_CHECKED, ORC_DIV_CHECKED
+};
+
+int orc_bit_width(int type_id);
+const char* orc_last_error(void);
+
+/* util/bitmap_ops.cc CountSetBits */
+int64_t orc_count_set_bits(const uint8_t* bitmap, int64_t offset, int64_t length);
+
+/* a1: GetFilterOutputSize, vector_selection.cc:61-88 */
+int64_t orc_filter_output_size(const orc_array* filter, int null_selection);
+
+/* a2: PrimitiveFilter, vector_selection.cc:786-835.  out_values must hold
+ * BytesForBits(out_len*bit_width); out_validity BytesForBits(out_len), zero-filled by
+ * this call (KernelContext::AllocateBitmap zero-fills, kernel.cc:48-60).
+ * out->has_validity tells whether the reference allocates buffers[0] (:809). */
+int orc_filter(const orc_array* values, const orc_array* filter, int null_selection,
+               void* out_values, uint8_t* out_validity, orc_out* out);
+
+/* a3: GetTakeIndices, vector_selection.cc:92-237.  *out_index_width = 16 or 32. */
+int orc_take_indices(const orc_array* filter, int null_selection, void* out_indices,
+                     uint8_t* out_validity, int* out_index_width, orc_out* out);
+
+/* a4: PrimitiveTake, vector_selection.cc:493-530 (+CheckIndexBounds int_util.cc:534-561).
+ * indices->type_id is one of the 8 integer types.  Always produces a validity buffer. */
+int orc_take(const orc_array* values, const orc_array* indices, int boundscheck,
+             void* out_values, uint8_t* out_validity, orc_out* out);
+
+/* b1-b3: array_sort_indices / ChunkedArraySorter, vector_sort.cc:373-575, 657-832.
+ * chunks[0..nchunks) are the chunks of one logical array; out has sum(length) entries. */
+int orc_sort_indices(const orc_array* chunks, int nchunks, int order, uint64_t* out);
+
+/* c1: Grouper::Consume, hash_aggregate.cc:358-408 -- dense ids in first-appearance
+ * order.  Stateful across batches.  Keys: up to 8 fixed-width columns. */
+typedef struct orc_grouper orc_grouper;
+orc_grouper* orc_grouper_new(int nkeys, const int* key_type_ids);
+void orc_grouper_free(orc_grouper*);
+int orc_grouper_consume(orc_grouper*, const orc_array* keys, uint32_t* out_ids);
+uint32_t orc_grouper_num_groups(const orc_grouper*);
+/* GetUniques, :410-428: key column k decoded -> values (num_groups * width bytes) +
+ * validity bitmap; *null_count as FixedWidthKeyEncoder::Decode reports it. */
+int orc_grouper_uniques(const orc_grouper*, int k, void* out_values, uint8_t* out_validity,
+                        int64_t* out_null_count);
+
+/* c2: GroupedSumImpl::Consume, hash_aggregate.cc:522-622.  sums: num_groups x 8 bytes
+ * (int64 / uint64 / double per FindAccumulatorType, aggregate_internal.h:29-50);
+ * accumulates INTO sums/counts (caller zero-initialises). */
+int orc_hash_sum(const orc_array* values, const uint32_t* ids, void* sums, int64_t* counts);
+/* c3: GroupedCountImpl::Consume, :466-517 */
+int orc_hash_count(const orc_array* values, const uint32_t* ids, int mode, int64_t* counts);
+/* c6: hash_mean(x)[g] = double(sum[g]) / count[g]; validity bit = count[g] > 0
+ * (mirrors MeanImpl::Finalize, aggregate_basic_internal.h:94-103). */
+int orc_hash_mean_finalize(int value_type_id, const void* sums, const int64_t* counts,
+                           int64_t num_groups, double* out_means, uint8_t* out_validity);
+
+/* One-shot grouped aggregate exactly as GroupBy drives a HashAggregateKernel over ONE
+ * batch (hash_aggregate.cc:928-960): func 0 = hash_sum, 1 = hash_count, 2 = hash_mean
+ * (c6; oracle only).  out_values: num_groups x 8 bytes; out_validity (zero-filled here,
+ * all ones when the reference leaves buffers[0] absent); out->has_validity as the
+ * reference reports it (hash_sum: only if some group has no valid value, :585-600;
+ * hash_count: never). */
+int orc_hash_aggregate(int func, const orc_array* values, const uint32_t* ids,
+                       int64_t num_groups, int count_mode, void* out_values,
+                       uint8_t* out_validity, orc_out* out);
+
+/* d1/d2: compare kernels, scalar_compare.cc:31-57,100-159; boolean output packed
+ * LSB-first with trailing bits zero (bitmap_generate.h:62-108).  Operand i is an array
+ * (lhs / rhs non-NULL) or a valid scalar (lhs_scalar / rhs_scalar -> one value of the
+ * array operand's type).  Op is applied to EVERY slot (codegen_internal.h:759-824).
+ * Output validity is what ScalarExecutor + NullPropagator produce (exec.cc:295-461,
+ * 553-716): always present, at offset 0; out->null_count 0 / the single nullable
+ * input's stored count / -1. */
+int orc_compare(int op, const orc_array* lhs, const void* lhs_scalar, const orc_array* rhs,
+                const void* rhs_scalar, uint8_t* out_bits, uint8_t* out_validity,
+                orc_out* out);
+
+/* e1/e2: arithmetic kernels, scalar_arithmetic.cc:69-251.  Unchecked add/sub/mul write
+ * every slot; divide and the checked ops only non-null pairs (null slots -> 0,
+ * codegen_internal.h:828-932).  Returns ORC_INVALID with message "overflow" /
+ * "divide by zero" as the reference does. */
+int orc_arith(int op, const orc_array* lhs, const void* lhs_scalar, const orc_array* rhs,
+              const void* rhs_scalar, void* out_values, uint8_t* out_validity,
+              orc_out* out);
+
+/* Headline composition (BASELINE.json config 5 on one shard): Filter(values, mask) and
+ * Filter(keys, mask) with DROP, then GroupBy{hash_sum(values)} by keys
+ * (vector_selection.cc:786-835 + hash_aggregate.cc:890-966).  Outputs in group order:
+ * sums (8 B each), counts, key values + key validity.  Returns num_groups. */
+int64_t orc_filter_groupby_sum(const orc_array* values, const orc_array* keys,
+                               const orc_array* mask, void* out_sums, int64_t* out_counts,
+                               void* out_keys, uint8_t* out_key_validity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORACLE_H_ */

@@ -1,0 +1,325 @@
+// ref_driver.cc -- OUR C-ABI over the REAL reference (arrow::compute built from
+// /root/reference by oracle/ref_build.mk).  TEST INFRASTRUCTURE ONLY.
+//
+// Exports ref_* with the signatures of orc_* in oracle.h, so that a test can run the
+// same inputs through the restatement and through the reference and compare bytes.
+// Everything goes through the reference's public entry points: CallFunction with an
+// ExecContext bound to a registry built by FunctionRegistry::Make() + the hot-path
+// Register* hooks (the reference's own extension mechanism, compute/exec_test.cc:651-717),
+// internal::Grouper and internal::GroupBy (compute/api_aggregate.h:313-403).
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "arrow/array.h"
+#include "arrow/array/data.h"
+#include "arrow/buffer.h"
+#include "arrow/chunked_array.h"
+#include "arrow/compute/api_aggregate.h"
+#include "arrow/compute/api_scalar.h"
+#include "arrow/compute/api_vector.h"
+#include "arrow/compute/exec.h"
+#include "arrow/compute/exec_internal.h"
+#include "arrow/compute/function.h"
+#include "arrow/compute/kernel.h"
+#include "arrow/compute/registry.h"
+#include "arrow/compute/registry_internal.h"
+#include "arrow/datum.h"
+#include "arrow/scalar.h"
+#include "arrow/type.h"
+#include "arrow/util/bit_util.h"
+#include "arrow/util/bitmap_ops.h"
+
+#include "oracle.h"
+
+using namespace arrow;           // NOLINT
+using namespace arrow::compute;  // NOLINT
+using arrow::internal::checked_cast;
+
+namespace {
+
+thread_local std::string g_err;
+int Fail(const Status& st) {
+  g_err = st.message();
+  return static_cast<int>(st.code());
+}
+
+FunctionRegistry* HotPathRegistry() {
+  static std::unique_ptr<FunctionRegistry> reg = [] {
+    auto r = FunctionRegistry::Make();
+    compute::internal::RegisterScalarArithmetic(r.get());
+    compute::internal::RegisterScalarComparison(r.get());
+    compute::internal::RegisterScalarBoolean(r.get());
+    compute::internal::RegisterScalarValidity(r.get());
+    compute::internal::RegisterVectorSelection(r.get());
+    compute::internal::RegisterVectorSort(r.get());
+    compute::internal::RegisterScalarAggregateBasic(r.get());
+    compute::internal::RegisterHashAggregateBasic(r.get());
+    return r;
+  }();
+  return reg.get();
+}
+ExecContext* Ctx() {
+  static ExecContext ctx(default_memory_pool(), HotPathRegistry());
+  return &ctx;
+}
+
+std::shared_ptr<DataType> TypeOf(int id) {
+  switch (id) {
+    case ORC_BOOL: return boolean();
+    case ORC_UINT8: return uint8();
+    case ORC_INT8: return int8();
+    case ORC_UINT16: return uint16();
+    case ORC_INT16: return int16();
+    case ORC_UINT32: return uint32();
+    case ORC_INT32: return int32();
+    case ORC_UINT64: return uint64();
+    case ORC_INT64: return int64();
+    case ORC_FLOAT: return float32();
+    case ORC_DOUBLE: return float64();
+  }
+  return nullptr;
+}
+int BitWidth(int id) {
+  auto t = TypeOf(id);
+  return t ? checked_cast<const FixedWidthType&>(*t).bit_width() : -1;
+}
+int64_t BufBytes(int bw, int64_t n) { return bw == 1 ? BitUtil::BytesForBits(n) : n * bw / 8; }
+
+// Wrap caller memory (no copy, no ownership) as ArrayData.
+std::shared_ptr<ArrayData> Wrap(const orc_array* a) {
+  const int bw = BitWidth(a->type_id);
+  const int64_t n = a->offset + a->length;
+  std::shared_ptr<Buffer> validity;
+  if (a->validity) validity = std::make_shared<Buffer>(a->validity, BitUtil::BytesForBits(n));
+  auto values = std::make_shared<Buffer>(reinterpret_cast<const uint8_t*>(a->values), BufBytes(bw, n));
+  return ArrayData::Make(TypeOf(a->type_id), a->length, {validity, values},
+                         a->validity ? a->null_count : 0, a->offset);
+}
+
+std::shared_ptr<Scalar> WrapScalar(int type_id, const void* p) {
+  switch (type_id) {
+    case ORC_BOOL: return std::make_shared<BooleanScalar>(*reinterpret_cast<const uint8_t*>(p) != 0);
+    case ORC_UINT8: return std::make_shared<UInt8Scalar>(*reinterpret_cast<const uint8_t*>(p));
+    case ORC_INT8: return std::make_shared<Int8Scalar>(*reinterpret_cast<const int8_t*>(p));
+    case ORC_UINT16: return std::make_shared<UInt16Scalar>(*reinterpret_cast<const uint16_t*>(p));
+    case ORC_INT16: return std::make_shared<Int16Scalar>(*reinterpret_cast<const int16_t*>(p));
+    case ORC_UINT32: return std::make_shared<UInt32Scalar>(*reinterpret_cast<const uint32_t*>(p));
+    case ORC_INT32: return std::make_shared<Int32Scalar>(*reinterpret_cast<const int32_t*>(p));
+    case ORC_UINT64: return std::make_shared<UInt64Scalar>(*reinterpret_cast<const uint64_t*>(p));
+    case ORC_INT64: return std::make_shared<Int64Scalar>(*reinterpret_cast<const int64_t*>(p));
+    case ORC_FLOAT: return std::make_shared<FloatScalar>(*reinterpret_cast<const float*>(p));
+    case ORC_DOUBLE: return std::make_shared<DoubleScalar>(*reinterpret_cast<const double*>(p));
+  }
+  return nullptr;
+}
+
+// Copy a produced primitive array out, normalised to bit offset 0.
+void Export(const ArrayData& d, void* out_values, uint8_t* out_validity, orc_out* out) {
+  const int bw = checked_cast<const FixedWidthType&>(*d.type).bit_width();
+  out->length = d.length;
+  out->null_count = d.null_count.load();
+  out->has_validity = d.buffers[0] != nullptr;
+  if (out_validity) {
+    std::memset(out_validity, 0, BitUtil::BytesForBits(d.length));
+    if (d.buffers[0] && d.length > 0)
+      arrow::internal::CopyBitmap(d.buffers[0]->data(), d.offset, d.length, out_validity, 0);
+  }
+  if (out_values && d.length > 0) {
+    if (bw == 1) {
+      std::memset(out_values, 0, BitUtil::BytesForBits(d.length));
+      arrow::internal::CopyBitmap(d.buffers[1]->data(), d.offset, d.length,
+                                  reinterpret_cast<uint8_t*>(out_values), 0);
+    } else {
+      std::memcpy(out_values, d.buffers[1]->data() + d.offset * bw / 8, d.length * bw / 8);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ref_last_error(void) { return g_err.c_str(); }
+
+int ref_num_functions(void) { return HotPathRegistry()->num_functions(); }
+
+int64_t ref_filter_output_size(const orc_array* filter, int null_selection) {
+  return compute::internal::GetFilterOutputSize(
+      *Wrap(filter), static_cast<FilterOptions::NullSelectionBehavior>(null_selection));
+}
+
+int ref_filter(const orc_array* values, const orc_array* filter, int null_selection,
+               void* out_values, uint8_t* out_validity, orc_out* out) {
+  FilterOptions opts(static_cast<FilterOptions::NullSelectionBehavior>(null_selection));
+  auto res = CallFunction("filter", {Datum(Wrap(values)), Datum(Wrap(filter))}, &opts, Ctx());
+  if (!res.ok()) return Fail(res.status());
+  Export(*res->array(), out_values, out_validity, out);
+  return 0;
+}
+
+int ref_take_indices(const orc_array* filter, int null_selection, void* out_indices,
+                     uint8_t* out_validity, int* out_index_width, orc_out* out) {
+  auto res = compute::internal::GetTakeIndices(
+      *Wrap(filter), static_cast<FilterOptions::NullSelectionBehavior>(null_selection));
+  if (!res.ok()) return Fail(res.status());
+  const ArrayData& d = **res;
+  *out_index_width = checked_cast<const FixedWidthType&>(*d.type).bit_width();
+  Export(d, out_indices, out_validity, out);
+  return 0;
+}
+
+int ref_take(const orc_array* values, const orc_array* indices, int boundscheck,
+             void* out_values, uint8_t* out_validity, orc_out* out) {
+  TakeOptions opts(boundscheck != 0);
+  auto res = CallFunction("take", {Datum(Wrap(values)), Datum(Wrap(indices))}, &opts, Ctx());
+  if (!res.ok()) return Fail(res.status());
+  Export(*res->array(), out_values, out_validity, out);
+  return 0;
+}
+
+int ref_sort_indices(const orc_array* chunks, int nchunks, int order, uint64_t* out) {
+  SortOrder so = order == ORC_DESCENDING ? SortOrder::Descending : SortOrder::Ascending;
+  Datum input;
+  if (nchunks == 1) {
+    input = Datum(Wrap(&chunks[0]));
+  } else {
+    ArrayVector arrs;
+    std::shared_ptr<DataType> type = nchunks ? TypeOf(chunks[0].type_id) : int64();
+    for (int c = 0; c < nchunks; ++c) arrs.push_back(MakeArray(Wrap(&chunks[c])));
+    input = Datum(std::make_shared<ChunkedArray>(arrs, type));
+  }
+  SortOptions opts({SortKey("", so)});
+  auto res = CallFunction("sort_indices", {input}, &opts, Ctx());
+  if (!res.ok()) return Fail(res.status());
+  const ArrayData& d = *res->array();
+  std::memcpy(out, d.buffers[1]->data() + d.offset * 8, d.length * 8);
+  return 0;
+}
+
+struct ref_grouper {
+  std::unique_ptr<compute::internal::Grouper> impl;
+  int nkeys;
+};
+
+ref_grouper* ref_grouper_new(int nkeys, const int* key_type_ids) {
+  std::vector<ValueDescr> descrs;
+  for (int k = 0; k < nkeys; ++k) descrs.push_back(ValueDescr::Array(TypeOf(key_type_ids[k])));
+  auto res = compute::internal::Grouper::Make(descrs, Ctx());
+  if (!res.ok()) { Fail(res.status()); return nullptr; }
+  auto* g = new ref_grouper;
+  g->impl = std::move(*res);
+  g->nkeys = nkeys;
+  return g;
+}
+void ref_grouper_free(ref_grouper* g) { delete g; }
+int ref_grouper_consume(ref_grouper* g, const orc_array* keys, uint32_t* out_ids) {
+  std::vector<Datum> cols;
+  for (int k = 0; k < g->nkeys; ++k) cols.emplace_back(Wrap(&keys[k]));
+  auto batch = ExecBatch::Make(cols);
+  if (!batch.ok()) return Fail(batch.status());
+  auto res = g->impl->Consume(*batch);
+  if (!res.ok()) return Fail(res.status());
+  const ArrayData& d = *res->array();
+  std::memcpy(out_ids, d.buffers[1]->data() + d.offset * 4, d.length * 4);
+  return 0;
+}
+uint32_t ref_grouper_num_groups(const ref_grouper* g) { return g->impl->num_groups(); }
+int ref_grouper_uniques(const ref_grouper* g, int k, void* out_values, uint8_t* out_validity,
+                        int64_t* out_null_count) {
+  auto res = g->impl->GetUniques();
+  if (!res.ok()) return Fail(res.status());
+  orc_out o;
+  Export(*res->values[k].array(), out_values, out_validity, &o);
+  if (!o.has_validity) {  // the restatement always fills the bitmap; absent == all valid
+    for (int64_t i = 0; i < o.length; ++i) BitUtil::SetBit(out_validity, i);
+  }
+  *out_null_count = o.null_count;
+  return 0;
+}
+
+// Drive one HashAggregateKernel the way GroupBy does (hash_aggregate.cc:809-859, 928-960).
+int ref_hash_aggregate(int func, const orc_array* values, const uint32_t* ids,
+                       int64_t num_groups, int count_mode, void* out_values,
+                       uint8_t* out_validity, orc_out* out) {
+  const char* name = func == 0 ? "hash_sum" : func == 1 ? "hash_count" : nullptr;
+  if (!name) { g_err = "hash_mean does not exist in the reference"; return ORC_KEY_ERROR; }
+  auto fres = Ctx()->func_registry()->GetFunction(name);
+  if (!fres.ok()) return Fail(fres.status());
+  auto vals = Wrap(values);
+  auto kres = (*fres)->DispatchExact(
+      {ValueDescr::Array(vals->type), ValueDescr::Array(uint32()), ValueDescr::Scalar(uint32())});
+  if (!kres.ok()) return Fail(kres.status());
+  auto kernel = static_cast<const HashAggregateKernel*>(*kres);
+  CountOptions copts(static_cast<CountOptions::Mode>(count_mode));
+  const FunctionOptions* options = func == 1 ? static_cast<const FunctionOptions*>(&copts) : nullptr;
+  KernelContext kctx(Ctx());
+  auto sres = kernel->init(&kctx, KernelInitArgs{kernel, {vals->type, uint32(), uint32()}, options});
+  if (!sres.ok()) return Fail(sres.status());
+  std::unique_ptr<KernelState> state = std::move(*sres);
+  kctx.SetState(state.get());
+  auto idbuf = std::make_shared<Buffer>(reinterpret_cast<const uint8_t*>(ids), values->length * 4);
+  auto id_arr = ArrayData::Make(uint32(), values->length, {nullptr, idbuf}, 0);
+  auto batch = ExecBatch::Make({Datum(vals), Datum(id_arr), Datum(static_cast<uint32_t>(num_groups))});
+  if (!batch.ok()) return Fail(batch.status());
+  Status st = kernel->consume(&kctx, *batch);
+  if (!st.ok()) return Fail(st);
+  Datum result;
+  st = kernel->finalize(&kctx, &result);
+  if (!st.ok()) return Fail(st);
+  Export(*result.array(), out_values, out_validity, out);
+  if (!out->has_validity)
+    for (int64_t i = 0; i < out->length; ++i) BitUtil::SetBit(out_validity, i);
+  return 0;
+}
+
+static const char* kCmpNames[] = {"equal", "not_equal", "greater", "greater_equal", "less", "less_equal"};
+static const char* kArithNames[] = {"add", "subtract", "multiply", "divide",
+                                    "add_checked", "subtract_checked", "multiply_checked", "divide_checked"};
+
+static int Binary(const char* name, const orc_array* lhs, const void* ls, const orc_array* rhs,
+                  const void* rs, void* out_values, uint8_t* out_validity, orc_out* out) {
+  const int t = lhs ? lhs->type_id : rhs->type_id;
+  Datum l = lhs ? Datum(Wrap(lhs)) : Datum(WrapScalar(t, ls));
+  Datum r = rhs ? Datum(Wrap(rhs)) : Datum(WrapScalar(t, rs));
+  auto res = CallFunction(name, {l, r}, nullptr, Ctx());
+  if (!res.ok()) return Fail(res.status());
+  Export(*res->array(), out_values, out_validity, out);
+  return 0;
+}
+
+int ref_compare(int op, const orc_array* lhs, const void* ls, const orc_array* rhs, const void* rs,
+                uint8_t* out_bits, uint8_t* out_validity, orc_out* out) {
+  return Binary(kCmpNames[op], lhs, ls, rhs, rs, out_bits, out_validity, out);
+}
+int ref_arith(int op, const orc_array* lhs, const void* ls, const orc_array* rhs, const void* rs,
+              void* out_values, uint8_t* out_validity, orc_out* out) {
+  return Binary(kArithNames[op], lhs, ls, rhs, rs, out_values, out_validity, out);
+}
+
+// Filter(values, mask), Filter(keys, mask), GroupBy({values}, {keys}, {hash_sum})
+int64_t ref_filter_groupby_sum(const orc_array* values, const orc_array* keys, const orc_array* mask,
+                               void* out_sums, int64_t* out_counts, void* out_keys,
+                               uint8_t* out_key_validity) {
+  FilterOptions fopts(FilterOptions::DROP);
+  auto fv = CallFunction("filter", {Datum(Wrap(values)), Datum(Wrap(mask))}, &fopts, Ctx());
+  if (!fv.ok()) return -Fail(fv.status());
+  auto fk = CallFunction("filter", {Datum(Wrap(keys)), Datum(Wrap(mask))}, &fopts, Ctx());
+  if (!fk.ok()) return -Fail(fk.status());
+  CountOptions copts(CountOptions::COUNT_NON_NULL);
+  auto res = compute::internal::GroupBy({*fv, *fv}, {*fk}, {{"hash_sum", nullptr}, {"hash_count", &copts}}, Ctx());
+  if (!res.ok()) return -Fail(res.status());
+  const ArrayData& st = *res->array();
+  orc_out o;
+  uint8_t* tmp = static_cast<uint8_t*>(std::malloc(BitUtil::BytesForBits(st.length) + 8));
+  Export(*st.child_data[0], out_sums, tmp, &o);
+  Export(*st.child_data[1], out_counts, tmp, &o);
+  Export(*st.child_data[2], out_keys, out_key_validity, &o);
+  if (!o.has_validity)
+    for (int64_t i = 0; i < o.length; ++i) BitUtil::SetBit(out_key_validity, i);
+  std::free(tmp);
+  return st.length;
+}
+
+}  // extern "C"
