@@ -1,0 +1,267 @@
+"""Host-side mirror (Python flavour) of the reference's operator API for the hot path:
+same function names and option meaning as arrow::compute::CallFunction
+(compute/exec.h:229-237, api_vector.h, api_scalar.h, api_aggregate.h), every call going
+straight to the HIP kernels through the C ABI (include/amdarrow.h).  The C++ flavour --
+what an Arrow C++ caller links -- lives in arrow-1_amd/host/.  Nothing here computes on
+the CPU."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+from ._abi import (BOOL, DROP, EMIT_NULL, ASCENDING, DESCENDING, COut, CArray, AmdArrowError, check)
+from .device import Context, DeviceArray, alloc_bytes, bit_width, NP_OF
+
+_CMP = {"equal": _abi.EQ, "not_equal": _abi.NE, "greater": _abi.GT, "greater_equal": _abi.GE,
+        "less": _abi.LT, "less_equal": _abi.LE}
+_ARITH = {"add": _abi.ADD, "subtract": _abi.SUB, "multiply": _abi.MUL, "divide": _abi.DIV,
+          "add_checked": _abi.ADD_CHECKED, "subtract_checked": _abi.SUB_CHECKED,
+          "multiply_checked": _abi.MUL_CHECKED, "divide_checked": _abi.DIV_CHECKED}
+_AGG = {"hash_sum": _abi.HASH_SUM, "hash_count": _abi.HASH_COUNT, "hash_mean": _abi.HASH_MEAN}
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _values_bytes(type_id, n):
+    return (n + 7) // 8 if type_id == BOOL else n * bit_width(type_id) // 8
+
+
+def filter(ctx, values, mask, null_selection=DROP, out_capacity=None):  # noqa: A001 (reference name)
+    """CallFunction("filter", {values, mask}, FilterOptions) -- vector_selection.cc:786-835."""
+    cap = values.length if out_capacity is None else out_capacity
+    dev = values.values.device
+    out_v = alloc_bytes(_values_bytes(values.type_id, cap), dev)
+    out_b = alloc_bytes((cap + 7) // 8, dev)
+    out = COut()
+    cv, cm = values.c(), mask.c()
+    check(ctx.lib, ctx.lib.amdarrow_filter(ctx.handle, C.byref(cv), C.byref(cm), null_selection, _ptr(out_v),
+                                           _ptr(out_b), cap, C.byref(out)))
+    return DeviceArray(values.type_id, out_v, out_b if out.has_validity else None, out.length, 0, out.null_count)
+
+
+def filter_output_size(ctx, mask, null_selection=DROP):
+    n = C.c_int64(0)
+    cm = mask.c()
+    check(ctx.lib, ctx.lib.amdarrow_filter_output_size(ctx.handle, C.byref(cm), null_selection, C.byref(n)))
+    return n.value
+
+
+def take_indices(ctx, mask, null_selection=DROP):
+    """internal::GetTakeIndices -- vector_selection.cc:92-237."""
+    cap = mask.length
+    dev = mask.values.device
+    out_v = alloc_bytes(cap * 4, dev)
+    out_b = alloc_bytes((cap + 7) // 8, dev)
+    out, w = COut(), C.c_int(0)
+    cm = mask.c()
+    check(ctx.lib, ctx.lib.amdarrow_take_indices(ctx.handle, C.byref(cm), null_selection, _ptr(out_v), _ptr(out_b),
+                                                 cap, C.byref(w), C.byref(out)))
+    t = _abi.UINT16 if w.value == 16 else _abi.UINT32
+    return DeviceArray(t, out_v, out_b if out.has_validity else None, out.length, 0, out.null_count)
+
+
+def take(ctx, values, indices, boundscheck=True):
+    """CallFunction("take", {values, indices}, TakeOptions) -- vector_selection.cc:493-530."""
+    n = indices.length
+    dev = values.values.device
+    out_v = alloc_bytes(_values_bytes(values.type_id, n), dev)
+    out_b = alloc_bytes((n + 7) // 8, dev)
+    out = COut()
+    cv, ci = values.c(), indices.c()
+    check(ctx.lib, ctx.lib.amdarrow_take(ctx.handle, C.byref(cv), C.byref(ci), int(boundscheck), _ptr(out_v),
+                                         _ptr(out_b), C.byref(out)))
+    return DeviceArray(values.type_id, out_v, out_b, out.length, 0, out.null_count)
+
+
+def sort_indices(ctx, chunks, order=ASCENDING):
+    """CallFunction("sort_indices", {array | chunked_array}, SortOptions) -- vector_sort.cc:1565-1630."""
+    if isinstance(chunks, DeviceArray):
+        chunks = [chunks]
+    total = sum(c.length for c in chunks)
+    dev = chunks[0].values.device if chunks else "cuda"
+    out = alloc_bytes(total * 8, dev)
+    arr = (CArray * max(len(chunks), 1))(*[c.c() for c in chunks])
+    check(ctx.lib, ctx.lib.amdarrow_sort_indices(ctx.handle, arr, len(chunks), order, _ptr(out)))
+    return DeviceArray(_abi.UINT64, out, None, total, 0, 0)
+
+
+def _binary(ctx, fn, op, lhs, rhs, out_type):
+    arr = lhs if isinstance(lhs, DeviceArray) else rhs
+    t, n = arr.type_id, arr.length
+    keep = []
+
+    def operand(x):
+        if isinstance(x, DeviceArray):
+            c = x.c()
+            keep.append(c)
+            return C.byref(c), None
+        s = np.array([x], dtype=np.uint8 if t == BOOL else NP_OF[t])
+        keep.append(s)
+        return None, s.ctypes.data_as(C.c_void_p)
+
+    la, ls = operand(lhs)
+    ra, rs = operand(rhs)
+    ot = t if out_type is None else out_type
+    dev = arr.values.device
+    out_v = alloc_bytes(_values_bytes(ot, n), dev)
+    out_b = alloc_bytes((n + 7) // 8, dev)
+    out = COut()
+    check(ctx.lib, fn(ctx.handle, op, la, ls, ra, rs, _ptr(out_v), _ptr(out_b), C.byref(out)))
+    return DeviceArray(ot, out_v, out_b, out.length, 0, out.null_count)
+
+
+def compare(ctx, op, lhs, rhs):
+    """equal / not_equal / greater / greater_equal / less / less_equal -- scalar_compare.cc:100-171."""
+    return _binary(ctx, ctx.lib.amdarrow_compare, op, lhs, rhs, BOOL)
+
+
+def arith(ctx, op, lhs, rhs):
+    """add / subtract / multiply / divide [+ _checked] -- scalar_arithmetic.cc:69-251."""
+    return _binary(ctx, ctx.lib.amdarrow_arith, op, lhs, rhs, None)
+
+
+def hash_aggregate(ctx, func, values, ids, num_groups, count_mode=0):
+    """One HashAggregateKernel (hash_sum / hash_count / hash_mean) over (values, ids, num_groups).
+    `ids`: torch.int32/uint32 tensor on the device."""
+    dev = values.values.device
+    out_v = alloc_bytes(num_groups * 8, dev)
+    out_b = alloc_bytes((num_groups + 7) // 8, dev)
+    out = COut()
+    cv = values.c()
+    check(ctx.lib, ctx.lib.amdarrow_hash_aggregate(ctx.handle, func, C.byref(cv), _ptr(ids), num_groups, count_mode,
+                                                   _ptr(out_v), _ptr(out_b), C.byref(out)))
+    t = values.type_id
+    if func == _abi.HASH_COUNT:
+        ot = _abi.INT64
+    elif func == _abi.HASH_MEAN or t in (_abi.FLOAT, _abi.DOUBLE):
+        ot = _abi.DOUBLE
+    elif t in (_abi.INT8, _abi.INT16, _abi.INT32, _abi.INT64):
+        ot = _abi.INT64
+    else:
+        ot = _abi.UINT64
+    return DeviceArray(ot, out_v, out_b if out.has_validity else None, out.length, 0, out.null_count)
+
+
+class Grouper:
+    """internal::Grouper (api_aggregate.h:313-403): Consume(keys) -> uint32 ids in first-appearance order."""
+
+    def __init__(self, ctx, key_type_ids):
+        self.ctx, self.types = ctx, list(key_type_ids)
+        h = C.c_void_p()
+        arr = (C.c_int * len(self.types))(*self.types)
+        check(ctx.lib, ctx.lib.amdarrow_grouper_create(ctx.handle, len(self.types), arr, C.byref(h)))
+        self.handle = h
+
+    def consume(self, keys):
+        n = keys[0].length
+        out = alloc_bytes(n * 4, keys[0].values.device)
+        arr = (CArray * len(keys))(*[k.c() for k in keys])
+        check(self.ctx.lib, self.ctx.lib.amdarrow_grouper_consume(self.handle, arr, _ptr(out)))
+        return DeviceArray(_abi.UINT32, out, None, n, 0, 0)
+
+    def num_groups(self):
+        n = C.c_uint32(0)
+        check(self.ctx.lib, self.ctx.lib.amdarrow_grouper_num_groups(self.handle, C.byref(n)))
+        return n.value
+
+    def uniques(self, k=0):
+        ng = self.num_groups()
+        t = self.types[k]
+        out_v = alloc_bytes(_values_bytes(t, ng), self.ctx.device)
+        out_b = alloc_bytes((ng + 7) // 8, self.ctx.device)
+        out = COut()
+        check(self.ctx.lib, self.ctx.lib.amdarrow_grouper_uniques(self.handle, k, _ptr(out_v), _ptr(out_b),
+                                                                  C.byref(out)))
+        return DeviceArray(t, out_v, out_b if out.has_validity else None, out.length, 0, out.null_count)
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.amdarrow_grouper_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GroupByResult:
+    """StructArray{hash_sum, hash_count, key_0} of internal::GroupBy (hash_aggregate.cc:962-965),
+    rows in first-appearance order, plus the first-row index of each group."""
+
+    def __init__(self, num_groups, sums, counts, keys, key_validity, first_rows, value_type, key_type):
+        self.num_groups, self.sums, self.counts = num_groups, sums, counts
+        self.keys, self.key_validity, self.first_rows = keys, key_validity, first_rows
+        self.value_type, self.key_type = value_type, key_type
+
+    def sums_numpy(self):
+        t = self.value_type
+        acc = np.float64 if t in (_abi.FLOAT, _abi.DOUBLE) else (
+            np.int64 if t in (_abi.INT8, _abi.INT16, _abi.INT32, _abi.INT64) else np.uint64)
+        return self.sums[:self.num_groups * 8].cpu().numpy().view(acc).copy()
+
+    def counts_numpy(self):
+        return self.counts[:self.num_groups * 8].cpu().numpy().view(np.int64).copy()
+
+    def keys_numpy(self):
+        w = bit_width(self.key_type) // 8
+        return self.keys[:self.num_groups * w].cpu().numpy().view(NP_OF[self.key_type]).copy()
+
+    def key_validity_numpy(self):
+        raw = self.key_validity[:(self.num_groups + 7) // 8].cpu().numpy()
+        return np.unpackbits(raw, bitorder="little")[:self.num_groups].astype(bool)
+
+    def first_rows_numpy(self):
+        return self.first_rows[:self.num_groups * 4].cpu().numpy().view(np.uint32).copy()
+
+
+class GroupByBuffers:
+    """Reusable output buffers for filter_groupby (so a timed loop allocates nothing)."""
+
+    def __init__(self, device, group_capacity, key_type):
+        self.cap = group_capacity
+        self.sums = alloc_bytes(group_capacity * 8, device)
+        self.counts = alloc_bytes(group_capacity * 8, device)
+        self.keys = alloc_bytes(group_capacity * bit_width(key_type) // 8, device)
+        self.key_validity = alloc_bytes((group_capacity + 7) // 8, device)
+        self.first_rows = alloc_bytes(group_capacity * 4, device)
+
+
+def filter_groupby(ctx, values, keys, mask=None, group_capacity=None, buffers=None):
+    """Filter(values, mask) + Filter(keys, mask) + GroupBy({values},{keys},{hash_sum, hash_count})
+    fused into one pass over HBM (BASELINE.json north_star)."""
+    cap = group_capacity if group_capacity is not None else (buffers.cap if buffers else values.length)
+    b = buffers or GroupByBuffers(values.values.device, cap, keys.type_id)
+    ng = C.c_int64(0)
+    cv, ck = values.c(), keys.c()
+    cm = mask.c() if mask is not None else None
+    check(ctx.lib, ctx.lib.amdarrow_filter_groupby(ctx.handle, C.byref(cv), C.byref(ck),
+                                                   C.byref(cm) if cm is not None else None, cap, _ptr(b.sums),
+                                                   _ptr(b.counts), _ptr(b.keys), _ptr(b.key_validity),
+                                                   _ptr(b.first_rows), C.byref(ng)))
+    return GroupByResult(ng.value, b.sums, b.counts, b.keys, b.key_validity, b.first_rows, values.type_id,
+                         keys.type_id)
+
+
+def call_function(ctx, name, args, options=None):
+    """CallFunction(name, args, options, ctx) for the functions on the path (same names as the
+    reference registry; unknown name -> KeyError like registry.cc:62-64)."""
+    options = options or {}
+    if name in ("filter", "array_filter"):
+        return filter(ctx, args[0], args[1], options.get("null_selection_behavior", DROP))
+    if name in ("take", "array_take"):
+        return take(ctx, args[0], args[1], options.get("boundscheck", True))
+    if name in ("sort_indices", "array_sort_indices"):
+        return sort_indices(ctx, args[0], options.get("order", ASCENDING))
+    if name in _CMP:
+        return compare(ctx, _CMP[name], args[0], args[1])
+    if name in _ARITH:
+        return arith(ctx, _ARITH[name], args[0], args[1])
+    if name in _AGG:
+        # function.cc:193-195: hash aggregates cannot be called directly
+        raise AmdArrowError(10, "Direct execution of HASH_AGGREGATE functions")
+    raise AmdArrowError(2, "No function registered with name: " + name)

@@ -1,0 +1,154 @@
+// common.h -- shared host/device helpers for the gfx950 kernels.  Internal; the public
+// surface is include/amdarrow.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <string>
+#include <unordered_map>
+
+#include "amdarrow.h"
+
+namespace amdarrow {
+
+constexpr int kWave = 64;  // CDNA4 wavefront
+
+// ---- status / errors ---------------------------------------------------------------------
+int SetError(int code, const std::string& msg);
+int HipError(hipError_t e, const char* what, const char* file, int line);
+
+#define AA_HIP(expr)                                                        \
+  do {                                                                      \
+    hipError_t _e = (expr);                                                 \
+    if (_e != hipSuccess) return ::amdarrow::HipError(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+#define AA_TRY(expr)             \
+  do {                           \
+    int _rc = (expr);            \
+    if (_rc != AMDARROW_OK) return _rc; \
+  } while (0)
+
+}  // namespace amdarrow
+
+// ---- context -----------------------------------------------------------------------------
+struct amdarrow_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  void* scratch = nullptr;  // grow-only HBM arena for per-call temporaries
+  size_t scratch_cap = 0;
+  void* pinned = nullptr;   // 4 KiB pinned host memory for small read-backs
+  int num_cus = 256;
+  int64_t bytes_allocated = 0;
+  int64_t max_memory = 0;
+  std::unordered_map<void*, int64_t> allocs;
+  std::mutex mu;
+};
+
+namespace amdarrow {
+
+// Ensure the scratch arena holds `bytes`; returns its base (256-B aligned).
+int Scratch(amdarrow_ctx* ctx, size_t bytes, void** out);
+
+// A bump allocator over the scratch arena (sizes rounded to 256 B).
+struct Carver {
+  size_t off = 0;
+  size_t Take(size_t bytes) {
+    size_t at = off;
+    off += (bytes + 255) & ~size_t(255);
+    return at;
+  }
+};
+
+// Copy `nbytes` (<= 4096) from device to the pinned word and wait for it.
+int ReadBack(amdarrow_ctx* ctx, const void* dev, size_t nbytes, void* host_out);
+
+inline int BitWidth(int type_id) {
+  switch (type_id) {
+    case AMDARROW_BOOL: return 1;
+    case AMDARROW_UINT8: case AMDARROW_INT8: return 8;
+    case AMDARROW_UINT16: case AMDARROW_INT16: return 16;
+    case AMDARROW_UINT32: case AMDARROW_INT32: case AMDARROW_FLOAT: return 32;
+    case AMDARROW_UINT64: case AMDARROW_INT64: case AMDARROW_DOUBLE: return 64;
+    default: return -1;
+  }
+}
+inline bool IsSignedInt(int t) { return t == AMDARROW_INT8 || t == AMDARROW_INT16 || t == AMDARROW_INT32 || t == AMDARROW_INT64; }
+inline bool IsUnsignedInt(int t) { return t == AMDARROW_UINT8 || t == AMDARROW_UINT16 || t == AMDARROW_UINT32 || t == AMDARROW_UINT64; }
+inline bool IsFloat(int t) { return t == AMDARROW_FLOAT || t == AMDARROW_DOUBLE; }
+inline int64_t BytesForBits(int64_t n) { return (n + 7) >> 3; }
+// GetPrimitiveArg (compute/kernels/util_internal.cc:45-58): 0 without a validity buffer,
+// else the stored count (possibly -1).
+inline int64_t ArgNullCount(const amdarrow_array* a) { return a->validity ? a->null_count : 0; }
+// ArrayData::MayHaveNulls
+inline bool MayHaveNulls(const amdarrow_array* a) { return a->validity && a->null_count != 0; }
+
+inline int GridFor(int64_t work_items, int per_block, int max_blocks) {
+  int64_t b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > max_blocks) b = max_blocks;
+  return static_cast<int>(b);
+}
+
+#ifdef __HIPCC__
+// ---- device bit helpers --------------------------------------------------------------------
+// 64 bits of `bm` starting at absolute bit position `pos`; bits at and beyond `nbits`
+// (1..64) are returned as zero.  Only aligned 8-byte words that contain a requested bit
+// are touched, so a buffer padded to the next 8-byte boundary is never over-read.
+__device__ __forceinline__ uint64_t LoadBits64(const uint8_t* __restrict__ bm, int64_t pos, int nbits) {
+  const uintptr_t addr = reinterpret_cast<uintptr_t>(bm) + static_cast<uintptr_t>(pos >> 3);
+  const uint64_t* w = reinterpret_cast<const uint64_t*>(addr & ~uintptr_t(7));
+  const int shift = static_cast<int>((addr & 7) << 3) + static_cast<int>(pos & 7);
+  uint64_t v = w[0] >> shift;
+  if (shift + nbits > 64) v |= w[1] << (64 - shift);
+  if (nbits < 64) v &= (uint64_t(1) << nbits) - 1;
+  return v;
+}
+// Same, but an absent bitmap reads as all ones.
+__device__ __forceinline__ uint64_t LoadBitsOrOnes(const uint8_t* __restrict__ bm, int64_t pos, int nbits) {
+  if (bm == nullptr) return nbits < 64 ? (uint64_t(1) << nbits) - 1 : ~uint64_t(0);
+  return LoadBits64(bm, pos, nbits);
+}
+__device__ __forceinline__ bool GetBit(const uint8_t* __restrict__ bm, int64_t pos) {
+  return (bm[pos >> 3] >> (pos & 7)) & 1;
+}
+__device__ __forceinline__ int LaneId() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0));
+}
+// popcount of the bits of `mask` below this lane
+__device__ __forceinline__ int RankBelowLane(uint64_t mask) {
+  return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
+                                   __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0));
+}
+// Store bitmap word `word_index` (64 bits) of a bitmap holding `total_bits` bits without
+// writing past BytesForBits(total_bits).  `bm` must be 8-byte aligned.
+__device__ __forceinline__ void StoreBitmapWord(uint8_t* __restrict__ bm, int64_t word_index, uint64_t w,
+                                                int64_t total_bits) {
+  const int64_t nbytes = (total_bits + 7) >> 3;
+  const int64_t byte0 = word_index << 3;
+  if (byte0 + 8 <= nbytes) {
+    reinterpret_cast<uint64_t*>(bm)[word_index] = w;
+  } else {
+    for (int64_t b = byte0; b < nbytes; ++b) bm[b] = static_cast<uint8_t>(w >> ((b - byte0) << 3));
+  }
+}
+// Inclusive scan of one value per lane across the 64-lane wave.
+__device__ __forceinline__ uint32_t WaveInclusiveScan(uint32_t v) {
+  const int lane = LaneId();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ uint64_t WaveReduceSum64(uint64_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+#endif  // __HIPCC__
+
+}  // namespace amdarrow

@@ -1,0 +1,705 @@
+// groupby.hip -- Grouper, hash_sum / hash_count / hash_mean, and the fused
+// Filter -> GroupBy of the north-star path.
+//
+// Reference semantics: compute/kernels/hash_aggregate.cc
+//   KeyEncoder / FixedWidthKeyEncoder / BooleanKeyEncoder :48-196  (null key = its own group,
+//       byte-wise equality: -0.0 != +0.0, NaNs with equal bits are one group)
+//   GrouperImpl::Consume :358-408   (group id = order of FIRST APPEARANCE, map_.emplace(key, num_groups_))
+//   GroupedCountImpl :466-517, GroupedSumImpl :522-622 (+FindAccumulatorType, aggregate_internal.h:29-50)
+//   GroupBy :890-966                (output rows = groups in id order)
+//
+// Design (see DESIGN.md "group-by"):
+//   * keys are packed into one 64-bit word x (value bits + one null flag per column) and
+//     hashed with the BIJECTIVE murmur3 finaliser h = fmix64(x); tables store h only -- equal
+//     h <=> equal key, and the key is recovered with the inverse at output time.
+//   * build: open-addressed table of h; per selected row  first_row = min(row),
+//     sum += v, count += 1.
+//   * first-appearance ids without a sort: set bit first_row of every group in an N-bit
+//     bitmap, exclusive popcount-scan the bitmap words, id(g) = rank of its first_row bit.
+//     Traffic N/8 bytes instead of a radix sort of the groups.
+//   * emit: scatter (x, sum, count, first_row) of each group to slot id, decode keys.
+#include "common.h"
+
+#include <cstring>
+#include <vector>
+
+namespace amdarrow {
+
+constexpr int kThreads = 256;
+constexpr uint64_t kEmpty = ~uint64_t(0);
+constexpr uint32_t kNoRow = 0xFFFFFFFFu;
+
+__host__ __device__ __forceinline__ uint64_t Fmix64(uint64_t h) {
+  h ^= h >> 33; h *= 0xff51afd7ed558ccdULL; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ULL; h ^= h >> 33;
+  return h;
+}
+__host__ __device__ __forceinline__ uint64_t Fmix64Inv(uint64_t h) {
+  h ^= h >> 33; h *= 0x9cb4b2f8129337dbULL; h ^= h >> 33; h *= 0x4f74430c22a54005ULL; h ^= h >> 33;
+  return h;
+}
+
+// ---- key packing ------------------------------------------------------------------------------
+constexpr int kMaxKeys = 4;
+struct KeyCol { const void* data; const uint8_t* valid; int64_t off; int bits; int shift; };
+struct KeySpec {
+  int nkeys;
+  int total_bits;      // sum of value bits
+  int wide_null_slot;  // single 64-bit key: a null key goes to the dedicated slot
+  KeyCol col[kMaxKeys];
+};
+
+__device__ __forceinline__ uint64_t LoadBitsOfWidth(const void* data, int64_t i, int bits) {
+  switch (bits) {
+    case 1: return GetBit(reinterpret_cast<const uint8_t*>(data), i);
+    case 8: return reinterpret_cast<const uint8_t*>(data)[i];
+    case 16: return reinterpret_cast<const uint16_t*>(data)[i];
+    case 32: return reinterpret_cast<const uint32_t*>(data)[i];
+    default: return reinterpret_cast<const uint64_t*>(data)[i];
+  }
+}
+// Returns true when the row's key is the null of a single 64-bit key column.
+__device__ __forceinline__ bool EncodeKey(const KeySpec& ks, int64_t row, uint64_t* x_out) {
+  uint64_t x = 0;
+#pragma unroll
+  for (int k = 0; k < kMaxKeys; ++k) {
+    if (k >= ks.nkeys) break;
+    const KeyCol& c = ks.col[k];
+    const bool valid = c.valid ? GetBit(c.valid, c.off + row) : true;
+    if (valid) x |= LoadBitsOfWidth(c.data, c.off + row, c.bits) << c.shift;   // [kValidByte][bytes]
+    else if (ks.wide_null_slot) return true;
+    else x |= uint64_t(1) << (ks.total_bits + k);                               // [kNullByte][zeros]
+  }
+  *x_out = x;
+  return false;
+}
+
+// ---- the group table --------------------------------------------------------------------------
+// T power-of-two slots + 2 special slots: [T] the null of a single 64-bit key, [T+1] the one
+// key whose hash equals the empty marker.
+struct GroupTable {
+  unsigned long long* hkeys;  // kEmpty = free
+  uint32_t* first;            // first selected row of the group; kNoRow = none yet
+  unsigned long long* sums;   // int64/uint64 (wrapping) or double bits
+  unsigned long long* counts; // valid values per group
+  uint32_t* ids;              // Grouper only: assigned dense id, kNoRow = unassigned
+  uint64_t mask;              // T - 1
+};
+
+__device__ __forceinline__ int64_t FindOrInsert(const GroupTable& t, uint64_t h, bool insert) {
+  if (h == kEmpty) return static_cast<int64_t>(t.mask) + 2;
+  uint64_t idx = h & t.mask;
+  for (uint64_t probes = 0; probes <= t.mask; ++probes) {
+    unsigned long long cur = t.hkeys[idx];
+    if (cur == h) return static_cast<int64_t>(idx);
+    if (cur == kEmpty) {
+      if (!insert) return -1;
+      cur = atomicCAS(&t.hkeys[idx], static_cast<unsigned long long>(kEmpty), static_cast<unsigned long long>(h));
+      if (cur == kEmpty || cur == h) return static_cast<int64_t>(idx);
+    }
+    idx = (idx + 1) & t.mask;
+  }
+  return -1;  // table full
+}
+
+struct ValueCol { const void* data; const uint8_t* valid; int64_t off; int type_id; };
+
+// value -> accumulator bits (FindAccumulatorType): signed -> int64, unsigned/bool -> uint64,
+// float/double -> double
+__device__ __forceinline__ uint64_t LoadAccum(const ValueCol& v, int64_t row, bool* is_double) {
+  const int64_t i = v.off + row;
+  *is_double = false;
+  switch (v.type_id) {
+    case AMDARROW_BOOL: return GetBit(reinterpret_cast<const uint8_t*>(v.data), i);
+    case AMDARROW_UINT8: return reinterpret_cast<const uint8_t*>(v.data)[i];
+    case AMDARROW_UINT16: return reinterpret_cast<const uint16_t*>(v.data)[i];
+    case AMDARROW_UINT32: return reinterpret_cast<const uint32_t*>(v.data)[i];
+    case AMDARROW_UINT64: return reinterpret_cast<const uint64_t*>(v.data)[i];
+    case AMDARROW_INT8: return static_cast<uint64_t>(static_cast<int64_t>(reinterpret_cast<const int8_t*>(v.data)[i]));
+    case AMDARROW_INT16: return static_cast<uint64_t>(static_cast<int64_t>(reinterpret_cast<const int16_t*>(v.data)[i]));
+    case AMDARROW_INT32: return static_cast<uint64_t>(static_cast<int64_t>(reinterpret_cast<const int32_t*>(v.data)[i]));
+    case AMDARROW_INT64: return static_cast<uint64_t>(reinterpret_cast<const int64_t*>(v.data)[i]);
+    case AMDARROW_FLOAT: { *is_double = true; double d = reinterpret_cast<const float*>(v.data)[i]; return __double_as_longlong(d); }
+    default: { *is_double = true; return reinterpret_cast<const uint64_t*>(v.data)[i]; }
+  }
+}
+__device__ __forceinline__ void Accumulate(unsigned long long* slot, uint64_t bits, bool is_double) {
+  if (is_double) atomicAdd(reinterpret_cast<double*>(slot), __longlong_as_double(bits));
+  else atomicAdd(slot, static_cast<unsigned long long>(bits));
+}
+
+// ---- build: generic path (global table) ---------------------------------------------------------
+// One row per lane.  mask: selected iff (mask_valid ? valid : 1) && bit  (Filter DROP semantics).
+__global__ __launch_bounds__(kThreads) void k_groupby_build(KeySpec ks, ValueCol v, int has_values,
+                                                            const uint8_t* m_data, const uint8_t* m_valid, int64_t m_off,
+                                                            int64_t n, GroupTable t, unsigned int* overflow) {
+  for (int64_t row = int64_t(blockIdx.x) * kThreads + threadIdx.x; row < n; row += int64_t(gridDim.x) * kThreads) {
+    if (m_data) {
+      if (!GetBit(m_data, m_off + row)) continue;
+      if (m_valid && !GetBit(m_valid, m_off + row)) continue;
+    }
+    uint64_t x;
+    int64_t idx;
+    if (EncodeKey(ks, row, &x)) idx = static_cast<int64_t>(t.mask) + 1;
+    else idx = FindOrInsert(t, Fmix64(x), true);
+    if (idx < 0) { *overflow = 1; continue; }
+    atomicMin(&t.first[idx], static_cast<uint32_t>(row));
+    if (has_values) {
+      const bool valid = v.valid ? GetBit(v.valid, v.off + row) : true;
+      if (valid) {
+        bool is_double;
+        const uint64_t bits = LoadAccum(v, row, &is_double);
+        Accumulate(&t.sums[idx], bits, is_double);
+        atomicAdd(&t.counts[idx], 1ull);
+      }
+    }
+  }
+}
+
+// ---- first-appearance numbering -----------------------------------------------------------------
+// Set bit first_row for every group that needs an id.
+__global__ __launch_bounds__(kThreads) void k_mark_first(GroupTable t, int64_t nslots, int only_unassigned,
+                                                         unsigned long long* bitmap) {
+  for (int64_t s = int64_t(blockIdx.x) * kThreads + threadIdx.x; s < nslots; s += int64_t(gridDim.x) * kThreads) {
+    const uint32_t fr = t.first[s];
+    if (fr == kNoRow) continue;
+    if (only_unassigned && t.ids[s] != kNoRow) continue;
+    atomicOr(&bitmap[fr >> 6], 1ull << (fr & 63));
+  }
+}
+// counts[b] = popcount of 1024 consecutive bitmap words
+__global__ __launch_bounds__(kThreads) void k_popc_blocks(const unsigned long long* bitmap, int64_t nwords, uint32_t* counts) {
+  __shared__ uint32_t s_sum;
+  if (threadIdx.x == 0) s_sum = 0;
+  __syncthreads();
+  const int64_t base = int64_t(blockIdx.x) * 1024;
+  uint32_t c = 0;
+  for (int k = 0; k < 4; ++k) {
+    const int64_t w = base + k * kThreads + threadIdx.x;
+    if (w < nwords) c += __popcll(bitmap[w]);
+  }
+  c = static_cast<uint32_t>(WaveReduceSum64(c));
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_sum, c);
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = s_sum;
+}
+// prefix[w] = number of set bits in words [0, w)
+__global__ __launch_bounds__(kThreads) void k_word_prefix(const unsigned long long* bitmap, int64_t nwords,
+                                                          const int64_t* block_offsets, uint32_t* prefix) {
+  __shared__ uint32_t s_wave[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t base = int64_t(blockIdx.x) * 1024;
+  uint32_t carry = static_cast<uint32_t>(block_offsets[blockIdx.x]);
+  for (int k = 0; k < 4; ++k) {
+    const int64_t w = base + k * kThreads + threadIdx.x;
+    const uint32_t pc = w < nwords ? __popcll(bitmap[w]) : 0;
+    const uint32_t incl = WaveInclusiveScan(pc);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+    for (int j = 0; j < 4; ++j) { if (j < wave) woff += s_wave[j]; total += s_wave[j]; }
+    if (w < nwords) prefix[w] = carry + woff + incl - pc;
+    carry += total;
+    __syncthreads();
+  }
+}
+
+struct EmitArgs {
+  GroupTable t; int64_t nslots; const unsigned long long* bitmap; const uint32_t* prefix;
+  int64_t capacity; uint32_t id_base; int only_unassigned;
+  unsigned long long* gx;     // key word per id
+  unsigned long long* sums;   // may be null
+  long long* counts;          // may be null
+  uint32_t* first_rows;       // may be null
+  uint32_t* wide_null_id;     // id of the null-key group of a single 64-bit key (kNoRow if none)
+};
+__global__ __launch_bounds__(kThreads) void k_emit_groups(EmitArgs a) {
+  for (int64_t s = int64_t(blockIdx.x) * kThreads + threadIdx.x; s < a.nslots; s += int64_t(gridDim.x) * kThreads) {
+    const uint32_t fr = a.t.first[s];
+    if (fr == kNoRow) continue;
+    if (a.only_unassigned && a.t.ids[s] != kNoRow) continue;
+    const uint64_t word = a.bitmap[fr >> 6];
+    const uint32_t id = a.id_base + a.prefix[fr >> 6] + __popcll(word & ((1ull << (fr & 63)) - 1));
+    if (a.t.ids) { a.t.ids[s] = id; a.t.first[s] = kNoRow; }
+    if (static_cast<int64_t>(id) >= a.capacity) continue;
+    const uint64_t T = a.t.mask + 1;
+    uint64_t x;
+    if (static_cast<uint64_t>(s) == T) { x = 0; *a.wide_null_id = id; }
+    else if (static_cast<uint64_t>(s) == T + 1) x = Fmix64Inv(kEmpty);
+    else x = Fmix64Inv(a.t.hkeys[s]);
+    a.gx[id] = x;
+    if (a.sums) a.sums[id] = a.t.sums[s];
+    if (a.counts) a.counts[id] = static_cast<long long>(a.t.counts[s]);
+    if (a.first_rows) a.first_rows[id] = fr;
+  }
+}
+
+// Decode key column `col` of ids [0, G): values + validity bitmap (one word per wave).
+__global__ __launch_bounds__(kThreads) void k_decode_keys(const unsigned long long* gx, int64_t G, int bits, int shift,
+                                                          int null_bit /* <0: none */, uint32_t wide_null_id,
+                                                          void* out_values, uint64_t* out_validity,
+                                                          unsigned long long* null_count) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ground = (G + 63) & ~int64_t(63);
+  for (int64_t g = int64_t(blockIdx.x) * kThreads + threadIdx.x; g < ground; g += int64_t(gridDim.x) * kThreads) {
+    bool valid = false;
+    uint64_t v = 0;
+    if (g < G) {
+      const uint64_t x = gx[g];
+      valid = (null_bit >= 0) ? !((x >> null_bit) & 1) : (static_cast<uint32_t>(g) != wide_null_id);
+      v = bits >= 64 ? x : ((x >> shift) & ((uint64_t(1) << bits) - 1));
+      if (!valid) v = 0;
+    }
+    const uint64_t vm = __ballot(valid);
+    if (bits == 1) {
+      const uint64_t bm = __ballot(v != 0);
+      if (lane == 0) reinterpret_cast<uint64_t*>(out_values)[g >> 6] = bm;
+    } else if (g < G) {
+      switch (bits) {
+        case 8: reinterpret_cast<uint8_t*>(out_values)[g] = static_cast<uint8_t>(v); break;
+        case 16: reinterpret_cast<uint16_t*>(out_values)[g] = static_cast<uint16_t>(v); break;
+        case 32: reinterpret_cast<uint32_t*>(out_values)[g] = static_cast<uint32_t>(v); break;
+        default: reinterpret_cast<uint64_t*>(out_values)[g] = v; break;
+      }
+    }
+    if (lane == 0) {
+      out_validity[g >> 6] = vm;
+      const int64_t live = G - g >= 64 ? 64 : G - g;
+      const int nulls = static_cast<int>(live) - __popcll(vm);
+      if (nulls) atomicAdd(null_count, static_cast<unsigned long long>(nulls));
+    }
+  }
+}
+
+// Grouper pass 2: out_ids[row] = ids[slot(key(row))]
+__global__ __launch_bounds__(kThreads) void k_lookup_ids(KeySpec ks, int64_t n, GroupTable t, uint32_t* out_ids) {
+  for (int64_t row = int64_t(blockIdx.x) * kThreads + threadIdx.x; row < n; row += int64_t(gridDim.x) * kThreads) {
+    uint64_t x;
+    int64_t idx;
+    if (EncodeKey(ks, row, &x)) idx = static_cast<int64_t>(t.mask) + 1;
+    else idx = FindOrInsert(t, Fmix64(x), false);
+    out_ids[row] = idx >= 0 ? t.ids[idx] : kNoRow;
+  }
+}
+// Grouper growth: re-insert the known groups (x per id) into a fresh table.
+__global__ __launch_bounds__(kThreads) void k_reinsert(const unsigned long long* gx, uint32_t G, uint32_t wide_null_id,
+                                                       GroupTable t) {
+  for (uint32_t g = blockIdx.x * kThreads + threadIdx.x; g < G; g += gridDim.x * kThreads) {
+    int64_t idx;
+    if (g == wide_null_id) idx = static_cast<int64_t>(t.mask) + 1;
+    else idx = FindOrInsert(t, Fmix64(gx[g]), true);
+    if (idx >= 0) t.ids[idx] = g;
+  }
+}
+
+// ---- hash_sum / hash_count / hash_mean over given ids ------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_hash_agg(ValueCol v, const uint32_t* ids, int64_t n, int func, int count_mode,
+                                                       unsigned long long* sums, unsigned long long* counts) {
+  for (int64_t row = int64_t(blockIdx.x) * kThreads + threadIdx.x; row < n; row += int64_t(gridDim.x) * kThreads) {
+    const bool valid = v.valid ? GetBit(v.valid, v.off + row) : true;
+    const uint32_t g = ids[row];
+    if (func == AMDARROW_HASH_COUNT) {
+      if (count_mode == AMDARROW_COUNT_NULL ? !valid : valid) atomicAdd(&counts[g], 1ull);  // :485-503
+    } else if (valid) {                                                                     // :539-545
+      bool is_double;
+      const uint64_t bits = LoadAccum(v, row, &is_double);
+      Accumulate(&sums[g], bits, is_double);
+      atomicAdd(&counts[g], 1ull);
+    }
+  }
+}
+// Finalize: validity = count > 0 (GroupedSumImpl::Finalize :581-604); mean = double(sum)/count.
+__global__ __launch_bounds__(kThreads) void k_agg_finalize(int func, int acc_kind /*0 u64, 1 i64, 2 f64*/, int64_t G,
+                                                           unsigned long long* values, const unsigned long long* counts,
+                                                           uint64_t* out_validity, unsigned long long* null_count) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ground = (G + 63) & ~int64_t(63);
+  for (int64_t g = int64_t(blockIdx.x) * kThreads + threadIdx.x; g < ground; g += int64_t(gridDim.x) * kThreads) {
+    bool valid = false;
+    if (g < G) {
+      const unsigned long long c = counts[g];
+      valid = func == AMDARROW_HASH_COUNT ? true : c > 0;
+      if (func == AMDARROW_HASH_COUNT) values[g] = c;
+      else if (func == AMDARROW_HASH_MEAN) {
+        double m = 0.0;
+        if (c > 0) {
+          const unsigned long long s = values[g];
+          const double sd = acc_kind == 2 ? __longlong_as_double(s)
+                          : acc_kind == 1 ? static_cast<double>(static_cast<long long>(s)) : static_cast<double>(s);
+          m = sd / static_cast<double>(c);  // MeanImpl::Finalize, aggregate_basic_internal.h:94-103
+        }
+        values[g] = __double_as_longlong(m);
+      }
+    }
+    const uint64_t vm = __ballot(valid);
+    if (lane == 0) {
+      out_validity[g >> 6] = vm;
+      const int64_t live = G - g >= 64 ? 64 : G - g;
+      const int nulls = static_cast<int>(live) - __popcll(vm);
+      if (nulls) atomicAdd(null_count, static_cast<unsigned long long>(nulls));
+    }
+  }
+}
+
+// ---- host helpers ---------------------------------------------------------------------------------
+int LaunchScanU32(amdarrow_ctx* ctx, const uint32_t* counts, int64_t n, int64_t* offsets);  // selection.hip
+
+static uint64_t NextPow2(uint64_t v) {
+  uint64_t p = 1024;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+static int MakeKeySpec(int nkeys, const amdarrow_array* keys, const int* types, KeySpec* ks) {
+  if (nkeys < 1 || nkeys > kMaxKeys)
+    return SetError(AMDARROW_NOT_IMPLEMENTED, "group-by: 1.." + std::to_string(kMaxKeys) + " key columns supported");
+  memset(ks, 0, sizeof *ks);
+  ks->nkeys = nkeys;
+  int bits = 0;
+  for (int k = 0; k < nkeys; ++k) {
+    const int t = keys ? keys[k].type_id : types[k];
+    const int bw = BitWidth(t);
+    if (bw < 0) return SetError(AMDARROW_NOT_IMPLEMENTED, "Keys of this type");  // hash_aggregate.cc:355
+    ks->col[k].bits = bw;
+    ks->col[k].shift = bits;
+    if (keys) { ks->col[k].data = keys[k].values; ks->col[k].valid = keys[k].validity; ks->col[k].off = keys[k].offset; }
+    bits += bw;
+  }
+  ks->total_bits = bits;
+  if (nkeys == 1 && bits == 64) ks->wide_null_slot = 1;
+  else if (bits + nkeys > 64)
+    return SetError(AMDARROW_NOT_IMPLEMENTED, "group-by: key columns wider than 64 bits in total (incl. one null flag each)");
+  return AMDARROW_OK;
+}
+
+struct TableMem { size_t hkeys, first, sums, counts, ids; };
+static size_t CarveTable(Carver* c, uint64_t T, bool with_ids, TableMem* m) {
+  const uint64_t n = T + 2;
+  m->hkeys = c->Take(8 * n); m->first = c->Take(4 * n); m->sums = c->Take(8 * n); m->counts = c->Take(8 * n);
+  m->ids = with_ids ? c->Take(4 * n) : 0;
+  return c->off;
+}
+static GroupTable BindTable(char* base, const TableMem& m, uint64_t T, bool with_ids) {
+  GroupTable t;
+  t.hkeys = reinterpret_cast<unsigned long long*>(base + m.hkeys);
+  t.first = reinterpret_cast<uint32_t*>(base + m.first);
+  t.sums = reinterpret_cast<unsigned long long*>(base + m.sums);
+  t.counts = reinterpret_cast<unsigned long long*>(base + m.counts);
+  t.ids = with_ids ? reinterpret_cast<uint32_t*>(base + m.ids) : nullptr;
+  t.mask = T - 1;
+  return t;
+}
+static int ClearTable(amdarrow_ctx* ctx, const GroupTable& t, bool with_ids) {
+  const uint64_t n = t.mask + 3;
+  AA_HIP(hipMemsetAsync(t.hkeys, 0xFF, 8 * n, ctx->stream));
+  AA_HIP(hipMemsetAsync(t.first, 0xFF, 4 * n, ctx->stream));
+  AA_HIP(hipMemsetAsync(t.sums, 0, 8 * n, ctx->stream));
+  AA_HIP(hipMemsetAsync(t.counts, 0, 8 * n, ctx->stream));
+  if (with_ids) AA_HIP(hipMemsetAsync(t.ids, 0xFF, 4 * n, ctx->stream));
+  return AMDARROW_OK;
+}
+
+// bitmap(first rows) -> per-word prefix; returns number of marked groups in *total.
+struct RankMem { unsigned long long* bitmap; uint32_t* prefix; uint32_t* block_counts; int64_t* block_offsets; int64_t nwords; int64_t nblocks; };
+static void CarveRank(Carver* c, int64_t n_rows, size_t off[4]) {
+  const int64_t nwords = (n_rows + 63) / 64 + 1;
+  const int64_t nblocks = (nwords + 1023) / 1024;
+  off[0] = c->Take(8 * nwords); off[1] = c->Take(4 * nwords); off[2] = c->Take(4 * nblocks); off[3] = c->Take(8 * (nblocks + 1));
+}
+static RankMem BindRank(char* base, const size_t off[4], int64_t n_rows) {
+  RankMem r;
+  r.nwords = (n_rows + 63) / 64 + 1;
+  r.nblocks = (r.nwords + 1023) / 1024;
+  r.bitmap = reinterpret_cast<unsigned long long*>(base + off[0]);
+  r.prefix = reinterpret_cast<uint32_t*>(base + off[1]);
+  r.block_counts = reinterpret_cast<uint32_t*>(base + off[2]);
+  r.block_offsets = reinterpret_cast<int64_t*>(base + off[3]);
+  return r;
+}
+static int RankFirstRows(amdarrow_ctx* ctx, const GroupTable& t, int only_unassigned, const RankMem& r, int64_t* total) {
+  const int64_t nslots = static_cast<int64_t>(t.mask) + 3;
+  AA_HIP(hipMemsetAsync(r.bitmap, 0, 8 * r.nwords, ctx->stream));
+  hipLaunchKernelGGL(k_mark_first, dim3(GridFor(nslots, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, t,
+                     nslots, only_unassigned, r.bitmap);
+  hipLaunchKernelGGL(k_popc_blocks, dim3(static_cast<unsigned>(r.nblocks)), dim3(kThreads), 0, ctx->stream, r.bitmap,
+                     r.nwords, r.block_counts);
+  AA_HIP(hipGetLastError());
+  AA_TRY(LaunchScanU32(ctx, r.block_counts, r.nblocks, r.block_offsets));
+  hipLaunchKernelGGL(k_word_prefix, dim3(static_cast<unsigned>(r.nblocks)), dim3(kThreads), 0, ctx->stream, r.bitmap,
+                     r.nwords, r.block_offsets, r.prefix);
+  AA_HIP(hipGetLastError());
+  AA_TRY(ReadBack(ctx, r.block_offsets + r.nblocks, 8, total));
+  return AMDARROW_OK;
+}
+
+static int AccKind(int t) { return IsFloat(t) ? 2 : (IsSignedInt(t) ? 1 : 0); }
+
+}  // namespace amdarrow
+
+using namespace amdarrow;
+
+// ---- Grouper ------------------------------------------------------------------------------------------
+struct amdarrow_grouper {
+  amdarrow_ctx* ctx;
+  int nkeys;
+  int types[kMaxKeys];
+  KeySpec spec;              // shifts/bits only (data pointers are per batch)
+  uint64_t T = 0;            // table slots
+  char* table_mem = nullptr; // hkeys | first | sums(unused) | counts(unused) | ids
+  TableMem tm;
+  unsigned long long* gx = nullptr;  // key word per group id
+  uint64_t gx_cap = 0;
+  uint32_t num_groups = 0;
+  uint32_t* wide_null_id = nullptr;  // device word
+};
+
+static int GrouperAllocTable(amdarrow_grouper* g, uint64_t T, char** mem, TableMem* tm) {
+  Carver c;
+  CarveTable(&c, T, true, tm);
+  AA_HIP(hipMalloc(reinterpret_cast<void**>(mem), c.off));
+  return ClearTable(g->ctx, BindTable(*mem, *tm, T, true), true);
+}
+
+extern "C" {
+
+int amdarrow_grouper_create(amdarrow_ctx* ctx, int nkeys, const int* key_type_ids, amdarrow_grouper** out) {
+  KeySpec ks;
+  AA_TRY(MakeKeySpec(nkeys, nullptr, key_type_ids, &ks));
+  auto* g = new amdarrow_grouper;
+  g->ctx = ctx;
+  g->nkeys = nkeys;
+  for (int k = 0; k < nkeys; ++k) g->types[k] = key_type_ids[k];
+  g->spec = ks;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  g->T = 4096;
+  int rc = GrouperAllocTable(g, g->T, &g->table_mem, &g->tm);
+  if (rc != AMDARROW_OK) { delete g; return rc; }
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&g->wide_null_id), 256);
+  if (e != hipSuccess) { delete g; return HipError(e, "hipMalloc", __FILE__, __LINE__); }
+  AA_HIP(hipMemsetAsync(g->wide_null_id, 0xFF, 256, ctx->stream));
+  *out = g;
+  return AMDARROW_OK;
+}
+
+int amdarrow_grouper_destroy(amdarrow_grouper* g) {
+  if (!g) return AMDARROW_OK;
+  (void)hipStreamSynchronize(g->ctx->stream);
+  if (g->table_mem) (void)hipFree(g->table_mem);
+  if (g->gx) (void)hipFree(g->gx);
+  if (g->wide_null_id) (void)hipFree(g->wide_null_id);
+  delete g;
+  return AMDARROW_OK;
+}
+
+int amdarrow_grouper_num_groups(amdarrow_grouper* g, uint32_t* out) {
+  *out = g->num_groups;
+  return AMDARROW_OK;
+}
+
+int amdarrow_grouper_consume(amdarrow_grouper* g, const amdarrow_array* keys, uint32_t* out_ids) {
+  amdarrow_ctx* ctx = g->ctx;
+  const int64_t n = keys[0].length;
+  for (int k = 0; k < g->nkeys; ++k) {
+    if (keys[k].type_id != g->types[k]) return SetError(AMDARROW_TYPE_ERROR, "grouper: key type differs from Make()");
+    if (keys[k].length != n) return SetError(AMDARROW_INVALID, "Array arguments must all be the same length");
+  }
+  if (n == 0) return AMDARROW_OK;
+  if (n >= (int64_t(1) << 32) - 1) return SetError(AMDARROW_NOT_IMPLEMENTED, "grouper: batches of 2^32 rows or more");
+  KeySpec ks;
+  AA_TRY(MakeKeySpec(g->nkeys, keys, nullptr, &ks));
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  // grow the table so that (known + possible new) groups stay under 50 % load
+  const uint64_t need = NextPow2(2 * (static_cast<uint64_t>(g->num_groups) + static_cast<uint64_t>(n)));
+  if (need > g->T) {
+    char* mem; TableMem tm;
+    AA_TRY(GrouperAllocTable(g, need, &mem, &tm));
+    GroupTable nt = BindTable(mem, tm, need, true);
+    if (g->num_groups) {
+      uint32_t wide = kNoRow;
+      AA_TRY(ReadBack(ctx, g->wide_null_id, 4, &wide));
+      hipLaunchKernelGGL(k_reinsert, dim3(GridFor(g->num_groups, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0,
+                         ctx->stream, g->gx, g->num_groups, wide, nt);
+      AA_HIP(hipGetLastError());
+    }
+    AA_HIP(hipStreamSynchronize(ctx->stream));
+    AA_HIP(hipFree(g->table_mem));
+    g->table_mem = mem; g->tm = tm; g->T = need;
+  }
+  if (g->num_groups + static_cast<uint64_t>(n) > g->gx_cap) {
+    const uint64_t cap = NextPow2(2 * (g->num_groups + static_cast<uint64_t>(n)));
+    unsigned long long* ngx;
+    AA_HIP(hipMalloc(reinterpret_cast<void**>(&ngx), 8 * cap));
+    if (g->num_groups) AA_HIP(hipMemcpyAsync(ngx, g->gx, 8ull * g->num_groups, hipMemcpyDeviceToDevice, ctx->stream));
+    AA_HIP(hipStreamSynchronize(ctx->stream));
+    if (g->gx) AA_HIP(hipFree(g->gx));
+    g->gx = ngx; g->gx_cap = cap;
+  }
+  GroupTable t = BindTable(g->table_mem, g->tm, g->T, true);
+  Carver c;
+  size_t roff[4];
+  CarveRank(&c, n, roff);
+  const size_t off_flag = c.Take(256);
+  void* base;
+  AA_TRY(Scratch(ctx, c.off, &base));
+  RankMem r = BindRank(static_cast<char*>(base), roff, n);
+  auto* overflow = reinterpret_cast<unsigned int*>(static_cast<char*>(base) + off_flag);
+  AA_HIP(hipMemsetAsync(overflow, 0, 4, ctx->stream));
+  // pass 1: insert keys, first_row = min(row) on every slot touched
+  ValueCol nov{};
+  hipLaunchKernelGGL(k_groupby_build, dim3(GridFor(n, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, ks, nov,
+                     0, static_cast<const uint8_t*>(nullptr), static_cast<const uint8_t*>(nullptr), int64_t(0), n, t,
+                     overflow);
+  AA_HIP(hipGetLastError());
+  // rank the NEW groups (no id yet) by first row; old groups just reset their first_row
+  int64_t new_groups = 0;
+  AA_TRY(RankFirstRows(ctx, t, /*only_unassigned=*/1, r, &new_groups));
+  EmitArgs e{};
+  e.t = t; e.nslots = static_cast<int64_t>(t.mask) + 3; e.bitmap = r.bitmap; e.prefix = r.prefix;
+  e.capacity = static_cast<int64_t>(g->gx_cap); e.id_base = g->num_groups; e.only_unassigned = 1;
+  e.gx = g->gx; e.wide_null_id = g->wide_null_id;
+  hipLaunchKernelGGL(k_emit_groups, dim3(GridFor(e.nslots, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, e);
+  AA_HIP(hipGetLastError());
+  // old groups touched by this batch still carry a first_row: clear it for the next batch
+  AA_HIP(hipMemsetAsync(t.first, 0xFF, 4 * (t.mask + 3), ctx->stream));
+  // pass 2: ids per row
+  hipLaunchKernelGGL(k_lookup_ids, dim3(GridFor(n, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, ks, n, t,
+                     out_ids);
+  AA_HIP(hipGetLastError());
+  g->num_groups += static_cast<uint32_t>(new_groups);
+  AA_HIP(hipStreamSynchronize(ctx->stream));
+  return AMDARROW_OK;
+}
+
+int amdarrow_grouper_uniques(amdarrow_grouper* g, int k, void* out_values, uint8_t* out_validity, amdarrow_out* out) {
+  amdarrow_ctx* ctx = g->ctx;
+  if (k < 0 || k >= g->nkeys) return SetError(AMDARROW_INVALID, "grouper_uniques: no such key column");
+  out->length = g->num_groups;
+  out->null_count = 0;
+  out->has_validity = 0;
+  if (g->num_groups == 0) return AMDARROW_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  void* base;
+  AA_TRY(Scratch(ctx, 256, &base));
+  auto* nulls = static_cast<unsigned long long*>(base);
+  AA_HIP(hipMemsetAsync(nulls, 0, 8, ctx->stream));
+  uint32_t wide = kNoRow;
+  AA_TRY(ReadBack(ctx, g->wide_null_id, 4, &wide));
+  const KeyCol& c = g->spec.col[k];
+  const int null_bit = g->spec.wide_null_slot ? -1 : g->spec.total_bits + k;
+  hipLaunchKernelGGL(k_decode_keys, dim3(GridFor(g->num_groups, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream,
+                     g->gx, static_cast<int64_t>(g->num_groups), c.bits, c.shift, null_bit, wide, out_values,
+                     reinterpret_cast<uint64_t*>(out_validity), nulls);
+  AA_HIP(hipGetLastError());
+  unsigned long long nn = 0;
+  AA_TRY(ReadBack(ctx, nulls, 8, &nn));
+  out->null_count = static_cast<int64_t>(nn);
+  out->has_validity = nn > 0;  // DecodeNulls allocates the bitmap only when a null key exists (:64-92)
+  return AMDARROW_OK;
+}
+
+int amdarrow_hash_aggregate(amdarrow_ctx* ctx, int func, const amdarrow_array* values, const uint32_t* ids,
+                            int64_t num_groups, int count_mode, void* out_values, uint8_t* out_validity,
+                            amdarrow_out* out) {
+  if (func < AMDARROW_HASH_SUM || func > AMDARROW_HASH_MEAN) return SetError(AMDARROW_KEY_ERROR, "No such hash aggregate");
+  const int t = values->type_id;
+  if (BitWidth(t) < 0) return SetError(AMDARROW_NOT_IMPLEMENTED, "Summing data of this type");  // :556-562
+  out->length = num_groups;
+  out->null_count = 0;
+  out->has_validity = 0;
+  if (num_groups == 0) return AMDARROW_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  Carver c;
+  const size_t off_counts = c.Take(8 * num_groups);
+  const size_t off_nulls = c.Take(256);
+  void* base;
+  AA_TRY(Scratch(ctx, c.off, &base));
+  auto* counts = reinterpret_cast<unsigned long long*>(static_cast<char*>(base) + off_counts);
+  auto* nulls = reinterpret_cast<unsigned long long*>(static_cast<char*>(base) + off_nulls);
+  auto* vals = static_cast<unsigned long long*>(out_values);
+  AA_HIP(hipMemsetAsync(counts, 0, 8 * num_groups, ctx->stream));
+  AA_HIP(hipMemsetAsync(nulls, 0, 8, ctx->stream));
+  AA_HIP(hipMemsetAsync(vals, 0, 8 * num_groups, ctx->stream));
+  ValueCol v{values->values, values->validity, values->offset, t};
+  if (values->length > 0) {
+    hipLaunchKernelGGL(k_hash_agg, dim3(GridFor(values->length, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream,
+                       v, ids, values->length, func, count_mode, vals, counts);
+    AA_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_agg_finalize, dim3(GridFor(num_groups, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream,
+                     func, AccKind(t), num_groups, vals, counts, reinterpret_cast<uint64_t*>(out_validity), nulls);
+  AA_HIP(hipGetLastError());
+  unsigned long long nn = 0;
+  AA_TRY(ReadBack(ctx, nulls, 8, &nn));
+  out->null_count = static_cast<int64_t>(nn);
+  out->has_validity = nn > 0;  // hash_sum: bitmap only if a group has no valid value; hash_count: never
+  return AMDARROW_OK;
+}
+
+int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, const amdarrow_array* keys,
+                            const amdarrow_array* mask, int64_t group_capacity, void* out_sums, int64_t* out_counts,
+                            void* out_keys, uint8_t* out_key_validity, uint32_t* out_first_rows,
+                            int64_t* out_num_groups) {
+  const int64_t n = keys->length;
+  *out_num_groups = 0;
+  if (values && values->length != n) return SetError(AMDARROW_INVALID, "Array arguments must all be the same length");
+  if (mask) {
+    if (mask->type_id != AMDARROW_BOOL) return SetError(AMDARROW_NOT_IMPLEMENTED, "Filter argument must be boolean type");
+    if (mask->length != n) return SetError(AMDARROW_INVALID, "Array arguments must all be the same length");
+  }
+  if (values && BitWidth(values->type_id) < 0) return SetError(AMDARROW_NOT_IMPLEMENTED, "Summing data of this type");
+  if (n >= (int64_t(1) << 32) - 1) return SetError(AMDARROW_NOT_IMPLEMENTED, "group-by: 2^32 rows or more per call");
+  if (n == 0) return AMDARROW_OK;
+  KeySpec ks;
+  AA_TRY(MakeKeySpec(1, keys, nullptr, &ks));
+  std::lock_guard<std::mutex> lock(ctx->mu);
+
+  const uint64_t T = NextPow2(2 * static_cast<uint64_t>(group_capacity < n ? group_capacity : n));
+  Carver c;
+  TableMem tm;
+  CarveTable(&c, T, false, &tm);
+  size_t roff[4];
+  CarveRank(&c, n, roff);
+  const size_t off_gx = c.Take(8 * static_cast<size_t>(group_capacity));
+  const size_t off_misc = c.Take(256);
+  void* base;
+  AA_TRY(Scratch(ctx, c.off, &base));
+  char* b = static_cast<char*>(base);
+  GroupTable t = BindTable(b, tm, T, false);
+  RankMem r = BindRank(b, roff, n);
+  auto* gx = reinterpret_cast<unsigned long long*>(b + off_gx);
+  auto* misc = reinterpret_cast<unsigned int*>(b + off_misc);  // [0] overflow, [2..3] null_count, [4] wide_null_id
+  AA_TRY(ClearTable(ctx, t, false));
+  AA_HIP(hipMemsetAsync(misc, 0, 16, ctx->stream));
+  AA_HIP(hipMemsetAsync(misc + 4, 0xFF, 4, ctx->stream));
+
+  ValueCol v{};
+  if (values) v = ValueCol{values->values, values->validity, values->offset, values->type_id};
+  hipLaunchKernelGGL(k_groupby_build, dim3(GridFor(n, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, ks, v,
+                     values ? 1 : 0, mask ? static_cast<const uint8_t*>(mask->values) : nullptr,
+                     mask ? mask->validity : nullptr, mask ? mask->offset : int64_t(0), n, t, misc);
+  AA_HIP(hipGetLastError());
+  int64_t G = 0;
+  AA_TRY(RankFirstRows(ctx, t, 0, r, &G));
+  unsigned int overflow = 0;
+  AA_TRY(ReadBack(ctx, misc, 4, &overflow));
+  if (overflow || G > group_capacity)
+    return SetError(AMDARROW_CAPACITY_ERROR, "group-by: more than group_capacity = " + std::to_string(group_capacity) + " groups");
+  *out_num_groups = G;
+  if (G == 0) return AMDARROW_OK;
+  EmitArgs e{};
+  e.t = t; e.nslots = static_cast<int64_t>(t.mask) + 3; e.bitmap = r.bitmap; e.prefix = r.prefix;
+  e.capacity = group_capacity; e.id_base = 0; e.only_unassigned = 0;
+  e.gx = gx; e.sums = static_cast<unsigned long long*>(out_sums); e.counts = reinterpret_cast<long long*>(out_counts);
+  e.first_rows = out_first_rows; e.wide_null_id = misc + 4;
+  hipLaunchKernelGGL(k_emit_groups, dim3(GridFor(e.nslots, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, e);
+  AA_HIP(hipGetLastError());
+  unsigned int wide = kNoRow;
+  AA_TRY(ReadBack(ctx, misc + 4, 4, &wide));
+  hipLaunchKernelGGL(k_decode_keys, dim3(GridFor(G, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, gx, G,
+                     ks.col[0].bits, 0, ks.wide_null_slot ? -1 : ks.total_bits, wide, out_keys,
+                     reinterpret_cast<uint64_t*>(out_key_validity), reinterpret_cast<unsigned long long*>(misc + 2));
+  AA_HIP(hipGetLastError());
+  AA_HIP(hipStreamSynchronize(ctx->stream));
+  return AMDARROW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,152 @@
+// runtime.hip -- context, device memory pool, error plumbing for the C ABI.
+#include "common.h"
+
+#include <cstdio>
+#include <cstring>
+
+namespace amdarrow {
+
+static thread_local std::string g_last_error;
+
+int SetError(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+int HipError(hipError_t e, const char* what, const char* file, int line) {
+  char buf[512];
+  snprintf(buf, sizeof buf, "HIP error %d (%s) in %s at %s:%d", static_cast<int>(e), hipGetErrorString(e), what,
+           file, line);
+  return SetError(e == hipErrorOutOfMemory ? AMDARROW_OUT_OF_MEMORY : AMDARROW_UNKNOWN_ERROR, buf);
+}
+
+int Scratch(amdarrow_ctx* ctx, size_t bytes, void** out) {
+  if (bytes > ctx->scratch_cap) {
+    // Growing the arena is a (rare) synchronising event: earlier kernels may still use it.
+    AA_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->scratch) AA_HIP(hipFree(ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_cap = 0;
+    size_t cap = (bytes + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
+    AA_HIP(hipMalloc(&ctx->scratch, cap));
+    ctx->scratch_cap = cap;
+  }
+  *out = ctx->scratch;
+  return AMDARROW_OK;
+}
+
+int ReadBack(amdarrow_ctx* ctx, const void* dev, size_t nbytes, void* host_out) {
+  if (nbytes > 4096) return SetError(AMDARROW_INVALID, "ReadBack: too large");
+  AA_HIP(hipMemcpyAsync(ctx->pinned, dev, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+  AA_HIP(hipStreamSynchronize(ctx->stream));
+  memcpy(host_out, ctx->pinned, nbytes);
+  return AMDARROW_OK;
+}
+
+}  // namespace amdarrow
+
+using namespace amdarrow;
+
+extern "C" {
+
+int amdarrow_abi_version(void) { return AMDARROW_ABI_VERSION; }
+
+const char* amdarrow_last_error(void) { return g_last_error.c_str(); }
+
+int amdarrow_device_count(int* out_count) {
+  AA_HIP(hipGetDeviceCount(out_count));
+  return AMDARROW_OK;
+}
+
+int amdarrow_ctx_create(int device, void* stream, int private_stream, amdarrow_ctx** out_ctx) {
+  int n = 0;
+  AA_HIP(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) return SetError(AMDARROW_INVALID, "amdarrow_ctx_create: no such device");
+  AA_HIP(hipSetDevice(device));
+  auto* ctx = new amdarrow_ctx;
+  ctx->device = device;
+  if (!private_stream) {
+    ctx->stream = static_cast<hipStream_t>(stream);  // nullptr = the default stream
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return HipError(e, "hipStreamCreate", __FILE__, __LINE__); }
+    ctx->own_stream = true;
+  }
+  hipError_t e = hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault);
+  if (e != hipSuccess) { delete ctx; return HipError(e, "hipHostMalloc", __FILE__, __LINE__); }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+  *out_ctx = ctx;
+  return AMDARROW_OK;
+}
+
+int amdarrow_ctx_destroy(amdarrow_ctx* ctx) {
+  if (!ctx) return AMDARROW_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  for (auto& kv : ctx->allocs) (void)hipFree(kv.first);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return AMDARROW_OK;
+}
+
+int amdarrow_ctx_synchronize(amdarrow_ctx* ctx) {
+  AA_HIP(hipStreamSynchronize(ctx->stream));
+  return AMDARROW_OK;
+}
+
+void* amdarrow_ctx_stream(amdarrow_ctx* ctx) { return ctx->stream; }
+
+int amdarrow_malloc(amdarrow_ctx* ctx, int64_t nbytes, void** out_ptr) {
+  if (nbytes < 0) return SetError(AMDARROW_INVALID, "amdarrow_malloc: negative size");
+  // capacity rounded up to 64 bytes like arrow::MemoryPool (memory_pool.cc:101, buffer.cc:196-216)
+  const int64_t cap = ((nbytes + 63) / 64) * 64 + (nbytes == 0 ? 64 : 0);
+  AA_HIP(hipSetDevice(ctx->device));
+  void* p = nullptr;
+  AA_HIP(hipMalloc(&p, static_cast<size_t>(cap)));
+  if (cap > nbytes) {
+    // zero the padding so word-at-a-time bitmap readers see defined bytes
+    AA_HIP(hipMemsetAsync(static_cast<char*>(p) + nbytes, 0, static_cast<size_t>(cap - nbytes), ctx->stream));
+  }
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  ctx->allocs[p] = cap;
+  ctx->bytes_allocated += cap;
+  if (ctx->bytes_allocated > ctx->max_memory) ctx->max_memory = ctx->bytes_allocated;
+  *out_ptr = p;
+  return AMDARROW_OK;
+}
+
+int amdarrow_free(amdarrow_ctx* ctx, void* ptr) {
+  if (!ptr) return AMDARROW_OK;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    auto it = ctx->allocs.find(ptr);
+    if (it == ctx->allocs.end()) return SetError(AMDARROW_INVALID, "amdarrow_free: pointer not from this pool");
+    ctx->bytes_allocated -= it->second;
+    ctx->allocs.erase(it);
+  }
+  AA_HIP(hipStreamSynchronize(ctx->stream));
+  AA_HIP(hipFree(ptr));
+  return AMDARROW_OK;
+}
+
+int64_t amdarrow_bytes_allocated(amdarrow_ctx* ctx) { return ctx->bytes_allocated; }
+int64_t amdarrow_max_memory(amdarrow_ctx* ctx) { return ctx->max_memory; }
+
+int amdarrow_memcpy_h2d(amdarrow_ctx* ctx, void* dst, const void* src, int64_t n) {
+  AA_HIP(hipMemcpyAsync(dst, src, static_cast<size_t>(n), hipMemcpyHostToDevice, ctx->stream));
+  AA_HIP(hipStreamSynchronize(ctx->stream));
+  return AMDARROW_OK;
+}
+int amdarrow_memcpy_d2h(amdarrow_ctx* ctx, void* dst, const void* src, int64_t n) {
+  AA_HIP(hipMemcpyAsync(dst, src, static_cast<size_t>(n), hipMemcpyDeviceToHost, ctx->stream));
+  AA_HIP(hipStreamSynchronize(ctx->stream));
+  return AMDARROW_OK;
+}
+int amdarrow_memset(amdarrow_ctx* ctx, void* dst, int value, int64_t n) {
+  AA_HIP(hipMemsetAsync(dst, value, static_cast<size_t>(n), ctx->stream));
+  return AMDARROW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,545 @@
+// selection.hip -- Filter / GetTakeIndices / Take for primitive (1/8/16/32/64-bit) arrays.
+//
+// Reference semantics: compute/kernels/vector_selection.cc
+//   GetFilterOutputSize :61-88, GetTakeIndices :92-237, PrimitiveTakeImpl :273-369,
+//   BooleanTakeImpl :371-468, PrimitiveFilterImpl :569-784, PrimitiveFilter :786-835.
+//
+// Filter is a three-kernel stream compaction, HBM-bound on the value column:
+//   (1) k_filter_tile_counts : one wave per 4096-row tile pops 64 filter words
+//   (2) k_scan_tiles         : one workgroup, exclusive scan of the tile counts
+//   (3) k_filter_compact     : per tile, ranks come from the 64 emit words (wave scan of
+//       their popcounts + mbcnt inside the word), selected values are staged in LDS at
+//       their rank and leave as one coalesced run; validity (and boolean values) are
+//       compacted through LDS byte flags -> wave ballot -> funnel-shift onto the output
+//       word grid; only the two edge words of a tile use a global atomicOr.
+// Values are loaded only for selected rows, so a 10 % filter does not read 100 % of HBM.
+#include "common.h"
+
+namespace amdarrow {
+
+constexpr int kTile = 4096;     // rows per tile = 64 bitmap words
+constexpr int kThreads = 256;   // 4 waves
+
+struct FilterArgs {
+  // filter
+  const uint8_t* f_data; const uint8_t* f_valid; int64_t f_off; int emit_null;
+  // values
+  const void* v_data; const uint8_t* v_valid; int64_t v_off;
+  int64_t length; int64_t ntiles;
+  // outputs
+  void* out_values; uint8_t* out_validity; int64_t out_capacity; int has_validity;
+  const int64_t* tile_offsets;  // exclusive scan, ntiles + 1 entries
+};
+
+// emit = rows that produce an output slot; sel = rows whose value is copied.
+//   DROP      : emit = sel = data & valid                       (:540-552, NextAndWord)
+//   EMIT_NULL : emit = data | ~valid, sel = data & valid        (:70-75, :700-709)
+__device__ __forceinline__ void FilterWords(const uint8_t* f_data, const uint8_t* f_valid, int64_t f_off,
+                                            int emit_null, int64_t row, int nbits, uint64_t* emit, uint64_t* sel) {
+  const uint64_t d = LoadBits64(f_data, f_off + row, nbits);
+  const uint64_t v = LoadBitsOrOnes(f_valid, f_off + row, nbits);
+  const uint64_t live = nbits < 64 ? (uint64_t(1) << nbits) - 1 : ~uint64_t(0);
+  *sel = d & v;
+  *emit = emit_null ? ((d | ~v) & live) : (d & v);
+}
+
+__global__ __launch_bounds__(kThreads) void k_filter_tile_counts(const uint8_t* f_data, const uint8_t* f_valid,
+                                                                 int64_t f_off, int emit_null, int64_t length,
+                                                                 int64_t ntiles, uint32_t* counts) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t tile = int64_t(blockIdx.x) * 4 + wave; tile < ntiles; tile += int64_t(gridDim.x) * 4) {
+    const int64_t row = tile * kTile + int64_t(lane) * 64;
+    int64_t left = length - row;
+    const int nbits = left >= 64 ? 64 : (left > 0 ? static_cast<int>(left) : 0);
+    uint64_t emit = 0, sel = 0;
+    if (nbits > 0) FilterWords(f_data, f_valid, f_off, emit_null, row, nbits, &emit, &sel);
+    uint64_t c = WaveReduceSum64(static_cast<uint64_t>(__popcll(emit)));
+    if (lane == 0) counts[tile] = static_cast<uint32_t>(c);
+  }
+}
+
+// Single-workgroup exclusive scan: offsets[i] = sum(counts[0..i)), offsets[n] = total.
+__global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* counts, int64_t n, int64_t* offsets) {
+  __shared__ uint64_t s_wave[16];
+  __shared__ uint64_t s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < n; base += 1024) {
+    const int64_t i = base + tid;
+    uint64_t v = i < n ? counts[i] : 0;
+    uint64_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      uint64_t t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint64_t wave_off = 0;
+    for (int w = 0; w < wave; ++w) wave_off += s_wave[w];
+    const uint64_t carry = s_carry;
+    if (i < n) offsets[i] = static_cast<int64_t>(carry + wave_off + incl - v);
+    __syncthreads();
+    if (tid == 1023) s_carry = carry + wave_off + incl;
+    __syncthreads();
+  }
+  if (tid == 0) offsets[n] = static_cast<int64_t>(s_carry);
+}
+
+int LaunchScanU32(amdarrow_ctx* ctx, const uint32_t* counts, int64_t n, int64_t* offsets) {
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, counts, n, offsets);
+  AA_HIP(hipGetLastError());
+  return AMDARROW_OK;
+}
+
+// Pack `count` LDS byte flags into the global bitmap `bm` at bit position `bit_base`.
+// `bm` has been zeroed; interior words are plain stores, the (at most two) words shared
+// with neighbouring tiles are merged with atomicOr.  Called by the whole workgroup.
+__device__ __forceinline__ void DepositFlags(const uint8_t* s_flags, uint64_t* s_packed, uint32_t count,
+                                             uint8_t* bm, int64_t bit_base) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t nlw = (count + 63) >> 6;
+  for (uint32_t lw = wave; lw < nlw; lw += kThreads / 64) {
+    const uint32_t i = lw * 64 + lane;
+    const uint64_t b = __ballot(i < count && s_flags[i] != 0);
+    if (lane == 0) s_packed[lw] = b;
+  }
+  __syncthreads();
+  const int s = static_cast<int>(bit_base & 63);
+  const int64_t g0 = bit_base >> 6;
+  const uint32_t ngw = (s + count + 63) >> 6;
+  unsigned long long* words = reinterpret_cast<unsigned long long*>(bm);
+  for (uint32_t i = tid; i < ngw; i += kThreads) {
+    uint64_t w = (i < nlw) ? (s_packed[i] << s) : 0;
+    if (s > 0 && i > 0) w |= s_packed[i - 1] >> (64 - s);
+    const bool owned = (i > 0 || s == 0) && (uint64_t(i + 1) * 64 <= uint64_t(s) + count);
+    if (owned) words[g0 + i] = w;
+    else if (w) atomicOr(&words[g0 + i], static_cast<unsigned long long>(w));
+  }
+}
+
+template <int W> struct UIntOf;
+template <> struct UIntOf<1> { using T = uint8_t; };
+template <> struct UIntOf<2> { using T = uint16_t; };
+template <> struct UIntOf<4> { using T = uint32_t; };
+template <> struct UIntOf<8> { using T = uint64_t; };
+
+// W = value bytes (1,2,4,8); W == 0 selects bit-packed (boolean) values.
+// IOTA: the "value" of row r is r itself (GetTakeIndices).
+template <int W, bool IOTA>
+__global__ __launch_bounds__(kThreads) void k_filter_compact(FilterArgs a) {
+  using T = typename UIntOf<(W == 0 ? 1 : W)>::T;
+  constexpr bool kBits = (W == 0);
+  __shared__ uint64_t s_emit[64], s_sel[64], s_vvalid[64], s_bvals[64];
+  __shared__ uint32_t s_base[64];
+  __shared__ uint32_t s_count;
+  __shared__ uint64_t s_packed[65];
+  __shared__ __attribute__((aligned(16))) T s_stage[kTile];  // values (or value-bit flags) by rank
+  __shared__ uint8_t s_vflag[kTile];                          // validity flags by rank
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const T* values = reinterpret_cast<const T*>(a.v_data);
+
+  for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * kTile;
+    if (tid < 64) {
+      const int64_t row = row0 + int64_t(tid) * 64;
+      const int64_t left = a.length - row;
+      const int nbits = left >= 64 ? 64 : (left > 0 ? static_cast<int>(left) : 0);
+      uint64_t emit = 0, sel = 0, vv = 0, bv = 0;
+      if (nbits > 0) {
+        FilterWords(a.f_data, a.f_valid, a.f_off, a.emit_null, row, nbits, &emit, &sel);
+        if (a.has_validity) vv = LoadBitsOrOnes(a.v_valid, a.v_off + row, nbits);
+        if (kBits && !IOTA) bv = LoadBits64(reinterpret_cast<const uint8_t*>(a.v_data), a.v_off + row, nbits);
+      }
+      s_emit[tid] = emit; s_sel[tid] = sel; s_vvalid[tid] = vv; s_bvals[tid] = bv;
+      const uint32_t pc = __popcll(emit);
+      const uint32_t incl = WaveInclusiveScan(pc);
+      s_base[tid] = incl - pc;
+      if (tid == 63) s_count = incl;
+    }
+    __syncthreads();
+    const uint32_t count = s_count;
+    const int64_t out_base = a.tile_offsets[tile];
+    const bool fits = out_base + count <= a.out_capacity;  // never write past the caller's buffers
+
+    // ---- gather selected values (loads only where the value is copied) ----
+    constexpr int kIters = kTile / kThreads;  // 16
+    T vals[kIters];
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      const int word = j * 4 + wave;
+      const bool s = (s_sel[word] >> lane) & 1;
+      const int64_t row = row0 + word * 64 + lane;
+      T v = 0;
+      if (s) {
+        if (IOTA) v = static_cast<T>(row);
+        else if (kBits) v = static_cast<T>((s_bvals[word] >> lane) & 1);
+        else v = values[a.v_off + row];
+      }
+      vals[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      const int word = j * 4 + wave;
+      const uint64_t emit = s_emit[word];
+      if ((emit >> lane) & 1) {
+        const uint32_t rank = s_base[word] + RankBelowLane(emit);
+        s_stage[rank] = vals[j];  // emitted-null slots carry 0 (:743-746)
+        if (a.has_validity) {
+          // WriteNotNull / WriteMaybeNull / WriteNull (:646-657, :706-709)
+          s_vflag[rank] = static_cast<uint8_t>(((s_sel[word] & s_vvalid[word]) >> lane) & 1);
+        }
+      }
+    }
+    __syncthreads();
+    if (fits) {
+      if (!kBits) {
+        T* out = reinterpret_cast<T*>(a.out_values) + out_base;
+        for (uint32_t i = tid; i < count; i += kThreads) out[i] = s_stage[i];
+      } else {
+        DepositFlags(reinterpret_cast<const uint8_t*>(s_stage), s_packed, count,
+                     reinterpret_cast<uint8_t*>(a.out_values), out_base);
+        __syncthreads();
+      }
+      if (a.has_validity) DepositFlags(s_vflag, s_packed, count, a.out_validity, out_base);
+    }
+    __syncthreads();
+  }
+}
+
+// ---- Take ---------------------------------------------------------------------------------
+struct TakeArgs {
+  const void* v_data; const uint8_t* v_valid; int64_t v_off; int64_t v_len; int v_may_null;
+  const void* i_data; const uint8_t* i_valid; int64_t i_off; int64_t n;
+  int boundscheck;
+  void* out_values; uint8_t* out_validity;
+  unsigned long long* valid_count;  // device
+  unsigned long long* err_pos;      // device, initialised to ~0
+};
+
+template <typename IdxT> struct IndexLoad {
+  __device__ static bool Load(const void* p, int64_t k, int64_t upper, int64_t* out) {
+    const IdxT v = reinterpret_cast<const IdxT*>(p)[k];
+    *out = static_cast<int64_t>(v);
+    // IsOutOfBounds, util/int_util.cc:548-551
+    if (static_cast<IdxT>(-1) < 0) return !(v < 0 || static_cast<uint64_t>(v) >= static_cast<uint64_t>(upper));
+    return static_cast<uint64_t>(v) < static_cast<uint64_t>(upper);
+  }
+};
+
+// One output element per lane; a wave produces one validity word with a ballot.
+template <int W, typename IdxT>
+__global__ __launch_bounds__(kThreads) void k_take(TakeArgs a) {
+  using T = typename UIntOf<(W == 0 ? 1 : W)>::T;
+  constexpr bool kBits = (W == 0);
+  __shared__ unsigned long long s_valid;
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) s_valid = 0;
+  __syncthreads();
+  unsigned long long my_valid = 0;
+  const int64_t nwaves_rows = (a.n + 63) & ~int64_t(63);
+  for (int64_t i = int64_t(blockIdx.x) * kThreads + tid; i < nwaves_rows; i += int64_t(gridDim.x) * kThreads) {
+    bool ok = i < a.n;
+    if (ok && a.i_valid) ok = GetBit(a.i_valid, a.i_off + i);
+    int64_t j = 0;
+    if (ok) {
+      const bool inb = IndexLoad<IdxT>::Load(a.i_data, a.i_off + i, a.v_len, &j);
+      if (!inb) {
+        ok = false;
+        if (a.boundscheck) atomicMin(a.err_pos, static_cast<unsigned long long>(i));
+      }
+    }
+    // values' validity is consulted only when values.null_count != 0 (:306, :338)
+    if (ok && a.v_may_null) ok = GetBit(a.v_valid, a.v_off + j);
+    T v = 0;
+    if (ok) {
+      if (kBits) v = GetBit(reinterpret_cast<const uint8_t*>(a.v_data), a.v_off + j);
+      else v = reinterpret_cast<const T*>(a.v_data)[a.v_off + j];
+    }
+    const uint64_t okmask = __ballot(ok);
+    if (kBits) {
+      const uint64_t vmask = __ballot(v != 0);
+      if (lane == 0) reinterpret_cast<uint64_t*>(a.out_values)[i >> 6] = vmask;
+    } else if (i < a.n) {
+      reinterpret_cast<T*>(a.out_values)[i] = v;  // null slots hold ValueCType{} (:318, :343)
+    }
+    if (lane == 0) {
+      reinterpret_cast<uint64_t*>(a.out_validity)[i >> 6] = okmask;
+      my_valid += __popcll(okmask);
+    }
+  }
+  if (lane == 0 && my_valid) atomicAdd(&s_valid, my_valid);
+  __syncthreads();
+  if (tid == 0 && s_valid) atomicAdd(a.valid_count, s_valid);
+}
+
+// ---- CountSetBits / GetFilterOutputSize -------------------------------------------------------
+// mode 0: popcount(a); 1: popcount(a & b); 2: popcount(a | ~b)
+__global__ __launch_bounds__(kThreads) void k_popcount(const uint8_t* a, int64_t a_off, const uint8_t* b, int64_t b_off,
+                                                       int mode, int64_t length, unsigned long long* total) {
+  __shared__ unsigned long long s_sum;
+  if (threadIdx.x == 0) s_sum = 0;
+  __syncthreads();
+  const int64_t nwords = (length + 63) >> 6;
+  unsigned long long acc = 0;
+  for (int64_t w = int64_t(blockIdx.x) * kThreads + threadIdx.x; w < nwords; w += int64_t(gridDim.x) * kThreads) {
+    const int64_t row = w << 6;
+    const int64_t left = length - row;
+    const int nbits = left >= 64 ? 64 : static_cast<int>(left);
+    const uint64_t live = nbits < 64 ? (uint64_t(1) << nbits) - 1 : ~uint64_t(0);
+    uint64_t x = LoadBits64(a, a_off + row, nbits);
+    if (mode == 1) x &= LoadBits64(b, b_off + row, nbits);
+    else if (mode == 2) x = (x | ~LoadBits64(b, b_off + row, nbits)) & live;
+    acc += __popcll(x);
+  }
+  acc = WaveReduceSum64(acc);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&s_sum, acc);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_sum) atomicAdd(total, s_sum);
+}
+
+static int PopcountImpl(amdarrow_ctx* ctx, const uint8_t* a, int64_t a_off, const uint8_t* b, int64_t b_off, int mode,
+                        int64_t length, int64_t* out) {
+  if (length <= 0) { *out = 0; return AMDARROW_OK; }
+  void* base;
+  AA_TRY(Scratch(ctx, 256, &base));
+  auto* total = static_cast<unsigned long long*>(base);
+  AA_HIP(hipMemsetAsync(total, 0, 8, ctx->stream));
+  const int grid = GridFor((length + 63) / 64, kThreads, ctx->num_cus * 8);
+  hipLaunchKernelGGL(k_popcount, dim3(grid), dim3(kThreads), 0, ctx->stream, a, a_off, b, b_off, mode, length, total);
+  AA_HIP(hipGetLastError());
+  unsigned long long host = 0;
+  AA_TRY(ReadBack(ctx, total, 8, &host));
+  *out = static_cast<int64_t>(host);
+  return AMDARROW_OK;
+}
+
+static int CheckFilter(const amdarrow_array* filter) {
+  if (!filter || filter->type_id != AMDARROW_BOOL)
+    return SetError(AMDARROW_NOT_IMPLEMENTED, "Filter argument must be boolean type");  // :1885-1887
+  if (filter->length < 0 || filter->offset < 0) return SetError(AMDARROW_INVALID, "negative length/offset");
+  return AMDARROW_OK;
+}
+
+template <int W, bool IOTA>
+static int LaunchCompact(amdarrow_ctx* ctx, const FilterArgs& a) {
+  const int grid = GridFor(a.ntiles, 1, ctx->num_cus * 5);
+  hipLaunchKernelGGL((k_filter_compact<W, IOTA>), dim3(grid), dim3(kThreads), 0, ctx->stream, a);
+  AA_HIP(hipGetLastError());
+  return AMDARROW_OK;
+}
+
+// Shared driver of Filter and GetTakeIndices.
+static int RunCompaction(amdarrow_ctx* ctx, FilterArgs a, int width_bytes /*0 = bits*/, bool iota, int64_t* total) {
+  a.ntiles = (a.length + kTile - 1) / kTile;
+  Carver c;
+  const size_t off_counts = c.Take(sizeof(uint32_t) * a.ntiles);
+  const size_t off_offsets = c.Take(sizeof(int64_t) * (a.ntiles + 1));
+  void* base;
+  AA_TRY(Scratch(ctx, c.off, &base));
+  auto* counts = reinterpret_cast<uint32_t*>(static_cast<char*>(base) + off_counts);
+  auto* offsets = reinterpret_cast<int64_t*>(static_cast<char*>(base) + off_offsets);
+  a.tile_offsets = offsets;
+
+  hipLaunchKernelGGL(k_filter_tile_counts, dim3(GridFor(a.ntiles, 4, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream,
+                     a.f_data, a.f_valid, a.f_off, a.emit_null, a.length, a.ntiles, counts);
+  AA_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, counts, a.ntiles, offsets);
+  AA_HIP(hipGetLastError());
+  // bitmaps are merged with atomicOr at tile edges: start from zero (also zeroes the tails)
+  const size_t bm_bytes = static_cast<size_t>((BytesForBits(a.out_capacity) + 7) & ~int64_t(7));
+  if (a.has_validity) AA_HIP(hipMemsetAsync(a.out_validity, 0, bm_bytes, ctx->stream));
+  if (width_bytes == 0) AA_HIP(hipMemsetAsync(a.out_values, 0, bm_bytes, ctx->stream));
+  int rc;
+  if (iota) {
+    rc = width_bytes == 2 ? LaunchCompact<2, true>(ctx, a) : LaunchCompact<4, true>(ctx, a);
+  } else {
+    switch (width_bytes) {
+      case 0: rc = LaunchCompact<0, false>(ctx, a); break;
+      case 1: rc = LaunchCompact<1, false>(ctx, a); break;
+      case 2: rc = LaunchCompact<2, false>(ctx, a); break;
+      case 4: rc = LaunchCompact<4, false>(ctx, a); break;
+      default: rc = LaunchCompact<8, false>(ctx, a); break;
+    }
+  }
+  AA_TRY(rc);
+  AA_TRY(ReadBack(ctx, offsets + a.ntiles, 8, total));
+  if (*total > a.out_capacity)
+    return SetError(AMDARROW_CAPACITY_ERROR, "filter: selection of " + std::to_string(*total) +
+                                                 " rows exceeds out_capacity " + std::to_string(a.out_capacity));
+  return AMDARROW_OK;
+}
+
+}  // namespace amdarrow
+
+using namespace amdarrow;
+
+extern "C" {
+
+int amdarrow_count_set_bits(amdarrow_ctx* ctx, const uint8_t* bitmap, int64_t offset, int64_t length,
+                            int64_t* out_count) {
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  return PopcountImpl(ctx, bitmap, offset, nullptr, 0, 0, length, out_count);
+}
+
+int amdarrow_filter_output_size(amdarrow_ctx* ctx, const amdarrow_array* filter, int null_selection,
+                                int64_t* out_length) {
+  AA_TRY(CheckFilter(filter));
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  const uint8_t* data = static_cast<const uint8_t*>(filter->values);
+  if (MayHaveNulls(filter)) {  // :64-82
+    return PopcountImpl(ctx, data, filter->offset, filter->validity, filter->offset,
+                        null_selection == AMDARROW_EMIT_NULL ? 2 : 1, filter->length, out_length);
+  }
+  return PopcountImpl(ctx, data, filter->offset, nullptr, 0, 0, filter->length, out_length);  // :85
+}
+
+int amdarrow_filter(amdarrow_ctx* ctx, const amdarrow_array* values, const amdarrow_array* filter,
+                    int null_selection, void* out_values, uint8_t* out_validity, int64_t out_capacity,
+                    amdarrow_out* out) {
+  AA_TRY(CheckFilter(filter));
+  const int bw = values ? BitWidth(values->type_id) : -1;
+  if (bw < 0) return SetError(AMDARROW_NOT_IMPLEMENTED, "filter: values must be a primitive fixed-width type");
+  if (values->length != filter->length)
+    return SetError(AMDARROW_INVALID, "Array arguments must all be the same length");  // compute/exec.cc:190-192
+  const int64_t v_nc = ArgNullCount(values), f_nc = ArgNullCount(filter);
+  out->null_count = (v_nc == 0 && (null_selection == AMDARROW_DROP || f_nc == 0)) ? 0 : -1;  // :799-804
+  out->has_validity = (v_nc != 0 || f_nc != 0);                                              // :809
+  out->length = 0;
+  if (out->has_validity && !out_validity) return SetError(AMDARROW_INVALID, "filter: out_validity required");
+  if (values->length == 0) return AMDARROW_OK;
+
+  FilterArgs a{};
+  const bool non_null_path = (f_nc == 0 && v_nc == 0);  // ExecNonNull :625-630 looks at data bits only
+  a.f_data = static_cast<const uint8_t*>(filter->values);
+  a.f_valid = non_null_path ? nullptr : filter->validity;
+  a.f_off = filter->offset;
+  a.emit_null = (null_selection == AMDARROW_EMIT_NULL && a.f_valid != nullptr);
+  a.v_data = values->values;
+  a.v_valid = values->validity;
+  a.v_off = values->offset;
+  a.length = values->length;
+  a.out_values = out_values;
+  a.out_validity = out_validity;
+  a.out_capacity = out_capacity;
+  a.has_validity = out->has_validity;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  int64_t total = 0;
+  AA_TRY(RunCompaction(ctx, a, bw == 1 ? 0 : bw / 8, /*iota=*/false, &total));
+  out->length = total;
+  return AMDARROW_OK;
+}
+
+int amdarrow_take_indices(amdarrow_ctx* ctx, const amdarrow_array* filter, int null_selection, void* out_indices,
+                          uint8_t* out_validity, int64_t out_capacity, int* out_index_width, amdarrow_out* out) {
+  AA_TRY(CheckFilter(filter));
+  if (filter->length > 0xFFFFFFFFLL)  // :230-235
+    return SetError(AMDARROW_NOT_IMPLEMENTED,
+                    "Filter length exceeds UINT32_MAX, consider a different strategy for selecting elements");
+  const int w = filter->length <= 65535 ? 2 : 4;  // :224-229
+  *out_index_width = w * 8;
+  const bool have_nulls = MayHaveNulls(filter);
+  const bool emit_nulls = have_nulls && null_selection == AMDARROW_EMIT_NULL;  // :103
+  out->has_validity = emit_nulls;
+  out->null_count = 0;
+  out->length = 0;
+  if (emit_nulls && !out_validity) return SetError(AMDARROW_INVALID, "take_indices: out_validity required");
+  if (filter->length == 0) return AMDARROW_OK;
+  FilterArgs a{};
+  a.f_data = static_cast<const uint8_t*>(filter->values);
+  a.f_valid = have_nulls ? filter->validity : nullptr;
+  a.f_off = filter->offset;
+  a.emit_null = emit_nulls;
+  a.length = filter->length;
+  a.out_values = out_indices;
+  a.out_validity = out_validity;
+  a.out_capacity = out_capacity;
+  a.has_validity = emit_nulls;  // validity of an emitted slot = the filter slot was valid-and-true
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  int64_t total = 0;
+  AA_TRY(RunCompaction(ctx, a, w, /*iota=*/true, &total));
+  out->length = total;
+  if (emit_nulls) {
+    // null_count of the builder's result = number of null filter slots
+    int64_t valid = 0;
+    AA_TRY(PopcountImpl(ctx, out_validity, 0, nullptr, 0, 0, total, &valid));
+    out->null_count = total - valid;
+  }
+  return AMDARROW_OK;
+}
+
+int amdarrow_take(amdarrow_ctx* ctx, const amdarrow_array* values, const amdarrow_array* indices, int boundscheck,
+                  void* out_values, uint8_t* out_validity, amdarrow_out* out) {
+  const int bw = values ? BitWidth(values->type_id) : -1;
+  if (bw < 0) return SetError(AMDARROW_NOT_IMPLEMENTED, "take: values must be a primitive fixed-width type");
+  const int it = indices->type_id;
+  if (!IsSignedInt(it) && !IsUnsignedInt(it))
+    return SetError(AMDARROW_NOT_IMPLEMENTED, "take: indices must be an integer type");  // :2067-2070
+  out->length = indices->length;
+  out->has_validity = 1;  // always allocated (:505-510)
+  out->null_count = 0;
+  if (indices->length == 0) return AMDARROW_OK;
+  if (!out_validity || !out_values) return SetError(AMDARROW_INVALID, "take: output buffers required");
+
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  void* base;
+  AA_TRY(Scratch(ctx, 256, &base));
+  auto* counters = static_cast<unsigned long long*>(base);
+  AA_HIP(hipMemsetAsync(counters, 0, 8, ctx->stream));
+  AA_HIP(hipMemsetAsync(counters + 1, 0xFF, 8, ctx->stream));
+  TakeArgs a{};
+  a.v_data = values->values; a.v_valid = values->validity; a.v_off = values->offset; a.v_len = values->length;
+  a.v_may_null = ArgNullCount(values) != 0;
+  a.i_data = indices->values; a.i_valid = indices->validity; a.i_off = indices->offset; a.n = indices->length;
+  a.boundscheck = boundscheck;
+  a.out_values = out_values; a.out_validity = out_validity;
+  a.valid_count = counters; a.err_pos = counters + 1;
+  const int grid = GridFor(a.n, kThreads, ctx->num_cus * 8);
+  const int iw = BitWidth(it) / 8;
+  const bool sgn = IsSignedInt(it);
+#define AA_TAKE(W)                                                                                              \
+  do {                                                                                                          \
+    if (iw == 1) { if (sgn) hipLaunchKernelGGL((k_take<W, int8_t>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); \
+                   else hipLaunchKernelGGL((k_take<W, uint8_t>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); } \
+    else if (iw == 2) { if (sgn) hipLaunchKernelGGL((k_take<W, int16_t>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); \
+                        else hipLaunchKernelGGL((k_take<W, uint16_t>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); } \
+    else if (iw == 4) { if (sgn) hipLaunchKernelGGL((k_take<W, int32_t>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); \
+                        else hipLaunchKernelGGL((k_take<W, uint32_t>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); } \
+    else { if (sgn) hipLaunchKernelGGL((k_take<W, int64_t>), dim3(grid), dim3(kThreads), 0, ctx->stream, a);    \
+           else hipLaunchKernelGGL((k_take<W, uint64_t>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }     \
+  } while (0)
+  switch (bw) {
+    case 1: AA_TAKE(0); break;
+    case 8: AA_TAKE(1); break;
+    case 16: AA_TAKE(2); break;
+    case 32: AA_TAKE(4); break;
+    default: AA_TAKE(8); break;
+  }
+#undef AA_TAKE
+  AA_HIP(hipGetLastError());
+  unsigned long long host[2];
+  AA_TRY(ReadBack(ctx, counters, 16, host));
+  if (boundscheck && host[1] != ~0ull) {
+    // Report the first offending index, as CheckIndexBounds does (util/int_util.cc:553-561)
+    unsigned char raw[8] = {0};
+    AA_HIP(hipMemcpyAsync(raw, static_cast<const char*>(indices->values) + (indices->offset + host[1]) * iw, iw,
+                          hipMemcpyDeviceToHost, ctx->stream));
+    AA_HIP(hipStreamSynchronize(ctx->stream));
+    std::string s;
+    if (sgn) {
+      long long v = iw == 1 ? *reinterpret_cast<int8_t*>(raw) : iw == 2 ? *reinterpret_cast<int16_t*>(raw)
+                  : iw == 4 ? *reinterpret_cast<int32_t*>(raw) : *reinterpret_cast<int64_t*>(raw);
+      s = std::to_string(v);
+    } else {
+      unsigned long long v = iw == 1 ? *reinterpret_cast<uint8_t*>(raw) : iw == 2 ? *reinterpret_cast<uint16_t*>(raw)
+                           : iw == 4 ? *reinterpret_cast<uint32_t*>(raw) : *reinterpret_cast<uint64_t*>(raw);
+      s = std::to_string(v);
+    }
+    return SetError(AMDARROW_INDEX_ERROR, "Index " + s + " out of bounds");
+  }
+  out->null_count = indices->length - static_cast<int64_t>(host[0]);  // :367
+  return AMDARROW_OK;
+}
+
+}  // extern "C"

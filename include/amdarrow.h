@@ -1,0 +1,198 @@
+/*
+ * amdarrow.h -- C ABI of the MI355X (gfx950) compute-kernel backend for the Arrow
+ * hot path: Filter/Take, sort_indices, hash_count/hash_sum/hash_mean over GroupBy,
+ * compare and arithmetic.  This is the drop-in boundary: it sits directly below
+ * `kernel->exec` of the reference's kernels (compute/kernel.h:94 ArrayKernelExec) and
+ * is what the host C++ layer (arrow-1_amd/host/, or the reference itself through the
+ * stub in INTEGRATION.md) binds.  Plain pointers and sizes only.
+ *
+ * All array pointers are DEVICE pointers (HBM) unless a parameter says "host".
+ * Every entry point returns an arrow::StatusCode value (arrow/status.h:77-99); the
+ * message of the last failure on the calling thread is amdarrow_last_error().
+ *
+ * Reference files cited as file:line are relative to /root/reference/cpp/src/arrow/.
+ */
+#ifndef AMDARROW_H_
+#define AMDARROW_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMDARROW_ABI_VERSION 1
+
+/* arrow::StatusCode, status.h:77-99 */
+enum {
+  AMDARROW_OK = 0,
+  AMDARROW_OUT_OF_MEMORY = 1,
+  AMDARROW_KEY_ERROR = 2,
+  AMDARROW_TYPE_ERROR = 3,
+  AMDARROW_INVALID = 4,
+  AMDARROW_CAPACITY_ERROR = 6,
+  AMDARROW_INDEX_ERROR = 7,
+  AMDARROW_UNKNOWN_ERROR = 9,
+  AMDARROW_NOT_IMPLEMENTED = 10
+};
+
+/* arrow::Type::type, type_fwd.h:277-313 (the primitive types on the path) */
+enum {
+  AMDARROW_BOOL = 1, AMDARROW_UINT8 = 2, AMDARROW_INT8 = 3, AMDARROW_UINT16 = 4,
+  AMDARROW_INT16 = 5, AMDARROW_UINT32 = 6, AMDARROW_INT32 = 7, AMDARROW_UINT64 = 8,
+  AMDARROW_INT64 = 9, AMDARROW_FLOAT = 11, AMDARROW_DOUBLE = 12
+};
+
+enum { AMDARROW_DROP = 0, AMDARROW_EMIT_NULL = 1 };      /* FilterOptions::NullSelectionBehavior, compute/api_vector.h:35-42 */
+enum { AMDARROW_ASCENDING = 0, AMDARROW_DESCENDING = 1 }; /* SortOrder, compute/api_vector.h:61-64 */
+enum { AMDARROW_COUNT_NON_NULL = 0, AMDARROW_COUNT_NULL = 1 }; /* CountOptions::Mode, compute/api_aggregate.h:47-52 */
+/* CompareOperator, compute/api_scalar.h:124-131 */
+enum { AMDARROW_EQ = 0, AMDARROW_NE, AMDARROW_GT, AMDARROW_GE, AMDARROW_LT, AMDARROW_LE };
+/* add/subtract/multiply/divide[_checked], compute/kernels/scalar_arithmetic.cc:69-251 */
+enum {
+  AMDARROW_ADD = 0, AMDARROW_SUB, AMDARROW_MUL, AMDARROW_DIV,
+  AMDARROW_ADD_CHECKED, AMDARROW_SUB_CHECKED, AMDARROW_MUL_CHECKED, AMDARROW_DIV_CHECKED
+};
+enum { AMDARROW_HASH_SUM = 0, AMDARROW_HASH_COUNT = 1, AMDARROW_HASH_MEAN = 2 };
+
+/* One primitive array = compute::internal::PrimitiveArg (compute/kernels/util_internal.h:35-47)
+ * before GetPrimitiveArg pre-offsets `data`: `values` is the base of buffers[1] (bit-packed
+ * for BOOL), `validity` the base of buffers[0] or NULL, `offset` in elements applies to
+ * both, `null_count` is ArrayData::null_count as stored (-1 = kUnknownNullCount; ignored
+ * when validity == NULL).  Buffers must be readable up to the next 8-byte boundary past
+ * their last element (Arrow buffers are padded to 64 bytes, memory_pool.cc:101). */
+typedef struct {
+  const void* values;
+  const uint8_t* validity;
+  int64_t length;
+  int64_t offset;
+  int32_t type_id;
+  int64_t null_count;
+} amdarrow_array;
+
+/* Shape of a produced array (what the reference sets on the output ArrayData). */
+typedef struct {
+  int64_t length;
+  int64_t null_count;   /* -1 = kUnknownNullCount */
+  int32_t has_validity; /* 0 => the reference leaves buffers[0] absent */
+} amdarrow_out;
+
+typedef struct amdarrow_ctx amdarrow_ctx;
+
+/* ---- runtime ------------------------------------------------------------------------- */
+int amdarrow_abi_version(void);
+const char* amdarrow_last_error(void);
+int amdarrow_device_count(int* out_count);
+/* One context = one device + one HIP stream + a grow-only HBM scratch arena + a pinned
+ * host word for size read-backs.  `stream` is an existing hipStream_t (the caller's
+ * current stream; NULL = the device's default stream); with `private_stream` != 0 the
+ * argument is ignored and the context creates (and owns) a non-blocking stream.  A context serialises its
+ * callers (KernelExecutor::Execute is "not thread-safe", compute/exec_internal.h:116-118);
+ * use one context per host thread for concurrent CallFunction. */
+int amdarrow_ctx_create(int device, void* stream, int private_stream, amdarrow_ctx** out_ctx);
+int amdarrow_ctx_destroy(amdarrow_ctx* ctx);
+int amdarrow_ctx_synchronize(amdarrow_ctx* ctx);
+void* amdarrow_ctx_stream(amdarrow_ctx* ctx);
+/* Device memory pool with MemoryPool's two counters (memory_pool.h:38-105). Allocations
+ * are 256-byte aligned and zero-padded to a multiple of 64 bytes. */
+int amdarrow_malloc(amdarrow_ctx* ctx, int64_t nbytes, void** out_ptr);
+int amdarrow_free(amdarrow_ctx* ctx, void* ptr);
+int64_t amdarrow_bytes_allocated(amdarrow_ctx* ctx);
+int64_t amdarrow_max_memory(amdarrow_ctx* ctx);
+int amdarrow_memcpy_h2d(amdarrow_ctx* ctx, void* dst_dev, const void* src_host, int64_t nbytes);
+int amdarrow_memcpy_d2h(amdarrow_ctx* ctx, void* dst_host, const void* src_dev, int64_t nbytes);
+int amdarrow_memset(amdarrow_ctx* ctx, void* dst_dev, int value, int64_t nbytes);
+
+/* ---- bit utilities (util/bitmap_ops.h) -------------------------------------------------- */
+/* CountSetBits(bitmap, offset, length) -> *out_count (host). */
+int amdarrow_count_set_bits(amdarrow_ctx* ctx, const uint8_t* bitmap, int64_t offset,
+                            int64_t length, int64_t* out_count);
+
+/* ---- vector_selection.cc ---------------------------------------------------------------- */
+/* GetFilterOutputSize, compute/kernels/vector_selection.cc:61-88 -> *out_length (host). */
+int amdarrow_filter_output_size(amdarrow_ctx* ctx, const amdarrow_array* filter,
+                                int null_selection, int64_t* out_length);
+/* PrimitiveFilter, vector_selection.cc:786-835 (+PrimitiveFilterImpl :569-784): stream
+ * compaction of 1/8/16/32/64-bit values and their validity.  out_values must hold
+ * `out_capacity` elements, out_validity BytesForBits(out_capacity) bytes; both are
+ * fully written (bitmap tails zeroed).  Fails with AMDARROW_CAPACITY_ERROR when the
+ * selection does not fit.  out_validity may be NULL iff out->has_validity would be 0
+ * (neither input has a validity buffer with nonzero null_count). */
+int amdarrow_filter(amdarrow_ctx* ctx, const amdarrow_array* values,
+                    const amdarrow_array* filter, int null_selection, void* out_values,
+                    uint8_t* out_validity, int64_t out_capacity, amdarrow_out* out);
+/* GetTakeIndices, vector_selection.cc:92-237: uint16 indices when filter.length <= 65535,
+ * else uint32 (*out_index_width = 16|32). */
+int amdarrow_take_indices(amdarrow_ctx* ctx, const amdarrow_array* filter, int null_selection,
+                          void* out_indices, uint8_t* out_validity, int64_t out_capacity,
+                          int* out_index_width, amdarrow_out* out);
+/* PrimitiveTake, vector_selection.cc:493-530 (+CheckIndexBounds util/int_util.cc:534-561):
+ * out[i] = values[indices[i]], null if index or value is null; validity always written;
+ * AMDARROW_INDEX_ERROR "Index N out of bounds" when boundscheck != 0. */
+int amdarrow_take(amdarrow_ctx* ctx, const amdarrow_array* values,
+                  const amdarrow_array* indices, int boundscheck, void* out_values,
+                  uint8_t* out_validity, amdarrow_out* out);
+
+/* ---- vector_sort.cc ------------------------------------------------------------------------ */
+/* array_sort_indices / ChunkedArraySorter, vector_sort.cc:373-575, 657-832: stable argsort
+ * of the logical concatenation of `chunks`; non-null non-NaN values by order, then NaNs,
+ * then nulls, ties by ascending index in both orders.  out_indices: sum(length) uint64. */
+int amdarrow_sort_indices(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks,
+                          int order, uint64_t* out_indices);
+
+/* ---- scalar_compare.cc / scalar_arithmetic.cc ---------------------------------------------- */
+/* Operand = array (lhs / rhs) or valid scalar (lhs_scalar / rhs_scalar: HOST pointer to one
+ * value of the array operand's type).  Output at bit/element offset 0 as ScalarExecutor
+ * preallocates it (compute/exec.cc:686-716); out_validity is always written
+ * (NullPropagator, exec.cc:295-461). */
+int amdarrow_compare(amdarrow_ctx* ctx, int op, const amdarrow_array* lhs,
+                     const void* lhs_scalar, const amdarrow_array* rhs, const void* rhs_scalar,
+                     uint8_t* out_bits, uint8_t* out_validity, amdarrow_out* out);
+/* Unchecked add/sub/mul write every slot (ScalarBinary, codegen_internal.h:758-824);
+ * divide and *_checked write 0 at null slots (ScalarBinaryNotNull, :828-932) and fail with
+ * AMDARROW_INVALID "overflow" / "divide by zero". */
+int amdarrow_arith(amdarrow_ctx* ctx, int op, const amdarrow_array* lhs,
+                   const void* lhs_scalar, const amdarrow_array* rhs, const void* rhs_scalar,
+                   void* out_values, uint8_t* out_validity, amdarrow_out* out);
+
+/* ---- hash_aggregate.cc ---------------------------------------------------------------------- */
+/* Grouper (hash_aggregate.cc:313-437): keys -> dense uint32 ids in FIRST-APPEARANCE order,
+ * stateful across Consume calls.  Key columns: fixed width, total <= 8 value bytes. */
+typedef struct amdarrow_grouper amdarrow_grouper;
+int amdarrow_grouper_create(amdarrow_ctx* ctx, int nkeys, const int* key_type_ids,
+                            amdarrow_grouper** out);
+int amdarrow_grouper_destroy(amdarrow_grouper* g);
+int amdarrow_grouper_consume(amdarrow_grouper* g, const amdarrow_array* keys, uint32_t* out_ids);
+int amdarrow_grouper_num_groups(amdarrow_grouper* g, uint32_t* out_num_groups);
+/* GetUniques (:410-428): key column k -> num_groups values + validity bitmap. */
+int amdarrow_grouper_uniques(amdarrow_grouper* g, int k, void* out_values,
+                             uint8_t* out_validity, amdarrow_out* out);
+/* One HashAggregateKernel consume+finalize over one batch (hash_aggregate.cc:466-622,
+ * 928-960): func = AMDARROW_HASH_{SUM,COUNT,MEAN}; `ids` device uint32[values.length];
+ * out_values: num_groups x 8 bytes (int64 / uint64 / double per FindAccumulatorType,
+ * aggregate_internal.h:29-50; hash_mean = double(sum)/count, null when count == 0). */
+int amdarrow_hash_aggregate(amdarrow_ctx* ctx, int func, const amdarrow_array* values,
+                            const uint32_t* ids, int64_t num_groups, int count_mode,
+                            void* out_values, uint8_t* out_validity, amdarrow_out* out);
+
+/* Fused Filter -> GroupBy (BASELINE.json north_star / config 5 on one shard):
+ *   Filter(values, mask, DROP), Filter(keys, mask, DROP), GroupBy({values}, {keys},
+ *   {hash_sum, hash_count})  (vector_selection.cc:786-835 + hash_aggregate.cc:890-966)
+ * in one pass over HBM.  `mask` may be NULL (plain GroupBy).  Outputs, in group
+ * (first-appearance) order, each with capacity `group_capacity`:
+ *   out_sums 8 B/group, out_counts int64 (valid values per group; sum is null where 0),
+ *   out_keys (key type) + out_key_validity, out_first_rows (optional, may be NULL):
+ *   row index, within this call's input, of the first selected row of each group --
+ *   what a multi-GPU merge orders groups by.
+ * *out_num_groups (host). */
+int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values,
+                            const amdarrow_array* keys, const amdarrow_array* mask,
+                            int64_t group_capacity, void* out_sums, int64_t* out_counts,
+                            void* out_keys, uint8_t* out_key_validity,
+                            uint32_t* out_first_rows, int64_t* out_num_groups);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMDARROW_H_ */

@@ -1,0 +1,97 @@
+"""The HIP path behind the same numpy-in / numpy-out interface as orc.Api, so parity tests
+read `gpu.filter(v, f) == oracle.filter(v, f)`.  Every call goes through the C ABI."""
+import numpy as np
+
+import orc
+from __graft_entry__ import load_package
+
+load_package()
+from arrow1_amd import _abi, compute, device  # noqa: E402
+
+
+class _Out:
+    def __init__(self, length, null_count, has_validity):
+        self.length, self.null_count, self.has_validity = length, null_count, has_validity
+
+
+def up(a):
+    return device.DeviceArray.from_numpy(a.type_id, a.data, a.valid, a.offset, a.length, a.null_count)
+
+
+def down(d, always_validity_bits=False):
+    """DeviceArray -> orc.Result"""
+    n = d.length
+    vals = d.values_numpy()
+    if d.validity is not None:
+        bits = d.validity[:(n + 7) // 8].cpu().numpy().copy()
+    else:
+        bits = np.zeros((n + 7) // 8, np.uint8)
+    return orc.Result(vals, bits, _Out(n, d.null_count, d.validity is not None), d.type_id)
+
+
+class GpuApi:
+    prefix = "gpu"
+
+    def __init__(self):
+        self.ctx = device.Context(0)
+
+    def _wrap(self, fn):
+        try:
+            return fn()
+        except _abi.AmdArrowError as e:
+            raise orc.StatusError(e.code, e.msg)
+
+    def filter_output_size(self, filt, null_sel=orc.DROP):
+        return self._wrap(lambda: compute.filter_output_size(self.ctx, up(filt), null_sel))
+
+    def filter(self, values, filt, null_sel=orc.DROP):
+        return self._wrap(lambda: down(compute.filter(self.ctx, up(values), up(filt), null_sel)))
+
+    def take_indices(self, filt, null_sel=orc.DROP):
+        return self._wrap(lambda: down(compute.take_indices(self.ctx, up(filt), null_sel)))
+
+    def take(self, values, indices, boundscheck=True):
+        return self._wrap(lambda: down(compute.take(self.ctx, up(values), up(indices), boundscheck)))
+
+    def sort_indices(self, chunks, order=orc.ASC):
+        if isinstance(chunks, orc.Arr):
+            chunks = [chunks]
+        return self._wrap(lambda: compute.sort_indices(self.ctx, [up(c) for c in chunks], order).values_numpy())
+
+    def compare(self, op, lhs, rhs):
+        f = lambda x: up(x) if isinstance(x, orc.Arr) else x  # noqa: E731
+        return self._wrap(lambda: down(compute.compare(self.ctx, op, f(lhs), f(rhs))))
+
+    def arith(self, op, lhs, rhs):
+        f = lambda x: up(x) if isinstance(x, orc.Arr) else x  # noqa: E731
+        return self._wrap(lambda: down(compute.arith(self.ctx, op, f(lhs), f(rhs))))
+
+    def group_ids(self, key_batches):
+        g = compute.Grouper(self.ctx, [k.type_id for k in key_batches[0]])
+        try:
+            ids = [self._wrap(lambda b=b: g.consume([up(k) for k in b]).values_numpy()) for b in key_batches]
+            ng = g.num_groups()
+            uniq = []
+            for k in range(len(key_batches[0])):
+                u = g.uniques(k)
+                uniq.append((u.values_numpy(), u.validity_numpy(), u.null_count))
+            return ids, ng, uniq
+        finally:
+            g.close()
+
+    def hash_aggregate(self, func, values, ids, num_groups, count_mode=0):
+        import torch
+        fid = {"sum": 0, "count": 1, "mean": 2}[func]
+        t = torch.from_numpy(np.ascontiguousarray(ids, np.uint32).view(np.int32)).cuda()
+        pad = torch.zeros(16, dtype=torch.int32, device="cuda")
+        t = torch.cat([t, pad])
+        d = self._wrap(lambda: compute.hash_aggregate(self.ctx, fid, up(values), t, num_groups, count_mode))
+        r = down(d)
+        if d.validity is None:  # same convention as orc.Api: bitmap shown as all ones when absent
+            bits = np.packbits(np.ones(num_groups, bool), bitorder="little")
+            r.validity_bits = bits
+        return r
+
+    def filter_groupby_sum(self, values, keys, mask):
+        r = self._wrap(lambda: compute.filter_groupby(self.ctx, up(values), up(keys), up(mask) if mask is not None else None))
+        return r.sums_numpy(), r.counts_numpy(), r.keys_numpy(), r.key_validity_numpy()
