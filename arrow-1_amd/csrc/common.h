@@ -65,6 +65,12 @@ struct Carver {
 // Copy `nbytes` (<= 4096) from device to the pinned word and wait for it.
 int ReadBack(amdarrow_ctx* ctx, const void* dev, size_t nbytes, void* host_out);
 
+// Single-workgroup exclusive scan of u32 counts into int64 offsets (offsets[n] = total).
+int LaunchScanU32(amdarrow_ctx* ctx, const uint32_t* counts, int64_t n, int64_t* offsets);
+// Device-wide in-place exclusive scan of u32 (total < 2^32).  sums: ceil(n/2048) u32,
+// sum_offsets: ceil(n/2048) + 1 int64 of scratch; sum_offsets[ceil(n/2048)] = total.
+int ScanU32InPlace(amdarrow_ctx* ctx, uint32_t* data, int64_t n, uint32_t* sums, int64_t* sum_offsets);
+
 inline int BitWidth(int type_id) {
   switch (type_id) {
     case AMDARROW_BOOL: return 1;

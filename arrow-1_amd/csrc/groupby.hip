@@ -20,6 +20,8 @@
 //   * emit: scatter (x, sum, count, first_row) of each group to slot id, decode keys.
 #include "common.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -433,6 +435,195 @@ static int RankFirstRows(amdarrow_ctx* ctx, const GroupTable& t, int only_unassi
 
 static int AccKind(int t) { return IsFloat(t) ? 2 : (IsSignedInt(t) ? 1 : 0); }
 
+// ==== fast path: hash-partition to LDS-sized pieces, aggregate each piece in LDS =================
+// Global atomics run at the memory side on MI355X (~20 G scattered atomics/s chip-wide), far
+// below what the 12 B/row input stream needs.  So for large inputs the rows are first
+// partitioned by the top bits of h into kP pieces (one 16-byte record {x, row|flags, value}
+// per selected row), and each piece is then aggregated by ONE workgroup in an open-addressed
+// LDS table (LDS atomics only).  A piece that does not fit its LDS table raises `overflow`
+// and the caller re-runs the generic path, so the fast path is an optimisation, never a
+// restriction.
+constexpr int kPBits = 9;
+constexpr int kP = 1 << kPBits;          // partitions
+constexpr int kSlots = 4096;             // LDS table slots per partition (96 KiB)
+constexpr int kSlotLimit = 3584;         // groups per partition before giving up (87.5 % load)
+constexpr int kPartThreads = 1024;
+constexpr int kPartRows = 8192;          // rows per tile of the partition pass (8 per thread)
+constexpr uint32_t kRecKeyNull = 0x80000000u, kRecValValid = 0x40000000u, kRecRowMask = 0x3FFFFFFFu;
+
+struct FastArgs {
+  const void* k_data; const uint8_t* k_valid; int64_t k_off; int k_bits;
+  ValueCol v; int has_values;
+  const uint8_t* m_data; const uint8_t* m_valid; int64_t m_off;
+  int64_t n; int64_t rows_per_block; int nblocks;
+};
+
+__device__ __forceinline__ bool FastSelected(const FastArgs& a, int64_t row) {
+  if (!a.m_data) return true;
+  if (!GetBit(a.m_data, a.m_off + row)) return false;
+  return !a.m_valid || GetBit(a.m_valid, a.m_off + row);
+}
+// x as EncodeKey builds it for one key column of <= 32 bits: value bits, null flag at bit k_bits
+__device__ __forceinline__ uint64_t FastKey(const FastArgs& a, int64_t row, bool* is_null) {
+  *is_null = a.k_valid && !GetBit(a.k_valid, a.k_off + row);
+  return *is_null ? (uint64_t(1) << a.k_bits) : LoadBitsOfWidth(a.k_data, a.k_off + row, a.k_bits);
+}
+
+// hist[p * nblocks + b] = selected rows of row-range b that hash to partition p
+__global__ __launch_bounds__(kPartThreads) void k_part_hist(FastArgs a, uint32_t* hist) {
+  __shared__ unsigned int s_cnt[kP];
+  if (threadIdx.x < kP) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t lo = int64_t(blockIdx.x) * a.rows_per_block;
+  const int64_t hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
+  for (int64_t row = lo + threadIdx.x; row < hi; row += kPartThreads) {
+    if (!FastSelected(a, row)) continue;
+    bool kn;
+    const uint64_t h = Fmix64(FastKey(a, row, &kn));
+    atomicAdd(&s_cnt[h >> (64 - kPBits)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < kP) hist[int64_t(threadIdx.x) * a.nblocks + blockIdx.x] = s_cnt[threadIdx.x];
+}
+
+// Scatter the selected rows of row-range b into the partition regions.  Per 8192-row tile the
+// records are staged in LDS grouped by partition, so every partition leaves as one contiguous
+// run; successive tiles of a block append to the same regions, which keeps the partially
+// written lines in this CU's L2 until they are complete.
+__global__ __launch_bounds__(kPartThreads) void k_part_scatter(FastArgs a, const uint32_t* offsets, uint4* records) {
+  __shared__ unsigned int s_cnt[kP];
+  __shared__ uint32_t s_off[kP];
+  __shared__ uint32_t s_cur[kP];
+  __shared__ uint32_t s_scan[8];
+  __shared__ uint4 s_rec[kPartRows];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int kIters = kPartRows / kPartThreads;  // 8
+  if (tid < kP) { s_cnt[tid] = 0; s_cur[tid] = offsets[int64_t(tid) * a.nblocks + blockIdx.x]; }
+  __syncthreads();
+  const int64_t lo = int64_t(blockIdx.x) * a.rows_per_block;
+  const int64_t hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
+  for (int64_t tile0 = lo; tile0 < hi; tile0 += kPartRows) {
+    uint32_t rx[kIters], rflags[kIters], rrank[kIters];
+    uint64_t rval[kIters];
+    int rpart[kIters];
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      const int64_t row = tile0 + j * kPartThreads + tid;
+      rpart[j] = -1;
+      if (row < hi && FastSelected(a, row)) {
+        bool kn;
+        const uint64_t x = FastKey(a, row, &kn);
+        const int p = static_cast<int>(Fmix64(x) >> (64 - kPBits));
+        rpart[j] = p;
+        rx[j] = static_cast<uint32_t>(x);
+        uint32_t f = static_cast<uint32_t>(row) | (kn ? kRecKeyNull : 0u);
+        uint64_t bits = 0;
+        if (a.has_values && (!a.v.valid || GetBit(a.v.valid, a.v.off + row))) {
+          bool is_double;
+          bits = LoadAccum(a.v, row, &is_double);
+          f |= kRecValValid;
+        }
+        rflags[j] = f;
+        rval[j] = bits;
+        rrank[j] = atomicAdd(&s_cnt[p], 1u);
+      }
+    }
+    __syncthreads();
+    uint32_t c = 0, incl = 0;
+    if (tid < kP) {
+      c = s_cnt[tid];
+      incl = WaveInclusiveScan(c);
+      if (lane == 63) s_scan[wave] = incl;
+    }
+    __syncthreads();
+    if (tid < kP) {
+      uint32_t woff = 0;
+      for (int w = 0; w < wave; ++w) woff += s_scan[w];
+      s_off[tid] = woff + incl - c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      if (rpart[j] >= 0) {
+        uint4 r;
+        r.x = rx[j]; r.y = rflags[j];
+        r.z = static_cast<uint32_t>(rval[j]); r.w = static_cast<uint32_t>(rval[j] >> 32);
+        s_rec[s_off[rpart[j]] + rrank[j]] = r;
+      }
+    }
+    __syncthreads();
+    const uint32_t total = s_off[kP - 1] + s_cnt[kP - 1];
+    for (uint32_t i = tid; i < total; i += kPartThreads) {
+      const uint4 r = s_rec[i];
+      const uint64_t x = (r.y & kRecKeyNull) ? (uint64_t(1) << a.k_bits) : uint64_t(r.x);
+      const int p = static_cast<int>(Fmix64(x) >> (64 - kPBits));
+      records[s_cur[p] + (i - s_off[p])] = r;
+    }
+    __syncthreads();
+    if (tid < kP) { s_cur[tid] += s_cnt[tid]; s_cnt[tid] = 0; }
+    __syncthreads();
+  }
+}
+
+// One workgroup per partition: aggregate its records in an LDS hash table, then publish the
+// table as slice p of the global GroupTable (T = kP * kSlots) for the shared numbering/emit.
+__global__ __launch_bounds__(kPartThreads) void k_part_aggregate(const uint4* records, const uint32_t* offsets,
+                                                                 int nblocks, int k_bits, int acc_double, GroupTable t,
+                                                                 unsigned int* overflow) {
+  __shared__ unsigned long long s_h[kSlots];
+  __shared__ unsigned long long s_sum[kSlots];
+  __shared__ uint32_t s_first[kSlots];
+  __shared__ unsigned int s_cnt[kSlots];
+  __shared__ unsigned int s_groups;
+  const int tid = threadIdx.x;
+  const int p = blockIdx.x;
+  for (int s = tid; s < kSlots; s += kPartThreads) { s_h[s] = kEmpty; s_sum[s] = 0; s_first[s] = kNoRow; s_cnt[s] = 0; }
+  if (tid == 0) s_groups = 0;
+  __syncthreads();
+  const int64_t lo = offsets[int64_t(p) * nblocks];
+  const int64_t hi = offsets[int64_t(p + 1) * nblocks];  // hist carries one extra zero entry at the end
+  bool failed = false;
+  for (int64_t i = lo + tid; i < hi; i += kPartThreads) {
+    const uint4 r = records[i];
+    const uint64_t x = (r.y & kRecKeyNull) ? (uint64_t(1) << k_bits) : uint64_t(r.x);
+    const uint64_t h = Fmix64(x);
+    uint32_t slot = static_cast<uint32_t>(h) & (kSlots - 1);
+    bool found = false;
+    for (int probes = 0; probes < kSlots; ++probes) {
+      unsigned long long cur = s_h[slot];
+      if (cur == h) { found = true; break; }
+      if (cur == kEmpty) {
+        if (s_groups >= kSlotLimit) break;
+        cur = atomicCAS(&s_h[slot], static_cast<unsigned long long>(kEmpty), static_cast<unsigned long long>(h));
+        if (cur == kEmpty) { atomicAdd(&s_groups, 1u); found = true; break; }
+        if (cur == h) { found = true; break; }
+      }
+      slot = (slot + 1) & (kSlots - 1);
+    }
+    if (!found) { failed = true; continue; }
+    atomicMin(&s_first[slot], r.y & kRecRowMask);
+    if (r.y & kRecValValid) {
+      const unsigned long long bits = (static_cast<unsigned long long>(r.w) << 32) | r.z;
+      if (acc_double) atomicAdd(reinterpret_cast<double*>(&s_sum[slot]), __longlong_as_double(bits));
+      else atomicAdd(&s_sum[slot], bits);
+      atomicAdd(&s_cnt[slot], 1u);
+    }
+  }
+  if (failed) *overflow = 1;
+  __syncthreads();
+  const int64_t g0 = int64_t(p) * kSlots;
+  for (int s = tid; s < kSlots; s += kPartThreads) {
+    t.hkeys[g0 + s] = s_h[s];
+    t.first[g0 + s] = s_first[s];
+    t.sums[g0 + s] = s_sum[s];
+    t.counts[g0 + s] = s_cnt[s];
+  }
+  if (p == 0 && tid < 2) {  // the two special slots stay empty on this path
+    const int64_t T = int64_t(kP) * kSlots;
+    t.hkeys[T + tid] = kEmpty; t.first[T + tid] = kNoRow; t.sums[T + tid] = 0; t.counts[T + tid] = 0;
+  }
+}
+
 }  // namespace amdarrow
 
 using namespace amdarrow;
@@ -652,38 +843,84 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
   AA_TRY(MakeKeySpec(1, keys, nullptr, &ks));
   std::lock_guard<std::mutex> lock(ctx->mu);
 
-  const uint64_t T = NextPow2(2 * static_cast<uint64_t>(group_capacity < n ? group_capacity : n));
-  Carver c;
-  TableMem tm;
-  CarveTable(&c, T, false, &tm);
-  size_t roff[4];
-  CarveRank(&c, n, roff);
-  const size_t off_gx = c.Take(8 * static_cast<size_t>(group_capacity));
-  const size_t off_misc = c.Take(256);
-  void* base;
-  AA_TRY(Scratch(ctx, c.off, &base));
-  char* b = static_cast<char*>(base);
-  GroupTable t = BindTable(b, tm, T, false);
-  RankMem r = BindRank(b, roff, n);
-  auto* gx = reinterpret_cast<unsigned long long*>(b + off_gx);
-  auto* misc = reinterpret_cast<unsigned int*>(b + off_misc);  // [0] overflow, [2..3] null_count, [4] wide_null_id
-  AA_TRY(ClearTable(ctx, t, false));
-  AA_HIP(hipMemsetAsync(misc, 0, 16, ctx->stream));
-  AA_HIP(hipMemsetAsync(misc + 4, 0xFF, 4, ctx->stream));
-
   ValueCol v{};
   if (values) v = ValueCol{values->values, values->validity, values->offset, values->type_id};
-  hipLaunchKernelGGL(k_groupby_build, dim3(GridFor(n, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, ks, v,
-                     values ? 1 : 0, mask ? static_cast<const uint8_t*>(mask->values) : nullptr,
-                     mask ? mask->validity : nullptr, mask ? mask->offset : int64_t(0), n, t, misc);
-  AA_HIP(hipGetLastError());
-  int64_t G = 0;
-  AA_TRY(RankFirstRows(ctx, t, 0, r, &G));
-  unsigned int overflow = 0;
-  AA_TRY(ReadBack(ctx, misc, 4, &overflow));
-  if (overflow || G > group_capacity)
-    return SetError(AMDARROW_CAPACITY_ERROR, "group-by: more than group_capacity = " + std::to_string(group_capacity) + " groups");
-  *out_num_groups = G;
+  const uint8_t* m_data = mask ? static_cast<const uint8_t*>(mask->values) : nullptr;
+  const uint8_t* m_valid = mask ? mask->validity : nullptr;
+  const int64_t m_off = mask ? mask->offset : 0;
+
+  bool fast = ks.total_bits <= 32 && n >= (int64_t(1) << 18) && n < (int64_t(1) << 30) &&
+              getenv("AMDARROW_GROUPBY_GENERIC") == nullptr;
+  GroupTable t{};
+  RankMem r{};
+  unsigned long long* gx = nullptr;
+  unsigned int* misc = nullptr;  // [0] overflow, [2..3] null_count, [4] wide_null_id
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const uint64_t T = fast ? uint64_t(kP) * kSlots
+                            : NextPow2(2 * static_cast<uint64_t>(group_capacity < n ? group_capacity : n));
+    Carver c;
+    TableMem tm;
+    CarveTable(&c, T, false, &tm);
+    size_t roff[4];
+    CarveRank(&c, n, roff);
+    const size_t off_gx = c.Take(8 * static_cast<size_t>(group_capacity));
+    const size_t off_misc = c.Take(256);
+    // fast path extras
+    const int nblocks = fast ? static_cast<int>(std::min<int64_t>(ctx->num_cus, (n + kPartRows - 1) / kPartRows)) : 0;
+    const int64_t hist_n = fast ? int64_t(kP) * nblocks + 1 : 0;
+    const int64_t scan_nb = (hist_n + 2047) / 2048;
+    const size_t off_hist = c.Take(4 * hist_n);
+    const size_t off_sums = c.Take(4 * scan_nb);
+    const size_t off_sumoff = c.Take(8 * (scan_nb + 1));
+    const size_t off_rec = c.Take(fast ? 16 * static_cast<size_t>(n) : 0);
+    void* base;
+    AA_TRY(Scratch(ctx, c.off, &base));
+    char* b = static_cast<char*>(base);
+    t = BindTable(b, tm, T, false);
+    r = BindRank(b, roff, n);
+    gx = reinterpret_cast<unsigned long long*>(b + off_gx);
+    misc = reinterpret_cast<unsigned int*>(b + off_misc);
+    AA_HIP(hipMemsetAsync(misc, 0, 16, ctx->stream));
+    AA_HIP(hipMemsetAsync(misc + 4, 0xFF, 4, ctx->stream));
+
+    if (fast) {
+      auto* hist = reinterpret_cast<uint32_t*>(b + off_hist);
+      auto* sums = reinterpret_cast<uint32_t*>(b + off_sums);
+      auto* sumoff = reinterpret_cast<int64_t*>(b + off_sumoff);
+      auto* records = reinterpret_cast<uint4*>(b + off_rec);
+      FastArgs fa{};
+      fa.k_data = keys->values; fa.k_valid = keys->validity; fa.k_off = keys->offset; fa.k_bits = ks.total_bits;
+      fa.v = v; fa.has_values = values ? 1 : 0;
+      fa.m_data = m_data; fa.m_valid = m_valid; fa.m_off = m_off;
+      fa.n = n; fa.nblocks = nblocks;
+      fa.rows_per_block = (((n + nblocks - 1) / nblocks + kPartRows - 1) / kPartRows) * kPartRows;
+      AA_HIP(hipMemsetAsync(hist + hist_n - 1, 0, 4, ctx->stream));
+      hipLaunchKernelGGL(k_part_hist, dim3(nblocks), dim3(kPartThreads), 0, ctx->stream, fa, hist);
+      AA_HIP(hipGetLastError());
+      AA_TRY(ScanU32InPlace(ctx, hist, hist_n, sums, sumoff));
+      hipLaunchKernelGGL(k_part_scatter, dim3(nblocks), dim3(kPartThreads), 0, ctx->stream, fa, hist, records);
+      AA_HIP(hipGetLastError());
+      hipLaunchKernelGGL(k_part_aggregate, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nblocks,
+                         ks.total_bits, values && IsFloat(values->type_id) ? 1 : 0, t, misc);
+      AA_HIP(hipGetLastError());
+    } else {
+      AA_TRY(ClearTable(ctx, t, false));
+      hipLaunchKernelGGL(k_groupby_build, dim3(GridFor(n, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, ks,
+                         v, values ? 1 : 0, m_data, m_valid, m_off, n, t, misc);
+      AA_HIP(hipGetLastError());
+    }
+    int64_t G = 0;
+    AA_TRY(RankFirstRows(ctx, t, 0, r, &G));
+    unsigned int overflow = 0;
+    AA_TRY(ReadBack(ctx, misc, 4, &overflow));
+    if (overflow && fast) { fast = false; continue; }  // a partition outgrew its LDS table: generic path
+    if (overflow || G > group_capacity)
+      return SetError(AMDARROW_CAPACITY_ERROR,
+                      "group-by: more than group_capacity = " + std::to_string(group_capacity) + " groups");
+    *out_num_groups = G;
+    break;
+  }
+  const int64_t G = *out_num_groups;
   if (G == 0) return AMDARROW_OK;
   EmitArgs e{};
   e.t = t; e.nslots = static_cast<int64_t>(t.mask) + 3; e.bitmap = r.bitmap; e.prefix = r.prefix;
@@ -693,7 +930,7 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
   hipLaunchKernelGGL(k_emit_groups, dim3(GridFor(e.nslots, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, e);
   AA_HIP(hipGetLastError());
   unsigned int wide = kNoRow;
-  AA_TRY(ReadBack(ctx, misc + 4, 4, &wide));
+  if (ks.wide_null_slot) AA_TRY(ReadBack(ctx, misc + 4, 4, &wide));
   hipLaunchKernelGGL(k_decode_keys, dim3(GridFor(G, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, gx, G,
                      ks.col[0].bits, 0, ks.wide_null_slot ? -1 : ks.total_bits, wide, out_keys,
                      reinterpret_cast<uint64_t*>(out_key_validity), reinterpret_cast<unsigned long long*>(misc + 2));

@@ -59,32 +59,29 @@ __global__ __launch_bounds__(kThreads) void k_filter_tile_counts(const uint8_t* 
 }
 
 // Single-workgroup exclusive scan: offsets[i] = sum(counts[0..i)), offsets[n] = total.
+// Each thread owns ceil(n/1024) consecutive entries: one pass to sum them, one block scan
+// of the 1024 partial sums, one pass to write the prefixes.
 __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* counts, int64_t n, int64_t* offsets) {
   __shared__ uint64_t s_wave[16];
-  __shared__ uint64_t s_carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) s_carry = 0;
-  __syncthreads();
-  for (int64_t base = 0; base < n; base += 1024) {
-    const int64_t i = base + tid;
-    uint64_t v = i < n ? counts[i] : 0;
-    uint64_t incl = v;
+  const int64_t per = (n + 1023) / 1024;
+  const int64_t lo = per * tid;
+  const int64_t hi = lo + per < n ? lo + per : n;
+  uint64_t sum = 0;
+  for (int64_t i = lo; i < hi; ++i) sum += counts[i];
+  uint64_t incl = sum;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      uint64_t t = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += t;
-    }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    uint64_t wave_off = 0;
-    for (int w = 0; w < wave; ++w) wave_off += s_wave[w];
-    const uint64_t carry = s_carry;
-    if (i < n) offsets[i] = static_cast<int64_t>(carry + wave_off + incl - v);
-    __syncthreads();
-    if (tid == 1023) s_carry = carry + wave_off + incl;
-    __syncthreads();
+  for (int d = 1; d < 64; d <<= 1) {
+    uint64_t t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
   }
-  if (tid == 0) offsets[n] = static_cast<int64_t>(s_carry);
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  uint64_t wave_off = 0, total = 0;
+  for (int w = 0; w < 16; ++w) { if (w < wave) wave_off += s_wave[w]; total += s_wave[w]; }
+  uint64_t run = wave_off + incl - sum;
+  for (int64_t i = lo; i < hi; ++i) { offsets[i] = static_cast<int64_t>(run); run += counts[i]; }
+  if (tid == 0) offsets[n] = static_cast<int64_t>(total);
 }
 
 int LaunchScanU32(amdarrow_ctx* ctx, const uint32_t* counts, int64_t n, int64_t* offsets) {

@@ -1,0 +1,480 @@
+// sort.hip -- sort_indices for numeric arrays / chunked arrays: a stable LSD radix sort.
+//
+// Reference semantics: compute/kernels/vector_sort.cc
+//   PartitionNulls[Only|Likes] :224-313  (nulls last, NaNs just before them, both in index order)
+//   ArrayCompareSorter :373-405          (std::stable_sort on `lhs < rhs`; Descending uses `rhs < lhs`,
+//                                          so ties keep ASCENDING index order in both directions)
+//   ArrayCountSorter :407-478            (same order by construction)
+//   ChunkedArraySorter :657-832          (logical index = position in the concatenation)
+// The required output is therefore unique: sort the non-null, non-NaN rows by
+// (order-preserving key, index), then NaN rows by index, then null rows by index.
+//
+// Pipeline (all HBM-bound, no comparisons):
+//   1. classify + stable 3-way partition per 2048-row tile (ballot ranks): sortable rows ->
+//      (key, index32) arrays, NaN / null rows -> their final slots at the tail of the output
+//   2. one pass builds the histograms of every 8-bit digit; digits on which all keys agree
+//      are skipped (an int64 column holding [-100, 100] needs 2 of 8 passes)
+//   3. per remaining digit: block histograms -> device-wide scan -> stable scatter.  Inside a
+//      4096-key block, ranks come from 8 ballots per 64-key step (match-any on the digit) and
+//      keys are first sorted by digit in LDS so each digit leaves as one contiguous run.
+// Keys: unsigned as is; signed with the sign bit flipped; IEEE floats with -0.0 folded onto
+// +0.0 (they tie under `<`) then sign-magnitude -> biased; Descending complements the key.
+#include "common.h"
+
+#include <cstring>
+#include <vector>
+
+namespace amdarrow {
+
+constexpr int kThreads = 256;
+constexpr int kCTile = 2048;   // classify tile: 256 threads x 8
+constexpr int kRTile = 4096;   // radix tile: 256 threads x 16
+
+struct SortChunk {
+  const void* values; const uint8_t* valid; int64_t off; int64_t length;
+  int64_t row_start;   // logical index of the chunk's first row
+  int64_t tile_start;  // first classify tile of the chunk
+};
+
+int LaunchScanU32(amdarrow_ctx* ctx, const uint32_t* counts, int64_t n, int64_t* offsets);  // selection.hip
+
+template <typename KeyT> __device__ __forceinline__ KeyT MakeKey(int type_id, const void* data, int64_t i, bool* is_nan);
+template <> __device__ __forceinline__ uint32_t MakeKey<uint32_t>(int t, const void* d, int64_t i, bool* is_nan) {
+  *is_nan = false;
+  switch (t) {
+    case AMDARROW_UINT8: return reinterpret_cast<const uint8_t*>(d)[i];
+    case AMDARROW_INT8: return static_cast<uint8_t>(reinterpret_cast<const uint8_t*>(d)[i] ^ 0x80u);
+    case AMDARROW_UINT16: return reinterpret_cast<const uint16_t*>(d)[i];
+    case AMDARROW_INT16: return static_cast<uint16_t>(reinterpret_cast<const uint16_t*>(d)[i] ^ 0x8000u);
+    case AMDARROW_UINT32: return reinterpret_cast<const uint32_t*>(d)[i];
+    case AMDARROW_INT32: return reinterpret_cast<const uint32_t*>(d)[i] ^ 0x80000000u;
+    default: {  // FLOAT
+      float f = reinterpret_cast<const float*>(d)[i];
+      *is_nan = f != f;
+      if (f == 0.0f) f = 0.0f;  // -0.0 == +0.0 is a tie
+      const uint32_t u = __float_as_uint(f);
+      return (u >> 31) ? ~u : (u | 0x80000000u);
+    }
+  }
+}
+template <> __device__ __forceinline__ uint64_t MakeKey<uint64_t>(int t, const void* d, int64_t i, bool* is_nan) {
+  *is_nan = false;
+  switch (t) {
+    case AMDARROW_UINT64: return reinterpret_cast<const uint64_t*>(d)[i];
+    case AMDARROW_INT64: return reinterpret_cast<const uint64_t*>(d)[i] ^ 0x8000000000000000ULL;
+    default: {  // DOUBLE
+      double f = reinterpret_cast<const double*>(d)[i];
+      *is_nan = f != f;
+      if (f == 0.0) f = 0.0;
+      const uint64_t u = static_cast<uint64_t>(__double_as_longlong(f));
+      return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
+    }
+  }
+}
+
+__device__ __forceinline__ int FindChunk(const SortChunk* chunks, int nchunks, int64_t tile) {
+  int lo = 0, hi = nchunks - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (chunks[mid].tile_start <= tile) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// class of a row: 0 sortable, 1 NaN, 2 null
+template <typename KeyT>
+__device__ __forceinline__ int Classify(const SortChunk& c, int type_id, int64_t r, KeyT key_mask, KeyT flip, KeyT* key) {
+  if (c.valid && !GetBit(c.valid, c.off + r)) return 2;
+  bool is_nan;
+  const KeyT k = MakeKey<KeyT>(type_id, c.values, c.off + r, &is_nan);
+  *key = (k ^ flip) & key_mask;
+  return is_nan ? 1 : 0;
+}
+
+// counts[class * ntiles + tile] for class 0..2
+template <typename KeyT>
+__global__ __launch_bounds__(kThreads) void k_sort_count(const SortChunk* chunks, int nchunks, int type_id, int64_t ntiles,
+                                                         uint32_t* counts) {
+  __shared__ uint32_t s_c[3];
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if (threadIdx.x < 3) s_c[threadIdx.x] = 0;
+    __syncthreads();
+    const SortChunk c = chunks[FindChunk(chunks, nchunks, tile)];
+    const int64_t r0 = (tile - c.tile_start) * kCTile;
+    uint32_t n1 = 0, n2 = 0, n0 = 0;
+    for (int k = 0; k < kCTile / kThreads; ++k) {
+      const int64_t r = r0 + k * kThreads + threadIdx.x;
+      if (r < c.length) {
+        KeyT key;
+        const int cls = Classify<KeyT>(c, type_id, r, ~KeyT(0), 0, &key);
+        n0 += cls == 0; n1 += cls == 1; n2 += cls == 2;
+      }
+    }
+    n0 = static_cast<uint32_t>(WaveReduceSum64(n0));
+    n1 = static_cast<uint32_t>(WaveReduceSum64(n1));
+    n2 = static_cast<uint32_t>(WaveReduceSum64(n2));
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_c[0], n0); atomicAdd(&s_c[1], n1); atomicAdd(&s_c[2], n2); }
+    __syncthreads();
+    if (threadIdx.x < 3) counts[threadIdx.x * ntiles + tile] = s_c[threadIdx.x];
+    __syncthreads();
+  }
+}
+
+// Stable 3-way partition.  offsets = exclusive scan of counts laid out [class][tile]: it is
+// directly the global output position (sortable rows first, then NaNs, then nulls).
+template <typename KeyT>
+__global__ __launch_bounds__(kThreads) void k_sort_partition(const SortChunk* chunks, int nchunks, int type_id, int64_t ntiles,
+                                                             const int64_t* offsets, KeyT key_mask, KeyT flip, KeyT* keys,
+                                                             uint32_t* idx, uint64_t* out_indices) {
+  __shared__ uint32_t s_wave[3][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int kIters = kCTile / kThreads;  // 8; wave w owns rows [w*512, (w+1)*512) of the tile, in order
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const SortChunk c = chunks[FindChunk(chunks, nchunks, tile)];
+    const int64_t r0 = (tile - c.tile_start) * kCTile + wave * (kIters * 64);
+    KeyT key[kIters];
+    int cls[kIters];
+    uint32_t tot[3] = {0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      const int64_t r = r0 + j * 64 + lane;
+      cls[j] = 3;
+      key[j] = 0;
+      if (r < c.length) cls[j] = Classify<KeyT>(c, type_id, r, key_mask, flip, &key[j]);
+      tot[0] += __popcll(__ballot(cls[j] == 0));
+      tot[1] += __popcll(__ballot(cls[j] == 1));
+      tot[2] += __popcll(__ballot(cls[j] == 2));
+    }
+    if (lane == 0) { s_wave[0][wave] = tot[0]; s_wave[1][wave] = tot[1]; s_wave[2][wave] = tot[2]; }
+    __syncthreads();
+    int64_t base[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      uint32_t w_off = 0;
+      for (int w = 0; w < wave; ++w) w_off += s_wave[k][w];
+      base[k] = offsets[k * ntiles + tile] + w_off;
+    }
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      const int64_t r = r0 + j * 64 + lane;
+      const uint64_t m0 = __ballot(cls[j] == 0), m1 = __ballot(cls[j] == 1), m2 = __ballot(cls[j] == 2);
+      const uint64_t gidx = static_cast<uint64_t>(c.row_start + r);
+      if (cls[j] == 0) {
+        const int64_t p = base[0] + RankBelowLane(m0);
+        keys[p] = key[j];
+        idx[p] = static_cast<uint32_t>(gidx);
+      } else if (cls[j] == 1) {
+        out_indices[base[1] + RankBelowLane(m1)] = gidx;
+      } else if (cls[j] == 2) {
+        out_indices[base[2] + RankBelowLane(m2)] = gidx;
+      }
+      base[0] += __popcll(m0); base[1] += __popcll(m1); base[2] += __popcll(m2);
+    }
+    __syncthreads();
+  }
+}
+
+// All passes' digit histograms in one read of the keys: hist[pass * 256 + digit].
+template <typename KeyT>
+__global__ __launch_bounds__(kThreads) void k_radix_global_hist(const KeyT* keys, int64_t n, unsigned int* hist) {
+  constexpr int kPasses = sizeof(KeyT);
+  __shared__ unsigned int s_h[kPasses * 256];
+  for (int i = threadIdx.x; i < kPasses * 256; i += kThreads) s_h[i] = 0;
+  __syncthreads();
+  for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < n; i += int64_t(gridDim.x) * kThreads) {
+    const KeyT k = keys[i];
+#pragma unroll
+    for (int p = 0; p < kPasses; ++p) atomicAdd(&s_h[p * 256 + ((k >> (8 * p)) & 255)], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kPasses * 256; i += kThreads)
+    if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
+}
+
+// block_hist[digit * nblocks + block]
+template <typename KeyT>
+__global__ __launch_bounds__(kThreads) void k_radix_block_hist(const KeyT* keys, int64_t n, int shift, int64_t nblocks,
+                                                               uint32_t* block_hist) {
+  __shared__ unsigned int s_h[256];
+  s_h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = int64_t(blockIdx.x) * kRTile;
+#pragma unroll 4
+  for (int k = 0; k < kRTile / kThreads; ++k) {
+    const int64_t i = base + k * kThreads + threadIdx.x;
+    if (i < n) atomicAdd(&s_h[(keys[i] >> shift) & 255], 1u);
+  }
+  __syncthreads();
+  block_hist[int64_t(threadIdx.x) * nblocks + blockIdx.x] = s_h[threadIdx.x];
+}
+
+// Device-wide exclusive scan of u32 (in place allowed): block sums -> single-block scan -> apply.
+__global__ __launch_bounds__(kThreads) void k_scan_block_sums(const uint32_t* in, int64_t n, uint32_t* sums) {
+  __shared__ unsigned int s_sum;
+  if (threadIdx.x == 0) s_sum = 0;
+  __syncthreads();
+  const int64_t base = int64_t(blockIdx.x) * 2048;
+  uint32_t c = 0;
+  for (int k = 0; k < 8; ++k) {
+    const int64_t i = base + k * kThreads + threadIdx.x;
+    if (i < n) c += in[i];
+  }
+  c = static_cast<uint32_t>(WaveReduceSum64(c));
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_sum, c);
+  __syncthreads();
+  if (threadIdx.x == 0) sums[blockIdx.x] = s_sum;
+}
+__global__ __launch_bounds__(kThreads) void k_scan_apply(const uint32_t* in, int64_t n, const int64_t* block_offsets,
+                                                         uint32_t* out) {
+  __shared__ uint32_t s_wave[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t base = int64_t(blockIdx.x) * 2048;
+  uint32_t carry = static_cast<uint32_t>(block_offsets[blockIdx.x]);
+  for (int k = 0; k < 8; ++k) {
+    const int64_t i = base + k * kThreads + threadIdx.x;
+    const uint32_t v = i < n ? in[i] : 0;
+    const uint32_t incl = WaveInclusiveScan(v);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+    for (int j = 0; j < 4; ++j) { if (j < wave) woff += s_wave[j]; total += s_wave[j]; }
+    if (i < n) out[i] = carry + woff + incl - v;
+    carry += total;
+    __syncthreads();
+  }
+}
+
+// Stable scatter of one digit.  LAST: write the final uint64 indices instead of (key, idx).
+template <typename KeyT, bool LAST>
+__global__ __launch_bounds__(kThreads) void k_radix_scatter(const KeyT* keys_in, const uint32_t* idx_in, int64_t n, int shift,
+                                                            int64_t nblocks, const uint32_t* block_offsets, KeyT* keys_out,
+                                                            uint32_t* idx_out, uint64_t* out64) {
+  constexpr int kIters = kRTile / kThreads;  // 16; wave w owns keys [w*1024, (w+1)*1024) of the tile, in order
+  __shared__ uint32_t s_whist[4][256];   // per-wave digit counts, then per-wave running local positions
+  __shared__ uint32_t s_dstart[256];     // first local position of each digit
+  __shared__ uint32_t s_gbase[256];      // global position of this block's run of each digit
+  __shared__ uint32_t s_scan[4];
+  __shared__ KeyT s_keys[kRTile];
+  __shared__ uint32_t s_idx[kRTile];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t base = int64_t(blockIdx.x) * kRTile;
+  const int64_t left = n - base;
+  const uint32_t count = left >= kRTile ? kRTile : static_cast<uint32_t>(left);
+
+  for (int w = 0; w < 4; ++w) s_whist[w][tid] = 0;
+  __syncthreads();
+  KeyT key[kIters];
+  uint32_t idx[kIters];
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+    key[j] = 0; idx[j] = 0;
+    if (li < count) {
+      key[j] = keys_in[base + li];
+      idx[j] = idx_in[base + li];
+      atomicAdd(&s_whist[wave][(key[j] >> shift) & 255], 1u);
+    }
+  }
+  __syncthreads();
+  {  // thread d: totals of digit d, exclusive scan over digits, per-wave bases
+    const uint32_t c0 = s_whist[0][tid], c1 = s_whist[1][tid], c2 = s_whist[2][tid], c3 = s_whist[3][tid];
+    const uint32_t tot = c0 + c1 + c2 + c3;
+    const uint32_t incl = WaveInclusiveScan(tot);
+    if (lane == 63) s_scan[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_scan[w];
+    const uint32_t dstart = woff + incl - tot;
+    s_dstart[tid] = dstart;
+    s_gbase[tid] = block_offsets[int64_t(tid) * nblocks + blockIdx.x];
+    s_whist[0][tid] = dstart;
+    s_whist[1][tid] = dstart + c0;
+    s_whist[2][tid] = dstart + c0 + c1;
+    s_whist[3][tid] = dstart + c0 + c1 + c2;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+    const bool live = li < count;
+    const uint32_t d = (key[j] >> shift) & 255;
+    // match-any on the 8 digit bits among live lanes
+    uint64_t m = __ballot(live);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const uint64_t bb = __ballot((d >> b) & 1);
+      m &= ((d >> b) & 1) ? bb : ~bb;
+    }
+    if (live) {
+      const uint32_t rank = RankBelowLane(m);
+      const uint32_t old = s_whist[wave][d];
+      __builtin_amdgcn_wave_barrier();
+      if (rank == 0) s_whist[wave][d] = old + __popcll(m);
+      const uint32_t lpos = old + rank;
+      s_keys[lpos] = key[j];
+      s_idx[lpos] = idx[j];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < count; i += kThreads) {
+    const KeyT k = s_keys[i];
+    const uint32_t d = (k >> shift) & 255;
+    const uint32_t gpos = s_gbase[d] + (i - s_dstart[d]);
+    if (LAST) {
+      out64[gpos] = s_idx[i];
+    } else {
+      keys_out[gpos] = k;
+      idx_out[gpos] = s_idx[i];
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_widen_indices(const uint32_t* idx, int64_t n, uint64_t* out) {
+  for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < n; i += int64_t(gridDim.x) * kThreads) out[i] = idx[i];
+}
+
+int ScanU32InPlace(amdarrow_ctx* ctx, uint32_t* data, int64_t n, uint32_t* sums, int64_t* sum_offsets) {
+  const int64_t nb = (n + 2047) / 2048;
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(static_cast<unsigned>(nb)), dim3(kThreads), 0, ctx->stream, data, n, sums);
+  AA_HIP(hipGetLastError());
+  AA_TRY(LaunchScanU32(ctx, sums, nb, sum_offsets));
+  hipLaunchKernelGGL(k_scan_apply, dim3(static_cast<unsigned>(nb)), dim3(kThreads), 0, ctx->stream, data, n, sum_offsets, data);
+  AA_HIP(hipGetLastError());
+  return AMDARROW_OK;
+}
+
+template <typename KeyT>
+static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks, int type_id, int order, int64_t n,
+                    uint64_t* out) {
+  constexpr int kPasses = sizeof(KeyT);
+  const int key_bits = BitWidth(type_id);
+  const KeyT key_mask = key_bits >= static_cast<int>(8 * sizeof(KeyT)) ? ~KeyT(0) : ((KeyT(1) << key_bits) - 1);
+  const KeyT flip = order == AMDARROW_DESCENDING ? key_mask : 0;  // Descending = complemented key
+  const int npasses = key_bits / 8;
+
+  // chunk table + classify tiles
+  std::vector<SortChunk> hc(nchunks);
+  int64_t row = 0, tiles = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    hc[c] = SortChunk{chunks[c].values, MayHaveNulls(&chunks[c]) ? chunks[c].validity : nullptr, chunks[c].offset,
+                      chunks[c].length, row, tiles};
+    row += chunks[c].length;
+    tiles += (chunks[c].length + kCTile - 1) / kCTile;
+  }
+  const int64_t ntiles = tiles;
+  const int64_t nblocks = (n + kRTile - 1) / kRTile;
+  const int64_t hist_n = 256 * nblocks;
+  const int64_t scan_nb = (hist_n + 2047) / 2048;
+
+  Carver cv;
+  const size_t o_chunks = cv.Take(sizeof(SortChunk) * nchunks);
+  const size_t o_counts = cv.Take(4 * 3 * ntiles);
+  const size_t o_offsets = cv.Take(8 * (3 * ntiles + 1));
+  const size_t o_keys_a = cv.Take(sizeof(KeyT) * n);
+  const size_t o_keys_b = cv.Take(sizeof(KeyT) * n);
+  const size_t o_idx_a = cv.Take(4 * n);
+  const size_t o_idx_b = cv.Take(4 * n);
+  const size_t o_ghist = cv.Take(4 * 256 * kPasses);
+  const size_t o_bhist = cv.Take(4 * hist_n);
+  const size_t o_sums = cv.Take(4 * scan_nb);
+  const size_t o_sumoff = cv.Take(8 * (scan_nb + 1));
+  void* base;
+  AA_TRY(Scratch(ctx, cv.off, &base));
+  char* b = static_cast<char*>(base);
+  auto* d_chunks = reinterpret_cast<SortChunk*>(b + o_chunks);
+  auto* counts = reinterpret_cast<uint32_t*>(b + o_counts);
+  auto* offsets = reinterpret_cast<int64_t*>(b + o_offsets);
+  KeyT* keys_a = reinterpret_cast<KeyT*>(b + o_keys_a);
+  KeyT* keys_b = reinterpret_cast<KeyT*>(b + o_keys_b);
+  uint32_t* idx_a = reinterpret_cast<uint32_t*>(b + o_idx_a);
+  uint32_t* idx_b = reinterpret_cast<uint32_t*>(b + o_idx_b);
+  auto* ghist = reinterpret_cast<unsigned int*>(b + o_ghist);
+  auto* bhist = reinterpret_cast<uint32_t*>(b + o_bhist);
+  auto* sums = reinterpret_cast<uint32_t*>(b + o_sums);
+  auto* sumoff = reinterpret_cast<int64_t*>(b + o_sumoff);
+
+  AA_HIP(hipMemcpyAsync(d_chunks, hc.data(), sizeof(SortChunk) * nchunks, hipMemcpyHostToDevice, ctx->stream));
+  AA_HIP(hipStreamSynchronize(ctx->stream));  // hc is pageable host memory
+
+  // 1. stable 3-way partition: sortable | NaN | null
+  const int grid_t = GridFor(ntiles, 1, ctx->num_cus * 8);
+  hipLaunchKernelGGL((k_sort_count<KeyT>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, d_chunks, nchunks, type_id, ntiles,
+                     counts);
+  AA_HIP(hipGetLastError());
+  AA_TRY(LaunchScanU32(ctx, counts, 3 * ntiles, offsets));
+  hipLaunchKernelGGL((k_sort_partition<KeyT>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, d_chunks, nchunks, type_id, ntiles,
+                     offsets, key_mask, flip, keys_a, idx_a, out);
+  AA_HIP(hipGetLastError());
+  int64_t n0 = 0;
+  AA_TRY(ReadBack(ctx, offsets + ntiles, 8, &n0));  // start of the NaN region = number of sortable rows
+  if (n0 == 0) return AMDARROW_OK;
+
+  // 2. histograms of every digit; skip digits on which all keys agree
+  AA_HIP(hipMemsetAsync(ghist, 0, 4 * 256 * kPasses, ctx->stream));
+  hipLaunchKernelGGL((k_radix_global_hist<KeyT>), dim3(GridFor(n0, kThreads * 16, ctx->num_cus * 4)), dim3(kThreads), 0,
+                     ctx->stream, keys_a, n0, ghist);
+  AA_HIP(hipGetLastError());
+  std::vector<unsigned int> h(256 * kPasses);
+  for (int p = 0; p < kPasses; p += 4)  // ReadBack moves at most 4 KiB
+    AA_TRY(ReadBack(ctx, ghist + 256 * p, 4 * 256 * (kPasses - p < 4 ? kPasses - p : 4), h.data() + 256 * p));
+  std::vector<int> active;
+  for (int p = 0; p < npasses; ++p) {
+    bool trivial = false;
+    for (int d = 0; d < 256; ++d) if (h[p * 256 + d] == static_cast<unsigned int>(n0)) trivial = true;
+    if (!trivial) active.push_back(p);
+  }
+  if (active.empty()) {
+    hipLaunchKernelGGL(k_widen_indices, dim3(GridFor(n0, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, idx_a, n0,
+                       out);
+    AA_HIP(hipGetLastError());
+    return AMDARROW_OK;
+  }
+  // 3. LSD passes
+  const int64_t nb0 = (n0 + kRTile - 1) / kRTile;
+  const int64_t hn0 = 256 * nb0;
+  for (size_t a = 0; a < active.size(); ++a) {
+    const int shift = 8 * active[a];
+    const bool last = a + 1 == active.size();
+    hipLaunchKernelGGL((k_radix_block_hist<KeyT>), dim3(static_cast<unsigned>(nb0)), dim3(kThreads), 0, ctx->stream, keys_a, n0,
+                       shift, nb0, bhist);
+    AA_HIP(hipGetLastError());
+    AA_TRY(ScanU32InPlace(ctx, bhist, hn0, sums, sumoff));
+    if (last)
+      hipLaunchKernelGGL((k_radix_scatter<KeyT, true>), dim3(static_cast<unsigned>(nb0)), dim3(kThreads), 0, ctx->stream, keys_a,
+                         idx_a, n0, shift, nb0, bhist, keys_b, idx_b, out);
+    else
+      hipLaunchKernelGGL((k_radix_scatter<KeyT, false>), dim3(static_cast<unsigned>(nb0)), dim3(kThreads), 0, ctx->stream, keys_a,
+                         idx_a, n0, shift, nb0, bhist, keys_b, idx_b, out);
+    AA_HIP(hipGetLastError());
+    std::swap(keys_a, keys_b);
+    std::swap(idx_a, idx_b);
+  }
+  return AMDARROW_OK;
+}
+
+}  // namespace amdarrow
+
+using namespace amdarrow;
+
+extern "C" int amdarrow_sort_indices(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks, int order,
+                                     uint64_t* out_indices) {
+  if (nchunks < 0) return SetError(AMDARROW_INVALID, "sort_indices: negative chunk count");
+  if (nchunks == 0) return AMDARROW_OK;
+  const int type_id = chunks[0].type_id;
+  int64_t n = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    if (chunks[c].type_id != type_id) return SetError(AMDARROW_TYPE_ERROR, "sort_indices: chunks differ in type");
+    n += chunks[c].length;
+  }
+  const int bw = BitWidth(type_id);
+  if (bw < 8) return SetError(AMDARROW_NOT_IMPLEMENTED, "sort_indices: numeric types only");  // vector_sort.cc:581-587
+  if (n >= (int64_t(1) << 32)) return SetError(AMDARROW_NOT_IMPLEMENTED, "sort_indices: 2^32 rows or more");
+  if (n == 0) return AMDARROW_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  int rc = bw <= 32 ? SortImpl<uint32_t>(ctx, chunks, nchunks, type_id, order, n, out_indices)
+                    : SortImpl<uint64_t>(ctx, chunks, nchunks, type_id, order, n, out_indices);
+  AA_TRY(rc);
+  AA_HIP(hipStreamSynchronize(ctx->stream));
+  return AMDARROW_OK;
+}

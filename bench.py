@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X Arrow compute backend.
+
+Default workload (BASELINE.json metric / SURVEY.md section 8d "headline"): fused
+Filter -> GroupBy-sum over 100 M int64 rows, int32 keys uniform over 1 M groups, Bernoulli(0.5)
+mask, one step = one pass over the resident batch.  Inputs are generated on the device and are
+HBM-resident before the timed region.  Algorithmic bytes = 12.125 B/row (8 value + 4 key + 1/8 mask).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--rows R]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, rows sharded by contiguous row range (weak scaling: every rank
+holds --rows rows), per-rank fused kernel, then ONE RCCL exchange for the group-by merge.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from __graft_entry__ import load_package  # noqa: E402
+
+load_package()
+from arrow1_amd import _abi, compute, device  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+SEED = 0x0ff1ce         # kRandomSeed, compute/kernels/test_util.h:123
+
+WORKLOADS = {
+    # name: (description, algorithmic bytes per row as a function of selectivity)
+    "filter_groupby_sum_i64": "Filter(mask 50%) -> GroupBy{hash_sum,hash_count}(int64) by int32 key, 1M groups",
+    "filter_i64": "Filter int64 + validity (p_null .01), Bernoulli(s) mask, DROP",
+    "take_i64": "Take int64 + validity by uint32 indices (monotonic = GetTakeIndices(mask))",
+    "sort_u64": "sort_indices uint64 full range",
+    "sort_f64": "sort_indices float64 U[0,1) + 0.1% NaN + 1% null",
+    "hash_agg_f64": "GroupBy sum/count over float64 (p_null .01), 1M int32 keys",
+    "compare_i64": "greater(int64 array, int64 array)",
+}
+
+
+def device_bitmap(n, p_true, gen, dev):
+    """Bernoulli(p) bitmap of n bits built on the device (LSB-first)."""
+    bits = torch.rand(((n + 7) // 8) * 8, device=dev, generator=gen) < p_true
+    if n % 8:
+        bits[n:] = False
+    w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=dev)
+    packed = (bits.view(-1, 8).to(torch.uint8) * w).sum(1, dtype=torch.int32).to(torch.uint8)
+    buf = device.alloc_bytes(packed.numel(), dev, zero=True)
+    buf[:packed.numel()] = packed
+    return buf
+
+
+def make_inputs(workload, n, dev, rank, sel):
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(SEED + rank)
+    d = {}
+    if workload in ("filter_groupby_sum_i64",):
+        vals = torch.randint(-100, 101, (n,), dtype=torch.int64, device=dev, generator=gen)
+        keys = torch.randint(0, 1_000_000, (n,), dtype=torch.int32, device=dev, generator=gen)
+        d["values"] = device.DeviceArray(_abi.INT64, vals.view(torch.uint8), None, n)
+        d["keys"] = device.DeviceArray(_abi.INT32, keys.view(torch.uint8), None, n)
+        d["mask"] = device.DeviceArray(_abi.BOOL, device_bitmap(n, sel, gen, dev), None, n)
+        d["_keep"] = (vals, keys)
+    elif workload in ("filter_i64", "take_i64"):
+        vals = torch.randint(-100, 101, (n,), dtype=torch.int64, device=dev, generator=gen)
+        d["values"] = device.DeviceArray(_abi.INT64, vals.view(torch.uint8), device_bitmap(n, 0.99, gen, dev), n, 0, -1)
+        d["mask"] = device.DeviceArray(_abi.BOOL, device_bitmap(n, sel, gen, dev), None, n)
+        d["_keep"] = (vals,)
+    elif workload == "sort_u64":
+        vals = torch.randint(-2**63, 2**63 - 1, (n,), dtype=torch.int64, device=dev, generator=gen)
+        d["values"] = device.DeviceArray(_abi.UINT64, vals.view(torch.uint8), None, n)
+        d["_keep"] = (vals,)
+    elif workload == "sort_f64":
+        vals = torch.rand(n, dtype=torch.float64, device=dev, generator=gen)
+        vals[torch.rand(n, device=dev, generator=gen) < 0.001] = float("nan")
+        d["values"] = device.DeviceArray(_abi.DOUBLE, vals.view(torch.uint8), device_bitmap(n, 0.99, gen, dev), n, 0, -1)
+        d["_keep"] = (vals,)
+    elif workload == "hash_agg_f64":
+        vals = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 1e3
+        keys = torch.randint(0, 1_000_000, (n,), dtype=torch.int32, device=dev, generator=gen)
+        d["values"] = device.DeviceArray(_abi.DOUBLE, vals.view(torch.uint8), device_bitmap(n, 0.99, gen, dev), n, 0, -1)
+        d["keys"] = device.DeviceArray(_abi.INT32, keys.view(torch.uint8), None, n)
+        d["_keep"] = (vals, keys)
+    elif workload == "compare_i64":
+        a = torch.randint(-100, 101, (n,), dtype=torch.int64, device=dev, generator=gen)
+        b = torch.randint(-100, 101, (n,), dtype=torch.int64, device=dev, generator=gen)
+        d["a"] = device.DeviceArray(_abi.INT64, a.view(torch.uint8), None, n)
+        d["b"] = device.DeviceArray(_abi.INT64, b.view(torch.uint8), None, n)
+        d["_keep"] = (a, b)
+    else:
+        raise SystemExit("unknown workload " + workload)
+    return d
+
+
+def bytes_per_row(workload, sel):
+    return {"filter_groupby_sum_i64": 12.125, "filter_i64": 8.25 + 8.125 * sel, "take_i64": 20.25 * sel,
+            "sort_u64": 16.0, "sort_f64": 16.0, "hash_agg_f64": 12.125, "compare_i64": 16.25}[workload]
+
+
+def make_step(workload, ctx, inp, sel, world, rank):
+    """Returns a zero-argument callable running ONE step on this rank's shard."""
+    if workload == "filter_groupby_sum_i64":
+        bufs = compute.GroupByBuffers(ctx.device, 1 << 21, _abi.INT32)
+        if world == 1:
+            return lambda: compute.filter_groupby(ctx, inp["values"], inp["keys"], inp["mask"], buffers=bufs)
+        from arrow1_amd import dist as adist
+        merger = adist.GroupByMerger(ctx, rank, world, key_type=_abi.INT32, value_type=_abi.INT64, group_capacity=1 << 21)
+        return lambda: merger.filter_groupby(inp["values"], inp["keys"], inp["mask"], bufs)
+    if workload == "hash_agg_f64":
+        bufs = compute.GroupByBuffers(ctx.device, 1 << 21, _abi.INT32)
+        return lambda: compute.filter_groupby(ctx, inp["values"], inp["keys"], None, buffers=bufs)
+    if workload == "filter_i64":
+        return lambda: compute.filter(ctx, inp["values"], inp["mask"])
+    if workload == "take_i64":
+        idx = compute.take_indices(ctx, inp["mask"])
+        return lambda: compute.take(ctx, inp["values"], idx)
+    if workload in ("sort_u64", "sort_f64"):
+        return lambda: compute.sort_indices(ctx, inp["values"])
+    if workload == "compare_i64":
+        return lambda: compute.compare(ctx, _abi.GT, inp["a"], inp["b"])
+    raise SystemExit("unknown workload " + workload)
+
+
+def cpu_baseline(workload, sel):
+    """Time the CPU path on a BOUNDED sample of the same workload on this box's host cores:
+    the real reference (oracle/_ref, kind 'reference') when it travelled with the repo, else
+    the oracle restatement (kind 'port').  1 thread: the reference compute layer is
+    single-threaded (compute/exec.h:86-92)."""
+    import orc
+    kind = "reference" if orc.have_ref() else "port"
+    api = orc.Api("ref" if kind == "reference" else "orc")
+    rng = np.random.default_rng(SEED)
+    if workload != "filter_groupby_sum_i64":
+        return None
+    n = 8_000_000
+    vals = orc.Arr(orc.INT64, rng.integers(-100, 101, n))
+    keys = orc.Arr(orc.INT32, rng.integers(0, 1_000_000, n))
+    mask = orc.Arr(orc.BOOL, rng.random(n) < sel)
+    t0 = time.time()
+    reps = 0
+    while True:
+        api.filter_groupby_sum(vals, keys, mask)
+        reps += 1
+        if time.time() - t0 > 10.0 or reps >= 20:
+            break
+    dt = (time.time() - t0) / reps
+    return {"value": n / dt, "unit": "rows/s", "cores": 1, "kind": kind,
+            "sample": "%d rows (same generator family, 1M keys, mask %.0f%%), %d reps of Filter+Filter+GroupBy{hash_sum,hash_count}" % (n, sel * 100, reps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="filter_groupby_sum_i64", choices=sorted(WORKLOADS))
+    ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU")
+    ap.add_argument("--selectivity", type=float, default=0.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as tdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        tdist.init_process_group("nccl", device_id=dev)
+
+    ctx = device.Context(local_rank)
+    n = args.rows
+    sel = args.selectivity
+    inp = make_inputs(args.workload, n, dev, rank, sel)
+    step = make_step(args.workload, ctx, inp, sel, world, rank)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        tdist.barrier()
+        torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()  # the kernels run on torch's current stream (device.Context binds it)
+    for _ in range(args.steps):
+        res = step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        tdist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_rows = n * world * args.steps
+        value = total_rows / elapsed
+        bpr = bytes_per_row(args.workload, sel)
+        step_s = dev_ms / 1e3 / args.steps  # HIP-event time of one step's launches on the kernel stream
+        achieved = bpr * n / step_s / 1e9
+        out = {
+            "metric": "rows/sec + achieved HBM GB/s, Filter+GroupBy-sum 100M int64 @1/2/4/8 GPU",
+            "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": {"filter_groupby_sum_i64": "int64", "filter_i64": "u64", "take_i64": "u64",
+                                            "sort_u64": "u64", "sort_f64": "f64", "hash_agg_f64": "f64",
+                                            "compare_i64": "int64"}[args.workload],
+            "data": "synthetic (device-generated, seed 0x0ff1ce + rank; HBM-resident before timing)",
+            "config": {"workload": args.workload + ": " + WORKLOADS[args.workload], "rows_per_gpu": n,
+                       "selectivity": sel, "groups": 1_000_000, "sharding": "row-range, %d shard(s)" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "note": "algorithmic %.3f B/row x %d rows / HIP-event time per step (%.3f ms) on the kernel stream; "
+                                 "whole step (all kernels of the op), rank 0" % (bpr, n, step_s * 1e3)},
+        }
+        if hasattr(res, "num_groups"):
+            out["config"]["result_groups"] = int(res.num_groups)
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.workload, sel)
+            except Exception as e:  # the baseline is a reported extra, never the measured value
+                out["cpu_baseline"] = {"error": str(e)}
+        print(json.dumps(out))
+    if world > 1:
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
