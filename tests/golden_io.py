@@ -1,0 +1,167 @@
+"""Shared by tests/golden/make_golden.py (which runs the REAL reference here, in the build
+container) and the tests that replay the committed vectors through the oracle (CPU) and the
+HIP path (GPU).  A fixture is data: inputs + the reference's outputs."""
+import json
+import os
+
+import numpy as np
+
+import orc
+from orc import Arr, BOOL, NUMERIC, INTS, FLOAT, DOUBLE, DROP, EMIT_NULL, ASC, DESC
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NPZ = os.path.join(GOLDEN_DIR, "ref_random.npz")
+MANIFEST = os.path.join(GOLDEN_DIR, "ref_random.json")
+SEED = 0x0ff1ce  # kRandomSeed, compute/kernels/test_util.h:123
+
+
+def iter_cases():
+    """Deterministic case list modelled on the reference's randomized tests:
+    ValidateFilter matrix (vector_selection_test.cc:1618-1636), ValidateTake (:1658-1690),
+    sort (vector_sort_test.cc:563-624, 692-758), GroupBy random (hash_aggregate_test.cc:704-723),
+    compare / arithmetic random (scalar_compare_test.cc:374-408)."""
+    rng = np.random.default_rng(SEED)
+    R = orc.random_arr
+    n = 200
+    for t in [BOOL, orc.INT8, orc.UINT16, orc.INT32, orc.INT64, orc.DOUBLE]:
+        for null_prob in [0.0, 0.01, 0.1, 1.0]:
+            for true_prob in [0.0, 0.1, 0.999, 1.0]:
+                for (vo, fo) in [(0, 0), (3, 4)]:
+                    v = R(rng, t, n, null_prob, vo)
+                    f = R(rng, BOOL, n, null_prob, fo, hi=true_prob)
+                    for ns in (DROP, EMIT_NULL):
+                        yield ("filter", dict(null_selection=ns), [v, f])
+    for null_prob in [0.0, 0.01, 1.0]:
+        for true_prob in [0.01, 0.999]:
+            f = R(rng, BOOL, 6401, null_prob, 0, hi=true_prob)
+            f7 = Arr(BOOL, f.data, f.valid, 7, 6401 - 7)
+            for ns in (DROP, EMIT_NULL):
+                yield ("take_indices", dict(null_selection=ns), [f])
+                yield ("take_indices", dict(null_selection=ns), [f7])
+    f = R(rng, BOOL, 65536, 0.01, 0, hi=0.99)  # uint16 -> uint32 switch
+    yield ("take_indices", dict(null_selection=DROP), [f])
+    yield ("take_indices", dict(null_selection=DROP), [Arr(BOOL, f.data, f.valid, 1, 65535)])
+    for t in [BOOL, orc.UINT8, orc.INT16, orc.FLOAT, orc.INT64]:
+        for it in INTS:
+            for null_prob in [0.0, 0.01, 0.25, 1.0]:
+                nv = 100 if it in (orc.UINT8, orc.INT8) else 1000
+                v = R(rng, t, nv, null_prob, 3)
+                i = R(rng, it, 200, null_prob, 2, lo=0, hi=nv - 1)
+                yield ("take", dict(boundscheck=True), [v, i])
+    for t in NUMERIC:
+        for null_prob in [0.0, 0.1, 0.5]:
+            for (lo, hi, m) in [(None, None, 500), (0, 5, 1100)]:
+                a = R(rng, t, m, null_prob, 3, lo=lo, hi=hi)
+                if t in (FLOAT, DOUBLE):
+                    d = a.data.copy()
+                    d[rng.random(len(d)) < 0.05] = np.nan
+                    d[rng.random(len(d)) < 0.05] = -0.0
+                    d[rng.random(len(d)) < 0.05] = 0.0
+                    a = Arr(t, d, a.valid, 3, m)
+                for order in (ASC, DESC):
+                    yield ("sort_indices", dict(order=order), [a])
+        chunks = [R(rng, t, m, 0.1, k, lo=-50, hi=50) for k, m in enumerate([100, 0, 133, 1, 64])]
+        for order in (ASC, DESC):
+            yield ("sort_indices", dict(order=order), chunks)
+    for kt in [BOOL, orc.INT8, orc.UINT16, orc.INT32, orc.INT64, orc.FLOAT, orc.DOUBLE]:
+        for null_prob in [0.0, 0.1]:
+            b1 = R(rng, kt, 300, null_prob, 0, lo=-20, hi=20)
+            b2 = R(rng, kt, 150, null_prob, 3, lo=-20, hi=20)
+            yield ("grouper", {}, [b1, b2])
+    for t in [BOOL] + NUMERIC:
+        for null_prob in [0.0, 0.25, 1.0]:
+            v = R(rng, t, 512, null_prob, 0)
+            ids = Arr(orc.UINT32, rng.integers(0, 95, 512))
+            if t != BOOL:
+                yield ("hash_aggregate", dict(func="sum", num_groups=100), [v, ids])
+            for mode in (0, 1):
+                yield ("hash_aggregate", dict(func="count", num_groups=100, count_mode=mode), [v, ids])
+    for t in NUMERIC:
+        for (p1, p2) in [(0.0, 0.0), (0.2, 0.0), (0.2, 0.3), (1.0, 0.0)]:
+            a = R(rng, t, 130, p1, 3, lo=-5, hi=5)
+            b = R(rng, t, 130, p2, 6, lo=1, hi=5)
+            if t in (FLOAT, DOUBLE):
+                d = a.data.copy()
+                d[::17] = np.nan
+                a = Arr(t, d, a.valid, 3, 130)
+            for op in range(6):
+                yield ("compare", dict(op=op), [a, b])
+                yield ("compare", dict(op=op, rhs_scalar=2), [a])
+            for op in range(8):
+                yield ("arith", dict(op=op), [a, b])
+    for vt in [orc.INT64, orc.DOUBLE, orc.INT32]:
+        v = R(rng, vt, 3000, 0.01, 0)
+        k = R(rng, orc.INT32, 3000, 0.05, 0, lo=0, hi=300)
+        m = R(rng, BOOL, 3000, 0.0, 0)
+        yield ("filter_groupby_sum", {}, [v, k, m])
+
+
+def run_case(api, op, params, arrs):
+    """-> dict name -> numpy array (or python scalars) describing the output."""
+    def res(r):
+        v = r.values
+        return {"values": v.view(np.uint8) if v.dtype != bool else v, "validity": r.validity(),
+                "meta": np.array([r.length, r.null_count, int(r.has_validity)], np.int64)}
+    try:
+        if op == "filter":
+            return res(api.filter(arrs[0], arrs[1], params["null_selection"]))
+        if op == "take_indices":
+            return res(api.take_indices(arrs[0], params["null_selection"]))
+        if op == "take":
+            return res(api.take(arrs[0], arrs[1], params["boundscheck"]))
+        if op == "sort_indices":
+            return {"indices": api.sort_indices(arrs, params["order"])}
+        if op == "grouper":
+            ids, ng, uniq = api.group_ids([[a] for a in arrs])
+            u = uniq[0]
+            return {"ids0": ids[0], "ids1": ids[1], "ng": np.array([ng, u[2]], np.int64),
+                    "uniq": u[0].view(np.uint8) if u[0].dtype != bool else u[0], "uniq_valid": u[1]}
+        if op == "hash_aggregate":
+            return res(api.hash_aggregate(params["func"], arrs[0], arrs[1].values(), params["num_groups"],
+                                          params.get("count_mode", 0)))
+        if op == "compare":
+            rhs = arrs[1] if len(arrs) > 1 else params["rhs_scalar"]
+            return res(api.compare(params["op"], arrs[0], rhs))
+        if op == "arith":
+            return res(api.arith(params["op"], arrs[0], arrs[1]))
+        if op == "filter_groupby_sum":
+            s, c, k, kv = api.filter_groupby_sum(*arrs)
+            return {"sums": s.view(np.uint8), "counts": c, "keys": k.view(np.uint8), "key_valid": kv}
+    except orc.StatusError as e:
+        return {"error": np.array([e.code], np.int64), "msg": np.frombuffer(e.msg.encode(), np.uint8)}
+    raise ValueError(op)
+
+
+def same_output(got, want, float_tol=False):
+    if set(got) != set(want):
+        return False, "keys %s vs %s" % (sorted(got), sorted(want))
+    for k in want:
+        a, b = np.asarray(got[k]), np.asarray(want[k])
+        if a.shape != b.shape or not np.array_equal(a, b):
+            if float_tol and k in ("values", "sums") and a.shape == b.shape and a.dtype == np.uint8 and a.size % 8 == 0:
+                if np.allclose(a.view(np.float64), b.view(np.float64), rtol=1e-12, atol=0, equal_nan=True):
+                    continue
+            return False, "field %s differs" % k
+    return True, ""
+
+
+def load_golden():
+    """-> list of (op, params, [Arr...], expected-output dict) from the committed fixtures."""
+    with open(MANIFEST) as f:
+        man = json.load(f)
+    blob = np.load(NPZ)["blob"]
+
+    def get(ref):
+        off, dt, count = ref
+        if dt == "bool":
+            raw = blob[off:off + (count + 7) // 8]
+            return np.unpackbits(raw, bitorder="little")[:count].astype(bool)
+        d = np.dtype(dt)
+        return blob[off:off + count * d.itemsize].view(d).copy()
+
+    out = []
+    for c in man["cases"]:
+        arrs = [Arr(i["type"], get(i["data"]), None if i["valid"] is None else get(i["valid"]), i["offset"],
+                    i["length"], i["null_count"]) for i in c["inputs"]]
+        out.append((c["op"], c["params"], arrs, {k: get(v) for k, v in c["outputs"].items()}))
+    return out

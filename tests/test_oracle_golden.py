@@ -1,0 +1,88 @@
+"""CPU: the oracle restatement against (1) the reference's own known-answer vectors,
+(2) committed outputs of the real reference on seeded random inputs, (3) the live reference
+where oracle/_ref is present."""
+import numpy as np
+import pytest
+
+import golden_io
+import literals
+import orc
+
+
+def test_oracle_matches_reference_literals(oracle):
+    fails = literals.run_all(oracle)
+    assert not fails, "\n".join(fails[:20])
+
+
+def test_reference_matches_its_own_literals(reference):
+    """Sanity of the harness itself: the real reference passes its own vectors through our driver."""
+    fails = literals.run_all(reference)
+    assert not fails, "\n".join(fails[:20])
+
+
+def test_oracle_matches_committed_reference_outputs(oracle):
+    cases = golden_io.load_golden()
+    assert len(cases) > 1000
+    bad = []
+    for i, (op, params, arrs, want) in enumerate(cases):
+        got = golden_io.run_case(oracle, op, params, arrs)
+        if "error" in want or "error" in got:
+            ok = "error" in want and "error" in got and np.array_equal(got["error"], want["error"]) and \
+                np.array_equal(got["msg"], want["msg"])
+            msg = "error differs"
+        else:
+            ok, msg = golden_io.same_output(got, want)
+        if not ok:
+            bad.append("case %d %s %s: %s" % (i, op, params, msg))
+    assert not bad, "\n".join(bad[:20])
+
+
+def test_committed_fixtures_are_reproducible(reference):
+    """Regenerating a sample of the fixtures from the live reference gives the committed bytes."""
+    cases = golden_io.load_golden()
+    for (op, params, arrs, want) in cases[::37]:
+        got = golden_io.run_case(reference, op, params, arrs)
+        ok, msg = golden_io.same_output(got, want) if "error" not in want else (True, "")
+        assert ok, (op, params, msg)
+
+
+def test_oracle_matches_live_reference_fresh_seed(oracle, reference):
+    rng = np.random.default_rng(20260101)
+    R = orc.random_arr
+    for t in [orc.BOOL, orc.INT16, orc.INT64, orc.FLOAT]:
+        for ns in (orc.DROP, orc.EMIT_NULL):
+            v, f = R(rng, t, 777, 0.1, 5), R(rng, orc.BOOL, 777, 0.1, 9)
+            assert oracle.filter(v, f, ns).same(reference.filter(v, f, ns))
+            assert oracle.take_indices(f, ns).same(reference.take_indices(f, ns))
+        i = R(rng, orc.INT32, 300, 0.1, 1, lo=0, hi=776)
+        tv = R(rng, t, 777, 0.1, 5)
+        assert oracle.take(tv, i).same(reference.take(tv, i))
+        if t != orc.BOOL:
+            a = R(rng, t, 999, 0.1, 2, lo=-9, hi=9)
+            for order in (orc.ASC, orc.DESC):
+                assert np.array_equal(oracle.sort_indices(a, order), reference.sort_indices(a, order))
+    v = R(rng, orc.INT64, 4000, 0.02)
+    k = R(rng, orc.INT32, 4000, 0.02, lo=0, hi=99)
+    m = R(rng, orc.BOOL, 4000, 0.0)
+    for x, y in zip(oracle.filter_groupby_sum(v, k, m), reference.filter_groupby_sum(v, k, m)):
+        assert np.array_equal(x, y)
+
+
+def test_edge_cases(oracle):
+    e = orc.Arr(orc.INT32, np.zeros(0, np.int32))
+    f = orc.Arr(orc.BOOL, np.zeros(0, bool))
+    assert oracle.filter(e, f).length == 0
+    assert oracle.sort_indices(e).tolist() == []
+    assert oracle.take(orc.Arr(orc.INT32, [1, 2, 3]), orc.Arr(orc.UINT8, np.zeros(0, np.uint8))).length == 0
+    with pytest.raises(orc.StatusError) as ei:
+        oracle.take(orc.Arr(orc.INT32, [1, 2, 3]), orc.Arr(orc.INT64, [3]))
+    assert ei.value.code == orc.INDEX_ERROR and "Index 3 out of bounds" in ei.value.msg
+    with pytest.raises(orc.StatusError) as ei:
+        oracle.arith(orc.DIV, orc.Arr(orc.INT32, [1, 2]), orc.Arr(orc.INT32, [1, 0]))
+    assert ei.value.code == orc.INVALID and ei.value.msg == "divide by zero"
+    with pytest.raises(orc.StatusError) as ei:
+        oracle.arith(orc.ADD_C, orc.Arr(orc.INT8, [127]), orc.Arr(orc.INT8, [1]))
+    assert ei.value.msg == "overflow"
+    # unchecked add wraps (SafeSignedAdd), int MIN / -1 unchecked -> 0
+    assert oracle.arith(orc.ADD, orc.Arr(orc.INT8, [127]), orc.Arr(orc.INT8, [1])).values.tolist() == [-128]
+    assert oracle.arith(orc.DIV, orc.Arr(orc.INT8, [-128]), orc.Arr(orc.INT8, [-1])).values.tolist() == [0]

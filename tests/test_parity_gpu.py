@@ -1,0 +1,358 @@
+"""GPU: the HIP path (through the C ABI) against the oracle -- the reference's known-answer
+vectors, the committed outputs of the real reference, seeded random sweeps modelled on the
+reference's randomized tests, edge cases, and full-size (100 M row) properties.
+
+Bar: bit-exact for Filter / Take / sort_indices / compare / integer arithmetic and integer
+aggregates; float64 sums within |d| <= 1e-12 * sum|x| (GPU adds in a different order)."""
+import numpy as np
+import pytest
+
+import golden_io
+import literals
+import orc
+from orc import (Arr, BOOL, NUMERIC, INTS, FLOAT, DOUBLE, DROP, EMIT_NULL, ASC, DESC, INT8, UINT8, INT16, UINT16,
+                 INT32, UINT32, INT64, UINT64)
+
+pytestmark = pytest.mark.gpu
+R = orc.random_arr
+F64_RTOL = 1e-12
+
+
+def test_native_library_is_loaded(gpu):
+    """The tests must exercise the in-tree HIP library, not a fallback."""
+    maps = open("/proc/self/maps").read()
+    assert "libamdarrow.so" in maps
+
+
+def test_reference_literals(gpu):
+    fails = literals.run_all(gpu)
+    assert not fails, "\n".join(fails[:20])
+
+
+def test_committed_reference_outputs(gpu):
+    bad = []
+    for i, (op, params, arrs, want) in enumerate(golden_io.load_golden()):
+        got = golden_io.run_case(gpu, op, params, arrs)
+        if "error" in want or "error" in got:
+            ok = "error" in want and "error" in got and np.array_equal(got["error"], want["error"]) and \
+                np.array_equal(got["msg"], want["msg"])
+            msg = "error differs: %s vs %s" % (bytes(got.get("msg", b"")), bytes(want.get("msg", b"")))
+        else:
+            is_f64 = op in ("hash_aggregate", "filter_groupby_sum") and arrs[0].type_id in (FLOAT, DOUBLE)
+            ok, msg = golden_io.same_output(got, want, float_tol=is_f64)
+        if not ok:
+            bad.append("case %d %s %s: %s" % (i, op, params, msg))
+    assert not bad, "\n".join(bad[:20])
+
+
+@pytest.mark.parametrize("t", [BOOL] + NUMERIC)
+def test_filter_random_matrix(gpu, oracle, t):
+    """vector_selection_test.cc:1618-1636: null_prob x true_prob x mismatched slice offsets."""
+    rng = np.random.default_rng(0x0ff1ce + t)
+    for vnp in [0, .01, .1, .999, 1]:
+        for fnp in [0, .1, 1]:
+            for tp in [0, .1, .999, 1]:
+                for (vo, fo) in [(0, 0), (3, 4)]:
+                    v, f = R(rng, t, 5000, vnp, vo), R(rng, BOOL, 5000, fnp, fo, hi=tp)
+                    for ns in (DROP, EMIT_NULL):
+                        assert gpu.filter(v, f, ns).same(oracle.filter(v, f, ns)), (t, vnp, fnp, tp, vo, fo, ns)
+                        assert gpu.filter_output_size(f, ns) == oracle.filter_output_size(f, ns)
+
+
+def test_filter_unknown_and_zero_null_counts(gpu, oracle):
+    rng = np.random.default_rng(1)
+    for nc in (-1, 0):
+        v = R(rng, INT64, 9000, 0.0, 3, force_validity=True, null_count=nc)
+        f = R(rng, BOOL, 9000, 0.0, 5, force_validity=True, null_count=nc)
+        for ns in (DROP, EMIT_NULL):
+            assert gpu.filter(v, f, ns).same(oracle.filter(v, f, ns))
+
+
+def test_take_indices_random(gpu, oracle):
+    rng = np.random.default_rng(2)
+    for n in (6401, 65535, 65536, 70001):
+        for fnp in (0, 0.01, 1.0):
+            f = R(rng, BOOL, n, fnp, 7, hi=0.3)
+            for ns in (DROP, EMIT_NULL):
+                assert gpu.take_indices(f, ns).same(oracle.take_indices(f, ns)), (n, fnp, ns)
+
+
+@pytest.mark.parametrize("t", [BOOL, INT8, UINT16, INT32, FLOAT, INT64, DOUBLE])
+def test_take_random(gpu, oracle, t):
+    """vector_selection_test.cc:1658-1690: 8 index types, sliced, null probabilities."""
+    rng = np.random.default_rng(3 + t)
+    for it in INTS:
+        for vnp in (0, .2):
+            for inp in (0, .01, .25, 1):
+                nv = 100 if it in (UINT8, INT8) else 3000
+                v = R(rng, t, nv, vnp, 5)
+                i = R(rng, it, 1777, inp, 3, lo=0, hi=nv - 1)
+                assert gpu.take(v, i).same(oracle.take(v, i)), (t, it, vnp, inp)
+
+
+def test_take_bounds_errors(gpu, oracle):
+    v = Arr(INT32, np.arange(10))
+    for it, val in [(INT8, -1), (INT64, 10), (UINT64, 10), (INT16, 11), (UINT8, 200)]:
+        i = Arr(it, [0, 1, val, 2])
+        with pytest.raises(orc.StatusError) as eo:
+            oracle.take(v, i)
+        with pytest.raises(orc.StatusError) as eg:
+            gpu.take(v, i)
+        assert (eg.value.code, eg.value.msg) == (eo.value.code, eo.value.msg)
+    # a null slot holding an out-of-range index is not an error (int_util.cc:552)
+    i = Arr(INT32, [0, 99, 2], [True, False, True])
+    assert gpu.take(v, i).same(oracle.take(v, i))
+
+
+@pytest.mark.parametrize("t", NUMERIC)
+def test_sort_indices_random(gpu, oracle, t):
+    rng = np.random.default_rng(4 + t)
+    for npb in (0, .1, 1):
+        for order in (ASC, DESC):
+            for (lo, hi, n) in [(None, None, 20000), (0, 5, 30000), (-3, 3, 500), (None, None, 1)]:
+                a = R(rng, t, n, npb, 3, lo=lo, hi=hi)
+                if t in (FLOAT, DOUBLE) and n > 10:
+                    d = a.data.copy()
+                    for val in (np.nan, -0.0, 0.0, np.inf, -np.inf):
+                        d[rng.random(len(d)) < 0.03] = val
+                    a = Arr(t, d, a.valid, 3, n)
+                assert np.array_equal(gpu.sort_indices(a, order), oracle.sort_indices(a, order)), (t, npb, order, n)
+            chunks = [R(rng, t, m, npb, k, lo=-50, hi=50) for k, m in enumerate([100, 0, 3333, 1, 64, 5000, 0])]
+            assert np.array_equal(gpu.sort_indices(chunks, order), oracle.sort_indices(chunks, order))
+    if t not in (FLOAT, DOUBLE):
+        info = np.iinfo(orc.NP_OF[t])
+        a = Arr(t, rng.integers(info.min, info.max, 100000, endpoint=True, dtype=orc.NP_OF[t]))
+        for order in (ASC, DESC):
+            assert np.array_equal(gpu.sort_indices(a, order), oracle.sort_indices(a, order))
+
+
+@pytest.mark.parametrize("t", NUMERIC + [BOOL])
+def test_compare_and_arithmetic_random(gpu, oracle, t):
+    rng = np.random.default_rng(5 + t)
+    for (p1, p2) in [(0, 0), (.2, 0), (.2, .3), (1, 0)]:
+        a, b = R(rng, t, 3001, p1, 3, lo=-5, hi=5), R(rng, t, 3001, p2, 6, lo=-5, hi=5)
+        if t in (FLOAT, DOUBLE):
+            d = a.data.copy()
+            d[::17] = np.nan
+            a = Arr(t, d, a.valid, 3, 3001)
+        for op in range(6):
+            assert gpu.compare(op, a, b).same(oracle.compare(op, a, b))
+            assert gpu.compare(op, a, 1).same(oracle.compare(op, a, 1))
+            assert gpu.compare(op, 1, b).same(oracle.compare(op, 1, b))
+        if t == BOOL:
+            continue
+        for op in range(8):
+            for args in [(a, b), (a, 3), (3, b)]:
+                res = []
+                for api in (oracle, gpu):
+                    try:
+                        x = api.arith(op, *args)
+                        res.append((x.values.view(np.uint8).tolist(), x.validity_bits.tolist(), x.null_count, x.length))
+                    except orc.StatusError as e:
+                        res.append((e.code, e.msg))
+                assert res[0] == res[1], (t, op)
+
+
+@pytest.mark.parametrize("t", INTS)
+def test_integer_overflow_semantics(gpu, oracle, t):
+    info = np.iinfo(orc.NP_OF[t])
+    a = Arr(t, [info.max, info.min, 1, info.min], [1, 1, 1, 0])
+    b = Arr(t, [1, 1 if info.min == 0 else -1, 0, 3])
+    for op in range(8):
+        res = []
+        for api in (oracle, gpu):
+            try:
+                x = api.arith(op, a, b)
+                res.append((x.values.tolist(), x.validity().tolist(), x.null_count))
+            except orc.StatusError as e:
+                res.append((e.code, e.msg))
+        assert res[0] == res[1], (t, op, res)
+
+
+@pytest.mark.parametrize("kt", [BOOL, INT8, UINT16, INT32, INT64, FLOAT, DOUBLE, UINT64])
+def test_grouper_first_appearance_ids(gpu, oracle, kt):
+    rng = np.random.default_rng(6 + kt)
+    for knp in (0, .1):
+        batches = [[R(rng, kt, n, knp, off, lo=-20, hi=20)] for n, off in [(1000, 0), (5000, 3), (77, 1)]]
+        if kt in (FLOAT, DOUBLE):
+            nb = []
+            for b in batches:
+                d = b[0].data.copy()
+                d[:10] = [0.0, -0.0, np.nan, np.nan, 1, 1, -0.0, 0.0, 2, np.nan]
+                nb.append([Arr(kt, d, b[0].valid, b[0].offset, b[0].length)])
+            batches = nb
+        io, ngo, uo = oracle.group_ids(batches)
+        ig, ngg, ug = gpu.group_ids(batches)
+        assert ngo == ngg
+        for x, y in zip(io, ig):
+            assert np.array_equal(x, y)
+        (va, vb, nca), (vc, vd, ncb) = uo[0], ug[0]
+        assert np.array_equal(va.view(np.uint8) if va.dtype != bool else va, vc.view(np.uint8) if vc.dtype != bool else vc)
+        assert np.array_equal(vb, vd) and nca == ncb
+
+
+def test_grouper_two_key_columns(gpu, oracle):
+    rng = np.random.default_rng(7)
+    batches = [[R(rng, INT32, 2000, .1, 1, lo=0, hi=5), R(rng, INT8, 2000, .1, 2, lo=0, hi=3)]]
+    io, ngo, uo = oracle.group_ids(batches)
+    ig, ngg, ug = gpu.group_ids(batches)
+    assert ngo == ngg and np.array_equal(io[0], ig[0])
+    for (va, vb, _), (vc, vd, _) in zip(uo, ug):
+        assert np.array_equal(va, vc) and np.array_equal(vb, vd)
+
+
+@pytest.mark.parametrize("t", [BOOL] + NUMERIC)
+def test_hash_aggregates_random(gpu, oracle, t):
+    """hash_aggregate_test.cc:704-723 shape: random values, ids 0..~100, null probabilities.
+    (hash_count on a SLICED input is a reference defect -- see oracle.c -- so the sliced case
+    is checked against the oracle's logical semantics only.)"""
+    rng = np.random.default_rng(8 + t)
+    for vnp in (0, .3, 1):
+        for off in (0, 5):
+            n, ng = 30000, 500
+            v = R(rng, t, n, vnp, off)
+            ids = rng.integers(0, ng - 5, n).astype(np.uint32)
+            for fn in ("sum", "count", "mean"):
+                for mode in ((0, 1) if fn == "count" else (0,)):
+                    a = oracle.hash_aggregate(fn, v, ids, ng, mode)
+                    b = gpu.hash_aggregate(fn, v, ids, ng, mode)
+                    if a.values.dtype == np.float64:
+                        assert (a.length, a.null_count, a.has_validity) == (b.length, b.null_count, b.has_validity)
+                        assert np.array_equal(a.validity_bits, b.validity_bits)
+                        assert np.allclose(a.values, b.values, rtol=F64_RTOL, atol=1e-9)
+                    else:
+                        assert a.same(b), (fn, t, vnp, mode)
+
+
+@pytest.mark.parametrize("n", [50_000, 600_000])
+def test_filter_groupby_generic_and_partitioned_paths(gpu, oracle, n):
+    """n = 50k runs the generic (global table) path, n = 600k the partitioned LDS path."""
+    rng = np.random.default_rng(9)
+    for vt in (INT64, DOUBLE, INT32, UINT8):
+        for kt, hi in [(INT32, 30000), (INT32, 200), (INT8, 100), (UINT16, 60000), (INT64, 1000)]:
+            for knp in (0, .05):
+                v, k = R(rng, vt, n, .01, 2), R(rng, kt, n, knp, 1, lo=0, hi=hi)
+                m = R(rng, BOOL, n, 0.1, 3)
+                for x, y in zip(oracle.filter_groupby_sum(v, k, m), gpu.filter_groupby_sum(v, k, m)):
+                    if x.dtype == np.float64:
+                        assert x.shape == y.shape and np.allclose(x, y, rtol=F64_RTOL)
+                    else:
+                        assert np.array_equal(x, y), (vt, kt, hi, knp)
+
+
+def test_filter_groupby_partition_overflow_falls_back(gpu, oracle):
+    """3 M distinct keys overflow the per-partition LDS tables: the result must still be exact."""
+    rng = np.random.default_rng(10)
+    n = 3_000_000
+    v = R(rng, INT64, n, 0, 0)
+    k = Arr(INT32, rng.permutation(n).astype(np.int32))
+    m = Arr(BOOL, np.ones(n, bool))
+    for x, y in zip(oracle.filter_groupby_sum(v, k, m), gpu.filter_groupby_sum(v, k, m)):
+        assert np.array_equal(x, y)
+
+
+def test_empty_and_ragged_inputs(gpu, oracle):
+    e, f = Arr(INT32, np.zeros(0, np.int32)), Arr(BOOL, np.zeros(0, bool))
+    assert gpu.filter(e, f).length == 0
+    assert gpu.sort_indices(e).tolist() == []
+    assert gpu.take(Arr(INT32, [1, 2, 3]), Arr(UINT8, np.zeros(0, np.uint8))).length == 0
+    with pytest.raises(orc.StatusError) as ei:
+        gpu.filter(Arr(INT32, [7, 8, 9]), f)
+    assert ei.value.code == orc.INVALID
+    rng = np.random.default_rng(11)
+    for n in (1, 63, 64, 65, 4095, 4096, 4097, 8191, 12289):
+        v, fl = R(rng, INT64, n, .1, 1), R(rng, BOOL, n, .1, 2)
+        for ns in (DROP, EMIT_NULL):
+            assert gpu.filter(v, fl, ns).same(oracle.filter(v, fl, ns)), n
+        assert np.array_equal(gpu.sort_indices(v), oracle.sort_indices(v))
+        assert gpu.compare(orc.GT, v, 0).same(oracle.compare(orc.GT, v, 0))
+
+
+# ---- full-size properties (BASELINE.json sizes; the oracle would take minutes there) ---------------
+N_FULL = 100_000_000
+
+
+@pytest.fixture(scope="module")
+def full(gpu):
+    import torch
+    from arrow1_amd import device
+    import bench
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x0ff1ce)
+    vals = torch.randint(-100, 101, (N_FULL,), dtype=torch.int64, device="cuda", generator=g)
+    keys = torch.randint(0, 1_000_000, (N_FULL,), dtype=torch.int32, device="cuda", generator=g)
+    valid = bench.device_bitmap(N_FULL, 0.99, g, "cuda")
+    mask = bench.device_bitmap(N_FULL, 0.5, g, "cuda")
+    return dict(vals=vals, keys=keys, valid=valid, mask=mask,
+                values=device.DeviceArray(orc.INT64, vals.view(torch.uint8), valid, N_FULL, 0, -1),
+                keys_arr=device.DeviceArray(orc.INT32, keys.view(torch.uint8), None, N_FULL),
+                mask_arr=device.DeviceArray(orc.BOOL, mask, None, N_FULL))
+
+
+def _bits(buf, n):
+    import torch
+    w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=buf.device)
+    return ((buf[:(n + 7) // 8].unsqueeze(1) & w) != 0).reshape(-1)[:n]
+
+
+def test_full_size_filter_take_roundtrip(gpu, full):
+    """Filter == Take(GetTakeIndices(mask)) at 100 M rows (the reference's ValidateFilter identity),
+    and the selected multiset is what torch's boolean indexing gives."""
+    import torch
+    from arrow1_amd import compute
+    out = compute.filter(gpu.ctx, full["values"], full["mask_arr"])
+    sel = _bits(full["mask"], N_FULL)
+    assert out.length == int(sel.sum())
+    got = out.values[:out.length * 8].view(torch.int64)
+    assert torch.equal(got, full["vals"][sel])
+    assert torch.equal(_bits(out.validity, out.length), _bits(full["valid"], N_FULL)[sel])
+    idx = compute.take_indices(gpu.ctx, full["mask_arr"])
+    assert idx.length == out.length
+    t = compute.take(gpu.ctx, full["values"], idx)
+    assert torch.equal(t.values[:t.length * 8].view(torch.int64) * _bits(t.validity, t.length),
+                       got * _bits(out.validity, out.length))
+    assert t.null_count == int((~_bits(out.validity, out.length)).sum())
+
+
+def test_full_size_groupby_conservation(gpu, full):
+    """Sum of group sums == sum of selected valid values, sum of counts == their number, keys
+    distinct, first rows strictly increasing (first-appearance order) -- exact in int64."""
+    import torch
+    from arrow1_amd import compute
+    r = compute.filter_groupby(gpu.ctx, full["values"], full["keys_arr"], full["mask_arr"], group_capacity=1 << 21)
+    sel = _bits(full["mask"], N_FULL)
+    ok = sel & _bits(full["valid"], N_FULL)
+    G = r.num_groups
+    sums = r.sums[:G * 8].view(torch.int64)
+    counts = r.counts[:G * 8].view(torch.int64)
+    keys = r.keys[:G * 4].view(torch.int32)
+    first = r.first_rows[:G * 4].view(torch.int32).to(torch.int64)
+    assert int(sums.sum()) == int(full["vals"][ok].sum())
+    assert int(counts.sum()) == int(ok.sum())
+    assert G == int(torch.unique(full["keys"][sel]).numel())
+    assert int(torch.unique(keys).numel()) == G
+    assert bool((first[1:] > first[:-1]).all())
+    assert torch.equal(full["keys"][first], keys)
+    # spot-check 1000 groups exactly
+    pick = torch.randint(0, G, (1000,), device="cuda")
+    for g in pick[:50].tolist():
+        rows = (full["keys"] == int(keys[g])) & ok
+        assert int(sums[g]) == int(full["vals"][rows].sum()) and int(counts[g]) == int(rows.sum())
+
+
+def test_full_size_sort_is_sorted_stable_permutation(gpu, full):
+    import torch
+    from arrow1_amd import compute, device
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    v = torch.randint(-2**63, 2**63 - 1, (N_FULL,), dtype=torch.int64, device="cuda", generator=g)
+    v[::1000] = v[0]  # ties
+    arr = device.DeviceArray(orc.UINT64, v.view(torch.uint8), None, N_FULL)
+    idx = compute.sort_indices(gpu.ctx, arr).values[:N_FULL * 8].view(torch.int64)
+    sv = v[idx] ^ (-2**63)  # unsigned order
+    assert bool((sv[1:] >= sv[:-1]).all())
+    ties = sv[1:] == sv[:-1]
+    assert bool((idx[1:][ties] > idx[:-1][ties]).all())  # stable
+    seen = torch.zeros(N_FULL, dtype=torch.bool, device="cuda")
+    seen[idx] = True
+    assert bool(seen.all())  # a permutation
