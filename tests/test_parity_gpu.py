@@ -356,3 +356,61 @@ def test_full_size_sort_is_sorted_stable_permutation(gpu, full):
     seen = torch.zeros(N_FULL, dtype=torch.bool, device="cuda")
     seen[idx] = True
     assert bool(seen.all())  # a permutation
+
+
+def test_sharded_groupby_merge_on_gpu(gpu, oracle):
+    """The multi-GPU merge path on one GPU: two row-range shards are run one after the other,
+    their partial tables concatenated as the all-gather would, and re-aggregated by the HIP
+    kernels; plus the RCCL collectives themselves on a 1-rank group."""
+    import os
+    import torch
+    import torch.distributed as tdist
+    from arrow1_amd import compute, device, dist as adist
+    rng = np.random.default_rng(12)
+    n = 700_000
+    for vt, knp in ((INT64, 0.0), (INT64, 0.05), (DOUBLE, 0.0)):
+        v, k, m = R(rng, vt, n, .01, 0), R(rng, INT32, n, knp, 0, lo=0, hi=40000), R(rng, BOOL, n, 0.0, 0)
+        es, ec, ek, ekv = oracle.filter_groupby_sum(v, k, m)
+        merger = adist.GroupByMerger(gpu.ctx, 0, 2, key_type=INT32, value_type=vt, group_capacity=1 << 17)
+        half = 350_016  # multiple of 64
+        parts = []
+        for lo, hi in ((0, half), (half, n)):
+            sl = lambda a: Arr(a.type_id, a.data[lo:hi], None if a.valid is None else a.valid[lo:hi])  # noqa: E731
+            up = lambda a: device.DeviceArray.from_numpy(a.type_id, a.data, a.valid, 0, len(a.data), None)  # noqa: E731
+            bufs = compute.GroupByBuffers("cuda", 1 << 17, INT32)
+            r = compute.filter_groupby(gpu.ctx, up(sl(v)), up(sl(k)), up(sl(m)), buffers=bufs)
+            parts.append(merger._partial_of(r))
+        gmax = max(p.num_groups for p in parts)
+
+        def pad(t):
+            out = torch.zeros(gmax, dtype=t.dtype, device="cuda")
+            out[:t.shape[0]] = t
+            return out
+        cat = lambda f: torch.cat([pad(f(p)) for p in parts])  # noqa: E731
+        live = torch.cat([torch.arange(gmax, device="cuda") < p.num_groups for p in parts])
+        r = merger._local_merge(cat(lambda p: p.keys), cat(lambda p: p.key_valid.to(torch.uint8)).bool(),
+                                cat(lambda p: p.sums), cat(lambda p: p.counts), live)
+        G = r.num_groups
+        assert G == len(es)
+        got_s = r.sums_numpy()
+        got_c = r.counts[:G * 8].cpu().numpy().view(np.int64)
+        if vt == DOUBLE:
+            assert np.allclose(got_s, es, rtol=F64_RTOL)
+        else:
+            assert np.array_equal(got_s, es)
+        assert np.array_equal(got_c, ec)
+        assert np.array_equal(r.key_validity_numpy(), ekv)
+        assert np.array_equal(r.keys_numpy()[ekv], ek[ekv])
+    # the collectives over RCCL (1-rank group): merge_partials must be the identity protocol
+    if not tdist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29733")
+        tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    merger1 = adist.GroupByMerger(gpu.ctx, 0, 1, key_type=INT32, value_type=INT64, group_capacity=1 << 17)
+    v, k, m = R(rng, INT64, n, .01, 0), R(rng, INT32, n, 0, 0, lo=0, hi=40000), R(rng, BOOL, n, 0.0, 0)
+    es, ec, ek, ekv = oracle.filter_groupby_sum(v, k, m)
+    up = lambda a: device.DeviceArray.from_numpy(a.type_id, a.data, a.valid, 0, len(a.data), None)  # noqa: E731
+    r = compute.filter_groupby(gpu.ctx, up(v), up(k), up(m), buffers=compute.GroupByBuffers("cuda", 1 << 17, INT32))
+    merged = adist.merge_partials(merger1._partial_of(r), merger1._local_merge, 1)
+    assert np.array_equal(merged.sums_numpy(), es) and np.array_equal(merged.keys_numpy(), ek)
+    tdist.destroy_process_group()
