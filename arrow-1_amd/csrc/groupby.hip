@@ -21,6 +21,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -37,6 +38,16 @@ __host__ __device__ __forceinline__ uint64_t Fmix64(uint64_t h) {
 }
 __host__ __device__ __forceinline__ uint64_t Fmix64Inv(uint64_t h) {
   h ^= h >> 33; h *= 0x9cb4b2f8129337dbULL; h ^= h >> 33; h *= 0x4f74430c22a54005ULL; h ^= h >> 33;
+  return h;
+}
+
+// 32-bit murmur3 finaliser: also a bijection; used where keys fit 32 bits (cheaper than fmix64).
+__host__ __device__ __forceinline__ uint32_t Fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+__host__ __device__ __forceinline__ uint32_t Fmix32Inv(uint32_t h) {
+  h ^= h >> 16; h *= 0x7ed1b41du; h ^= h >> 13; h ^= h >> 26; h *= 0xa5cb9243u; h ^= h >> 16;
   return h;
 }
 
@@ -469,21 +480,56 @@ __device__ __forceinline__ uint64_t FastKey(const FastArgs& a, int64_t row, bool
   return *is_null ? (uint64_t(1) << a.k_bits) : LoadBitsOfWidth(a.k_data, a.k_off + row, a.k_bits);
 }
 
+// Selection mask of the 64 consecutive rows starting at `row0` (one word per wave, every
+// lane loads the same address): bit i set <=> row0 + i is selected and < hi.
+__device__ __forceinline__ uint64_t FastMaskWord(const FastArgs& a, int64_t row0, int64_t hi) {
+  const int64_t left = hi - row0;
+  if (left <= 0) return 0;
+  const int nbits = left >= 64 ? 64 : static_cast<int>(left);
+  uint64_t w = nbits < 64 ? (uint64_t(1) << nbits) - 1 : ~uint64_t(0);
+  if (a.m_data) {
+    w = LoadBits64(a.m_data, a.m_off + row0, nbits);
+    if (a.m_valid) w &= LoadBits64(a.m_valid, a.m_off + row0, nbits);
+  }
+  return w;
+}
+__device__ __forceinline__ uint64_t FastKeyBits(const FastArgs& a, int64_t row) {
+  switch (a.k_bits) {
+    case 8: return reinterpret_cast<const uint8_t*>(a.k_data)[a.k_off + row];
+    case 16: return reinterpret_cast<const uint16_t*>(a.k_data)[a.k_off + row];
+    default: return reinterpret_cast<const uint32_t*>(a.k_data)[a.k_off + row];
+  }
+}
+
 // hist[p * nblocks + b] = selected rows of row-range b that hash to partition p
 __global__ __launch_bounds__(kPartThreads) void k_part_hist(FastArgs a, uint32_t* hist) {
   __shared__ unsigned int s_cnt[kP];
-  if (threadIdx.x < kP) s_cnt[threadIdx.x] = 0;
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid < kP) s_cnt[tid] = 0;
   __syncthreads();
   const int64_t lo = int64_t(blockIdx.x) * a.rows_per_block;
   const int64_t hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
-  for (int64_t row = lo + threadIdx.x; row < hi; row += kPartThreads) {
-    if (!FastSelected(a, row)) continue;
-    bool kn;
-    const uint64_t h = Fmix64(FastKey(a, row, &kn));
-    atomicAdd(&s_cnt[h >> (64 - kPBits)], 1u);
+  constexpr int kIters = kPartRows / kPartThreads;  // 8 independent loads in flight per thread
+  for (int64_t tile0 = lo; tile0 < hi; tile0 += kPartRows) {
+    uint64_t x[kIters];
+    bool sel[kIters];
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      const int64_t row = tile0 + j * kPartThreads + tid;
+      const uint64_t w = FastMaskWord(a, row - lane, hi);
+      sel[j] = (w >> lane) & 1;
+      x[j] = 0;
+      if (sel[j]) {
+        const bool kn = a.k_valid && !GetBit(a.k_valid, a.k_off + row);
+        x[j] = kn ? (uint64_t(1) << a.k_bits) : FastKeyBits(a, row);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kIters; ++j)
+      if (sel[j]) atomicAdd(&s_cnt[Fmix64(x[j]) >> (64 - kPBits)], 1u);
   }
   __syncthreads();
-  if (threadIdx.x < kP) hist[int64_t(threadIdx.x) * a.nblocks + blockIdx.x] = s_cnt[threadIdx.x];
+  if (tid < kP) hist[int64_t(tid) * a.nblocks + blockIdx.x] = s_cnt[tid];
 }
 
 // Scatter the selected rows of row-range b into the partition regions.  Per 8192-row tile the
@@ -506,25 +552,33 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(FastArgs a, const
     uint32_t rx[kIters], rflags[kIters], rrank[kIters];
     uint64_t rval[kIters];
     int rpart[kIters];
+    // phase 1a: issue every load of the tile (mask word, key, value) before anything waits
 #pragma unroll
     for (int j = 0; j < kIters; ++j) {
       const int64_t row = tile0 + j * kPartThreads + tid;
+      const uint64_t w = FastMaskWord(a, row - lane, hi);
       rpart[j] = -1;
-      if (row < hi && FastSelected(a, row)) {
-        bool kn;
-        const uint64_t x = FastKey(a, row, &kn);
-        const int p = static_cast<int>(Fmix64(x) >> (64 - kPBits));
-        rpart[j] = p;
-        rx[j] = static_cast<uint32_t>(x);
+      rx[j] = 0; rflags[j] = 0; rval[j] = 0;
+      if ((w >> lane) & 1) {
+        rpart[j] = 0;
+        const bool kn = a.k_valid && !GetBit(a.k_valid, a.k_off + row);
+        rx[j] = kn ? 0u : static_cast<uint32_t>(FastKeyBits(a, row));
         uint32_t f = static_cast<uint32_t>(row) | (kn ? kRecKeyNull : 0u);
-        uint64_t bits = 0;
         if (a.has_values && (!a.v.valid || GetBit(a.v.valid, a.v.off + row))) {
           bool is_double;
-          bits = LoadAccum(a.v, row, &is_double);
+          rval[j] = LoadAccum(a.v, row, &is_double);
           f |= kRecValValid;
         }
         rflags[j] = f;
-        rval[j] = bits;
+      }
+    }
+    // phase 1b: partition + rank inside the tile (LDS atomics)
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      if (rpart[j] >= 0) {
+        const uint64_t x = (rflags[j] & kRecKeyNull) ? (uint64_t(1) << a.k_bits) : uint64_t(rx[j]);
+        const int p = static_cast<int>(Fmix64(x) >> (64 - kPBits));
+        rpart[j] = p;
         rrank[j] = atomicAdd(&s_cnt[p], 1u);
       }
     }
@@ -583,30 +637,43 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate(const uint4* re
   const int64_t lo = offsets[int64_t(p) * nblocks];
   const int64_t hi = offsets[int64_t(p + 1) * nblocks];  // hist carries one extra zero entry at the end
   bool failed = false;
-  for (int64_t i = lo + tid; i < hi; i += kPartThreads) {
-    const uint4 r = records[i];
-    const uint64_t x = (r.y & kRecKeyNull) ? (uint64_t(1) << k_bits) : uint64_t(r.x);
-    const uint64_t h = Fmix64(x);
-    uint32_t slot = static_cast<uint32_t>(h) & (kSlots - 1);
-    bool found = false;
-    for (int probes = 0; probes < kSlots; ++probes) {
-      unsigned long long cur = s_h[slot];
-      if (cur == h) { found = true; break; }
-      if (cur == kEmpty) {
-        if (s_groups >= kSlotLimit) break;
-        cur = atomicCAS(&s_h[slot], static_cast<unsigned long long>(kEmpty), static_cast<unsigned long long>(h));
-        if (cur == kEmpty) { atomicAdd(&s_groups, 1u); found = true; break; }
-        if (cur == h) { found = true; break; }
-      }
-      slot = (slot + 1) & (kSlots - 1);
+  constexpr int kUnroll = 4;
+  for (int64_t i0 = lo + tid; i0 < hi; i0 += int64_t(kUnroll) * kPartThreads) {
+    uint4 rec[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t i = i0 + int64_t(u) * kPartThreads;
+      rec[u] = make_uint4(0, 0, 0, 0);
+      if (i < hi) rec[u] = records[i];
     }
-    if (!found) { failed = true; continue; }
-    atomicMin(&s_first[slot], r.y & kRecRowMask);
-    if (r.y & kRecValValid) {
-      const unsigned long long bits = (static_cast<unsigned long long>(r.w) << 32) | r.z;
-      if (acc_double) atomicAdd(reinterpret_cast<double*>(&s_sum[slot]), __longlong_as_double(bits));
-      else atomicAdd(&s_sum[slot], bits);
-      atomicAdd(&s_cnt[slot], 1u);
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t i = i0 + int64_t(u) * kPartThreads;
+      if (i >= hi) break;
+      const uint4 r = rec[u];
+      const uint64_t x = (r.y & kRecKeyNull) ? (uint64_t(1) << k_bits) : uint64_t(r.x);
+      const uint64_t h = Fmix64(x);
+      uint32_t slot = static_cast<uint32_t>(h) & (kSlots - 1);
+      bool found = false;
+      for (int probes = 0; probes < kSlots; ++probes) {
+        unsigned long long cur = s_h[slot];
+        if (cur == h) { found = true; break; }
+        if (cur == kEmpty) {
+          if (s_groups >= kSlotLimit) break;
+          cur = atomicCAS(&s_h[slot], static_cast<unsigned long long>(kEmpty), static_cast<unsigned long long>(h));
+          if (cur == kEmpty) { atomicAdd(&s_groups, 1u); found = true; break; }
+          if (cur == h) { found = true; break; }
+        }
+        slot = (slot + 1) & (kSlots - 1);
+      }
+      if (!found) { failed = true; continue; }
+      atomicMin(&s_first[slot], r.y & kRecRowMask);
+      if (r.y & kRecValValid) {
+        const unsigned long long bits = (static_cast<unsigned long long>(r.w) << 32) | r.z;
+        if (acc_double) atomicAdd(reinterpret_cast<double*>(&s_sum[slot]), __longlong_as_double(bits));
+        else atomicAdd(&s_sum[slot], bits);
+        atomicAdd(&s_cnt[slot], 1u);
+      }
     }
   }
   if (failed) *overflow = 1;
@@ -619,6 +686,205 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate(const uint4* re
     t.counts[g0 + s] = s_cnt[s];
   }
   if (p == 0 && tid < 2) {  // the two special slots stay empty on this path
+    const int64_t T = int64_t(kP) * kSlots;
+    t.hkeys[T + tid] = kEmpty; t.first[T + tid] = kNoRow; t.sums[T + tid] = 0; t.counts[T + tid] = 0;
+  }
+}
+
+
+// ==== fast path, one pass: private (row-range block, partition) regions ==========================
+// Each scatter workgroup owns, for every partition, a fixed-capacity region; a record goes to
+// region[p][b][cursor++] with the cursor kept in LDS, so there is no histogram pass and no
+// global scan.  Hash partitioning makes the per-region fill Poisson-like, so a capacity of
+// mean*1.25 + 8*sqrt(mean) + 16 overflows only on heavily skewed keys -- then `overflow` is
+// raised and the exact two-pass variant above (k_part_hist / k_part_scatter) is used instead.
+// Partial 128-byte lines of a region are completed by later rows of the same workgroup while
+// the line is still in this XCD's L2.
+constexpr int kDThreads = kPartThreads;  // 1024
+constexpr int kDRows = kPartRows;         // 8192 rows per tile: 8 per thread
+
+__device__ __forceinline__ uint32_t FastPartition32(uint32_t x, bool is_null) {
+  return is_null ? 0u : (Fmix32(x) >> (32 - kPBits));
+}
+
+struct TileRegs {
+  uint32_t x[kDRows / kDThreads], flags[kDRows / kDThreads];
+  uint64_t val[kDRows / kDThreads];
+  bool sel[kDRows / kDThreads];
+};
+// Issue every load of one tile (mask word, key, value); nothing here waits on memory.
+__device__ __forceinline__ void LoadTile(const FastArgs& a, int64_t tile0, int64_t hi, int tid, int lane, TileRegs* t) {
+#pragma unroll
+  for (int j = 0; j < kDRows / kDThreads; ++j) {
+    const int64_t row = tile0 + j * kDThreads + tid;
+    const uint64_t w = FastMaskWord(a, row - lane, hi);
+    t->sel[j] = (w >> lane) & 1;
+    t->x[j] = 0; t->flags[j] = 0; t->val[j] = 0;
+    if (t->sel[j]) {
+      const bool kn = a.k_valid && !GetBit(a.k_valid, a.k_off + row);
+      t->x[j] = kn ? 0u : static_cast<uint32_t>(FastKeyBits(a, row));
+      uint32_t f = static_cast<uint32_t>(row) | (kn ? kRecKeyNull : 0u);
+      if (a.has_values && (!a.v.valid || GetBit(a.v.valid, a.v.off + row))) {
+        bool is_double;
+        t->val[j] = LoadAccum(a.v, row, &is_double);
+        f |= kRecValValid;
+      }
+      t->flags[j] = f;
+    }
+  }
+}
+
+// Per 8192-row tile: rank records per partition with LDS atomics, stage them in LDS grouped by
+// partition, then copy every partition's run to the tail of this workgroup's private region.
+// The loads of tile i+1 are issued before the copy-out of tile i, so HBM latency hides behind it.
+__global__ __launch_bounds__(kDThreads) void k_part_scatter_direct(FastArgs a, int64_t cap, uint4* regions,
+                                                                   uint32_t* counts, unsigned int* overflow) {
+  __shared__ unsigned int s_cnt[2][kP];
+  __shared__ uint32_t s_off[kP];
+  __shared__ uint32_t s_cur[kP];
+  __shared__ uint32_t s_scan[8];
+  __shared__ uint4 s_rec[kDRows];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int kIters = kDRows / kDThreads;
+  if (tid < kP) { s_cnt[0][tid] = 0; s_cnt[1][tid] = 0; s_cur[tid] = 0; }
+  __syncthreads();
+  const int64_t lo = int64_t(blockIdx.x) * a.rows_per_block;
+  const int64_t hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
+  bool over = false;
+  TileRegs t;
+  LoadTile(a, lo, hi, tid, lane, &t);
+  int buf = 0;
+  for (int64_t tile0 = lo; tile0 < hi; tile0 += kDRows, buf ^= 1) {
+    uint32_t rrank[kIters];
+    uint32_t rpart[kIters];
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      if (t.sel[j]) {
+        rpart[j] = FastPartition32(t.x[j], t.flags[j] & kRecKeyNull);
+        rrank[j] = atomicAdd(&s_cnt[buf][rpart[j]], 1u);
+      }
+    }
+    __syncthreads();
+    uint32_t c = 0, incl = 0;
+    if (tid < kP) {
+      c = s_cnt[buf][tid];
+      incl = WaveInclusiveScan(c);
+      if (lane == 63) s_scan[wave] = incl;
+    }
+    __syncthreads();
+    if (tid < kP) {
+      uint32_t woff = 0;
+      for (int w = 0; w < wave; ++w) woff += s_scan[w];
+      s_off[tid] = woff + incl - c;
+      s_cnt[buf ^ 1][tid] = 0;  // the other counter set is idle until the next tile
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      if (t.sel[j]) {
+        uint4 r;
+        r.x = t.x[j]; r.y = t.flags[j];
+        r.z = static_cast<uint32_t>(t.val[j]); r.w = static_cast<uint32_t>(t.val[j] >> 32);
+        s_rec[s_off[rpart[j]] + rrank[j]] = r;
+      }
+    }
+    __syncthreads();
+    if (tile0 + kDRows < hi) LoadTile(a, tile0 + kDRows, hi, tid, lane, &t);  // in flight during the copy-out
+    const uint32_t total = s_off[kP - 1] + s_cnt[buf][kP - 1];
+    for (uint32_t i = tid; i < total; i += kDThreads) {
+      const uint4 r = s_rec[i];
+      const uint32_t p = FastPartition32(r.x, r.y & kRecKeyNull);
+      const uint32_t idx = s_cur[p] + (i - s_off[p]);
+      if (idx < cap) regions[(int64_t(p) * a.nblocks + blockIdx.x) * cap + idx] = r;
+      else over = true;
+    }
+    __syncthreads();
+    if (tid < kP) s_cur[tid] += s_cnt[buf][tid];
+  }
+  if (over) *overflow = 1;
+  __syncthreads();
+  if (tid < kP) {
+    const uint32_t c = s_cur[tid];
+    counts[int64_t(tid) * a.nblocks + blockIdx.x] = c < cap ? c : static_cast<uint32_t>(cap);
+  }
+}
+
+// One workgroup per partition; every wave walks whole regions (segments) of the partition.
+__global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const uint4* regions, const uint32_t* counts,
+                                                                        int nblocks, int64_t cap, int k_bits,
+                                                                        int acc_double, GroupTable t,
+                                                                        unsigned int* overflow) {
+  constexpr unsigned long long kOcc = 1ull << 33, kNullTag = 1ull << 32;
+  __shared__ unsigned long long s_tag[kSlots];   // 0 = free, else kOcc | null<<32 | fmix32(x)
+  __shared__ unsigned long long s_sum[kSlots];
+  __shared__ uint32_t s_first[kSlots];
+  __shared__ unsigned int s_cnt[kSlots];
+  __shared__ unsigned int s_groups;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = blockIdx.x;
+  for (int s = tid; s < kSlots; s += kPartThreads) { s_tag[s] = 0; s_sum[s] = 0; s_first[s] = kNoRow; s_cnt[s] = 0; }
+  if (tid == 0) s_groups = 0;
+  __syncthreads();
+  bool failed = false;
+  constexpr int kUnroll = 4;
+  for (int b = wave; b < nblocks; b += kPartThreads / 64) {
+    const uint32_t cnt = counts[int64_t(p) * nblocks + b];
+    const uint4* seg = regions + (int64_t(p) * nblocks + b) * cap;
+    for (uint32_t i0 = lane; i0 < cnt; i0 += 64 * kUnroll) {
+      uint4 rec[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const uint32_t i = i0 + 64 * u;
+        rec[u] = make_uint4(0, 0, 0, 0);
+        if (i < cnt) rec[u] = seg[i];
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        if (i0 + 64 * u >= cnt) break;
+        const uint4 r = rec[u];
+        const bool kn = r.y & kRecKeyNull;
+        const uint32_t h = kn ? 0u : Fmix32(r.x);
+        const unsigned long long tag = kOcc | (kn ? kNullTag : 0ull) | h;
+        uint32_t slot = h & (kSlots - 1);
+        bool found = false;
+        for (int probes = 0; probes < kSlots; ++probes) {
+          unsigned long long cur = s_tag[slot];
+          if (cur == tag) { found = true; break; }
+          if (cur == 0) {
+            if (s_groups >= kSlotLimit) break;
+            cur = atomicCAS(&s_tag[slot], 0ull, tag);
+            if (cur == 0) { atomicAdd(&s_groups, 1u); found = true; break; }
+            if (cur == tag) { found = true; break; }
+          }
+          slot = (slot + 1) & (kSlots - 1);
+        }
+        if (!found) { failed = true; continue; }
+        atomicMin(&s_first[slot], r.y & kRecRowMask);
+        if (r.y & kRecValValid) {
+          const unsigned long long bits = (static_cast<unsigned long long>(r.w) << 32) | r.z;
+          if (acc_double) atomicAdd(reinterpret_cast<double*>(&s_sum[slot]), __longlong_as_double(bits));
+          else atomicAdd(&s_sum[slot], bits);
+          atomicAdd(&s_cnt[slot], 1u);
+        }
+      }
+    }
+  }
+  if (failed) *overflow = 1;
+  __syncthreads();
+  const int64_t g0 = int64_t(p) * kSlots;
+  for (int s = tid; s < kSlots; s += kPartThreads) {
+    const unsigned long long tag = s_tag[s];
+    unsigned long long hk = kEmpty;
+    if (tag) {
+      const uint64_t x = (tag & kNullTag) ? (uint64_t(1) << k_bits) : uint64_t(Fmix32Inv(static_cast<uint32_t>(tag)));
+      hk = Fmix64(x);  // the shared numbering / emit kernels speak fmix64
+    }
+    t.hkeys[g0 + s] = hk;
+    t.first[g0 + s] = s_first[s];
+    t.sums[g0 + s] = s_sum[s];
+    t.counts[g0 + s] = s_cnt[s];
+  }
+  if (p == 0 && tid < 2) {
     const int64_t T = int64_t(kP) * kSlots;
     t.hkeys[T + tid] = kEmpty; t.first[T + tid] = kNoRow; t.sums[T + tid] = 0; t.counts[T + tid] = 0;
   }
@@ -849,13 +1115,17 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
   const uint8_t* m_valid = mask ? mask->validity : nullptr;
   const int64_t m_off = mask ? mask->offset : 0;
 
-  bool fast = ks.total_bits <= 32 && n >= (int64_t(1) << 18) && n < (int64_t(1) << 30) &&
-              getenv("AMDARROW_GROUPBY_GENERIC") == nullptr;
+  // path 2: one-pass partition into private regions; 1: exact two-pass partition; 0: generic
+  // global table.  Each falls back to the next when its capacity assumption fails.
+  const bool fast_ok = ks.total_bits <= 32 && n >= (int64_t(1) << 18) && n < (int64_t(1) << 30);
+  int path = fast_ok ? 2 : 0;
+  if (const char* env = getenv("AMDARROW_GROUPBY_PATH")) path = std::min(path, atoi(env));
   GroupTable t{};
   RankMem r{};
   unsigned long long* gx = nullptr;
   unsigned int* misc = nullptr;  // [0] overflow, [2..3] null_count, [4] wide_null_id
-  for (int attempt = 0; attempt < 2; ++attempt) {
+  for (;; --path) {
+    const bool fast = path > 0;
     const uint64_t T = fast ? uint64_t(kP) * kSlots
                             : NextPow2(2 * static_cast<uint64_t>(group_capacity < n ? group_capacity : n));
     Carver c;
@@ -865,14 +1135,27 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
     CarveRank(&c, n, roff);
     const size_t off_gx = c.Take(8 * static_cast<size_t>(group_capacity));
     const size_t off_misc = c.Take(256);
-    // fast path extras
-    const int nblocks = fast ? static_cast<int>(std::min<int64_t>(ctx->num_cus, (n + kPartRows - 1) / kPartRows)) : 0;
-    const int64_t hist_n = fast ? int64_t(kP) * nblocks + 1 : 0;
+    // partition scratch
+    int nblocks = 0;
+    int64_t rows_per_block = 0, cap = 0, hist_n = 0;
+    if (path == 2) {
+      nblocks = static_cast<int>(std::min<int64_t>(ctx->num_cus, (n + kDRows - 1) / kDRows));
+      rows_per_block = (((n + nblocks - 1) / nblocks + kDRows - 1) / kDRows) * kDRows;
+      const double mean = static_cast<double>(rows_per_block) / kP;
+      cap = static_cast<int64_t>(mean * 1.25 + 8.0 * std::sqrt(mean) + 16.0);
+      hist_n = int64_t(kP) * nblocks;
+    } else if (path == 1) {
+      nblocks = static_cast<int>(std::min<int64_t>(ctx->num_cus, (n + kPartRows - 1) / kPartRows));
+      rows_per_block = (((n + nblocks - 1) / nblocks + kPartRows - 1) / kPartRows) * kPartRows;
+      hist_n = int64_t(kP) * nblocks + 1;
+    }
     const int64_t scan_nb = (hist_n + 2047) / 2048;
     const size_t off_hist = c.Take(4 * hist_n);
     const size_t off_sums = c.Take(4 * scan_nb);
     const size_t off_sumoff = c.Take(8 * (scan_nb + 1));
-    const size_t off_rec = c.Take(fast ? 16 * static_cast<size_t>(n) : 0);
+    const size_t rec_bytes = path == 2 ? 16 * static_cast<size_t>(cap) * kP * nblocks
+                           : path == 1 ? 16 * static_cast<size_t>(n) : 0;
+    const size_t off_rec = c.Take(rec_bytes);
     void* base;
     AA_TRY(Scratch(ctx, c.off, &base));
     char* b = static_cast<char*>(base);
@@ -892,17 +1175,26 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
       fa.k_data = keys->values; fa.k_valid = keys->validity; fa.k_off = keys->offset; fa.k_bits = ks.total_bits;
       fa.v = v; fa.has_values = values ? 1 : 0;
       fa.m_data = m_data; fa.m_valid = m_valid; fa.m_off = m_off;
-      fa.n = n; fa.nblocks = nblocks;
-      fa.rows_per_block = (((n + nblocks - 1) / nblocks + kPartRows - 1) / kPartRows) * kPartRows;
-      AA_HIP(hipMemsetAsync(hist + hist_n - 1, 0, 4, ctx->stream));
-      hipLaunchKernelGGL(k_part_hist, dim3(nblocks), dim3(kPartThreads), 0, ctx->stream, fa, hist);
-      AA_HIP(hipGetLastError());
-      AA_TRY(ScanU32InPlace(ctx, hist, hist_n, sums, sumoff));
-      hipLaunchKernelGGL(k_part_scatter, dim3(nblocks), dim3(kPartThreads), 0, ctx->stream, fa, hist, records);
-      AA_HIP(hipGetLastError());
-      hipLaunchKernelGGL(k_part_aggregate, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nblocks,
-                         ks.total_bits, values && IsFloat(values->type_id) ? 1 : 0, t, misc);
-      AA_HIP(hipGetLastError());
+      fa.n = n; fa.nblocks = nblocks; fa.rows_per_block = rows_per_block;
+      const int acc_double = values && IsFloat(values->type_id) ? 1 : 0;
+      if (path == 2) {
+        hipLaunchKernelGGL(k_part_scatter_direct, dim3(nblocks), dim3(kDThreads), 0, ctx->stream, fa, cap, records, hist,
+                           misc);
+        AA_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_part_aggregate_direct, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nblocks,
+                           cap, ks.total_bits, acc_double, t, misc);
+        AA_HIP(hipGetLastError());
+      } else {
+        AA_HIP(hipMemsetAsync(hist + hist_n - 1, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(k_part_hist, dim3(nblocks), dim3(kPartThreads), 0, ctx->stream, fa, hist);
+        AA_HIP(hipGetLastError());
+        AA_TRY(ScanU32InPlace(ctx, hist, hist_n, sums, sumoff));
+        hipLaunchKernelGGL(k_part_scatter, dim3(nblocks), dim3(kPartThreads), 0, ctx->stream, fa, hist, records);
+        AA_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_part_aggregate, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nblocks,
+                           ks.total_bits, acc_double, t, misc);
+        AA_HIP(hipGetLastError());
+      }
     } else {
       AA_TRY(ClearTable(ctx, t, false));
       hipLaunchKernelGGL(k_groupby_build, dim3(GridFor(n, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, ks,
@@ -913,7 +1205,7 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
     AA_TRY(RankFirstRows(ctx, t, 0, r, &G));
     unsigned int overflow = 0;
     AA_TRY(ReadBack(ctx, misc, 4, &overflow));
-    if (overflow && fast) { fast = false; continue; }  // a partition outgrew its LDS table: generic path
+    if (overflow && fast) continue;  // capacity assumption failed: next (more general) path
     if (overflow || G > group_capacity)
       return SetError(AMDARROW_CAPACITY_ERROR,
                       "group-by: more than group_capacity = " + std::to_string(group_capacity) + " groups");

@@ -414,3 +414,31 @@ def test_sharded_groupby_merge_on_gpu(gpu, oracle):
     merged = adist.merge_partials(merger1._partial_of(r), merger1._local_merge, 1)
     assert np.array_equal(merged.sums_numpy(), es) and np.array_equal(merged.keys_numpy(), ek)
     tdist.destroy_process_group()
+
+
+@pytest.mark.parametrize("path", ["2", "1", "0"])
+def test_filter_groupby_every_path(gpu, oracle, path, monkeypatch):
+    """AMDARROW_GROUPBY_PATH caps the strategy: 2 one-pass partition, 1 two-pass partition,
+    0 generic global table.  All three must give the reference's rows."""
+    monkeypatch.setenv("AMDARROW_GROUPBY_PATH", path)
+    rng = np.random.default_rng(13)
+    n = 400_000
+    for vt, kt, knp in ((INT64, INT32, 0.03), (DOUBLE, INT16, 0.0), (INT32, UINT8, 0.1)):
+        v, k, m = R(rng, vt, n, .01, 2), R(rng, kt, n, knp, 1, lo=0, hi=20000), R(rng, BOOL, n, 0.05, 3)
+        for x, y in zip(oracle.filter_groupby_sum(v, k, m), gpu.filter_groupby_sum(v, k, m)):
+            if x.dtype == np.float64:
+                assert x.shape == y.shape and np.allclose(x, y, rtol=F64_RTOL)
+            else:
+                assert np.array_equal(x, y), (path, vt, kt)
+
+
+def test_filter_groupby_skewed_keys_overflow_one_pass_regions(gpu, oracle):
+    """A heavy-hitter key (40 % of the rows) overflows the fixed-capacity regions of the
+    one-pass partition; the exact two-pass variant must take over transparently."""
+    rng = np.random.default_rng(14)
+    n = 2_000_000
+    keys = rng.integers(0, 50_000, n).astype(np.int32)
+    keys[rng.random(n) < 0.4] = 7
+    v, k, m = R(rng, INT64, n, .01, 0), Arr(INT32, keys), R(rng, BOOL, n, 0.0, 0)
+    for x, y in zip(oracle.filter_groupby_sum(v, k, m), gpu.filter_groupby_sum(v, k, m)):
+        assert np.array_equal(x, y)
