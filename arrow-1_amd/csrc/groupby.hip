@@ -467,6 +467,7 @@ struct FastArgs {
   ValueCol v; int has_values;
   const uint8_t* m_data; const uint8_t* m_valid; int64_t m_off;
   int64_t n; int64_t rows_per_block; int nblocks;
+  int dbg;  // experiments only (AMDARROW_DBG): bit0 skip region stores, bit1 skip staging+copy-out
 };
 
 __device__ __forceinline__ bool FastSelected(const FastArgs& a, int64_t row) {
@@ -809,24 +810,156 @@ __global__ __launch_bounds__(kDThreads) void k_part_scatter_direct(FastArgs a, i
   }
 }
 
+// Specialisation of k_part_scatter_direct for the headline shape: 32-bit keys without nulls and
+// 8-byte values accumulated as raw bits (int64 / uint64 / double).  Everything is straight-line:
+// loads are unconditional (unselected lanes read a row that is resident anyway), so the 8
+// rows of a thread are 8 + 8 (+8) independent loads in flight before the first wait.
+template <bool MASK, bool VVALID>
+__global__ __launch_bounds__(kDThreads) void k_part_scatter_fast(FastArgs a, int64_t cap, uint4* regions, uint32_t* counts,
+                                                                 unsigned int* overflow) {
+  __shared__ unsigned int s_cnt[2][kP];
+  __shared__ uint32_t s_off[kP];
+  __shared__ uint32_t s_cur[kP];
+  __shared__ uint32_t s_scan[8];
+  __shared__ uint4 s_rec[kDRows];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int kIters = kDRows / kDThreads;
+  if (tid < kP) { s_cnt[0][tid] = 0; s_cnt[1][tid] = 0; s_cur[tid] = 0; }
+  __syncthreads();
+  const int64_t lo = int64_t(blockIdx.x) * a.rows_per_block;
+  const int64_t hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
+  const uint32_t* keys = reinterpret_cast<const uint32_t*>(a.k_data) + a.k_off;
+  const uint64_t* vals = reinterpret_cast<const uint64_t*>(a.v.data) + a.v.off;
+  bool over = false;
+  uint32_t kx[kIters];
+  uint64_t kv[kIters], mw[kIters];
+  uint8_t vb[kIters];
+  auto load = [&](int64_t tile0) {
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      const int64_t row = tile0 + j * kDThreads + tid;
+      const int64_t rc = row < hi ? row : hi - 1;  // always a valid row of this block
+      mw[j] = MASK ? FastMaskWord(a, row - lane, hi) : (row < hi ? ~uint64_t(0) : 0);
+      kx[j] = keys[rc];
+      kv[j] = vals[rc];
+      if (VVALID) vb[j] = a.v.valid[(a.v.off + rc) >> 3];
+    }
+  };
+  if (lo < hi) load(lo);
+  int buf = 0;
+  for (int64_t tile0 = lo; tile0 < hi; tile0 += kDRows, buf ^= 1) {
+    uint32_t rrank[kIters], rpart[kIters], rflags[kIters];
+    bool sel[kIters];
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      const int64_t row = tile0 + j * kDThreads + tid;
+      sel[j] = (mw[j] >> lane) & 1;
+      rpart[j] = Fmix32(kx[j]) >> (32 - kPBits);
+      bool vvalid = true;
+      if (VVALID) vvalid = (vb[j] >> ((a.v.off + row) & 7)) & 1;
+      rflags[j] = static_cast<uint32_t>(row) | (vvalid ? kRecValValid : 0u);
+      if (!vvalid) kv[j] = 0;
+      if (sel[j]) rrank[j] = atomicAdd(&s_cnt[buf][rpart[j]], 1u);
+    }
+    __syncthreads();
+    uint32_t c = 0, incl = 0;
+    if (tid < kP) {
+      c = s_cnt[buf][tid];
+      incl = WaveInclusiveScan(c);
+      if (lane == 63) s_scan[wave] = incl;
+    }
+    __syncthreads();
+    if (tid < kP) {
+      uint32_t woff = 0;
+      for (int w = 0; w < wave; ++w) woff += s_scan[w];
+      s_off[tid] = woff + incl - c;
+      s_cnt[buf ^ 1][tid] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      if (sel[j]) {
+        uint4 r;
+        r.x = kx[j]; r.y = rflags[j];
+        r.z = static_cast<uint32_t>(kv[j]); r.w = static_cast<uint32_t>(kv[j] >> 32);
+        s_rec[s_off[rpart[j]] + rrank[j]] = r;
+      }
+    }
+    __syncthreads();
+    if (tile0 + kDRows < hi) load(tile0 + kDRows);  // in flight during the copy-out
+    const uint32_t total = s_off[kP - 1] + s_cnt[buf][kP - 1];
+    for (uint32_t i = tid; i < total; i += kDThreads) {
+      const uint4 r = s_rec[i];
+      const uint32_t p = Fmix32(r.x) >> (32 - kPBits);
+      const uint32_t idx = s_cur[p] + (i - s_off[p]);
+      if (a.dbg & 1) { if (r.x == 0x12345678u && r.y == 77) over = true; continue; }
+      if (idx < cap) regions[(int64_t(p) * a.nblocks + blockIdx.x) * cap + idx] = r;
+      else over = true;
+    }
+    __syncthreads();
+    if (tid < kP) s_cur[tid] += s_cnt[buf][tid];
+  }
+  if (over) *overflow = 1;
+  __syncthreads();
+  if (tid < kP) {
+    const uint32_t c = s_cur[tid];
+    counts[int64_t(tid) * a.nblocks + blockIdx.x] = c < cap ? c : static_cast<uint32_t>(cap);
+  }
+}
+
 // One workgroup per partition; every wave walks whole regions (segments) of the partition.
+// LDS table: 32-bit tags (fmix32 of the key, a bijection, so tag equality is key equality),
+// 0xFFFFFFFF = free; the null key and the one key whose tag equals the free marker live in
+// two side slots.  Per step a lane takes 4 records: 4 unconditional 16-byte loads, then the
+// 4 first probes are issued together; only mismatches enter the probe loop.
+constexpr uint32_t kTagFree = 0xFFFFFFFFu;
+constexpr int kSideNull = kSlots, kSideFree = kSlots + 1;
+
+// The LDS table is bucketised: 1024 buckets of 4 tags (one ds_read_b128 fetches a bucket).  At
+// <= 50 % load a key is almost always found in, or inserted into, its home bucket, so the
+// expensive divergent probe loop of plain linear probing disappears.
+constexpr int kBucket = 4;
+constexpr int kBuckets = kSlots / kBucket;
+
+__device__ __forceinline__ int MatchBucket(const uint4& b, uint32_t h) {
+  return b.x == h ? 0 : b.y == h ? 1 : b.z == h ? 2 : b.w == h ? 3 : -1;
+}
+// Slow path: (re)read buckets until the key is found or inserted.  Returns slot or -1 (full).
+__device__ __forceinline__ int ProbeInsert(unsigned int* s_tag, unsigned int* s_groups, uint32_t h, uint32_t bucket) {
+  for (int probes = 0; probes < kBuckets; ++probes) {
+    for (;;) {
+      const uint4 b = *reinterpret_cast<const uint4*>(&s_tag[bucket * kBucket]);
+      int j = MatchBucket(b, h);
+      if (j >= 0) return static_cast<int>(bucket * kBucket + j);
+      j = MatchBucket(b, kTagFree);
+      if (j < 0) break;  // bucket full: next bucket
+      if (*s_groups >= kSlotLimit) return -1;
+      const unsigned int old = atomicCAS(&s_tag[bucket * kBucket + j], kTagFree, h);
+      if (old == kTagFree) { atomicAdd(s_groups, 1u); return static_cast<int>(bucket * kBucket + j); }
+      if (old == h) return static_cast<int>(bucket * kBucket + j);
+      // another key took the free entry: look at the bucket again
+    }
+    bucket = (bucket + 1) & (kBuckets - 1);
+  }
+  return -1;
+}
+
 __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const uint4* regions, const uint32_t* counts,
                                                                         int nblocks, int64_t cap, int k_bits,
                                                                         int acc_double, GroupTable t,
-                                                                        unsigned int* overflow) {
-  constexpr unsigned long long kOcc = 1ull << 33, kNullTag = 1ull << 32;
-  __shared__ unsigned long long s_tag[kSlots];   // 0 = free, else kOcc | null<<32 | fmix32(x)
-  __shared__ unsigned long long s_sum[kSlots];
-  __shared__ uint32_t s_first[kSlots];
-  __shared__ unsigned int s_cnt[kSlots];
+                                                                        unsigned int* overflow, int dbg) {
+  __shared__ __attribute__((aligned(16))) unsigned int s_tag[kSlots + 4];
+  __shared__ unsigned long long s_sum[kSlots + 2];
+  __shared__ uint32_t s_first[kSlots + 2];
+  __shared__ unsigned int s_cnt[kSlots + 2];
   __shared__ unsigned int s_groups;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = blockIdx.x;
-  for (int s = tid; s < kSlots; s += kPartThreads) { s_tag[s] = 0; s_sum[s] = 0; s_first[s] = kNoRow; s_cnt[s] = 0; }
+  for (int s = tid; s < kSlots + 2; s += kPartThreads) { s_tag[s] = kTagFree; s_sum[s] = 0; s_first[s] = kNoRow; s_cnt[s] = 0; }
   if (tid == 0) s_groups = 0;
   __syncthreads();
   bool failed = false;
-  constexpr int kUnroll = 4;
+  constexpr int kUnroll = 8;
   for (int b = wave; b < nblocks; b += kPartThreads / 64) {
     const uint32_t cnt = counts[int64_t(p) * nblocks + b];
     const uint4* seg = regions + (int64_t(p) * nblocks + b) * cap;
@@ -835,36 +968,40 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
         const uint32_t i = i0 + 64 * u;
-        rec[u] = make_uint4(0, 0, 0, 0);
-        if (i < cnt) rec[u] = seg[i];
+        rec[u] = seg[i < cnt ? i : cnt - 1];  // unconditional: 4 loads in flight
+      }
+      uint32_t h[kUnroll];
+      int slot[kUnroll];
+      uint4 home[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        h[u] = Fmix32(rec[u].x);
+        slot[u] = static_cast<int>(h[u] & (kBuckets - 1));  // home bucket
+        home[u] = *reinterpret_cast<const uint4*>(&s_tag[slot[u] * kBucket]);
       }
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
-        if (i0 + 64 * u >= cnt) break;
-        const uint4 r = rec[u];
-        const bool kn = r.y & kRecKeyNull;
-        const uint32_t h = kn ? 0u : Fmix32(r.x);
-        const unsigned long long tag = kOcc | (kn ? kNullTag : 0ull) | h;
-        uint32_t slot = h & (kSlots - 1);
-        bool found = false;
-        for (int probes = 0; probes < kSlots; ++probes) {
-          unsigned long long cur = s_tag[slot];
-          if (cur == tag) { found = true; break; }
-          if (cur == 0) {
-            if (s_groups >= kSlotLimit) break;
-            cur = atomicCAS(&s_tag[slot], 0ull, tag);
-            if (cur == 0) { atomicAdd(&s_groups, 1u); found = true; break; }
-            if (cur == tag) { found = true; break; }
-          }
-          slot = (slot + 1) & (kSlots - 1);
+        if (i0 + 64 * u >= cnt) { slot[u] = -2; continue; }
+        if (rec[u].y & kRecKeyNull) slot[u] = kSideNull;
+        else if (h[u] == kTagFree) slot[u] = kSideFree;
+        else {
+          const int j = MatchBucket(home[u], h[u]);
+          if (j >= 0) slot[u] = slot[u] * kBucket + j;
+          else slot[u] = ProbeInsert(s_tag, &s_groups, h[u], static_cast<uint32_t>(slot[u]));
         }
-        if (!found) { failed = true; continue; }
-        atomicMin(&s_first[slot], r.y & kRecRowMask);
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        if (slot[u] == -2) continue;
+        if (slot[u] < 0) { failed = true; continue; }
+        const uint4 r = rec[u];
+        if (dbg & 4) { if (r.x == 0x12345678u && r.y == 99) failed = true; continue; }
+        atomicMin(&s_first[slot[u]], r.y & kRecRowMask);
         if (r.y & kRecValValid) {
           const unsigned long long bits = (static_cast<unsigned long long>(r.w) << 32) | r.z;
-          if (acc_double) atomicAdd(reinterpret_cast<double*>(&s_sum[slot]), __longlong_as_double(bits));
-          else atomicAdd(&s_sum[slot], bits);
-          atomicAdd(&s_cnt[slot], 1u);
+          if (acc_double) atomicAdd(reinterpret_cast<double*>(&s_sum[slot[u]]), __longlong_as_double(bits));
+          else atomicAdd(&s_sum[slot[u]], bits);
+          atomicAdd(&s_cnt[slot[u]], 1u);
         }
       }
     }
@@ -873,16 +1010,29 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
   __syncthreads();
   const int64_t g0 = int64_t(p) * kSlots;
   for (int s = tid; s < kSlots; s += kPartThreads) {
-    const unsigned long long tag = s_tag[s];
-    unsigned long long hk = kEmpty;
-    if (tag) {
-      const uint64_t x = (tag & kNullTag) ? (uint64_t(1) << k_bits) : uint64_t(Fmix32Inv(static_cast<uint32_t>(tag)));
-      hk = Fmix64(x);  // the shared numbering / emit kernels speak fmix64
-    }
-    t.hkeys[g0 + s] = hk;
+    const unsigned int tag = s_tag[s];
+    // the shared numbering / emit kernels speak fmix64 of the packed key word
+    t.hkeys[g0 + s] = tag == kTagFree ? kEmpty : Fmix64(uint64_t(Fmix32Inv(tag)));
     t.first[g0 + s] = s_first[s];
     t.sums[g0 + s] = s_sum[s];
     t.counts[g0 + s] = s_cnt[s];
+  }
+  // side slots -> two spare regular slots of the global table: partition p's slice is only
+  // kSlotLimit full, so the (at most two) extra groups go to free slots of the slice.
+  __syncthreads();
+  if (tid == 0) {
+    for (int side = kSideNull; side <= kSideFree; ++side) {
+      if (s_first[side] == kNoRow) continue;
+      const uint64_t x = side == kSideNull ? (uint64_t(1) << k_bits) : uint64_t(Fmix32Inv(kTagFree));
+      for (int s = 0; s < kSlots; ++s) {
+        if (s_tag[s] == kTagFree) {
+          s_tag[s] = 0;  // claimed (value irrelevant from here on)
+          t.hkeys[g0 + s] = Fmix64(x); t.first[g0 + s] = s_first[side]; t.sums[g0 + s] = s_sum[side];
+          t.counts[g0 + s] = s_cnt[side];
+          break;
+        }
+      }
+    }
   }
   if (p == 0 && tid < 2) {
     const int64_t T = int64_t(kP) * kSlots;
@@ -1176,13 +1326,22 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
       fa.v = v; fa.has_values = values ? 1 : 0;
       fa.m_data = m_data; fa.m_valid = m_valid; fa.m_off = m_off;
       fa.n = n; fa.nblocks = nblocks; fa.rows_per_block = rows_per_block;
+      if (const char* d = getenv("AMDARROW_DBG")) fa.dbg = atoi(d);
       const int acc_double = values && IsFloat(values->type_id) ? 1 : 0;
       if (path == 2) {
-        hipLaunchKernelGGL(k_part_scatter_direct, dim3(nblocks), dim3(kDThreads), 0, ctx->stream, fa, cap, records, hist,
-                           misc);
+        const bool headline_shape = ks.total_bits == 32 && !keys->validity && values && BitWidth(values->type_id) == 64;
+        if (headline_shape) {
+          const bool M = m_data != nullptr, V = values->validity != nullptr;
+#define AA_FAST(MM, VV) hipLaunchKernelGGL((k_part_scatter_fast<MM, VV>), dim3(nblocks), dim3(kDThreads), 0, ctx->stream, fa, cap, records, hist, misc)
+          if (M && V) AA_FAST(true, true); else if (M) AA_FAST(true, false); else if (V) AA_FAST(false, true); else AA_FAST(false, false);
+#undef AA_FAST
+        } else {
+          hipLaunchKernelGGL(k_part_scatter_direct, dim3(nblocks), dim3(kDThreads), 0, ctx->stream, fa, cap, records, hist,
+                             misc);
+        }
         AA_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_part_aggregate_direct, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nblocks,
-                           cap, ks.total_bits, acc_double, t, misc);
+                           cap, ks.total_bits, acc_double, t, misc, fa.dbg);
         AA_HIP(hipGetLastError());
       } else {
         AA_HIP(hipMemsetAsync(hist + hist_n - 1, 0, 4, ctx->stream));
