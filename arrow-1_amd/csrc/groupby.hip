@@ -810,99 +810,185 @@ __global__ __launch_bounds__(kDThreads) void k_part_scatter_direct(FastArgs a, i
   }
 }
 
+// Row mapping of the fast scatter: wave w owns rows [tile0 + 512 w, +512); step j covers 64
+// consecutive rows, one per lane.  The 8 mask (and value-validity) words of a wave are then 64
+// consecutive bytes: lane l keeps word (l & 7) and step j fetches it with a shuffle -- 2 VGPRs
+// instead of 16.
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it
+// would wait for the prefetched tile's global loads at every barrier and serialise HBM latency
+// with the LDS phases; the staged records never leave LDS between these barriers.
+__device__ __forceinline__ void LdsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct ScatterShared {
+  unsigned int cnt[2][kP];
+  uint32_t off[kP];
+  uint32_t cur[kP];
+  uint32_t scan[8];
+  uint4 rec[kDRows];
+};
+
+// Branch-free raw fetch of the (up to) two aligned words that hold 64 bits starting at bit
+// `pos`; combined later by CombineBits.  No control flow and no use of the loaded data here,
+// so the loads stay in flight (a data-dependent branch would force `s_waitcnt vmcnt(0)` and
+// drain the prefetched tile).
+struct RawBits { uint64_t lo, hi; };
+__device__ __forceinline__ RawBits LoadRawBits(const uint8_t* __restrict__ bm, int64_t pos, int nbits) {
+  const uintptr_t addr = reinterpret_cast<uintptr_t>(bm) + static_cast<uintptr_t>(pos >> 3);
+  const uint64_t* w = reinterpret_cast<const uint64_t*>(addr & ~uintptr_t(7));
+  const int shift = static_cast<int>((addr & 7) << 3) + static_cast<int>(pos & 7);
+  RawBits r;
+  r.lo = w[0];
+  r.hi = w[(shift + nbits > 64) ? 1 : 0];  // never touches a word that holds no requested bit
+  return r;
+}
+__device__ __forceinline__ uint64_t CombineBits(const uint8_t* bm, int64_t pos, int nbits, RawBits r) {
+  const uintptr_t addr = reinterpret_cast<uintptr_t>(bm) + static_cast<uintptr_t>(pos >> 3);
+  const int shift = static_cast<int>((addr & 7) << 3) + static_cast<int>(pos & 7);
+  uint64_t v = r.lo >> shift;
+  if (shift + nbits > 64) v |= r.hi << (64 - shift);
+  if (nbits < 64) v &= (uint64_t(1) << nbits) - 1;
+  return nbits > 0 ? v : 0;
+}
+
+template <bool MASK, bool VVALID>
+__device__ __forceinline__ void FastLoadTile(const FastArgs& a, const uint32_t* __restrict__ keys,
+                                             const uint64_t* __restrict__ vals, int64_t tile0, int64_t hi, int wave,
+                                             int lane, uint32_t (&kx)[8], uint64_t (&kv)[8], RawBits& mraw,
+                                             RawBits& vraw) {
+  const int64_t wrow0 = tile0 + wave * 512;
+  const int64_t mrow = wrow0 + 64 * (lane & 7);
+  const int64_t left = hi - mrow;
+  const int nbits = left >= 64 ? 64 : (left > 0 ? static_cast<int>(left) : 0);
+  const int64_t mrow_c = nbits > 0 ? mrow : hi - 1;  // keep the address inside the buffers
+  if (MASK) mraw = LoadRawBits(a.m_data, a.m_off + mrow_c, nbits > 0 ? nbits : 1);
+  if (VVALID) vraw = LoadRawBits(a.v.valid, a.v.off + mrow_c, nbits > 0 ? nbits : 1);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int64_t row = wrow0 + j * 64 + lane;
+    const int64_t rc = row < hi ? row : hi - 1;  // always a valid row of this block
+    kx[j] = keys[rc];
+    kv[j] = vals[rc];
+  }
+}
+
+// Phase 1 of a tile: partition id and rank (LDS atomic) of every selected row.  This is the
+// first consumer of the tile's registers, i.e. where the wave waits for its prefetched loads.
+__device__ __forceinline__ void FastRankTile(ScatterShared& sh, int buf, int lane, const uint32_t (&kx)[8],
+                                             uint64_t mword, uint32_t (&rpart)[8], uint32_t (&rrank)[8], bool (&sel)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sel[j] = (__shfl(mword, j, 64) >> lane) & 1;
+    rpart[j] = Fmix32(kx[j]) >> (32 - kPBits);
+    rrank[j] = 0;
+    if (sel[j]) rrank[j] = atomicAdd(&sh.cnt[buf][rpart[j]], 1u);
+  }
+}
+// Phases 2-4: scan the partition counts, stage the records in LDS grouped by partition, copy
+// every partition's run to the tail of this workgroup's private region.
+template <bool VVALID>
+__device__ __forceinline__ void FastFinishTile(ScatterShared& sh, int buf, int64_t tile0, int64_t cap, int nblocks,
+                                               uint4* __restrict__ regions, int tid, int wave, int lane,
+                                               const uint32_t (&kx)[8], const uint64_t (&kv)[8], uint64_t vword,
+                                               const uint32_t (&rpart)[8], const uint32_t (&rrank)[8],
+                                               const bool (&sel)[8], bool* over, int dbg) {
+  const int64_t wrow0 = tile0 + wave * 512;
+  LdsBarrier();
+  uint32_t c = 0, incl = 0;
+  if (tid < kP) {
+    c = sh.cnt[buf][tid];
+    incl = WaveInclusiveScan(c);
+    if (lane == 63) sh.scan[wave] = incl;
+  }
+  LdsBarrier();
+  if (tid < kP) {
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += sh.scan[w];
+    sh.off[tid] = woff + incl - c;
+    sh.cnt[buf ^ 1][tid] = 0;
+  }
+  LdsBarrier();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    // the shuffle must run with the whole wave active (the source lane may be unselected)
+    const bool vvalid = VVALID ? ((__shfl(vword, j, 64) >> lane) & 1) : true;
+    if (sel[j] && !(dbg & 2)) {
+      const uint64_t v = vvalid ? kv[j] : 0;
+      uint4 q;
+      q.x = kx[j];
+      q.y = static_cast<uint32_t>(wrow0 + j * 64 + lane) | (vvalid ? kRecValValid : 0u);
+      q.z = static_cast<uint32_t>(v); q.w = static_cast<uint32_t>(v >> 32);
+      sh.rec[sh.off[rpart[j]] + rrank[j]] = q;
+    }
+  }
+  LdsBarrier();
+  const uint32_t total = (dbg & 2) ? 0 : sh.off[kP - 1] + sh.cnt[buf][kP - 1];
+  for (uint32_t i = tid; i < total; i += kDThreads) {
+    const uint4 q = sh.rec[i];
+    const uint32_t p = Fmix32(q.x) >> (32 - kPBits);
+    const uint32_t idx = sh.cur[p] + (i - sh.off[p]);
+    if (dbg & 1) { if (q.x == 0x12345678u && q.y == 77) *over = true; continue; }
+    if (idx < cap) regions[(int64_t(p) * nblocks + blockIdx.x) * cap + idx] = q;
+    else *over = true;
+  }
+  LdsBarrier();
+  if (tid < kP) sh.cur[tid] += sh.cnt[buf][tid];
+}
+
 // Specialisation of k_part_scatter_direct for the headline shape: 32-bit keys without nulls and
-// 8-byte values accumulated as raw bits (int64 / uint64 / double).  Everything is straight-line:
-// loads are unconditional (unselected lanes read a row that is resident anyway), so the 8
-// rows of a thread are 8 + 8 (+8) independent loads in flight before the first wait.
+// 8-byte values accumulated as raw bits (int64 / uint64 / double).  Straight-line code, loads
+// unconditional, and TWO register sets: the loads of tile i+1 are issued before tile i is
+// processed, so they have a whole tile of LDS work to land (all CUs run in near lock-step; a
+// one-tile-late prefetch left HBM idle during the staging phases).
 template <bool MASK, bool VVALID>
 __global__ __launch_bounds__(kDThreads) void k_part_scatter_fast(FastArgs a, int64_t cap, uint4* regions, uint32_t* counts,
                                                                  unsigned int* overflow) {
-  __shared__ unsigned int s_cnt[2][kP];
-  __shared__ uint32_t s_off[kP];
-  __shared__ uint32_t s_cur[kP];
-  __shared__ uint32_t s_scan[8];
-  __shared__ uint4 s_rec[kDRows];
+  __shared__ ScatterShared sh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int kIters = kDRows / kDThreads;
-  if (tid < kP) { s_cnt[0][tid] = 0; s_cnt[1][tid] = 0; s_cur[tid] = 0; }
+  if (tid < kP) { sh.cnt[0][tid] = 0; sh.cnt[1][tid] = 0; sh.cur[tid] = 0; }
   __syncthreads();
   const int64_t lo = int64_t(blockIdx.x) * a.rows_per_block;
   const int64_t hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
   const uint32_t* keys = reinterpret_cast<const uint32_t*>(a.k_data) + a.k_off;
   const uint64_t* vals = reinterpret_cast<const uint64_t*>(a.v.data) + a.v.off;
   bool over = false;
-  uint32_t kx[kIters];
-  uint64_t kv[kIters], mw[kIters];
-  uint8_t vb[kIters];
-  auto load = [&](int64_t tile0) {
-#pragma unroll
-    for (int j = 0; j < kIters; ++j) {
-      const int64_t row = tile0 + j * kDThreads + tid;
-      const int64_t rc = row < hi ? row : hi - 1;  // always a valid row of this block
-      mw[j] = MASK ? FastMaskWord(a, row - lane, hi) : (row < hi ? ~uint64_t(0) : 0);
-      kx[j] = keys[rc];
-      kv[j] = vals[rc];
-      if (VVALID) vb[j] = a.v.valid[(a.v.off + rc) >> 3];
-    }
+  uint32_t kxA[8], kxB[8];
+  uint64_t kvA[8], kvB[8];
+  RawBits mA{}, vA{}, mB{}, vB{};
+  // mask / validity word of this lane's (lane & 7)-th 64-row step of the tile starting at t0
+  auto words = [&](int64_t t0, const RawBits& mraw, const RawBits& vraw, uint64_t* mword, uint64_t* vword) {
+    const int64_t mrow = t0 + wave * 512 + 64 * (lane & 7);
+    const int64_t left = hi - mrow;
+    const int nbits = left >= 64 ? 64 : (left > 0 ? static_cast<int>(left) : 0);
+    const int64_t mrow_c = nbits > 0 ? mrow : hi - 1;
+    const uint64_t live = nbits == 0 ? 0 : (nbits < 64 ? (uint64_t(1) << nbits) - 1 : ~uint64_t(0));
+    *mword = MASK ? (CombineBits(a.m_data, a.m_off + mrow_c, nbits > 0 ? nbits : 1, mraw) & live) : live;
+    *vword = VVALID ? (CombineBits(a.v.valid, a.v.off + mrow_c, nbits > 0 ? nbits : 1, vraw) & live) : live;
   };
-  if (lo < hi) load(lo);
-  int buf = 0;
-  for (int64_t tile0 = lo; tile0 < hi; tile0 += kDRows, buf ^= 1) {
-    uint32_t rrank[kIters], rpart[kIters], rflags[kIters];
-    bool sel[kIters];
-#pragma unroll
-    for (int j = 0; j < kIters; ++j) {
-      const int64_t row = tile0 + j * kDThreads + tid;
-      sel[j] = (mw[j] >> lane) & 1;
-      rpart[j] = Fmix32(kx[j]) >> (32 - kPBits);
-      bool vvalid = true;
-      if (VVALID) vvalid = (vb[j] >> ((a.v.off + row) & 7)) & 1;
-      rflags[j] = static_cast<uint32_t>(row) | (vvalid ? kRecValValid : 0u);
-      if (!vvalid) kv[j] = 0;
-      if (sel[j]) rrank[j] = atomicAdd(&s_cnt[buf][rpart[j]], 1u);
-    }
-    __syncthreads();
-    uint32_t c = 0, incl = 0;
-    if (tid < kP) {
-      c = s_cnt[buf][tid];
-      incl = WaveInclusiveScan(c);
-      if (lane == 63) s_scan[wave] = incl;
-    }
-    __syncthreads();
-    if (tid < kP) {
-      uint32_t woff = 0;
-      for (int w = 0; w < wave; ++w) woff += s_scan[w];
-      s_off[tid] = woff + incl - c;
-      s_cnt[buf ^ 1][tid] = 0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kIters; ++j) {
-      if (sel[j]) {
-        uint4 r;
-        r.x = kx[j]; r.y = rflags[j];
-        r.z = static_cast<uint32_t>(kv[j]); r.w = static_cast<uint32_t>(kv[j] >> 32);
-        s_rec[s_off[rpart[j]] + rrank[j]] = r;
-      }
-    }
-    __syncthreads();
-    if (tile0 + kDRows < hi) load(tile0 + kDRows);  // in flight during the copy-out
-    const uint32_t total = s_off[kP - 1] + s_cnt[buf][kP - 1];
-    for (uint32_t i = tid; i < total; i += kDThreads) {
-      const uint4 r = s_rec[i];
-      const uint32_t p = Fmix32(r.x) >> (32 - kPBits);
-      const uint32_t idx = s_cur[p] + (i - s_off[p]);
-      if (a.dbg & 1) { if (r.x == 0x12345678u && r.y == 77) over = true; continue; }
-      if (idx < cap) regions[(int64_t(p) * a.nblocks + blockIdx.x) * cap + idx] = r;
-      else over = true;
-    }
-    __syncthreads();
-    if (tid < kP) s_cur[tid] += s_cnt[buf][tid];
+  // Order per tile X: rank(X) [first use of X's registers = the only vmcnt wait], then issue the
+  // loads of the NEXT tile, then scan / stage / copy-out of X.  The next tile's loads are the
+  // youngest outstanding memory operations when they are issued, so they fly during three LDS
+  // phases and the copy-out.  (Issuing them any earlier makes the compiler wait vmcnt(0) on
+  // them: vmcnt retires in order and the copy-out issues a data-dependent number of stores.)
+  uint32_t rpart[8], rrank[8];
+  bool sel[8];
+  uint64_t mw, vw;
+  if (lo < hi) FastLoadTile<MASK, VVALID>(a, keys, vals, lo, hi, wave, lane, kxA, kvA, mA, vA);
+  for (int64_t tile0 = lo; tile0 < hi; tile0 += 2 * kDRows) {
+    const bool has_b = tile0 + kDRows < hi;
+    words(tile0, mA, vA, &mw, &vw);
+    FastRankTile(sh, 0, lane, kxA, mw, rpart, rrank, sel);
+    if (has_b) FastLoadTile<MASK, VVALID>(a, keys, vals, tile0 + kDRows, hi, wave, lane, kxB, kvB, mB, vB);
+    FastFinishTile<VVALID>(sh, 0, tile0, cap, a.nblocks, regions, tid, wave, lane, kxA, kvA, vw, rpart, rrank, sel, &over, a.dbg);
+    if (!has_b) break;
+    words(tile0 + kDRows, mB, vB, &mw, &vw);
+    FastRankTile(sh, 1, lane, kxB, mw, rpart, rrank, sel);
+    if (tile0 + 2 * kDRows < hi) FastLoadTile<MASK, VVALID>(a, keys, vals, tile0 + 2 * kDRows, hi, wave, lane, kxA, kvA, mA, vA);
+    FastFinishTile<VVALID>(sh, 1, tile0 + kDRows, cap, a.nblocks, regions, tid, wave, lane, kxB, kvB, vw, rpart, rrank, sel, &over, a.dbg);
   }
   if (over) *overflow = 1;
   __syncthreads();
   if (tid < kP) {
-    const uint32_t c = s_cur[tid];
+    const uint32_t c = sh.cur[tid];
     counts[int64_t(tid) * a.nblocks + blockIdx.x] = c < cap ? c : static_cast<uint32_t>(cap);
   }
 }
@@ -1329,7 +1415,8 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
       if (const char* d = getenv("AMDARROW_DBG")) fa.dbg = atoi(d);
       const int acc_double = values && IsFloat(values->type_id) ? 1 : 0;
       if (path == 2) {
-        const bool headline_shape = ks.total_bits == 32 && !keys->validity && values && BitWidth(values->type_id) == 64;
+        const bool headline_shape = ks.total_bits == 32 && !keys->validity && values && BitWidth(values->type_id) == 64 &&
+                                    !m_valid;
         if (headline_shape) {
           const bool M = m_data != nullptr, V = values->validity != nullptr;
 #define AA_FAST(MM, VV) hipLaunchKernelGGL((k_part_scatter_fast<MM, VV>), dim3(nblocks), dim3(kDThreads), 0, ctx->stream, fa, cap, records, hist, misc)
