@@ -428,11 +428,14 @@ static RankMem BindRank(char* base, const size_t off[4], int64_t n_rows) {
   r.block_offsets = reinterpret_cast<int64_t*>(base + off[3]);
   return r;
 }
-static int RankFirstRows(amdarrow_ctx* ctx, const GroupTable& t, int only_unassigned, const RankMem& r, int64_t* total) {
+static int RankFirstRows(amdarrow_ctx* ctx, const GroupTable& t, int only_unassigned, const RankMem& r, int64_t* total,
+                         bool already_marked = false) {
   const int64_t nslots = static_cast<int64_t>(t.mask) + 3;
+  if (!already_marked) {
   AA_HIP(hipMemsetAsync(r.bitmap, 0, 8 * r.nwords, ctx->stream));
   hipLaunchKernelGGL(k_mark_first, dim3(GridFor(nslots, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, t,
                      nslots, only_unassigned, r.bitmap);
+  }
   hipLaunchKernelGGL(k_popc_blocks, dim3(static_cast<unsigned>(r.nblocks)), dim3(kThreads), 0, ctx->stream, r.bitmap,
                      r.nwords, r.block_counts);
   AA_HIP(hipGetLastError());
@@ -467,7 +470,6 @@ struct FastArgs {
   ValueCol v; int has_values;
   const uint8_t* m_data; const uint8_t* m_valid; int64_t m_off;
   int64_t n; int64_t rows_per_block; int nblocks;
-  int dbg;  // experiments only (AMDARROW_DBG): bit0 skip region stores, bit1 skip staging+copy-out
 };
 
 __device__ __forceinline__ bool FastSelected(const FastArgs& a, int64_t row) {
@@ -694,8 +696,9 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate(const uint4* re
 
 
 // ==== fast path, one pass: private (row-range block, partition) regions ==========================
-// Each scatter workgroup owns, for every partition, a fixed-capacity region; a record goes to
-// region[p][b][cursor++] with the cursor kept in LDS, so there is no histogram pass and no
+// Each scatter workgroup owns, for every partition, a fixed-capacity region (laid out
+// [workgroup][partition][cap], so one workgroup writes within a few MB = a few TLB pages); a
+// record goes to region[b][p][cursor++] with the cursor kept in LDS, so there is no histogram pass and no
 // global scan.  Hash partitioning makes the per-region fill Poisson-like, so a capacity of
 // mean*1.25 + 8*sqrt(mean) + 16 overflows only on heavily skewed keys -- then `overflow` is
 // raised and the exact two-pass variant above (k_part_hist / k_part_scatter) is used instead.
@@ -796,7 +799,7 @@ __global__ __launch_bounds__(kDThreads) void k_part_scatter_direct(FastArgs a, i
       const uint4 r = s_rec[i];
       const uint32_t p = FastPartition32(r.x, r.y & kRecKeyNull);
       const uint32_t idx = s_cur[p] + (i - s_off[p]);
-      if (idx < cap) regions[(int64_t(p) * a.nblocks + blockIdx.x) * cap + idx] = r;
+      if (idx < cap) regions[(int64_t(blockIdx.x) * kP + p) * cap + idx] = r;
       else over = true;
     }
     __syncthreads();
@@ -818,14 +821,6 @@ __global__ __launch_bounds__(kDThreads) void k_part_scatter_direct(FastArgs a, i
 // would wait for the prefetched tile's global loads at every barrier and serialise HBM latency
 // with the LDS phases; the staged records never leave LDS between these barriers.
 __device__ __forceinline__ void LdsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-struct ScatterShared {
-  unsigned int cnt[2][kP];
-  uint32_t off[kP];
-  uint32_t cur[kP];
-  uint32_t scan[8];
-  uint4 rec[kDRows];
-};
 
 // Branch-free raw fetch of the (up to) two aligned words that hold 64 bits starting at bit
 // `pos`; combined later by CombineBits.  No control flow and no use of the loaded data here,
@@ -850,12 +845,29 @@ __device__ __forceinline__ uint64_t CombineBits(const uint8_t* bm, int64_t pos, 
   return nbits > 0 ? v : 0;
 }
 
+// Tile geometry of the fast scatter: 7 steps of 64 rows per wave (7168 rows per tile), which
+// leaves LDS room for the per-partition carry buffers below.
+constexpr int kFSteps = 7;
+constexpr int kFRows = kFSteps * kDThreads;  // 7168
+constexpr int kSector = 4;                   // records per 64-byte sector
+
+struct ScatterShared {
+  unsigned int cnt[2][kP];
+  uint32_t off[kP];
+  uint32_t cur[kP];         // records already written to this workgroup's region of partition p (multiple of 4)
+  uint32_t wcnt[kP];        // records of (carry + this tile) that go out this tile (multiple of 4); bit 31 = overflow
+  uint32_t carry_cnt[kP];   // 0..3 records waiting for their sector to fill
+  uint32_t scan[8];
+  uint4 carry[kP][kSector - 1];
+  uint4 rec[kFRows];
+};
+
 template <bool MASK, bool VVALID>
 __device__ __forceinline__ void FastLoadTile(const FastArgs& a, const uint32_t* __restrict__ keys,
                                              const uint64_t* __restrict__ vals, int64_t tile0, int64_t hi, int wave,
-                                             int lane, uint32_t (&kx)[8], uint64_t (&kv)[8], RawBits& mraw,
+                                             int lane, uint32_t (&kx)[kFSteps], uint64_t (&kv)[kFSteps], RawBits& mraw,
                                              RawBits& vraw) {
-  const int64_t wrow0 = tile0 + wave * 512;
+  const int64_t wrow0 = tile0 + wave * (kFSteps * 64);
   const int64_t mrow = wrow0 + 64 * (lane & 7);
   const int64_t left = hi - mrow;
   const int nbits = left >= 64 ? 64 : (left > 0 ? static_cast<int>(left) : 0);
@@ -863,7 +875,7 @@ __device__ __forceinline__ void FastLoadTile(const FastArgs& a, const uint32_t* 
   if (MASK) mraw = LoadRawBits(a.m_data, a.m_off + mrow_c, nbits > 0 ? nbits : 1);
   if (VVALID) vraw = LoadRawBits(a.v.valid, a.v.off + mrow_c, nbits > 0 ? nbits : 1);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < kFSteps; ++j) {
     const int64_t row = wrow0 + j * 64 + lane;
     const int64_t rc = row < hi ? row : hi - 1;  // always a valid row of this block
     kx[j] = keys[rc];
@@ -873,10 +885,11 @@ __device__ __forceinline__ void FastLoadTile(const FastArgs& a, const uint32_t* 
 
 // Phase 1 of a tile: partition id and rank (LDS atomic) of every selected row.  This is the
 // first consumer of the tile's registers, i.e. where the wave waits for its prefetched loads.
-__device__ __forceinline__ void FastRankTile(ScatterShared& sh, int buf, int lane, const uint32_t (&kx)[8],
-                                             uint64_t mword, uint32_t (&rpart)[8], uint32_t (&rrank)[8], bool (&sel)[8]) {
+__device__ __forceinline__ void FastRankTile(ScatterShared& sh, int buf, int lane, const uint32_t (&kx)[kFSteps],
+                                             uint64_t mword, uint32_t (&rpart)[kFSteps], uint32_t (&rrank)[kFSteps],
+                                             bool (&sel)[kFSteps]) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < kFSteps; ++j) {
     sel[j] = (__shfl(mword, j, 64) >> lane) & 1;
     rpart[j] = Fmix32(kx[j]) >> (32 - kPBits);
     rrank[j] = 0;
@@ -884,14 +897,22 @@ __device__ __forceinline__ void FastRankTile(ScatterShared& sh, int buf, int lan
   }
 }
 // Phases 2-4: scan the partition counts, stage the records in LDS grouped by partition, copy
-// every partition's run to the tail of this workgroup's private region.
+// every partition's run to the tail of this workgroup's private region -- in whole 64-byte
+// sectors only: up to 3 trailing records per partition wait in an LDS carry buffer for the
+// next tile, so HBM never sees a partially written sector (partial sectors evicted from L2
+// made the region stores cost as much as the rest of the kernel).
 template <bool VVALID>
 __device__ __forceinline__ void FastFinishTile(ScatterShared& sh, int buf, int64_t tile0, int64_t cap, int nblocks,
                                                uint4* __restrict__ regions, int tid, int wave, int lane,
-                                               const uint32_t (&kx)[8], const uint64_t (&kv)[8], uint64_t vword,
-                                               const uint32_t (&rpart)[8], const uint32_t (&rrank)[8],
-                                               const bool (&sel)[8], bool* over, int dbg) {
-  const int64_t wrow0 = tile0 + wave * 512;
+                                               const uint32_t (&kx)[kFSteps], const uint64_t (&kv)[kFSteps],
+                                               uint64_t vword, const uint32_t (&rpart)[kFSteps],
+                                               const uint32_t (&rrank)[kFSteps], const bool (&sel)[kFSteps]) {
+  const int64_t wrow0 = tile0 + wave * (kFSteps * 64);
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+  // this workgroup's regions as one buffer: 32-bit offsets, cache policy per store (aux)
+  uint4* const block_base = regions + int64_t(blockIdx.x) * kP * cap;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(block_base, 0, static_cast<int>(kP * cap * 16), 0x00020000);
   LdsBarrier();
   uint32_t c = 0, incl = 0;
   if (tid < kP) {
@@ -905,13 +926,23 @@ __device__ __forceinline__ void FastFinishTile(ScatterShared& sh, int buf, int64
     for (int w = 0; w < wave; ++w) woff += sh.scan[w];
     sh.off[tid] = woff + incl - c;
     sh.cnt[buf ^ 1][tid] = 0;
+    // sectors that become complete with this tile; the old carry leads them out
+    const uint32_t cc = sh.carry_cnt[tid];
+    const uint32_t w = (cc + c) & ~uint32_t(kSector - 1);
+    const uint32_t cur = sh.cur[tid];
+    const bool ovf = cur + w > cap;
+    sh.wcnt[tid] = w | (ovf ? 0x80000000u : 0u);
+    if (w > 0 && !ovf) {
+      uint4* dst = regions + (int64_t(blockIdx.x) * kP + tid) * cap + cur;
+      for (uint32_t k = 0; k < cc; ++k) dst[k] = sh.carry[tid][k];
+    }
   }
   LdsBarrier();
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < kFSteps; ++j) {
     // the shuffle must run with the whole wave active (the source lane may be unselected)
     const bool vvalid = VVALID ? ((__shfl(vword, j, 64) >> lane) & 1) : true;
-    if (sel[j] && !(dbg & 2)) {
+    if (sel[j]) {
       const uint64_t v = vvalid ? kv[j] : 0;
       uint4 q;
       q.x = kx[j];
@@ -921,42 +952,53 @@ __device__ __forceinline__ void FastFinishTile(ScatterShared& sh, int buf, int64
     }
   }
   LdsBarrier();
-  const uint32_t total = (dbg & 2) ? 0 : sh.off[kP - 1] + sh.cnt[buf][kP - 1];
+  const uint32_t total = sh.off[kP - 1] + sh.cnt[buf][kP - 1];
   for (uint32_t i = tid; i < total; i += kDThreads) {
     const uint4 q = sh.rec[i];
     const uint32_t p = Fmix32(q.x) >> (32 - kPBits);
-    const uint32_t idx = sh.cur[p] + (i - sh.off[p]);
-    if (dbg & 1) { if (q.x == 0x12345678u && q.y == 77) *over = true; continue; }
-    if (idx < cap) regions[(int64_t(p) * nblocks + blockIdx.x) * cap + idx] = q;
-    else *over = true;
+    const uint32_t k = sh.carry_cnt[p] + (i - sh.off[p]);  // position in (old carry + this tile's run)
+    const uint32_t w = sh.wcnt[p];
+    if (k < (w & 0x7FFFFFFFu)) {
+      if (!(w >> 31)) {
+        const uint32_t voff = static_cast<uint32_t>((int64_t(p) * cap + sh.cur[p] + k) * 16);
+        u32x4 v = {q.x, q.y, q.z, q.w};
+        // nt: the region lines are written once and read once by another CU -- streaming them past
+        // the L2 replacement queue measured 10 % faster than default-policy stores (sc1 write-through: 45 % slower)
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 2);
+      }
+    } else {
+      sh.carry[p][k - (w & 0x7FFFFFFFu)] = q;  // < 3 by construction
+    }
   }
   LdsBarrier();
-  if (tid < kP) sh.cur[tid] += sh.cnt[buf][tid];
+  if (tid < kP) {
+    const uint32_t w = sh.wcnt[tid] & 0x7FFFFFFFu;
+    sh.carry_cnt[tid] = sh.carry_cnt[tid] + sh.cnt[buf][tid] - w;
+    sh.cur[tid] += w;
+  }
 }
 
 // Specialisation of k_part_scatter_direct for the headline shape: 32-bit keys without nulls and
 // 8-byte values accumulated as raw bits (int64 / uint64 / double).  Straight-line code, loads
-// unconditional, and TWO register sets: the loads of tile i+1 are issued before tile i is
-// processed, so they have a whole tile of LDS work to land (all CUs run in near lock-step; a
-// one-tile-late prefetch left HBM idle during the staging phases).
+// unconditional, and TWO register sets so that the next tile's loads are in flight while the
+// current tile goes through its LDS phases.
 template <bool MASK, bool VVALID>
 __global__ __launch_bounds__(kDThreads) void k_part_scatter_fast(FastArgs a, int64_t cap, uint4* regions, uint32_t* counts,
                                                                  unsigned int* overflow) {
   __shared__ ScatterShared sh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < kP) { sh.cnt[0][tid] = 0; sh.cnt[1][tid] = 0; sh.cur[tid] = 0; }
+  if (tid < kP) { sh.cnt[0][tid] = 0; sh.cnt[1][tid] = 0; sh.cur[tid] = 0; sh.carry_cnt[tid] = 0; sh.wcnt[tid] = 0; }
   __syncthreads();
   const int64_t lo = int64_t(blockIdx.x) * a.rows_per_block;
   const int64_t hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
   const uint32_t* keys = reinterpret_cast<const uint32_t*>(a.k_data) + a.k_off;
   const uint64_t* vals = reinterpret_cast<const uint64_t*>(a.v.data) + a.v.off;
-  bool over = false;
-  uint32_t kxA[8], kxB[8];
-  uint64_t kvA[8], kvB[8];
+  uint32_t kxA[kFSteps], kxB[kFSteps];
+  uint64_t kvA[kFSteps], kvB[kFSteps];
   RawBits mA{}, vA{}, mB{}, vB{};
   // mask / validity word of this lane's (lane & 7)-th 64-row step of the tile starting at t0
   auto words = [&](int64_t t0, const RawBits& mraw, const RawBits& vraw, uint64_t* mword, uint64_t* vword) {
-    const int64_t mrow = t0 + wave * 512 + 64 * (lane & 7);
+    const int64_t mrow = t0 + wave * (kFSteps * 64) + 64 * (lane & 7);
     const int64_t left = hi - mrow;
     const int nbits = left >= 64 ? 64 : (left > 0 ? static_cast<int>(left) : 0);
     const int64_t mrow_c = nbits > 0 ? mrow : hi - 1;
@@ -969,27 +1011,33 @@ __global__ __launch_bounds__(kDThreads) void k_part_scatter_fast(FastArgs a, int
   // youngest outstanding memory operations when they are issued, so they fly during three LDS
   // phases and the copy-out.  (Issuing them any earlier makes the compiler wait vmcnt(0) on
   // them: vmcnt retires in order and the copy-out issues a data-dependent number of stores.)
-  uint32_t rpart[8], rrank[8];
-  bool sel[8];
+  uint32_t rpart[kFSteps], rrank[kFSteps];
+  bool sel[kFSteps];
   uint64_t mw, vw;
   if (lo < hi) FastLoadTile<MASK, VVALID>(a, keys, vals, lo, hi, wave, lane, kxA, kvA, mA, vA);
-  for (int64_t tile0 = lo; tile0 < hi; tile0 += 2 * kDRows) {
-    const bool has_b = tile0 + kDRows < hi;
+  for (int64_t tile0 = lo; tile0 < hi; tile0 += 2 * kFRows) {
+    const bool has_b = tile0 + kFRows < hi;
     words(tile0, mA, vA, &mw, &vw);
     FastRankTile(sh, 0, lane, kxA, mw, rpart, rrank, sel);
-    if (has_b) FastLoadTile<MASK, VVALID>(a, keys, vals, tile0 + kDRows, hi, wave, lane, kxB, kvB, mB, vB);
-    FastFinishTile<VVALID>(sh, 0, tile0, cap, a.nblocks, regions, tid, wave, lane, kxA, kvA, vw, rpart, rrank, sel, &over, a.dbg);
+    if (has_b) FastLoadTile<MASK, VVALID>(a, keys, vals, tile0 + kFRows, hi, wave, lane, kxB, kvB, mB, vB);
+    FastFinishTile<VVALID>(sh, 0, tile0, cap, a.nblocks, regions, tid, wave, lane, kxA, kvA, vw, rpart, rrank, sel);
     if (!has_b) break;
-    words(tile0 + kDRows, mB, vB, &mw, &vw);
+    words(tile0 + kFRows, mB, vB, &mw, &vw);
     FastRankTile(sh, 1, lane, kxB, mw, rpart, rrank, sel);
-    if (tile0 + 2 * kDRows < hi) FastLoadTile<MASK, VVALID>(a, keys, vals, tile0 + 2 * kDRows, hi, wave, lane, kxA, kvA, mA, vA);
-    FastFinishTile<VVALID>(sh, 1, tile0 + kDRows, cap, a.nblocks, regions, tid, wave, lane, kxB, kvB, vw, rpart, rrank, sel, &over, a.dbg);
+    if (tile0 + 2 * kFRows < hi) FastLoadTile<MASK, VVALID>(a, keys, vals, tile0 + 2 * kFRows, hi, wave, lane, kxA, kvA, mA, vA);
+    FastFinishTile<VVALID>(sh, 1, tile0 + kFRows, cap, a.nblocks, regions, tid, wave, lane, kxB, kvB, vw, rpart, rrank, sel);
   }
-  if (over) *overflow = 1;
   __syncthreads();
   if (tid < kP) {
-    const uint32_t c = sh.cur[tid];
-    counts[int64_t(tid) * a.nblocks + blockIdx.x] = c < cap ? c : static_cast<uint32_t>(cap);
+    // flush the last (partial) sector of every partition and publish the region fill
+    const uint32_t cc = sh.carry_cnt[tid], cur = sh.cur[tid];
+    bool over = (sh.wcnt[tid] >> 31) != 0 || cur + cc > cap;
+    if (!over) {
+      uint4* dst = regions + (int64_t(blockIdx.x) * kP + tid) * cap + cur;
+      for (uint32_t k = 0; k < cc; ++k) dst[k] = sh.carry[tid][k];
+    }
+    counts[int64_t(tid) * a.nblocks + blockIdx.x] = over ? 0 : cur + cc;
+    if (over) *overflow = 1;
   }
 }
 
@@ -1033,7 +1081,8 @@ __device__ __forceinline__ int ProbeInsert(unsigned int* s_tag, unsigned int* s_
 __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const uint4* regions, const uint32_t* counts,
                                                                         int nblocks, int64_t cap, int k_bits,
                                                                         int acc_double, GroupTable t,
-                                                                        unsigned int* overflow, int dbg) {
+                                                                        unsigned long long* first_bitmap,
+                                                                        unsigned int* overflow) {
   __shared__ __attribute__((aligned(16))) unsigned int s_tag[kSlots + 4];
   __shared__ unsigned long long s_sum[kSlots + 2];
   __shared__ uint32_t s_first[kSlots + 2];
@@ -1048,13 +1097,15 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
   constexpr int kUnroll = 8;
   for (int b = wave; b < nblocks; b += kPartThreads / 64) {
     const uint32_t cnt = counts[int64_t(p) * nblocks + b];
-    const uint4* seg = regions + (int64_t(p) * nblocks + b) * cap;
+    const uint4* seg = regions + (int64_t(b) * kP + p) * cap;
     for (uint32_t i0 = lane; i0 < cnt; i0 += 64 * kUnroll) {
       uint4 rec[kUnroll];
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
         const uint32_t i = i0 + 64 * u;
-        rec[u] = seg[i < cnt ? i : cnt - 1];  // unconditional: 4 loads in flight
+        using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(&seg[i < cnt ? i : cnt - 1]));
+        rec[u] = make_uint4(v.x, v.y, v.z, v.w);  // unconditional (clamped) and streamed once
       }
       uint32_t h[kUnroll];
       int slot[kUnroll];
@@ -1081,7 +1132,6 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
         if (slot[u] == -2) continue;
         if (slot[u] < 0) { failed = true; continue; }
         const uint4 r = rec[u];
-        if (dbg & 4) { if (r.x == 0x12345678u && r.y == 99) failed = true; continue; }
         atomicMin(&s_first[slot[u]], r.y & kRecRowMask);
         if (r.y & kRecValValid) {
           const unsigned long long bits = (static_cast<unsigned long long>(r.w) << 32) | r.z;
@@ -1099,9 +1149,12 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
     const unsigned int tag = s_tag[s];
     // the shared numbering / emit kernels speak fmix64 of the packed key word
     t.hkeys[g0 + s] = tag == kTagFree ? kEmpty : Fmix64(uint64_t(Fmix32Inv(tag)));
-    t.first[g0 + s] = s_first[s];
+    const uint32_t fr = s_first[s];
+    t.first[g0 + s] = fr;
     t.sums[g0 + s] = s_sum[s];
     t.counts[g0 + s] = s_cnt[s];
+    // mark the group's first row for the first-appearance numbering (was a separate kernel)
+    if (fr != kNoRow) atomicOr(&first_bitmap[fr >> 6], 1ull << (fr & 63));
   }
   // side slots -> two spare regular slots of the global table: partition p's slice is only
   // kSlotLimit full, so the (at most two) extra groups go to free slots of the slice.
@@ -1115,6 +1168,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
           s_tag[s] = 0;  // claimed (value irrelevant from here on)
           t.hkeys[g0 + s] = Fmix64(x); t.first[g0 + s] = s_first[side]; t.sums[g0 + s] = s_sum[side];
           t.counts[g0 + s] = s_cnt[side];
+          atomicOr(&first_bitmap[s_first[side] >> 6], 1ull << (s_first[side] & 63));
           break;
         }
       }
@@ -1378,7 +1432,7 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
       nblocks = static_cast<int>(std::min<int64_t>(ctx->num_cus, (n + kDRows - 1) / kDRows));
       rows_per_block = (((n + nblocks - 1) / nblocks + kDRows - 1) / kDRows) * kDRows;
       const double mean = static_cast<double>(rows_per_block) / kP;
-      cap = static_cast<int64_t>(mean * 1.25 + 8.0 * std::sqrt(mean) + 16.0);
+      cap = (static_cast<int64_t>(mean * 1.25 + 8.0 * std::sqrt(mean) + 16.0) + 3) & ~int64_t(3);  // whole 64-byte sectors
       hist_n = int64_t(kP) * nblocks;
     } else if (path == 1) {
       nblocks = static_cast<int>(std::min<int64_t>(ctx->num_cus, (n + kPartRows - 1) / kPartRows));
@@ -1412,7 +1466,6 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
       fa.v = v; fa.has_values = values ? 1 : 0;
       fa.m_data = m_data; fa.m_valid = m_valid; fa.m_off = m_off;
       fa.n = n; fa.nblocks = nblocks; fa.rows_per_block = rows_per_block;
-      if (const char* d = getenv("AMDARROW_DBG")) fa.dbg = atoi(d);
       const int acc_double = values && IsFloat(values->type_id) ? 1 : 0;
       if (path == 2) {
         const bool headline_shape = ks.total_bits == 32 && !keys->validity && values && BitWidth(values->type_id) == 64 &&
@@ -1427,8 +1480,9 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
                              misc);
         }
         AA_HIP(hipGetLastError());
+        AA_HIP(hipMemsetAsync(r.bitmap, 0, 8 * r.nwords, ctx->stream));
         hipLaunchKernelGGL(k_part_aggregate_direct, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nblocks,
-                           cap, ks.total_bits, acc_double, t, misc, fa.dbg);
+                           cap, ks.total_bits, acc_double, t, r.bitmap, misc);
         AA_HIP(hipGetLastError());
       } else {
         AA_HIP(hipMemsetAsync(hist + hist_n - 1, 0, 4, ctx->stream));
@@ -1448,7 +1502,7 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
       AA_HIP(hipGetLastError());
     }
     int64_t G = 0;
-    AA_TRY(RankFirstRows(ctx, t, 0, r, &G));
+    AA_TRY(RankFirstRows(ctx, t, 0, r, &G, /*already_marked=*/path == 2));
     unsigned int overflow = 0;
     AA_TRY(ReadBack(ctx, misc, 4, &overflow));
     if (overflow && fast) continue;  // capacity assumption failed: next (more general) path
