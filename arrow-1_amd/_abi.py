@@ -45,6 +45,7 @@ SYMBOLS = {
     "amdarrow_max_memory": (C.c_int64, [_P]),
     "amdarrow_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_int64]),
     "amdarrow_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_int64]),
+    "amdarrow_memcpy_d2d": (C.c_int, [_P, _P, _P, C.c_int64]),
     "amdarrow_memset": (C.c_int, [_P, _P, C.c_int, C.c_int64]),
     "amdarrow_count_set_bits": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
     "amdarrow_filter_output_size": (C.c_int, [_P, _A, C.c_int, C.POINTER(C.c_int64)]),
@@ -60,6 +61,8 @@ SYMBOLS = {
     "amdarrow_grouper_num_groups": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "amdarrow_grouper_uniques": (C.c_int, [_P, C.c_int, _P, _P, _O]),
     "amdarrow_hash_aggregate": (C.c_int, [_P, C.c_int, _A, _P, C.c_int64, C.c_int, _P, _P, _O]),
+    "amdarrow_hash_accumulate": (C.c_int, [_P, C.c_int, _A, _P, C.c_int, _P, _P]),
+    "amdarrow_hash_finalize": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, _P, _P, _O]),
     "amdarrow_filter_groupby": (C.c_int, [_P, _A, _A, _A, C.c_int64, _P, _P, _P, _P, _P, C.POINTER(C.c_int64)]),
 }
 

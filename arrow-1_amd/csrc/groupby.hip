@@ -1343,42 +1343,62 @@ int amdarrow_grouper_uniques(amdarrow_grouper* g, int k, void* out_values, uint8
   return AMDARROW_OK;
 }
 
-int amdarrow_hash_aggregate(amdarrow_ctx* ctx, int func, const amdarrow_array* values, const uint32_t* ids,
-                            int64_t num_groups, int count_mode, void* out_values, uint8_t* out_validity,
-                            amdarrow_out* out) {
+int amdarrow_hash_accumulate(amdarrow_ctx* ctx, int func, const amdarrow_array* values, const uint32_t* ids,
+                             int count_mode, void* sums, int64_t* counts) {
   if (func < AMDARROW_HASH_SUM || func > AMDARROW_HASH_MEAN) return SetError(AMDARROW_KEY_ERROR, "No such hash aggregate");
   const int t = values->type_id;
   if (BitWidth(t) < 0) return SetError(AMDARROW_NOT_IMPLEMENTED, "Summing data of this type");  // :556-562
+  if (values->length == 0) return AMDARROW_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  ValueCol v{values->values, values->validity, values->offset, t};
+  hipLaunchKernelGGL(k_hash_agg, dim3(GridFor(values->length, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, v,
+                     ids, values->length, func, count_mode, static_cast<unsigned long long*>(sums),
+                     reinterpret_cast<unsigned long long*>(counts));
+  AA_HIP(hipGetLastError());
+  return AMDARROW_OK;
+}
+
+int amdarrow_hash_finalize(amdarrow_ctx* ctx, int func, int value_type_id, int64_t num_groups, void* sums,
+                           const int64_t* counts, uint8_t* out_validity, amdarrow_out* out) {
+  if (func < AMDARROW_HASH_SUM || func > AMDARROW_HASH_MEAN) return SetError(AMDARROW_KEY_ERROR, "No such hash aggregate");
   out->length = num_groups;
   out->null_count = 0;
   out->has_validity = 0;
   if (num_groups == 0) return AMDARROW_OK;
   std::lock_guard<std::mutex> lock(ctx->mu);
-  Carver c;
-  const size_t off_counts = c.Take(8 * num_groups);
-  const size_t off_nulls = c.Take(256);
   void* base;
-  AA_TRY(Scratch(ctx, c.off, &base));
-  auto* counts = reinterpret_cast<unsigned long long*>(static_cast<char*>(base) + off_counts);
-  auto* nulls = reinterpret_cast<unsigned long long*>(static_cast<char*>(base) + off_nulls);
-  auto* vals = static_cast<unsigned long long*>(out_values);
-  AA_HIP(hipMemsetAsync(counts, 0, 8 * num_groups, ctx->stream));
+  AA_TRY(Scratch(ctx, 256, &base));
+  auto* nulls = static_cast<unsigned long long*>(base);
   AA_HIP(hipMemsetAsync(nulls, 0, 8, ctx->stream));
-  AA_HIP(hipMemsetAsync(vals, 0, 8 * num_groups, ctx->stream));
-  ValueCol v{values->values, values->validity, values->offset, t};
-  if (values->length > 0) {
-    hipLaunchKernelGGL(k_hash_agg, dim3(GridFor(values->length, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream,
-                       v, ids, values->length, func, count_mode, vals, counts);
-    AA_HIP(hipGetLastError());
-  }
   hipLaunchKernelGGL(k_agg_finalize, dim3(GridFor(num_groups, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream,
-                     func, AccKind(t), num_groups, vals, counts, reinterpret_cast<uint64_t*>(out_validity), nulls);
+                     func, AccKind(value_type_id), num_groups, static_cast<unsigned long long*>(sums),
+                     reinterpret_cast<const unsigned long long*>(counts), reinterpret_cast<uint64_t*>(out_validity), nulls);
   AA_HIP(hipGetLastError());
   unsigned long long nn = 0;
   AA_TRY(ReadBack(ctx, nulls, 8, &nn));
   out->null_count = static_cast<int64_t>(nn);
-  out->has_validity = nn > 0;  // hash_sum: bitmap only if a group has no valid value; hash_count: never
+  out->has_validity = nn > 0;  // hash_sum: bitmap only if a group has no valid value (:585-600); hash_count: never
   return AMDARROW_OK;
+}
+
+int amdarrow_hash_aggregate(amdarrow_ctx* ctx, int func, const amdarrow_array* values, const uint32_t* ids,
+                            int64_t num_groups, int count_mode, void* out_values, uint8_t* out_validity,
+                            amdarrow_out* out) {
+  out->length = num_groups;
+  out->null_count = 0;
+  out->has_validity = 0;
+  if (num_groups == 0) return AMDARROW_OK;
+  void* counts = nullptr;
+  AA_TRY(amdarrow_malloc(ctx, 8 * num_groups, &counts));
+  int rc = AMDARROW_OK;
+  if (hipMemsetAsync(counts, 0, 8 * num_groups, ctx->stream) != hipSuccess ||
+      hipMemsetAsync(out_values, 0, 8 * num_groups, ctx->stream) != hipSuccess)
+    rc = SetError(AMDARROW_UNKNOWN_ERROR, "hipMemsetAsync failed");
+  if (rc == AMDARROW_OK) rc = amdarrow_hash_accumulate(ctx, func, values, ids, count_mode, out_values, static_cast<int64_t*>(counts));
+  if (rc == AMDARROW_OK)
+    rc = amdarrow_hash_finalize(ctx, func, values->type_id, num_groups, out_values, static_cast<int64_t*>(counts), out_validity, out);
+  (void)amdarrow_free(ctx, counts);
+  return rc;
 }
 
 int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, const amdarrow_array* keys,

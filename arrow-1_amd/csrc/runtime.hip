@@ -144,6 +144,10 @@ int amdarrow_memcpy_d2h(amdarrow_ctx* ctx, void* dst, const void* src, int64_t n
   AA_HIP(hipStreamSynchronize(ctx->stream));
   return AMDARROW_OK;
 }
+int amdarrow_memcpy_d2d(amdarrow_ctx* ctx, void* dst, const void* src, int64_t n) {
+  AA_HIP(hipMemcpyAsync(dst, src, static_cast<size_t>(n), hipMemcpyDeviceToDevice, ctx->stream));
+  return AMDARROW_OK;
+}
 int amdarrow_memset(amdarrow_ctx* ctx, void* dst, int value, int64_t n) {
   AA_HIP(hipMemsetAsync(dst, value, static_cast<size_t>(n), ctx->stream));
   return AMDARROW_OK;

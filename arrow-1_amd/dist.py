@@ -11,8 +11,8 @@ all rows returns; int64 sums are exact at any world size, float64 sums carry the
 reordering tolerance.
 
 The protocol is written against torch tensors and two callables so that the world_size-2
-`gloo` test on CPU (tests/test_dist_gloo.py) drives exactly this code with the oracle standing
-in for the kernels."""
+`gloo` test on CPU (tests/test_dist_gloo.py) can drive exactly this protocol with a CPU
+stand-in supplied BY THE TEST for the two kernel callables."""
 import torch
 import torch.distributed as tdist
 

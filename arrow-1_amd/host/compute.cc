@@ -1,0 +1,543 @@
+// compute.cc -- runtime of the C++ host mirror: Status, data model glue, ExecBatchIterator,
+// Function dispatch, executors, FunctionRegistry, CallFunction.  Follows the control flow of the
+// reference's compute/{exec,function,registry}.cc (cited per function); no kernel lives here.
+#include "amdarrow_compute.h"
+
+#include <algorithm>
+#include <cstring>
+#include <limits>
+#include <sstream>
+
+namespace amdarrow {
+
+// ---- Status -------------------------------------------------------------------------------------
+Status Status::FromAbi(int code) {
+  if (code == AMDARROW_OK) return Status::OK();
+  return Status(static_cast<StatusCode>(code), amdarrow_last_error());
+}
+std::string Status::ToString() const {
+  static const char* names[] = {"OK", "Out of memory", "Key error", "Type error", "Invalid", "IOError", "Capacity error",
+                                "Index error", "Cancelled", "Unknown error", "NotImplemented"};
+  if (ok()) return "OK";
+  const int c = static_cast<int>(code_);
+  return std::string(c >= 0 && c <= 10 ? names[c] : "Error") + ": " + msg_;
+}
+
+// ---- types ----------------------------------------------------------------------------------------
+int DataType::bit_width() const {
+  switch (id_) {
+    case Type::BOOL: return 1;
+    case Type::UINT8: case Type::INT8: return 8;
+    case Type::UINT16: case Type::INT16: case Type::HALF_FLOAT: return 16;
+    case Type::UINT32: case Type::INT32: case Type::FLOAT: return 32;
+    case Type::UINT64: case Type::INT64: case Type::DOUBLE: return 64;
+    default: return -1;
+  }
+}
+std::string DataType::ToString() const {
+  static const char* names[] = {"null", "bool", "uint8", "int8", "uint16", "int16", "uint32", "int32", "uint64", "int64",
+                                "halffloat", "float", "double"};
+  return names[id_];
+}
+std::shared_ptr<DataType> TypeFromId(Type::type id) {
+  static std::shared_ptr<DataType> types[13];
+  static std::once_flag once;
+  std::call_once(once, [] { for (int i = 0; i < 13; ++i) types[i] = std::make_shared<DataType>(static_cast<Type::type>(i)); });
+  return types[id];
+}
+std::shared_ptr<DataType> boolean() { return TypeFromId(Type::BOOL); }
+std::shared_ptr<DataType> uint8() { return TypeFromId(Type::UINT8); }
+std::shared_ptr<DataType> int8() { return TypeFromId(Type::INT8); }
+std::shared_ptr<DataType> uint16() { return TypeFromId(Type::UINT16); }
+std::shared_ptr<DataType> int16() { return TypeFromId(Type::INT16); }
+std::shared_ptr<DataType> uint32() { return TypeFromId(Type::UINT32); }
+std::shared_ptr<DataType> int32() { return TypeFromId(Type::INT32); }
+std::shared_ptr<DataType> uint64() { return TypeFromId(Type::UINT64); }
+std::shared_ptr<DataType> int64() { return TypeFromId(Type::INT64); }
+std::shared_ptr<DataType> float32() { return TypeFromId(Type::FLOAT); }
+std::shared_ptr<DataType> float64() { return TypeFromId(Type::DOUBLE); }
+bool is_signed_integer(Type::type id) { return id == Type::INT8 || id == Type::INT16 || id == Type::INT32 || id == Type::INT64; }
+bool is_integer(Type::type id) { return id >= Type::UINT8 && id <= Type::INT64; }
+bool is_floating(Type::type id) { return id == Type::FLOAT || id == Type::DOUBLE; }
+
+// ---- memory ---------------------------------------------------------------------------------------
+Result<std::shared_ptr<MemoryPool>> MemoryPool::Make(int device, void* stream) {
+  auto pool = std::shared_ptr<MemoryPool>(new MemoryPool());
+  const int rc = amdarrow_ctx_create(device, stream, /*private_stream=*/0, &pool->ctx_);
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  return pool;
+}
+MemoryPool::~MemoryPool() {
+  if (ctx_) amdarrow_ctx_destroy(ctx_);
+}
+int64_t MemoryPool::bytes_allocated() const { return amdarrow_bytes_allocated(ctx_); }
+int64_t MemoryPool::max_memory() const { return amdarrow_max_memory(ctx_); }
+
+Buffer::~Buffer() {
+  if (owned_ && pool_ && data_) amdarrow_free(pool_->ctx(), data_);
+}
+std::shared_ptr<Buffer> Buffer::WrapHost(const void* data, int64_t size) {
+  return std::make_shared<Buffer>(const_cast<void*>(data), size, nullptr, false);
+}
+Result<std::shared_ptr<Buffer>> AllocateBuffer(int64_t nbytes, const std::shared_ptr<MemoryPool>& pool) {
+  if (!pool) return Status::Invalid("AllocateBuffer: no device memory pool (this backend has no CPU path)");
+  void* p = nullptr;
+  const int rc = amdarrow_malloc(pool->ctx(), nbytes, &p);
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  return std::make_shared<Buffer>(p, nbytes, pool, true);
+}
+Result<std::shared_ptr<Buffer>> AllocateBitmap(int64_t nbits, const std::shared_ptr<MemoryPool>& pool) {
+  const int64_t nbytes = (nbits + 7) / 8;
+  AMD_ASSIGN_OR_RAISE(auto buf, AllocateBuffer(nbytes, pool));
+  if (nbytes > 0) {
+    // the pool rounds capacity up to 64 bytes, so zeroing whole 8-byte words is in bounds
+    const int rc = amdarrow_memset(pool->ctx(), buf->mutable_data(), 0, ((nbytes + 7) / 8) * 8);
+    if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  }
+  return buf;
+}
+
+// ---- ArrayData --------------------------------------------------------------------------------------
+std::shared_ptr<ArrayData> ArrayData::Make(std::shared_ptr<DataType> type, int64_t length,
+                                           std::vector<std::shared_ptr<Buffer>> buffers, int64_t null_count, int64_t offset) {
+  auto d = std::make_shared<ArrayData>();
+  d->type = std::move(type);
+  d->length = length;
+  d->buffers = std::move(buffers);
+  if (d->buffers.size() < 2) d->buffers.resize(2);
+  d->null_count = d->buffers[0] ? null_count : 0;
+  d->offset = offset;
+  return d;
+}
+std::shared_ptr<ArrayData> ArrayData::Slice(int64_t off, int64_t len) const {
+  auto d = std::make_shared<ArrayData>(*this);
+  d->offset = offset + off;
+  d->length = len;
+  // array/data.cc: a slice keeps 0, otherwise the count becomes unknown
+  d->null_count = (null_count == 0 || !buffers[0]) ? 0 : (len == length ? null_count : kUnknownNullCount);
+  return d;
+}
+amdarrow_array ArrayData::abi() const {
+  amdarrow_array a;
+  a.values = buffers[1] ? buffers[1]->data() : nullptr;
+  a.validity = buffers[0] ? buffers[0]->data() : nullptr;
+  a.length = length;
+  a.offset = offset;
+  a.type_id = static_cast<int32_t>(type->id());
+  a.null_count = null_count;
+  return a;
+}
+Result<std::shared_ptr<ArrayData>> ArrayFromHost(const std::shared_ptr<MemoryPool>& pool, std::shared_ptr<DataType> type,
+                                                 const void* values, int64_t length, const uint8_t* validity_bits,
+                                                 int64_t null_count) {
+  const int bw = type->bit_width();
+  const int64_t vbytes = bw == 1 ? (length + 7) / 8 : length * bw / 8;
+  AMD_ASSIGN_OR_RAISE(auto vbuf, AllocateBuffer(vbytes, pool));
+  if (vbytes) {
+    const int rc = amdarrow_memcpy_h2d(pool->ctx(), vbuf->mutable_data(), values, vbytes);
+    if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  }
+  std::shared_ptr<Buffer> nbuf;
+  if (validity_bits) {
+    AMD_ASSIGN_OR_RAISE(nbuf, AllocateBuffer((length + 7) / 8, pool));
+    if (length) {
+      const int rc = amdarrow_memcpy_h2d(pool->ctx(), nbuf->mutable_data(), validity_bits, (length + 7) / 8);
+      if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+    }
+  }
+  return ArrayData::Make(std::move(type), length, {nbuf, vbuf}, null_count);
+}
+Status CopyValuesToHost(const ArrayData& a, const std::shared_ptr<MemoryPool>& pool, void* out_values,
+                        uint8_t* out_validity_bits) {
+  const int bw = a.type->bit_width();
+  if (a.offset != 0) return Status::NotImplemented("CopyValuesToHost: sliced arrays");
+  const int64_t vbytes = bw == 1 ? (a.length + 7) / 8 : a.length * bw / 8;
+  if (vbytes && out_values) {
+    const int rc = amdarrow_memcpy_d2h(pool->ctx(), out_values, a.buffers[1]->data(), vbytes);
+    if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  }
+  if (out_validity_bits && a.length) {
+    if (a.buffers[0]) {
+      const int rc = amdarrow_memcpy_d2h(pool->ctx(), out_validity_bits, a.buffers[0]->data(), (a.length + 7) / 8);
+      if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+    } else {
+      memset(out_validity_bits, 0xFF, (a.length + 7) / 8);
+    }
+  }
+  return Status::OK();
+}
+
+ChunkedArray::ChunkedArray(std::vector<std::shared_ptr<ArrayData>> chunks, std::shared_ptr<DataType> type)
+    : chunks_(std::move(chunks)), type_(std::move(type)) {
+  for (const auto& c : chunks_) {
+    length_ += c->length;
+    if (null_count_ >= 0) null_count_ = c->null_count < 0 ? kUnknownNullCount : null_count_ + c->null_count;
+  }
+}
+
+std::string ValueDescr::ToString() const {
+  return std::string(shape == ARRAY ? "array[" : shape == SCALAR ? "scalar[" : "any[") + (type ? type->ToString() : "?") + "]";
+}
+std::shared_ptr<DataType> Datum::type() const {
+  switch (kind_) {
+    case ARRAY: return array_->type;
+    case CHUNKED_ARRAY: return chunked_->type();
+    case SCALAR: return scalar_->type;
+    default: return nullptr;
+  }
+}
+int64_t Datum::length() const {
+  switch (kind_) {
+    case ARRAY: return array_->length;
+    case CHUNKED_ARRAY: return chunked_->length();
+    case SCALAR: return 1;
+    default: return -1;
+  }
+}
+ValueDescr Datum::descr() const {
+  return kind_ == SCALAR ? ValueDescr::Scalar(type()) : ValueDescr::Array(type());
+}
+
+namespace compute {
+
+ExecContext::ExecContext(std::shared_ptr<MemoryPool> pool, FunctionRegistry* func_registry)
+    : pool_(std::move(pool)), func_registry_(func_registry ? func_registry : GetFunctionRegistry()) {}
+
+// ---- ExecBatch / ExecBatchIterator -----------------------------------------------------------------
+Result<ExecBatch> ExecBatch::Make(std::vector<Datum> values) {  // exec.cc:60-84
+  if (values.empty()) return Status::Invalid("Cannot infer ExecBatch length without at least one value");
+  int64_t length = -1;
+  for (const auto& v : values) {
+    if (v.is_scalar()) {
+      if (length == -1) length = 1;
+      continue;
+    }
+    if (!v.is_array()) return Status::Invalid("ExecBatch::Make: only ARRAY and SCALAR values");
+    if (length == -1 || length == 1) {
+      length = v.length();
+      continue;
+    }
+    if (length != v.length()) return Status::Invalid("Arrays used to construct an ExecBatch must have equal length");
+  }
+  return ExecBatch(std::move(values), length);
+}
+std::vector<ValueDescr> ExecBatch::GetDescriptors() const {
+  std::vector<ValueDescr> d;
+  for (const auto& v : values) d.push_back(v.descr());
+  return d;
+}
+
+namespace detail {
+Result<std::unique_ptr<ExecBatchIterator>> ExecBatchIterator::Make(std::vector<Datum> args, int64_t max_chunksize) {
+  // exec.cc:158-196: every array-like argument must have the same length
+  int64_t length = 1;
+  bool length_set = false;
+  for (const auto& arg : args) {
+    if (!(arg.is_arraylike() || arg.is_scalar()))
+      return Status::Invalid("ExecBatchIterator only works with Scalar, Array, and ChunkedArray arguments");
+    if (arg.is_scalar()) continue;
+    if (!length_set) {
+      length = arg.length();
+      length_set = true;
+    } else if (arg.length() != length) {
+      return Status::Invalid("Array arguments must all be the same length");  // exec.cc:190-192
+    }
+  }
+  auto it = std::unique_ptr<ExecBatchIterator>(new ExecBatchIterator());
+  it->args_ = std::move(args);
+  it->chunk_indexes_.assign(it->args_.size(), 0);
+  it->chunk_positions_.assign(it->args_.size(), 0);
+  it->length_ = length;
+  it->max_chunksize_ = std::min(length, max_chunksize);
+  return it;
+}
+bool ExecBatchIterator::Next(ExecBatch* batch) {  // exec.cc:198-252
+  if (position_ == length_) return false;
+  int64_t iteration_size = std::min(length_ - position_, max_chunksize_);
+  // first pass: the largest slice available in every chunked argument
+  for (size_t i = 0; i < args_.size() && iteration_size > 0; ++i) {
+    if (args_[i].kind() != Datum::CHUNKED_ARRAY) continue;
+    const ChunkedArray& arg = *args_[i].chunked_array();
+    while (chunk_indexes_[i] < arg.num_chunks()) {
+      const ArrayData& chunk = *arg.chunk(chunk_indexes_[i]);
+      if (chunk_positions_[i] == chunk.length) {  // chunk exhausted (or empty): advance
+        ++chunk_indexes_[i];
+        chunk_positions_[i] = 0;
+        continue;
+      }
+      iteration_size = std::min(chunk.length - chunk_positions_[i], iteration_size);
+      break;
+    }
+  }
+  batch->values.resize(args_.size());
+  batch->length = iteration_size;
+  for (size_t i = 0; i < args_.size(); ++i) {
+    if (args_[i].is_scalar()) {
+      batch->values[i] = args_[i];
+    } else if (args_[i].is_array()) {
+      batch->values[i] = Datum(args_[i].array()->Slice(position_, iteration_size));
+    } else {
+      const ChunkedArray& carr = *args_[i].chunked_array();
+      const auto& chunk = carr.chunk(chunk_indexes_[i]);
+      batch->values[i] = Datum(chunk->Slice(chunk_positions_[i], iteration_size));
+      chunk_positions_[i] += iteration_size;
+    }
+  }
+  position_ += iteration_size;
+  return true;
+}
+}  // namespace detail
+
+// ---- signatures -------------------------------------------------------------------------------------
+InputType InputType::Exact(Type::type id, ValueDescr::Shape shape) {
+  InputType t;
+  t.matches = [id, shape](const ValueDescr& d) { return d.type && d.type->id() == id && (shape == ValueDescr::ANY || shape == d.shape); };
+  t.repr = TypeFromId(id)->ToString();
+  return t;
+}
+InputType InputType::Primitive() {
+  InputType t;
+  t.matches = [](const ValueDescr& d) { return d.type && d.type->bit_width() > 0 && d.type->id() != Type::HALF_FLOAT; };
+  t.repr = "primitive";
+  return t;
+}
+InputType InputType::Integer() {
+  InputType t;
+  t.matches = [](const ValueDescr& d) { return d.type && is_integer(d.type->id()); };
+  t.repr = "integer";
+  return t;
+}
+InputType InputType::Any() {
+  InputType t;
+  t.matches = [](const ValueDescr&) { return true; };
+  t.repr = "any";
+  return t;
+}
+bool KernelSignature::MatchesInputs(const std::vector<ValueDescr>& args) const {
+  if (args.size() != in_types.size()) return false;
+  for (size_t i = 0; i < args.size(); ++i)
+    if (!in_types[i].matches(args[i])) return false;
+  return true;
+}
+
+// ---- Function ------------------------------------------------------------------------------------------
+Status Function::CheckArity(int passed) const {  // function.cc:41-56
+  if (arity_.is_varargs && passed < arity_.num_args)
+    return Status::Invalid("VarArgs function " + name_ + " needs at least " + std::to_string(arity_.num_args) +
+                           " arguments but kernel accepts only " + std::to_string(passed));
+  if (!arity_.is_varargs && passed != arity_.num_args)
+    return Status::Invalid("Function " + name_ + " accepts " + std::to_string(arity_.num_args) + " arguments but attempted to look up kernel(s) with " +
+                           std::to_string(passed));
+  return Status::OK();
+}
+Result<Datum> Function::Execute(const std::vector<Datum>&, const FunctionOptions*, ExecContext*) const {
+  return Status::NotImplemented("Function " + name_ + " cannot be executed");
+}
+
+static std::string DescrsToString(const std::vector<ValueDescr>& v) {
+  std::string s = "(";
+  for (size_t i = 0; i < v.size(); ++i) s += (i ? ", " : "") + v[i].ToString();
+  return s + ")";
+}
+template <typename K>
+static Result<const K*> Dispatch(const std::string& name, const std::vector<K>& kernels, const std::vector<ValueDescr>& values) {
+  for (const auto& k : kernels)
+    if (k.signature.MatchesInputs(values)) return &k;
+  // function.cc:112-125 DispatchExactImpl -> NoMatchingKernel
+  return Status::NotImplemented("Function " + name + " has no kernel matching input types " + DescrsToString(values));
+}
+Status ScalarFunction::AddKernel(ScalarKernel kernel) {
+  if (static_cast<int>(kernel.signature.in_types.size()) != arity_.num_args && !arity_.is_varargs)
+    return Status::Invalid("In function " + name_ + ": number of argument types != function arity");
+  kernels_.push_back(std::move(kernel));
+  return Status::OK();
+}
+Status VectorFunction::AddKernel(VectorKernel kernel) {
+  if (static_cast<int>(kernel.signature.in_types.size()) != arity_.num_args && !arity_.is_varargs)
+    return Status::Invalid("In function " + name_ + ": number of argument types != function arity");
+  kernels_.push_back(std::move(kernel));
+  return Status::OK();
+}
+Status HashAggregateFunction::AddKernel(HashAggregateKernel kernel) {
+  kernels_.push_back(std::move(kernel));
+  return Status::OK();
+}
+Result<const ScalarKernel*> ScalarFunction::DispatchExact(const std::vector<ValueDescr>& v) const {
+  AMD_RETURN_NOT_OK(CheckArity(static_cast<int>(v.size())));
+  return Dispatch(name_, kernels_, v);
+}
+Result<const VectorKernel*> VectorFunction::DispatchExact(const std::vector<ValueDescr>& v) const {
+  AMD_RETURN_NOT_OK(CheckArity(static_cast<int>(v.size())));
+  return Dispatch(name_, kernels_, v);
+}
+Result<const HashAggregateKernel*> HashAggregateFunction::DispatchExact(const std::vector<ValueDescr>& v) const {
+  AMD_RETURN_NOT_OK(CheckArity(static_cast<int>(v.size())));
+  return Dispatch(name_, kernels_, v);
+}
+
+static bool HaveChunkedArray(const std::vector<Datum>& args) {
+  for (const auto& a : args) if (a.kind() == Datum::CHUNKED_ARRAY) return true;
+  return false;
+}
+// exec.cc:463-480 ToChunkedArray: empty chunks are dropped
+static Datum WrapResults(const std::vector<Datum>& inputs, std::vector<Datum> outputs, const std::shared_ptr<DataType>& type,
+                         const std::shared_ptr<MemoryPool>& pool) {
+  if (HaveChunkedArray(inputs) || outputs.size() > 1) {
+    std::vector<std::shared_ptr<ArrayData>> chunks;
+    for (auto& o : outputs) if (o.array()->length > 0) chunks.push_back(o.array());
+    return Datum(std::make_shared<ChunkedArray>(std::move(chunks), type));
+  }
+  if (outputs.size() == 1) return outputs[0];
+  return Datum(ArrayData::Make(type, 0, {nullptr, nullptr}, 0));
+}
+
+// ScalarExecutor (exec.cc:553-716).  Output preallocation and null propagation happen behind the
+// C ABI for the kernels of this backend (they receive out buffers at offset 0), so a batch split
+// by exec_chunksize yields one output chunk per batch -- what the reference does for kernels with
+// can_write_into_slices == false.
+Result<Datum> ScalarFunction::Execute(const std::vector<Datum>& args, const FunctionOptions* options, ExecContext* ctx) const {
+  AMD_RETURN_NOT_OK(CheckArity(static_cast<int>(args.size())));
+  std::vector<ValueDescr> descrs;
+  bool all_scalar = true;
+  for (const auto& a : args) {
+    if (!(a.is_arraylike() || a.is_scalar())) return Status::NotImplemented("Unsupported Datum kind for scalar function " + name_);
+    descrs.push_back(a.descr());
+    all_scalar &= a.is_scalar();
+  }
+  AMD_ASSIGN_OR_RAISE(const ScalarKernel* kernel, DispatchExact(descrs));
+  if (all_scalar) return Status::NotImplemented("Function " + name_ + ": all-scalar execution is left to the CPU caller");
+  AMD_ASSIGN_OR_RAISE(auto out_type, kernel->signature.out_type(descrs));
+  KernelContext kctx(ctx);
+  kctx.SetOptions(options ? options : default_options_);
+  AMD_ASSIGN_OR_RAISE(auto it, detail::ExecBatchIterator::Make(args, ctx->exec_chunksize()));
+  std::vector<Datum> outputs;
+  ExecBatch batch;
+  while (it->Next(&batch)) {
+    Datum out;
+    AMD_RETURN_NOT_OK(kernel->exec(&kctx, batch, &out));
+    outputs.push_back(std::move(out));
+  }
+  return WrapResults(args, std::move(outputs), out_type, ctx->memory_pool());
+}
+
+// VectorExecutor (exec.cc:748-800)
+Result<Datum> VectorFunction::Execute(const std::vector<Datum>& args, const FunctionOptions* options, ExecContext* ctx) const {
+  AMD_RETURN_NOT_OK(CheckArity(static_cast<int>(args.size())));
+  std::vector<ValueDescr> descrs;
+  for (const auto& a : args) {
+    if (!(a.is_arraylike() || a.is_scalar())) return Status::NotImplemented("Unsupported Datum kind for vector function " + name_);
+    descrs.push_back(a.descr());
+  }
+  AMD_ASSIGN_OR_RAISE(const VectorKernel* kernel, DispatchExact(descrs));
+  AMD_ASSIGN_OR_RAISE(auto out_type, kernel->signature.out_type(descrs));
+  KernelContext kctx(ctx);
+  kctx.SetOptions(options ? options : default_options_);
+  std::vector<Datum> outputs;
+  if (kernel->can_execute_chunkwise) {
+    AMD_ASSIGN_OR_RAISE(auto it, detail::ExecBatchIterator::Make(args, ctx->exec_chunksize()));
+    ExecBatch batch;
+    while (it->Next(&batch)) {
+      Datum out;
+      AMD_RETURN_NOT_OK(kernel->exec(&kctx, batch, &out));
+      outputs.push_back(std::move(out));
+    }
+  } else {
+    // PackBatchNoChunks (exec.cc:718-738): the kernel sees the arguments whole
+    int64_t length = 0;
+    for (const auto& a : args) length = std::max(length, a.length());
+    ExecBatch batch(args, length);
+    Datum out;
+    AMD_RETURN_NOT_OK(kernel->exec(&kctx, batch, &out));
+    if (out.kind() == Datum::CHUNKED_ARRAY) return out;
+    outputs.push_back(std::move(out));
+    return outputs[0];
+  }
+  return WrapResults(args, std::move(outputs), out_type, ctx->memory_pool());
+}
+
+Result<Datum> HashAggregateFunction::Execute(const std::vector<Datum>&, const FunctionOptions*, ExecContext*) const {
+  return Status::NotImplemented("Direct execution of HASH_AGGREGATE functions");  // function.cc:193-195
+}
+Result<Datum> MetaFunction::Execute(const std::vector<Datum>& args, const FunctionOptions* options, ExecContext* ctx) const {
+  AMD_RETURN_NOT_OK(CheckArity(static_cast<int>(args.size())));  // function.cc:281-291
+  return ExecuteImpl(args, options ? options : default_options_, ctx);
+}
+
+// ---- registry (registry.cc:35-110) -----------------------------------------------------------------------
+std::unique_ptr<FunctionRegistry> FunctionRegistry::Make() { return std::unique_ptr<FunctionRegistry>(new FunctionRegistry()); }
+Status FunctionRegistry::AddFunction(std::shared_ptr<Function> function, bool allow_overwrite) {
+  std::lock_guard<std::mutex> lock(mutex_);
+  const std::string& name = function->name();
+  if (!allow_overwrite && name_to_function_.count(name))
+    return Status::KeyError("Already have a function registered with name: " + name);
+  name_to_function_[name] = std::move(function);
+  return Status::OK();
+}
+Status FunctionRegistry::AddAlias(const std::string& target_name, const std::string& source_name) {
+  std::lock_guard<std::mutex> lock(mutex_);
+  auto it = name_to_function_.find(source_name);
+  if (it == name_to_function_.end()) return Status::KeyError("No function registered with name: " + source_name);
+  name_to_function_[target_name] = it->second;
+  return Status::OK();
+}
+Result<std::shared_ptr<Function>> FunctionRegistry::GetFunction(const std::string& name) const {
+  auto it = name_to_function_.find(name);  // reads take no lock (registry.cc:60-66)
+  if (it == name_to_function_.end()) return Status::KeyError("No function registered with name: " + name);
+  return it->second;
+}
+std::vector<std::string> FunctionRegistry::GetFunctionNames() const {
+  std::vector<std::string> names;
+  for (const auto& kv : name_to_function_) names.push_back(kv.first);
+  std::sort(names.begin(), names.end());
+  return names;
+}
+int FunctionRegistry::num_functions() const { return static_cast<int>(name_to_function_.size()); }
+
+FunctionRegistry* GetFunctionRegistry() {  // registry.cc:115-150, hot-path subset
+  static std::unique_ptr<FunctionRegistry> g_registry = [] {
+    auto r = FunctionRegistry::Make();
+    internal::RegisterScalarArithmetic(r.get());
+    internal::RegisterScalarComparison(r.get());
+    internal::RegisterVectorSelection(r.get());
+    internal::RegisterVectorSort(r.get());
+    internal::RegisterHashAggregateBasic(r.get());
+    return r;
+  }();
+  return g_registry.get();
+}
+
+// ---- CallFunction (exec.cc:972-990) ---------------------------------------------------------------------
+Result<Datum> CallFunction(const std::string& func_name, const std::vector<Datum>& args, const FunctionOptions* options,
+                           ExecContext* ctx) {
+  if (ctx == nullptr) return Status::Invalid("CallFunction: this backend needs an ExecContext bound to a device MemoryPool");
+  AMD_ASSIGN_OR_RAISE(std::shared_ptr<Function> func, ctx->func_registry()->GetFunction(func_name));
+  return func->Execute(args, options, ctx);
+}
+Result<Datum> CallFunction(const std::string& func_name, const std::vector<Datum>& args, ExecContext* ctx) {
+  return CallFunction(func_name, args, nullptr, ctx);
+}
+
+Result<Datum> Filter(const Datum& values, const Datum& filter, const FilterOptions& options, ExecContext* ctx) {
+  return CallFunction("filter", {values, filter}, &options, ctx);  // api_vector.cc:95-99
+}
+Result<Datum> Take(const Datum& values, const Datum& indices, const TakeOptions& options, ExecContext* ctx) {
+  return CallFunction("take", {values, indices}, &options, ctx);  // api_vector.cc:101-107
+}
+Result<Datum> SortIndices(const Datum& values, SortOrder order, ExecContext* ctx) {
+  SortOptions options({SortKey("not-used", order)});  // api_vector.cc:54-58
+  return CallFunction("sort_indices", {values}, &options, ctx);
+}
+Result<Datum> Compare(const Datum& left, const Datum& right, CompareOperator op, ExecContext* ctx) {
+  static const char* names[] = {"equal", "not_equal", "greater", "greater_equal", "less", "less_equal"};  // api_scalar.cc:122-146
+  return CallFunction(names[op], {left, right}, nullptr, ctx);
+}
+static Result<Datum> Arith(const char* name, const Datum& l, const Datum& r, ArithmeticOptions o, ExecContext* ctx) {
+  return CallFunction(o.check_overflow ? std::string(name) + "_checked" : std::string(name), {l, r}, nullptr, ctx);  // api_scalar.cc:52-63
+}
+Result<Datum> Add(const Datum& l, const Datum& r, ArithmeticOptions o, ExecContext* ctx) { return Arith("add", l, r, o, ctx); }
+Result<Datum> Subtract(const Datum& l, const Datum& r, ArithmeticOptions o, ExecContext* ctx) { return Arith("subtract", l, r, o, ctx); }
+Result<Datum> Multiply(const Datum& l, const Datum& r, ArithmeticOptions o, ExecContext* ctx) { return Arith("multiply", l, r, o, ctx); }
+Result<Datum> Divide(const Datum& l, const Datum& r, ArithmeticOptions o, ExecContext* ctx) { return Arith("divide", l, r, o, ctx); }
+
+}  // namespace compute
+}  // namespace amdarrow

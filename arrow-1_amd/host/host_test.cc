@@ -1,0 +1,421 @@
+// host_test.cc -- tests of the C++ host mirror, driven by pytest (tests/test_host_cpp.py).
+//
+//   host_test cpu   plumbing with toy kernels over HOST buffers, no device: registry semantics,
+//                   arity / dispatch errors, ExecBatchIterator chunking, executor result wrapping --
+//                   the pattern of the reference's compute/exec_test.cc:462-515, 635-800 and
+//                   registry_test.cc.
+//   host_test gpu   CallFunction / GroupBy on the device against the reference's known-answer
+//                   vectors (vector_selection_test.cc:296-321, 1038-1051; vector_sort_test.cc:423-464,
+//                   629-647; hash_aggregate_test.cc:251-292, 480-605; scalar_compare_test.cc:248-296;
+//                   scalar_arithmetic_test.cc:337-362) and its error codes.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+
+#include "amdarrow_compute.h"
+
+using namespace amdarrow;           // NOLINT
+using namespace amdarrow::compute;  // NOLINT
+
+static int g_failures = 0, g_checks = 0;
+#define CHECK(cond)                                                              \
+  do {                                                                           \
+    ++g_checks;                                                                  \
+    if (!(cond)) { ++g_failures; fprintf(stderr, "FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); } \
+  } while (0)
+#define CHECK_OK(expr)                                                           \
+  do {                                                                           \
+    ++g_checks;                                                                  \
+    auto _s = (expr);                                                            \
+    if (!_s.ok()) { ++g_failures; fprintf(stderr, "FAIL %s:%d: %s -> %s\n", __FILE__, __LINE__, #expr, _s.ToString().c_str()); } \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------- cpu
+static std::shared_ptr<ArrayData> HostInt32(const std::vector<int32_t>& v) {
+  auto* copy = new std::vector<int32_t>(v);  // leaked on purpose: test-lifetime storage
+  return ArrayData::Make(int32(), static_cast<int64_t>(v.size()), {nullptr, Buffer::WrapHost(copy->data(), 4 * copy->size())}, 0);
+}
+
+static int RunCpu() {
+  // ---- registry semantics (registry.cc:35-110; registry_test.cc) ----
+  auto registry = FunctionRegistry::Make();
+  CHECK(registry->num_functions() == 0);
+  auto f1 = std::make_shared<ScalarFunction>("f1", Arity::Unary());
+  CHECK_OK(registry->AddFunction(f1));
+  CHECK(registry->AddFunction(std::make_shared<ScalarFunction>("f1", Arity::Unary())).IsKeyError());   // no overwrite by default
+  CHECK_OK(registry->AddFunction(std::make_shared<ScalarFunction>("f1", Arity::Binary()), /*allow_overwrite=*/true));
+  CHECK_OK(registry->AddAlias("f1_alias", "f1"));
+  CHECK(registry->AddAlias("x", "no_such").IsKeyError());
+  CHECK(registry->num_functions() == 2);
+  CHECK(registry->GetFunction("nope").status().IsKeyError());
+  CHECK(registry->GetFunction("nope").status().message() == "No function registered with name: nope");
+  auto names = registry->GetFunctionNames();
+  CHECK(names.size() == 2 && names[0] == "f1" && names[1] == "f1_alias");
+
+  // ---- toy kernels on host memory (exec_test.cc "test_copy" style) ----
+  ExecContext ctx(nullptr, registry.get());
+  int exec_calls = 0;
+  std::vector<int64_t> seen_lengths;
+  auto copy_fn = std::make_shared<VectorFunction>("test_copy", Arity::Unary());
+  VectorKernel k;
+  k.signature.in_types = {InputType::Exact(Type::INT32)};
+  k.signature.out_type = [](const std::vector<ValueDescr>& d) -> Result<std::shared_ptr<DataType>> { return d[0].type; };
+  k.exec = [&](KernelContext*, const ExecBatch& batch, Datum* out) -> Status {
+    ++exec_calls;
+    seen_lengths.push_back(batch.length);
+    *out = batch[0];  // zero-copy "copy"
+    return Status::OK();
+  };
+  CHECK_OK(copy_fn->AddKernel(k));
+  CHECK_OK(registry->AddFunction(copy_fn));
+  auto arr = HostInt32({1, 2, 3, 4, 5, 6, 7, 8, 9, 10});
+  {
+    auto r = CallFunction("test_copy", {Datum(arr)}, &ctx);
+    CHECK_OK(r.status());
+    CHECK(r->is_array() && r->array()->length == 10 && exec_calls == 1);
+  }
+  {  // exec_chunksize splits the array into batches -> ChunkedArray out (exec.cc:762-776)
+    ctx.set_exec_chunksize(4);
+    exec_calls = 0; seen_lengths.clear();
+    auto r = CallFunction("test_copy", {Datum(arr)}, &ctx);
+    CHECK_OK(r.status());
+    CHECK(exec_calls == 3 && seen_lengths == std::vector<int64_t>({4, 4, 2}));
+    CHECK(r->kind() == Datum::CHUNKED_ARRAY && r->chunked_array()->num_chunks() == 3 && r->chunked_array()->length() == 10);
+    CHECK(r->chunked_array()->chunk(1)->offset == 4);
+    ctx.set_exec_chunksize(kDefaultExecChunksize);
+  }
+  {  // chunked input -> one exec per chunk, empty chunks dropped (exec.cc:468-471)
+    auto ca = std::make_shared<ChunkedArray>(std::vector<std::shared_ptr<ArrayData>>{HostInt32({1, 2, 3}), HostInt32({}), HostInt32({4, 5})}, int32());
+    exec_calls = 0; seen_lengths.clear();
+    auto r = CallFunction("test_copy", {Datum(ca)}, &ctx);
+    CHECK_OK(r.status());
+    CHECK(seen_lengths == std::vector<int64_t>({3, 2}));
+    CHECK(r->kind() == Datum::CHUNKED_ARRAY && r->chunked_array()->num_chunks() == 2);
+  }
+  // arity -> Invalid (function.cc:41-56); no matching kernel -> NotImplemented; unknown -> KeyError
+  CHECK(CallFunction("test_copy", {Datum(arr), Datum(arr)}, &ctx).status().IsInvalid());
+  auto f64arr = ArrayData::Make(float64(), 0, {nullptr, Buffer::WrapHost(nullptr, 0)}, 0);
+  CHECK(CallFunction("test_copy", {Datum(f64arr)}, &ctx).status().IsNotImplemented());
+  CHECK(CallFunction("no_such_function", {Datum(arr)}, &ctx).status().IsKeyError());
+
+  // ---- ExecBatchIterator (exec_test.cc:462-515) ----
+  {
+    auto a = HostInt32({0, 1, 2, 3, 4, 5, 6, 7, 8, 9});
+    auto ca = std::make_shared<ChunkedArray>(std::vector<std::shared_ptr<ArrayData>>{HostInt32({0, 1, 2, 3}), HostInt32({4, 5, 6, 7, 8, 9})}, int32());
+    auto s = Scalar::Make(int32(), int32_t(7));
+    auto it = detail::ExecBatchIterator::Make({Datum(a), Datum(ca), Datum(s)}, 3);
+    CHECK_OK(it.status());
+    std::vector<int64_t> lens;
+    ExecBatch b;
+    while ((*it)->Next(&b)) {
+      lens.push_back(b.length);
+      CHECK(b[0].array()->length == b.length && b[1].array()->length == b.length && b[2].is_scalar());
+    }
+    CHECK(lens == std::vector<int64_t>({3, 1, 3, 3}));  // chunk boundary at 4 respected
+    CHECK((*it)->position() == 10);
+    // length mismatch -> Invalid "Array arguments must all be the same length" (exec.cc:190-192)
+    auto bad = detail::ExecBatchIterator::Make({Datum(a), Datum(HostInt32({1, 2}))}, 100);
+    CHECK(bad.status().IsInvalid() && bad.status().message() == "Array arguments must all be the same length");
+  }
+  {  // ExecBatch::Make
+    auto ok = ExecBatch::Make({Datum(HostInt32({1, 2})), Datum(Scalar::Make(int32(), int32_t(1)))});
+    CHECK_OK(ok.status());
+    CHECK(ok->length == 2);
+    CHECK(ExecBatch::Make({Datum(HostInt32({1, 2})), Datum(HostInt32({1}))}).status().IsInvalid());
+  }
+  // ---- the default (device) registry carries the hot-path functions under the reference's names ----
+  {
+    FunctionRegistry* dev = GetFunctionRegistry();
+    for (const char* n : {"filter", "array_filter", "take", "array_take", "sort_indices", "array_sort_indices", "equal", "not_equal",
+                          "greater", "greater_equal", "less", "less_equal", "add", "subtract", "multiply", "divide", "add_checked",
+                          "subtract_checked", "multiply_checked", "divide_checked", "hash_sum", "hash_count", "hash_mean"})
+      CHECK(dev->GetFunction(n).ok());
+    auto f = dev->GetFunction("hash_sum");
+    CHECK((*f)->kind() == Function::HASH_AGGREGATE && (*f)->arity().num_args == 3);
+    ExecContext dctx(nullptr);  // no pool: anything that must allocate fails loudly, never falls back
+    auto direct = CallFunction("hash_sum", {Datum(arr), Datum(arr), Datum(arr)}, &dctx);
+    CHECK(direct.status().IsNotImplemented() && direct.status().message() == "Direct execution of HASH_AGGREGATE functions");
+    CHECK((*dev->GetFunction("filter"))->kind() == Function::META);
+    CHECK((*dev->GetFunction("array_take"))->num_kernels() == 1);
+    CHECK((*dev->GetFunction("array_sort_indices"))->num_kernels() == 10);
+    // a product call without a device pool must raise, not compute on the CPU
+    auto nofallback = CallFunction("add", {Datum(arr), Datum(arr)}, &dctx);
+    CHECK(!nofallback.ok());
+  }
+  printf("host_test cpu: %d checks, %d failures\n", g_checks, g_failures);
+  return g_failures ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------- gpu
+template <typename T> struct Opt { bool valid; T v; };
+template <typename T>
+static std::shared_ptr<ArrayData> Dev(const std::shared_ptr<MemoryPool>& pool, std::shared_ptr<DataType> type, const std::vector<Opt<T>>& items) {
+  std::vector<T> vals;
+  std::vector<uint8_t> bits((items.size() + 7) / 8 + 1, 0);
+  bool any_null = false;
+  int64_t nulls = 0;
+  for (size_t i = 0; i < items.size(); ++i) {
+    vals.push_back(items[i].valid ? items[i].v : T{});
+    if (items[i].valid) bits[i / 8] |= uint8_t(1u << (i % 8)); else { any_null = true; ++nulls; }
+  }
+  if (vals.empty()) vals.push_back(T{});
+  auto r = ArrayFromHost(pool, type, vals.data(), static_cast<int64_t>(items.size()), any_null ? bits.data() : nullptr, nulls);
+  return r.ok() ? *r : nullptr;
+}
+static std::shared_ptr<ArrayData> DevBool(const std::shared_ptr<MemoryPool>& pool, const std::vector<int>& items /* -1 = null */) {
+  std::vector<uint8_t> vals((items.size() + 7) / 8 + 1, 0), bits((items.size() + 7) / 8 + 1, 0);
+  bool any_null = false;
+  int64_t nulls = 0;
+  for (size_t i = 0; i < items.size(); ++i) {
+    if (items[i] > 0) vals[i / 8] |= uint8_t(1u << (i % 8));
+    if (items[i] >= 0) bits[i / 8] |= uint8_t(1u << (i % 8)); else { any_null = true; ++nulls; }
+  }
+  auto r = ArrayFromHost(pool, boolean(), vals.data(), static_cast<int64_t>(items.size()), any_null ? bits.data() : nullptr, nulls);
+  return r.ok() ? *r : nullptr;
+}
+template <typename T>
+static std::vector<Opt<T>> Host(const std::shared_ptr<MemoryPool>& pool, const ArrayData& a) {
+  std::vector<T> vals(a.length + 1);
+  std::vector<uint8_t> bits((a.length + 7) / 8 + 1, 0);
+  auto st = CopyValuesToHost(a, pool, vals.data(), bits.data());
+  std::vector<Opt<T>> out;
+  if (!st.ok()) { ++g_failures; fprintf(stderr, "copy failed: %s\n", st.ToString().c_str()); return out; }
+  for (int64_t i = 0; i < a.length; ++i) out.push_back({bool((bits[i / 8] >> (i % 8)) & 1), vals[i]});
+  return out;
+}
+static std::vector<int> HostBool(const std::shared_ptr<MemoryPool>& pool, const ArrayData& a) {
+  std::vector<uint8_t> vals((a.length + 7) / 8 + 1, 0), bits((a.length + 7) / 8 + 1, 0);
+  auto st = CopyValuesToHost(a, pool, vals.data(), bits.data());
+  std::vector<int> out;
+  if (!st.ok()) { ++g_failures; return out; }
+  for (int64_t i = 0; i < a.length; ++i) out.push_back(((bits[i / 8] >> (i % 8)) & 1) ? int((vals[i / 8] >> (i % 8)) & 1) : -1);
+  return out;
+}
+template <typename T>
+static bool Same(const std::vector<Opt<T>>& got, const std::vector<Opt<T>>& want) {
+  if (got.size() != want.size()) return false;
+  for (size_t i = 0; i < got.size(); ++i) {
+    if (got[i].valid != want[i].valid) return false;
+    if (got[i].valid && !(got[i].v == want[i].v || (got[i].v != got[i].v && want[i].v != want[i].v))) return false;
+  }
+  return true;
+}
+#define N(T) Opt<T>{false, T{}}
+#define V(T, x) Opt<T>{true, T(x)}
+
+template <typename T>
+static void TypedTests(const std::shared_ptr<MemoryPool>& pool, ExecContext* ctx, std::shared_ptr<DataType> type) {
+  using O = Opt<T>;
+  // FilterNumeric (vector_selection_test.cc:296-321)
+  struct FC { std::vector<O> values; std::vector<int> filter; std::vector<O> emit_null, drop; };
+  std::vector<FC> fcs = {
+      {{V(T, 9)}, {0}, {}, {}}, {{V(T, 9)}, {1}, {V(T, 9)}, {V(T, 9)}}, {{V(T, 9)}, {-1}, {N(T)}, {}},
+      {{N(T)}, {1}, {N(T)}, {N(T)}}, {{N(T)}, {-1}, {N(T)}, {}},
+      {{V(T, 7), V(T, 8), V(T, 9)}, {0, 1, 0}, {V(T, 8)}, {V(T, 8)}},
+      {{V(T, 7), V(T, 8), V(T, 9)}, {1, 0, 1}, {V(T, 7), V(T, 9)}, {V(T, 7), V(T, 9)}},
+      {{N(T), V(T, 8), V(T, 9)}, {0, 1, 0}, {V(T, 8)}, {V(T, 8)}},
+      {{V(T, 7), V(T, 8), V(T, 9)}, {-1, 1, 0}, {N(T), V(T, 8)}, {V(T, 8)}},
+      {{V(T, 7), V(T, 8), V(T, 9)}, {1, -1, 1}, {V(T, 7), N(T), V(T, 9)}, {V(T, 7), V(T, 9)}},
+  };
+  for (const auto& c : fcs) {
+    for (int mode = 0; mode < 2; ++mode) {
+      FilterOptions opts(mode ? FilterOptions::EMIT_NULL : FilterOptions::DROP);
+      auto r = Filter(Datum(Dev<T>(pool, type, c.values)), Datum(DevBool(pool, c.filter)), opts, ctx);
+      CHECK_OK(r.status());
+      if (r.ok()) CHECK(Same(Host<T>(pool, *r->array()), mode ? c.emit_null : c.drop));
+    }
+  }
+  {  // sliced filter: [0,1,1,1,0,1].Slice(3,3) over [7,8,9] -> [7,9]
+    auto f = DevBool(pool, {0, 1, 1, 1, 0, 1})->Slice(3, 3);
+    auto r = Filter(Datum(Dev<T>(pool, type, {V(T, 7), V(T, 8), V(T, 9)})), Datum(f), FilterOptions::Defaults(), ctx);
+    CHECK_OK(r.status());
+    if (r.ok()) CHECK(Same(Host<T>(pool, *r->array()), {V(T, 7), V(T, 9)}));
+    auto bad = Filter(Datum(Dev<T>(pool, type, {V(T, 7), V(T, 8), V(T, 9)})), Datum(DevBool(pool, {})), FilterOptions::Defaults(), ctx);
+    CHECK(bad.status().IsInvalid());  // :317-320
+  }
+  // TakeNumeric (:1038-1051) with int8 and uint32 indices
+  {
+    auto vals = Dev<T>(pool, type, {N(T), V(T, 8), V(T, 9)});
+    auto r = Take(Datum(vals), Datum(Dev<int8_t>(pool, int8(), {V(int8_t, 0), V(int8_t, 1), V(int8_t, 0)})), TakeOptions::Defaults(), ctx);
+    CHECK_OK(r.status());
+    if (r.ok()) { CHECK(Same(Host<T>(pool, *r->array()), {N(T), V(T, 8), N(T)})); CHECK(r->array()->null_count == 2); }
+    auto r2 = Take(Datum(Dev<T>(pool, type, {V(T, 7), V(T, 8), V(T, 9)})), Datum(Dev<uint32_t>(pool, uint32(), {N(uint32_t), V(uint32_t, 1), V(uint32_t, 0)})),
+                   TakeOptions::Defaults(), ctx);
+    CHECK_OK(r2.status());
+    if (r2.ok()) CHECK(Same(Host<T>(pool, *r2->array()), {N(T), V(T, 8), V(T, 7)}));
+    auto oob = Take(Datum(vals), Datum(Dev<int8_t>(pool, int8(), {V(int8_t, 0), V(int8_t, 9), V(int8_t, 0)})), TakeOptions::Defaults(), ctx);
+    CHECK(oob.status().IsIndexError() && oob.status().message() == "Index 9 out of bounds");
+    auto neg = Take(Datum(vals), Datum(Dev<int8_t>(pool, int8(), {V(int8_t, 0), V(int8_t, -1), V(int8_t, 0)})), TakeOptions::Defaults(), ctx);
+    CHECK(neg.status().IsIndexError());
+  }
+  // sort_indices (vector_sort_test.cc:448-464)
+  {
+    auto a = Dev<T>(pool, type, {V(T, 10), V(T, 12), V(T, 4), V(T, 50), V(T, 50), V(T, 32), V(T, 11)});
+    auto asc = SortIndices(Datum(a), SortOrder::Ascending, ctx);
+    auto desc = SortIndices(Datum(a), SortOrder::Descending, ctx);
+    CHECK_OK(asc.status()); CHECK_OK(desc.status());
+    if (asc.ok()) CHECK(Same(Host<uint64_t>(pool, *asc->array()), {V(uint64_t, 2), V(uint64_t, 0), V(uint64_t, 6), V(uint64_t, 1), V(uint64_t, 5), V(uint64_t, 3), V(uint64_t, 4)}));
+    if (desc.ok()) CHECK(Same(Host<uint64_t>(pool, *desc->array()), {V(uint64_t, 3), V(uint64_t, 4), V(uint64_t, 5), V(uint64_t, 1), V(uint64_t, 6), V(uint64_t, 0), V(uint64_t, 2)}));
+    auto n = Dev<T>(pool, type, {N(T), V(T, 1), V(T, 3), N(T), V(T, 2), V(T, 5)});
+    auto r = SortIndices(Datum(n), SortOrder::Descending, ctx);
+    CHECK_OK(r.status());
+    if (r.ok()) CHECK(Same(Host<uint64_t>(pool, *r->array()), {V(uint64_t, 5), V(uint64_t, 2), V(uint64_t, 4), V(uint64_t, 1), V(uint64_t, 0), V(uint64_t, 3)}));
+  }
+  // compare with a scalar (scalar_compare_test.cc:248-296) and arithmetic (scalar_arithmetic_test.cc:337-362)
+  {
+    auto one = Datum(Scalar::Make(type, T(1)));
+    auto a = Dev<T>(pool, type, {N(T), V(T, 0), V(T, 1), V(T, 1)});
+    auto r = Compare(Datum(a), one, GREATER_EQUAL, ctx);
+    CHECK_OK(r.status());
+    if (r.ok()) CHECK(HostBool(pool, *r->array()) == std::vector<int>({-1, 0, 1, 1}));
+    auto r2 = Compare(Datum(Dev<T>(pool, type, {V(T, 0), V(T, 1), V(T, 2), V(T, 3), V(T, 4), V(T, 5)})), one, LESS_EQUAL, ctx);
+    CHECK_OK(r2.status());
+    if (r2.ok()) CHECK(HostBool(pool, *r2->array()) == std::vector<int>({1, 1, 0, 0, 0, 0}));
+    for (bool checked : {false, true}) {
+      auto s = Add(Datum(Dev<T>(pool, type, {N(T), V(T, 1), V(T, 2)})), Datum(Dev<T>(pool, type, {V(T, 3), V(T, 4), N(T)})), ArithmeticOptions(checked), ctx);
+      CHECK_OK(s.status());
+      if (s.ok()) CHECK(Same(Host<T>(pool, *s->array()), {N(T), V(T, 5), N(T)}));
+      auto s2 = Subtract(Datum(Scalar::Make(type, T(3))), Datum(Dev<T>(pool, type, {N(T), V(T, 2)})), ArithmeticOptions(checked), ctx);
+      CHECK_OK(s2.status());
+      if (s2.ok()) CHECK(Same(Host<T>(pool, *s2->array()), {N(T), V(T, 1)}));
+      auto s3 = Add(Datum(Dev<T>(pool, type, {V(T, 1), V(T, 2)})), Datum(Scalar::MakeNull(type)), ArithmeticOptions(checked), ctx);
+      CHECK_OK(s3.status());
+      if (s3.ok()) CHECK(Same(Host<T>(pool, *s3->array()), {N(T), N(T)}));
+    }
+  }
+  // Grouper.NumericKey (hash_aggregate_test.cc:251-278)
+  {
+    auto g = internal::Grouper::Make({ValueDescr::Array(type)}, ctx);
+    CHECK_OK(g.status());
+    if (g.ok()) {
+      auto consume = [&](const std::vector<O>& keys, const std::vector<Opt<uint32_t>>& want) {
+        auto b = ExecBatch::Make({Datum(Dev<T>(pool, type, keys))});
+        auto ids = (*g)->Consume(*b);
+        CHECK_OK(ids.status());
+        if (ids.ok()) CHECK(Same(Host<uint32_t>(pool, *ids->array()), want));
+      };
+      consume({V(T, 3), V(T, 3)}, {V(uint32_t, 0), V(uint32_t, 0)});
+      consume({V(T, 3), V(T, 3)}, {V(uint32_t, 0), V(uint32_t, 0)});
+      consume({V(T, 27), V(T, 81)}, {V(uint32_t, 1), V(uint32_t, 2)});
+      consume({V(T, 3), V(T, 27), V(T, 3), V(T, 27), N(T), V(T, 81), V(T, 27), V(T, 81)},
+              {V(uint32_t, 0), V(uint32_t, 1), V(uint32_t, 0), V(uint32_t, 1), V(uint32_t, 3), V(uint32_t, 2), V(uint32_t, 1), V(uint32_t, 2)});
+      CHECK((*g)->num_groups() == 4);
+      auto u = (*g)->GetUniques();
+      CHECK_OK(u.status());
+      if (u.ok()) CHECK(Same(Host<T>(pool, *u->values[0].array()), {V(T, 3), V(T, 27), V(T, 81), N(T)}));
+    }
+  }
+}
+
+static int RunGpu() {
+  auto pool_r = MemoryPool::Make(0);
+  if (!pool_r.ok()) { fprintf(stderr, "no device: %s\n", pool_r.status().ToString().c_str()); return 2; }
+  auto pool = *pool_r;
+  ExecContext ctx(pool);  // default registry = the HIP-backed one
+  TypedTests<uint8_t>(pool, &ctx, uint8());
+  TypedTests<int8_t>(pool, &ctx, int8());
+  TypedTests<uint16_t>(pool, &ctx, uint16());
+  TypedTests<int16_t>(pool, &ctx, int16());
+  TypedTests<uint32_t>(pool, &ctx, uint32());
+  TypedTests<int32_t>(pool, &ctx, int32());
+  TypedTests<uint64_t>(pool, &ctx, uint64());
+  TypedTests<int64_t>(pool, &ctx, int64());
+  TypedTests<float>(pool, &ctx, float32());
+  TypedTests<double>(pool, &ctx, float64());
+
+  const double nan = std::numeric_limits<double>::quiet_NaN();
+  {  // SortReal with NaN and null (vector_sort_test.cc:436-439), chunked NaN case (:639-647)
+    auto a = Dev<double>(pool, float64(), {V(double, 3), V(double, 4), V(double, nan), V(double, 1), V(double, 2), N(double)});
+    auto r = SortIndices(Datum(a), SortOrder::Descending, &ctx);
+    CHECK_OK(r.status());
+    if (r.ok()) CHECK(Same(Host<uint64_t>(pool, *r->array()), {V(uint64_t, 1), V(uint64_t, 0), V(uint64_t, 4), V(uint64_t, 3), V(uint64_t, 2), V(uint64_t, 5)}));
+    auto ca = std::make_shared<ChunkedArray>(
+        std::vector<std::shared_ptr<ArrayData>>{Dev<float>(pool, float32(), {N(float), V(float, 1)}), Dev<float>(pool, float32(), {V(float, 3), N(float), V(float, nan)}),
+                                                Dev<float>(pool, float32(), {V(float, nan), V(float, 1)})}, float32());
+    auto rc = SortIndices(Datum(ca), SortOrder::Ascending, &ctx);
+    CHECK_OK(rc.status());
+    if (rc.ok()) CHECK(Same(Host<uint64_t>(pool, *rc->array()), {V(uint64_t, 1), V(uint64_t, 6), V(uint64_t, 2), V(uint64_t, 4), V(uint64_t, 5), V(uint64_t, 0), V(uint64_t, 3)}));
+  }
+  {  // chunked filter follows the input chunking (vector_selection_test.cc:733-746)
+    auto values = std::make_shared<ChunkedArray>(std::vector<std::shared_ptr<ArrayData>>{Dev<int32_t>(pool, int32(), {V(int32_t, 7)}),
+                                                                                         Dev<int32_t>(pool, int32(), {V(int32_t, 8), V(int32_t, 9)})}, int32());
+    auto filter = std::make_shared<ChunkedArray>(std::vector<std::shared_ptr<ArrayData>>{DevBool(pool, {0, 1}), DevBool(pool, {1})}, boolean());
+    auto r = Filter(Datum(values), Datum(filter), FilterOptions::Defaults(), &ctx);
+    CHECK_OK(r.status());
+    if (r.ok()) {
+      CHECK(r->kind() == Datum::CHUNKED_ARRAY && r->chunked_array()->length() == 2);
+      std::vector<int32_t> all;
+      for (const auto& c : r->chunked_array()->chunks()) for (auto& o : Host<int32_t>(pool, *c)) all.push_back(o.v);
+      CHECK(all == std::vector<int32_t>({8, 9}));
+    }
+    auto nb = CallFunction("filter", {Datum(Dev<int32_t>(pool, int32(), {V(int32_t, 7)})), Datum(Dev<int32_t>(pool, int32(), {V(int32_t, 1)}))}, &ctx);
+    CHECK(nb.status().IsNotImplemented());  // non-boolean filter (:1885-1887)
+  }
+  {  // checked arithmetic errors and wrap-around (scalar_arithmetic.cc:69-251)
+    auto mx = Dev<int8_t>(pool, int8(), {V(int8_t, 127)});
+    auto one = Dev<int8_t>(pool, int8(), {V(int8_t, 1)});
+    auto w = Add(Datum(mx), Datum(one), ArithmeticOptions(false), &ctx);
+    CHECK_OK(w.status());
+    if (w.ok()) CHECK(Same(Host<int8_t>(pool, *w->array()), {V(int8_t, -128)}));
+    auto e = Add(Datum(mx), Datum(one), ArithmeticOptions(true), &ctx);
+    CHECK(e.status().IsInvalid() && e.status().message() == "overflow");
+    auto d = Divide(Datum(one), Datum(Dev<int8_t>(pool, int8(), {V(int8_t, 0)})), ArithmeticOptions(false), &ctx);
+    CHECK(d.status().IsInvalid() && d.status().message() == "divide by zero");
+  }
+  {  // GroupBy.CountAndSum (hash_aggregate_test.cc:561-605) + hash_mean
+    auto argument = Dev<double>(pool, float64(), {V(double, 1.0), N(double), V(double, 0.0), N(double), V(double, 4.0), V(double, 3.25), V(double, 0.125),
+                                                  V(double, -0.25), V(double, 0.75), N(double)});
+    auto key = Dev<int64_t>(pool, int64(), {V(int64_t, 1), V(int64_t, 1), V(int64_t, 2), V(int64_t, 3), N(int64_t), V(int64_t, 1), V(int64_t, 2),
+                                            V(int64_t, 2), N(int64_t), V(int64_t, 3)});
+    CountOptions count_options;
+    auto r = internal::GroupBy({Datum(argument), Datum(argument), Datum(key), Datum(argument)}, {Datum(key)},
+                               {{"hash_count", &count_options}, {"hash_sum", nullptr}, {"hash_sum", nullptr}, {"hash_mean", nullptr}}, &ctx);
+    CHECK_OK(r.status());
+    if (r.ok()) {
+      CHECK(r->length == 4 && r->field_names == std::vector<std::string>({"hash_count", "hash_sum", "hash_sum", "hash_mean", "key_0"}));
+      CHECK(Same(Host<int64_t>(pool, *r->columns[0]), {V(int64_t, 2), V(int64_t, 3), V(int64_t, 0), V(int64_t, 2)}));
+      CHECK(Same(Host<double>(pool, *r->columns[1]), {V(double, 4.25), V(double, -0.125), N(double), V(double, 4.75)}));
+      CHECK(Same(Host<int64_t>(pool, *r->columns[2]), {V(int64_t, 3), V(int64_t, 6), V(int64_t, 6), N(int64_t)}));
+      CHECK(Same(Host<double>(pool, *r->columns[3]), {V(double, 2.125), V(double, -0.125 / 3), N(double), V(double, 2.375)}));
+      CHECK(Same(Host<int64_t>(pool, *r->columns[4]), {V(int64_t, 1), V(int64_t, 2), V(int64_t, 3), N(int64_t)}));
+      CHECK(r->columns[0]->buffers[0] == nullptr);  // hash_count never carries a bitmap
+    }
+    // multi-batch: exec_chunksize 3 -> same rows (groups keep first-appearance ids across batches)
+    ctx.set_exec_chunksize(3);
+    auto r2 = internal::GroupBy({Datum(argument)}, {Datum(key)}, {{"hash_sum", nullptr}}, &ctx);
+    ctx.set_exec_chunksize(kDefaultExecChunksize);
+    CHECK_OK(r2.status());
+    if (r2.ok()) {
+      CHECK(Same(Host<double>(pool, *r2->columns[0]), {V(double, 4.25), V(double, -0.125), N(double), V(double, 4.75)}));
+      CHECK(Same(Host<int64_t>(pool, *r2->columns[1]), {V(int64_t, 1), V(int64_t, 2), V(int64_t, 3), N(int64_t)}));
+    }
+    auto bad = internal::GroupBy({Datum(argument)}, {Datum(key)}, {{"hash_sum", nullptr}, {"hash_count", nullptr}}, &ctx);
+    CHECK(bad.status().IsInvalid());  // aggregates.size() != arguments.size() (:811-815)
+    CHECK(CallFunction("hash_sum", {Datum(argument), Datum(key), Datum(key)}, &ctx).status().IsNotImplemented());
+  }
+  {  // FloatingPointKey (hash_aggregate_test.cc:280-292): -0.0 != 0.0, NaNs with equal bits group
+    auto g = internal::Grouper::Make({ValueDescr::Array(float32())}, &ctx);
+    CHECK_OK(g.status());
+    if (g.ok()) {
+      auto b1 = ExecBatch::Make({Datum(Dev<float>(pool, float32(), {V(float, 0.0f), V(float, -0.0f)}))});
+      auto i1 = (*g)->Consume(*b1);
+      CHECK_OK(i1.status());
+      if (i1.ok()) CHECK(Same(Host<uint32_t>(pool, *i1->array()), {V(uint32_t, 0), V(uint32_t, 1)}));
+      auto b2 = ExecBatch::Make({Datum(Dev<float>(pool, float32(), {V(float, float(nan)), V(float, float(nan))}))});
+      auto i2 = (*g)->Consume(*b2);
+      CHECK_OK(i2.status());
+      if (i2.ok()) CHECK(Same(Host<uint32_t>(pool, *i2->array()), {V(uint32_t, 2), V(uint32_t, 2)}));
+    }
+  }
+  CHECK(pool->bytes_allocated() >= 0 && pool->max_memory() > 0);  // the MemoryPool counters (memory_pool.h:38-105)
+  printf("host_test gpu: %d checks, %d failures\n", g_checks, g_failures);
+  return g_failures ? 1 : 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc >= 2 && !strcmp(argv[1], "cpu")) return RunCpu();
+  if (argc >= 2 && !strcmp(argv[1], "gpu")) return RunGpu();
+  fprintf(stderr, "usage: host_test cpu|gpu\n");
+  return 64;
+}

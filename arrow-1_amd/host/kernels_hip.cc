@@ -1,0 +1,500 @@
+// kernels_hip.cc -- the Register* hooks of the hot-path kernel files, each kernel's exec being a
+// call into the C ABI (include/amdarrow.h).  Mirrors what the reference registers:
+//   RegisterVectorSelection   compute/kernels/vector_selection.cc:2130-2187
+//   RegisterVectorSort        compute/kernels/vector_sort.cc:1739-1765
+//   RegisterScalarComparison  compute/kernels/scalar_compare.cc:100-220
+//   RegisterScalarArithmetic  compute/kernels/scalar_arithmetic.cc:414-606
+//   RegisterHashAggregateBasic + Grouper + GroupBy   compute/kernels/hash_aggregate.cc:313-437, 770-966, 1039-1062
+#include <cstring>
+
+#include "amdarrow_compute.h"
+
+namespace amdarrow {
+namespace compute {
+namespace internal {
+
+namespace {
+
+const Type::type kNumeric[] = {Type::UINT8, Type::INT8, Type::UINT16, Type::INT16, Type::UINT32,
+                               Type::INT32, Type::UINT64, Type::INT64, Type::FLOAT, Type::DOUBLE};
+
+int64_t ValueBytes(const DataType& t, int64_t n) { return t.bit_width() == 1 ? (n + 7) / 8 : n * t.bit_width() / 8; }
+
+std::function<Result<std::shared_ptr<DataType>>(const std::vector<ValueDescr>&)> FixedOut(std::shared_ptr<DataType> t) {
+  return [t](const std::vector<ValueDescr>&) -> Result<std::shared_ptr<DataType>> { return t; };
+}
+std::function<Result<std::shared_ptr<DataType>>(const std::vector<ValueDescr>&)> FirstArgOut() {
+  return [](const std::vector<ValueDescr>& d) -> Result<std::shared_ptr<DataType>> { return d[0].type; };
+}
+
+// ---- array_filter: PrimitiveFilter (vector_selection.cc:786-835) ------------------------------------
+Status ExecFilter(KernelContext* ctx, const ExecBatch& batch, Datum* out) {
+  const auto* opts = static_cast<const FilterOptions*>(ctx->options());
+  const int null_sel = opts ? static_cast<int>(opts->null_selection_behavior) : AMDARROW_DROP;
+  const ArrayData& values = *batch[0].array();
+  const ArrayData& filter = *batch[1].array();
+  amdarrow_array v = values.abi(), f = filter.abi();
+  int64_t out_len = 0;  // GetFilterOutputSize (:792), then PreallocateData (:244-259)
+  int rc = amdarrow_filter_output_size(ctx->abi(), &f, null_sel, &out_len);
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  const bool allocate_validity = (values.buffers[0] ? values.null_count : 0) != 0 || (filter.buffers[0] ? filter.null_count : 0) != 0;
+  AMD_ASSIGN_OR_RAISE(auto vbuf, ctx->Allocate(ValueBytes(*values.type, out_len)));
+  std::shared_ptr<Buffer> nbuf;
+  if (allocate_validity) { AMD_ASSIGN_OR_RAISE(nbuf, ctx->AllocateBitmap(out_len)); }
+  amdarrow_out o;
+  rc = amdarrow_filter(ctx->abi(), &v, &f, null_sel, vbuf->mutable_data(), nbuf ? nbuf->mutable_data() : nullptr, out_len, &o);
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  *out = Datum(ArrayData::Make(values.type, o.length, {nbuf, vbuf}, o.null_count));
+  return Status::OK();
+}
+
+// ---- array_take: PrimitiveTake (vector_selection.cc:493-530) ---------------------------------------
+Status ExecTake(KernelContext* ctx, const ExecBatch& batch, Datum* out) {
+  const auto* opts = static_cast<const TakeOptions*>(ctx->options());
+  const ArrayData& values = *batch[0].array();
+  const ArrayData& indices = *batch[1].array();
+  amdarrow_array v = values.abi(), i = indices.abi();
+  AMD_ASSIGN_OR_RAISE(auto vbuf, ctx->Allocate(ValueBytes(*values.type, indices.length)));
+  AMD_ASSIGN_OR_RAISE(auto nbuf, ctx->AllocateBitmap(indices.length));  // always allocated (:505-510)
+  amdarrow_out o;
+  const int rc = amdarrow_take(ctx->abi(), &v, &i, !opts || opts->boundscheck, vbuf->mutable_data(), nbuf->mutable_data(), &o);
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  *out = Datum(ArrayData::Make(values.type, o.length, {nbuf, vbuf}, o.null_count));
+  return Status::OK();
+}
+
+// ---- array_sort_indices (vector_sort.cc:558-575) ---------------------------------------------------
+Status SortChunks(KernelContext* ctx, const std::vector<std::shared_ptr<ArrayData>>& chunks, SortOrder order, Datum* out) {
+  std::vector<amdarrow_array> abi;
+  int64_t total = 0;
+  for (const auto& c : chunks) { abi.push_back(c->abi()); total += c->length; }
+  AMD_ASSIGN_OR_RAISE(auto buf, ctx->Allocate(8 * total));
+  const int rc = amdarrow_sort_indices(ctx->abi(), abi.data(), static_cast<int>(abi.size()),
+                                       order == SortOrder::Descending ? AMDARROW_DESCENDING : AMDARROW_ASCENDING,
+                                       reinterpret_cast<uint64_t*>(buf->mutable_data()));
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  *out = Datum(ArrayData::Make(uint64(), total, {nullptr, buf}, 0));  // OUTPUT_NOT_NULL (vector_sort.cc:1745-1747)
+  return Status::OK();
+}
+Status ExecArraySortIndices(KernelContext* ctx, const ExecBatch& batch, Datum* out) {
+  const auto* opts = static_cast<const ArraySortOptions*>(ctx->options());
+  return SortChunks(ctx, {batch[0].array()}, opts ? opts->order : SortOrder::Ascending, out);
+}
+
+// ---- compare / arithmetic (ScalarBinary applicators, codegen_internal.h:758-932) -------------------
+struct BinaryOperands {
+  amdarrow_array l, r;
+  const amdarrow_array* lp = nullptr;
+  const amdarrow_array* rp = nullptr;
+  const void* ls = nullptr;
+  const void* rs = nullptr;
+  int64_t length = 0;
+  bool null_scalar = false;
+};
+BinaryOperands Unpack(const ExecBatch& batch) {
+  BinaryOperands b;
+  if (batch[0].is_array()) { b.l = batch[0].array()->abi(); b.lp = &b.l; b.length = b.l.length; }
+  else { b.ls = &batch[0].scalar()->bits; b.null_scalar |= !batch[0].scalar()->is_valid; }
+  if (batch[1].is_array()) { b.r = batch[1].array()->abi(); b.rp = &b.r; b.length = b.r.length; }
+  else { b.rs = &batch[1].scalar()->bits; b.null_scalar |= !batch[1].scalar()->is_valid; }
+  return b;
+}
+// A null scalar operand makes every slot null (AllNullShortCircuit, exec.cc:326-348); the value
+// buffer content is unspecified in the reference, here it is the op applied to a zero scalar.
+Status FinishAllNull(KernelContext* ctx, int64_t length, std::shared_ptr<Buffer> nbuf, amdarrow_out* o) {
+  if (length > 0) {
+    const int rc = amdarrow_memset(ctx->abi(), nbuf->mutable_data(), 0, (length + 7) / 8);
+    if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  }
+  o->null_count = length;
+  return Status::OK();
+}
+
+template <int kOp>
+Status ExecCompare(KernelContext* ctx, const ExecBatch& batch, Datum* out) {
+  BinaryOperands b = Unpack(batch);
+  AMD_ASSIGN_OR_RAISE(auto vbuf, ctx->AllocateBitmap(b.length));
+  AMD_ASSIGN_OR_RAISE(auto nbuf, ctx->AllocateBitmap(b.length));
+  amdarrow_out o;
+  const int rc = amdarrow_compare(ctx->abi(), kOp, b.lp, b.ls, b.rp, b.rs, vbuf->mutable_data(), nbuf->mutable_data(), &o);
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  if (b.null_scalar) AMD_RETURN_NOT_OK(FinishAllNull(ctx, b.length, nbuf, &o));
+  *out = Datum(ArrayData::Make(boolean(), o.length, {nbuf, vbuf}, o.null_count));
+  return Status::OK();
+}
+template <int kOp>
+Status ExecArith(KernelContext* ctx, const ExecBatch& batch, Datum* out) {
+  BinaryOperands b = Unpack(batch);
+  auto type = batch[0].type();
+  if (b.null_scalar && kOp >= AMDARROW_DIV) {
+    // ScalarBinaryNotNull with a null scalar never calls the op (codegen_internal.h:853-881): no error can be raised
+    AMD_ASSIGN_OR_RAISE(auto vbuf0, ctx->Allocate(ValueBytes(*type, b.length)));
+    AMD_ASSIGN_OR_RAISE(auto nbuf0, ctx->AllocateBitmap(b.length));
+    if (b.length > 0) {
+      const int rc0 = amdarrow_memset(ctx->abi(), vbuf0->mutable_data(), 0, ValueBytes(*type, b.length));
+      if (rc0 != AMDARROW_OK) return Status::FromAbi(rc0);
+    }
+    *out = Datum(ArrayData::Make(type, b.length, {nbuf0, vbuf0}, b.length));
+    return Status::OK();
+  }
+  AMD_ASSIGN_OR_RAISE(auto vbuf, ctx->Allocate(ValueBytes(*type, b.length)));
+  AMD_ASSIGN_OR_RAISE(auto nbuf, ctx->AllocateBitmap(b.length));
+  amdarrow_out o;
+  const int rc = amdarrow_arith(ctx->abi(), kOp, b.lp, b.ls, b.rp, b.rs, vbuf->mutable_data(), nbuf->mutable_data(), &o);
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  if (b.null_scalar) AMD_RETURN_NOT_OK(FinishAllNull(ctx, b.length, nbuf, &o));
+  *out = Datum(ArrayData::Make(type, o.length, {nbuf, vbuf}, o.null_count));
+  return Status::OK();
+}
+
+// ---- meta functions ------------------------------------------------------------------------------------
+// FilterMetaFunction (vector_selection.cc:1877-1903): array / chunked values with an array / chunked
+// boolean filter go to "array_filter" (chunk-wise through the executor); batches and tables are
+// callers of the path and stay with the CPU caller.
+class FilterMetaFunction : public MetaFunction {
+ public:
+  FilterMetaFunction() : MetaFunction("filter", Arity::Binary(), {}, &kDefaults) {}
+  Result<Datum> ExecuteImpl(const std::vector<Datum>& args, const FunctionOptions* options, ExecContext* ctx) const override {
+    if (!args[1].type() || args[1].type()->id() != Type::BOOL)
+      return Status::NotImplemented("Filter argument must be boolean type");  // :1885-1887
+    if (args[0].is_arraylike() && args[1].is_arraylike()) return CallFunction("array_filter", args, options, ctx);
+    return Status::NotImplemented("Unsupported types for filter operation (record batches and tables are filtered by the caller)");
+  }
+  static FilterOptions kDefaults;
+};
+FilterOptions FilterMetaFunction::kDefaults = FilterOptions::Defaults();
+
+// TakeMetaFunction (vector_selection.cc:2026-2072): TakeAA and TakeAC here; chunked VALUES are
+// concatenated by the reference first (:1938-1940) -- a copy that belongs to the caller.
+class TakeMetaFunction : public MetaFunction {
+ public:
+  TakeMetaFunction() : MetaFunction("take", Arity::Binary(), {}, &kDefaults) {}
+  Result<Datum> ExecuteImpl(const std::vector<Datum>& args, const FunctionOptions* options, ExecContext* ctx) const override {
+    if (args[0].is_array() && args[1].is_array()) return CallFunction("array_take", args, options, ctx);
+    if (args[0].is_array() && args[1].kind() == Datum::CHUNKED_ARRAY) {  // TakeAC :1957-1969
+      std::vector<std::shared_ptr<ArrayData>> chunks;
+      for (const auto& idx : args[1].chunked_array()->chunks()) {
+        AMD_ASSIGN_OR_RAISE(Datum piece, CallFunction("array_take", {args[0], Datum(idx)}, options, ctx));
+        chunks.push_back(piece.array());
+      }
+      return Datum(std::make_shared<ChunkedArray>(std::move(chunks), args[0].type()));
+    }
+    return Status::NotImplemented("Unsupported types for take operation: chunked or tabular values are gathered by the caller");  // :2067-2070
+  }
+  static TakeOptions kDefaults;
+};
+TakeOptions TakeMetaFunction::kDefaults = TakeOptions::Defaults();
+
+// SortIndicesMetaFunction (vector_sort.cc:1565-1711): arrays and chunked arrays (single sort key)
+class SortIndicesMetaFunction : public MetaFunction {
+ public:
+  SortIndicesMetaFunction() : MetaFunction("sort_indices", Arity::Unary(), {}, &kDefaults) {}
+  Result<Datum> ExecuteImpl(const std::vector<Datum>& args, const FunctionOptions* options, ExecContext* ctx) const override {
+    const auto* so = static_cast<const SortOptions*>(options);
+    SortOrder order = SortOrder::Ascending;
+    if (so && !so->sort_keys.empty()) order = so->sort_keys[0].order;
+    if (args[0].is_array()) {
+      ArraySortOptions ao(order);
+      return CallFunction("array_sort_indices", args, &ao, ctx);  // :1598-1606
+    }
+    if (args[0].kind() == Datum::CHUNKED_ARRAY) {  // :1608-1630
+      const auto& t = args[0].type();
+      if (!t || t->bit_width() < 8 || t->id() == Type::HALF_FLOAT) return Status::NotImplemented("sort_indices: numeric types only");
+      KernelContext kctx(ctx);
+      Datum out;
+      AMD_RETURN_NOT_OK(SortChunks(&kctx, args[0].chunked_array()->chunks(), order, &out));
+      return out;
+    }
+    return Status::NotImplemented("Unsupported types for sort_indices operation: multi-key record batches / tables are next (SURVEY 8f)");
+  }
+  static SortOptions kDefaults;
+};
+SortOptions SortIndicesMetaFunction::kDefaults = SortOptions::Defaults();
+
+// ---- hash aggregates -------------------------------------------------------------------------------------
+// KernelState of hash_sum / hash_count / hash_mean: device sums + counts that grow with the groups
+// (GroupedSumImpl / GroupedCountImpl, hash_aggregate.cc:466-622).
+struct GroupedState : KernelState {
+  int func = AMDARROW_HASH_SUM;
+  int count_mode = AMDARROW_COUNT_NON_NULL;
+  std::shared_ptr<DataType> in_type;
+  std::shared_ptr<Buffer> sums, counts;
+  int64_t num_groups = 0, capacity = 0;
+};
+Status Reserve(KernelContext* ctx, GroupedState* st, int64_t new_groups) {  // MaybeReserve :450-459
+  if (new_groups <= st->num_groups) return Status::OK();
+  if (new_groups > st->capacity) {
+    const int64_t cap = std::max<int64_t>(1024, 2 * new_groups);
+    AMD_ASSIGN_OR_RAISE(auto s, ctx->Allocate(8 * cap));
+    AMD_ASSIGN_OR_RAISE(auto c, ctx->Allocate(8 * cap));
+    int rc = amdarrow_memset(ctx->abi(), s->mutable_data(), 0, 8 * cap);
+    if (rc == AMDARROW_OK) rc = amdarrow_memset(ctx->abi(), c->mutable_data(), 0, 8 * cap);
+    if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+    if (st->num_groups > 0) {
+      // carry the existing groups over (stream-ordered device copies)
+      rc = amdarrow_memcpy_d2d(ctx->abi(), s->mutable_data(), st->sums->data(), 8 * st->num_groups);
+      if (rc == AMDARROW_OK) rc = amdarrow_memcpy_d2d(ctx->abi(), c->mutable_data(), st->counts->data(), 8 * st->num_groups);
+      if (rc == AMDARROW_OK) rc = amdarrow_ctx_synchronize(ctx->abi());  // the old buffers are released below
+      if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+    }
+    st->sums = s; st->counts = c; st->capacity = cap;
+  }
+  st->num_groups = new_groups;
+  return Status::OK();
+}
+HashAggregateKernel MakeHashKernel(int func) {  // MakeKernel :770-807
+  HashAggregateKernel k;
+  k.signature.in_types = {InputType::Primitive(), InputType::Exact(Type::UINT32, ValueDescr::ARRAY),
+                          InputType::Exact(Type::UINT32, ValueDescr::SCALAR)};
+  k.signature.out_type = [func](const std::vector<ValueDescr>& d) -> Result<std::shared_ptr<DataType>> {
+    if (func == AMDARROW_HASH_COUNT) return int64();
+    const Type::type t = d[0].type->id();
+    if (func == AMDARROW_HASH_MEAN || is_floating(t)) return float64();
+    return is_signed_integer(t) ? int64() : uint64();  // FindAccumulatorType, aggregate_internal.h:29-50
+  };
+  k.init = [func](KernelContext*, const std::shared_ptr<DataType>& in, const FunctionOptions* opts) -> Result<std::unique_ptr<KernelState>> {
+    auto st = std::unique_ptr<GroupedState>(new GroupedState());
+    st->func = func;
+    st->in_type = in;
+    if (func == AMDARROW_HASH_COUNT && opts) st->count_mode = static_cast<const CountOptions*>(opts)->count_mode;
+    return std::unique_ptr<KernelState>(std::move(st));
+  };
+  k.consume = [](KernelContext* ctx, KernelState* state, const ExecBatch& batch) -> Status {
+    auto* st = static_cast<GroupedState*>(state);
+    uint32_t ng;
+    memcpy(&ng, &batch[2].scalar()->bits, 4);
+    AMD_RETURN_NOT_OK(Reserve(ctx, st, ng));
+    amdarrow_array v = batch[0].array()->abi();
+    const ArrayData& ids = *batch[1].array();
+    const int rc = amdarrow_hash_accumulate(ctx->abi(), st->func, &v,
+                                            reinterpret_cast<const uint32_t*>(ids.buffers[1]->data()) + ids.offset,
+                                            st->count_mode, st->sums->mutable_data(), reinterpret_cast<int64_t*>(st->counts->mutable_data()));
+    return Status::FromAbi(rc);
+  };
+  k.merge = [](KernelContext*, KernelState&&, KernelState*) -> Status {
+    return Status::NotImplemented("Merge hashed aggregations");  // :795-798
+  };
+  k.finalize = [](KernelContext* ctx, KernelState* state, Datum* out) -> Status {
+    auto* st = static_cast<GroupedState*>(state);
+    std::shared_ptr<DataType> ot = st->func == AMDARROW_HASH_COUNT ? int64()
+                                 : (st->func == AMDARROW_HASH_MEAN || is_floating(st->in_type->id())) ? float64()
+                                 : is_signed_integer(st->in_type->id()) ? int64() : uint64();
+    if (st->num_groups == 0) { *out = Datum(ArrayData::Make(ot, 0, {nullptr, nullptr}, 0)); return Status::OK(); }
+    AMD_ASSIGN_OR_RAISE(auto nbuf, ctx->AllocateBitmap(st->num_groups));
+    amdarrow_out o;
+    const int rc = amdarrow_hash_finalize(ctx->abi(), st->func, static_cast<int>(st->in_type->id()), st->num_groups,
+                                          st->sums->mutable_data(), reinterpret_cast<const int64_t*>(st->counts->data()),
+                                          nbuf->mutable_data(), &o);
+    if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+    *out = Datum(ArrayData::Make(ot, st->num_groups, {o.has_validity ? nbuf : nullptr, st->sums}, o.null_count));
+    return Status::OK();
+  };
+  return k;
+}
+
+template <typename Fn>
+void AddBinaryFunctions(FunctionRegistry* registry, const char* const* names, int n, bool compare, Fn make_exec) {
+  for (int op = 0; op < n; ++op) {
+    auto func = std::make_shared<ScalarFunction>(names[op], Arity::Binary());
+    for (Type::type t : kNumeric) {
+      ScalarKernel k;
+      k.signature.in_types = {InputType::Exact(t), InputType::Exact(t)};
+      k.signature.out_type = compare ? FixedOut(boolean()) : FirstArgOut();
+      k.exec = make_exec(op);
+      k.can_write_into_slices = false;
+      (void)func->AddKernel(std::move(k));
+    }
+    if (compare) {  // boolean comparisons too (scalar_compare.cc:106-110)
+      ScalarKernel k;
+      k.signature.in_types = {InputType::Exact(Type::BOOL), InputType::Exact(Type::BOOL)};
+      k.signature.out_type = FixedOut(boolean());
+      k.exec = make_exec(op);
+      k.can_write_into_slices = false;
+      (void)func->AddKernel(std::move(k));
+    }
+    (void)registry->AddFunction(std::move(func));
+  }
+}
+
+}  // namespace
+
+void RegisterVectorSelection(FunctionRegistry* registry) {
+  {
+    static FilterOptions defaults = FilterOptions::Defaults();
+    auto f = std::make_shared<VectorFunction>("array_filter", Arity::Binary(), FunctionDoc{}, &defaults);
+    VectorKernel k;  // {match::Primitive(), boolean()} -> PrimitiveFilter (:2133)
+    k.signature.in_types = {InputType::Primitive(), InputType::Exact(Type::BOOL)};
+    k.signature.out_type = FirstArgOut();
+    k.exec = ExecFilter;
+    (void)f->AddKernel(std::move(k));
+    (void)registry->AddFunction(std::move(f));
+    (void)registry->AddFunction(std::make_shared<FilterMetaFunction>());
+  }
+  {
+    static TakeOptions defaults = TakeOptions::Defaults();
+    auto f = std::make_shared<VectorFunction>("array_take", Arity::Binary(), FunctionDoc{}, &defaults);
+    VectorKernel k;  // {match::Primitive(), match::Integer()} -> PrimitiveTake (:2160-2163)
+    k.signature.in_types = {InputType::Primitive(), InputType::Integer()};
+    k.signature.out_type = FirstArgOut();
+    k.exec = ExecTake;
+    k.can_execute_chunkwise = false;  // :2156
+    (void)f->AddKernel(std::move(k));
+    (void)registry->AddFunction(std::move(f));
+    (void)registry->AddFunction(std::make_shared<TakeMetaFunction>());
+  }
+}
+
+void RegisterVectorSort(FunctionRegistry* registry) {
+  static ArraySortOptions defaults = ArraySortOptions::Defaults();
+  auto f = std::make_shared<VectorFunction>("array_sort_indices", Arity::Unary(), FunctionDoc{}, &defaults);
+  for (Type::type t : kNumeric) {  // AddSortingKernels over NumericTypes() (:581-587)
+    VectorKernel k;
+    k.signature.in_types = {InputType::Exact(t, ValueDescr::ARRAY)};
+    k.signature.out_type = FixedOut(uint64());
+    k.exec = ExecArraySortIndices;
+    k.mem_allocation = MemAllocation::PREALLOCATE;
+    k.null_handling = NullHandling::OUTPUT_NOT_NULL;
+    k.can_execute_chunkwise = false;
+    (void)f->AddKernel(std::move(k));
+  }
+  (void)registry->AddFunction(std::move(f));
+  (void)registry->AddFunction(std::make_shared<SortIndicesMetaFunction>());
+}
+
+template <int... kOps>
+ArrayKernelExec PickCompare(int op) {
+  static const ArrayKernelExec table[] = {ExecCompare<kOps>...};
+  return table[op];
+}
+template <int... kOps>
+ArrayKernelExec PickArith(int op) {
+  static const ArrayKernelExec table[] = {ExecArith<kOps>...};
+  return table[op];
+}
+
+void RegisterScalarComparison(FunctionRegistry* registry) {
+  static const char* names[] = {"equal", "not_equal", "greater", "greater_equal", "less", "less_equal"};
+  AddBinaryFunctions(registry, names, 6, true, [](int op) { return PickCompare<0, 1, 2, 3, 4, 5>(op); });
+}
+void RegisterScalarArithmetic(FunctionRegistry* registry) {
+  static const char* names[] = {"add", "subtract", "multiply", "divide",
+                                "add_checked", "subtract_checked", "multiply_checked", "divide_checked"};
+  AddBinaryFunctions(registry, names, 8, false, [](int op) { return PickArith<0, 1, 2, 3, 4, 5, 6, 7>(op); });
+}
+
+void RegisterHashAggregateBasic(FunctionRegistry* registry) {
+  static CountOptions count_defaults = CountOptions::Defaults();
+  struct Def { const char* name; int func; const FunctionOptions* opts; };
+  const Def defs[] = {{"hash_count", AMDARROW_HASH_COUNT, &count_defaults}, {"hash_sum", AMDARROW_HASH_SUM, nullptr},
+                      {"hash_mean", AMDARROW_HASH_MEAN, nullptr}};  // hash_mean: SURVEY 8a row c6
+  for (const auto& d : defs) {
+    auto f = std::make_shared<HashAggregateFunction>(d.name, Arity::Ternary(), FunctionDoc{}, d.opts);
+    (void)f->AddKernel(MakeHashKernel(d.func));
+    (void)registry->AddFunction(std::move(f));
+  }
+}
+
+// ---- Grouper (api_aggregate.h:313-340, hash_aggregate.cc:313-437) ---------------------------------------
+Grouper::~Grouper() {
+  if (impl_) amdarrow_grouper_destroy(impl_);
+}
+Result<std::unique_ptr<Grouper>> Grouper::Make(const std::vector<ValueDescr>& descrs, ExecContext* ctx) {
+  auto g = std::unique_ptr<Grouper>(new Grouper());
+  g->ctx_ = ctx;
+  g->descrs_ = descrs;
+  std::vector<int> types;
+  for (const auto& d : descrs) types.push_back(static_cast<int>(d.type->id()));
+  const int rc = amdarrow_grouper_create(ctx->memory_pool()->ctx(), static_cast<int>(types.size()), types.data(), &g->impl_);
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  return g;
+}
+Result<Datum> Grouper::Consume(const ExecBatch& batch) {
+  std::vector<amdarrow_array> keys;
+  for (const auto& v : batch.values) {
+    if (!v.is_array()) return Status::NotImplemented("Grouper::Consume: array keys only");
+    keys.push_back(v.array()->abi());
+  }
+  AMD_ASSIGN_OR_RAISE(auto buf, AllocateBuffer(4 * batch.length, ctx_->memory_pool()));
+  const int rc = amdarrow_grouper_consume(impl_, keys.data(), reinterpret_cast<uint32_t*>(buf->mutable_data()));
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  return Datum(ArrayData::Make(uint32(), batch.length, {nullptr, buf}, 0));
+}
+uint32_t Grouper::num_groups() const {
+  uint32_t n = 0;
+  amdarrow_grouper_num_groups(impl_, &n);
+  return n;
+}
+Result<ExecBatch> Grouper::GetUniques() {
+  const uint32_t ng = num_groups();
+  ExecBatch out({}, ng);
+  for (size_t k = 0; k < descrs_.size(); ++k) {
+    const auto& t = descrs_[k].type;
+    AMD_ASSIGN_OR_RAISE(auto vbuf, AllocateBuffer(ValueBytes(*t, ng), ctx_->memory_pool()));
+    AMD_ASSIGN_OR_RAISE(auto nbuf, AllocateBitmap(ng, ctx_->memory_pool()));
+    amdarrow_out o;
+    const int rc = amdarrow_grouper_uniques(impl_, static_cast<int>(k), vbuf->mutable_data(), nbuf->mutable_data(), &o);
+    if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+    out.values.push_back(Datum(ArrayData::Make(t, ng, {o.has_validity ? nbuf : nullptr, vbuf}, o.null_count)));
+  }
+  return out;
+}
+
+// ---- GroupBy (hash_aggregate.cc:890-966) -----------------------------------------------------------------
+Result<GroupByResult> GroupBy(const std::vector<Datum>& arguments, const std::vector<Datum>& keys,
+                              const std::vector<Aggregate>& aggregates, ExecContext* ctx) {
+  if (aggregates.size() != arguments.size())  // GetKernels :811-815
+    return Status::Invalid(std::to_string(aggregates.size()) + " aggregate functions were specified but " +
+                           std::to_string(arguments.size()) + " arguments were provided.");
+  std::vector<const HashAggregateKernel*> kernels;
+  std::vector<std::unique_ptr<KernelState>> states;
+  std::vector<const FunctionOptions*> opts;
+  for (size_t i = 0; i < aggregates.size(); ++i) {
+    AMD_ASSIGN_OR_RAISE(auto function, ctx->func_registry()->GetFunction(aggregates[i].function));
+    if (function->kind() != Function::HASH_AGGREGATE) return Status::Invalid(aggregates[i].function + " is not a hash aggregate function");
+    auto* hf = static_cast<const HashAggregateFunction*>(function.get());
+    AMD_ASSIGN_OR_RAISE(const HashAggregateKernel* kernel,
+                        hf->DispatchExact({ValueDescr::Array(arguments[i].type()), ValueDescr::Array(uint32()), ValueDescr::Scalar(uint32())}));
+    const FunctionOptions* o = aggregates[i].options ? aggregates[i].options : function->default_options();  // InitKernels :840-846
+    KernelContext kctx(ctx);
+    AMD_ASSIGN_OR_RAISE(auto state, kernel->init(&kctx, arguments[i].type(), o));
+    kernels.push_back(kernel);
+    states.push_back(std::move(state));
+    opts.push_back(o);
+  }
+  std::vector<ValueDescr> key_descrs;
+  for (const auto& k : keys) key_descrs.push_back(ValueDescr::Array(k.type()));
+  AMD_ASSIGN_OR_RAISE(auto grouper, Grouper::Make(key_descrs, ctx));
+  AMD_ASSIGN_OR_RAISE(auto arg_it, detail::ExecBatchIterator::Make(arguments, ctx->exec_chunksize()));
+  AMD_ASSIGN_OR_RAISE(auto key_it, detail::ExecBatchIterator::Make(keys, ctx->exec_chunksize()));
+  ExecBatch key_batch, arg_batch;
+  while (arg_it->Next(&arg_batch) && key_it->Next(&key_batch)) {  // :928-943
+    if (key_batch.length == 0) continue;
+    if (arg_batch.length != key_batch.length)
+      return Status::NotImplemented("GroupBy: arguments and keys must share their chunk layout");
+    AMD_ASSIGN_OR_RAISE(Datum id_batch, grouper->Consume(key_batch));
+    for (size_t i = 0; i < kernels.size(); ++i) {
+      KernelContext kctx(ctx);
+      ExecBatch batch({arg_batch[static_cast<int>(i)], id_batch, Datum(Scalar::Make(uint32(), grouper->num_groups()))}, key_batch.length);
+      AMD_RETURN_NOT_OK(kernels[i]->consume(&kctx, states[i].get(), batch));
+    }
+  }
+  GroupByResult result;
+  result.length = grouper->num_groups();
+  for (size_t i = 0; i < kernels.size(); ++i) {
+    KernelContext kctx(ctx);
+    Datum out;
+    AMD_RETURN_NOT_OK(kernels[i]->finalize(&kctx, states[i].get(), &out));
+    result.field_names.push_back(aggregates[i].function);  // field(aggregates[i].function, ...) :874
+    result.columns.push_back(out.array());
+  }
+  AMD_ASSIGN_OR_RAISE(ExecBatch uniques, grouper->GetUniques());
+  for (size_t k = 0; k < uniques.values.size(); ++k) {
+    result.field_names.push_back("key_" + std::to_string(k));  // :917-919
+    result.columns.push_back(uniques.values[k].array());
+  }
+  return result;
+}
+
+}  // namespace internal
+}  // namespace compute
+}  // namespace amdarrow

@@ -102,6 +102,7 @@ int64_t amdarrow_bytes_allocated(amdarrow_ctx* ctx);
 int64_t amdarrow_max_memory(amdarrow_ctx* ctx);
 int amdarrow_memcpy_h2d(amdarrow_ctx* ctx, void* dst_dev, const void* src_host, int64_t nbytes);
 int amdarrow_memcpy_d2h(amdarrow_ctx* ctx, void* dst_host, const void* src_dev, int64_t nbytes);
+int amdarrow_memcpy_d2d(amdarrow_ctx* ctx, void* dst_dev, const void* src_dev, int64_t nbytes); /* async on the stream */
 int amdarrow_memset(amdarrow_ctx* ctx, void* dst_dev, int value, int64_t nbytes);
 
 /* ---- bit utilities (util/bitmap_ops.h) -------------------------------------------------- */
@@ -175,6 +176,17 @@ int amdarrow_grouper_uniques(amdarrow_grouper* g, int k, void* out_values,
 int amdarrow_hash_aggregate(amdarrow_ctx* ctx, int func, const amdarrow_array* values,
                             const uint32_t* ids, int64_t num_groups, int count_mode,
                             void* out_values, uint8_t* out_validity, amdarrow_out* out);
+
+/* The same kernel split as the reference's HashAggregateKernel consume / finalize pair
+ * (compute/kernel.h:681-721) for multi-batch GroupBy: accumulate adds one batch into caller-owned
+ * device state -- sums (num_groups x 8 bytes) and counts (num_groups x int64), zeroed by the caller
+ * when a group is created; finalize turns the state into the output array IN PLACE in `sums`
+ * (hash_count: the counts; hash_mean: double(sum)/count) and writes the validity bitmap. */
+int amdarrow_hash_accumulate(amdarrow_ctx* ctx, int func, const amdarrow_array* values,
+                             const uint32_t* ids, int count_mode, void* sums, int64_t* counts);
+int amdarrow_hash_finalize(amdarrow_ctx* ctx, int func, int value_type_id, int64_t num_groups,
+                           void* sums, const int64_t* counts, uint8_t* out_validity,
+                           amdarrow_out* out);
 
 /* Fused Filter -> GroupBy (BASELINE.json north_star / config 5 on one shard):
  *   Filter(values, mask, DROP), Filter(keys, mask, DROP), GroupBy({values}, {keys},
