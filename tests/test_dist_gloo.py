@@ -50,11 +50,19 @@ def _worker(rank, world, port, n, null_keys, q):
         return adist.Partial(torch.from_numpy(k2), torch.from_numpy(kv2), torch.from_numpy(s2), torch.from_numpy(c2))
 
     merged = adist.merge_partials(part, local_merge, world)
+    # the dense (all-reduce) protocol on the same partials
+    lo_k, hi_k = adist.key_range(part)
+    st = adist.DenseState(lo_k - 3, hi_k - lo_k + 1 + 9, torch.int64, torch.device("cpu"))
+    dpart, n_present = adist.merge_dense(part, st, rank)
+    G = int(n_present.item())
     if rank == 0:
         es, ec, ek, ekv = o.filter_groupby_sum(*arrs(slice(0, n)))
         ok = (np.array_equal(merged.sums.numpy(), es) and np.array_equal(merged.counts.numpy(), ec) and
               np.array_equal(merged.keys.numpy()[ekv], ek[ekv]) and np.array_equal(merged.key_valid.numpy(), ekv))
-        q.put(bool(ok))
+        ok_dense = (G == len(es) and int(st.bad.item()) == 0 and np.array_equal(dpart.sums[:G].numpy(), es) and
+                    np.array_equal(dpart.counts[:G].numpy(), ec) and np.array_equal(dpart.key_valid[:G].numpy(), ekv) and
+                    np.array_equal(dpart.keys[:G].numpy()[ekv], ek[ekv].astype(np.int64)))
+        q.put(bool(ok and ok_dense))
     tdist.barrier()
     tdist.destroy_process_group()
 

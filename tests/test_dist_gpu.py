@@ -1,0 +1,72 @@
+"""GPU: the multi-rank GroupByMerger code path (side stream, double buffering, dense all-reduce
+merge) with TWO ranks sharing one GPU.  RCCL refuses two ranks per device, so the collectives go
+through gloo here (CUDA tensors staged by gloo); everything else -- the fused HIP kernel per shard,
+the dense scatter, the ordering, the stream/event choreography -- is the code `bench.py --gpus N`
+runs under RCCL."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as tdist
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import orc
+    from __graft_entry__ import load_package
+    load_package()
+    from arrow1_amd import _abi, device, dist as adist
+    ctx = device.Context(0)
+    rng = np.random.default_rng(0x0ff1ce)
+    vals = rng.integers(-100, 101, n)
+    keys = rng.integers(0, 50_000, n).astype(np.int32)
+    mask = rng.random(n) < 0.5
+    per = ((n // world + 63) // 64) * 64
+    lo, hi = rank * per, min(n, (rank + 1) * per)
+
+    def up(t, a):
+        return device.DeviceArray.from_numpy(t, a)
+
+    merger = adist.GroupByMerger(ctx, rank, world, key_type=_abi.INT32, value_type=_abi.INT64, group_capacity=1 << 17)
+    results = []
+    for step in range(4):  # several steps: exercises the double buffering and the side stream
+        r = merger.filter_groupby(up(_abi.INT64, vals[lo:hi]), up(_abi.INT32, keys[lo:hi]), up(_abi.BOOL, mask[lo:hi]))
+        results.append(r)
+    merger.finish()
+    torch.cuda.synchronize()
+    if rank == 0:
+        o = orc.Api("orc")
+        es, ec, ek, ekv = o.filter_groupby_sum(orc.Arr(orc.INT64, vals), orc.Arr(orc.INT32, keys), orc.Arr(orc.BOOL, mask))
+        ok = True
+        for r in results[-2:]:  # the two results whose buffers are still live
+            k, kv, s, c = r.tensors()
+            ok &= r.num_groups == len(es)
+            ok &= np.array_equal(s.cpu().numpy(), es) and np.array_equal(c.cpu().numpy(), ec)
+            ok &= np.array_equal(k.cpu().numpy(), ek.astype(np.int64)) and bool(kv.all())
+        q.put(bool(ok))
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_dense_merge():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + os.getpid() % 300
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 700_000, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True

@@ -411,8 +411,17 @@ def test_sharded_groupby_merge_on_gpu(gpu, oracle):
     es, ec, ek, ekv = oracle.filter_groupby_sum(v, k, m)
     up = lambda a: device.DeviceArray.from_numpy(a.type_id, a.data, a.valid, 0, len(a.data), None)  # noqa: E731
     r = compute.filter_groupby(gpu.ctx, up(v), up(k), up(m), buffers=compute.GroupByBuffers("cuda", 1 << 17, INT32))
-    merged = adist.merge_partials(merger1._partial_of(r), merger1._local_merge, 1)
+    part = merger1._partial_of(r)
+    merged = adist.merge_partials(part, merger1._local_merge, 1)
     assert np.array_equal(merged.sums_numpy(), es) and np.array_equal(merged.keys_numpy(), ek)
+    # dense protocol: two all-reduces over RCCL, ordering by the packed (owner rank, local id) word
+    lo, hi = adist.key_range(part)
+    st = adist.DenseState(lo - 5, hi - lo + 11, torch.int64, torch.device("cuda"))
+    dpart, n_present = adist.merge_dense(part, st, 0)
+    G = int(n_present.item())
+    assert G == len(es) and int(st.bad.item()) == 0
+    assert np.array_equal(dpart.sums[:G].cpu().numpy(), es) and np.array_equal(dpart.counts[:G].cpu().numpy(), ec)
+    assert np.array_equal(dpart.keys[:G].cpu().numpy(), ek.astype(np.int64))
     tdist.destroy_process_group()
 
 
