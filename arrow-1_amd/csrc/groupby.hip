@@ -428,8 +428,10 @@ static RankMem BindRank(char* base, const size_t off[4], int64_t n_rows) {
   r.block_offsets = reinterpret_cast<int64_t*>(base + off[3]);
   return r;
 }
+// `extra_dev` (optional): a second device word fetched in the same round trip as the total.
 static int RankFirstRows(amdarrow_ctx* ctx, const GroupTable& t, int only_unassigned, const RankMem& r, int64_t* total,
-                         bool already_marked = false) {
+                         bool already_marked = false, const unsigned int* extra_dev = nullptr,
+                         unsigned int* extra_host = nullptr) {
   const int64_t nslots = static_cast<int64_t>(t.mask) + 3;
   if (!already_marked) {
   AA_HIP(hipMemsetAsync(r.bitmap, 0, 8 * r.nwords, ctx->stream));
@@ -443,6 +445,15 @@ static int RankFirstRows(amdarrow_ctx* ctx, const GroupTable& t, int only_unassi
   hipLaunchKernelGGL(k_word_prefix, dim3(static_cast<unsigned>(r.nblocks)), dim3(kThreads), 0, ctx->stream, r.bitmap,
                      r.nwords, r.block_offsets, r.prefix);
   AA_HIP(hipGetLastError());
+  if (extra_dev) {  // one synchronisation for both words
+    char* pinned = static_cast<char*>(ctx->pinned);
+    AA_HIP(hipMemcpyAsync(pinned, r.block_offsets + r.nblocks, 8, hipMemcpyDeviceToHost, ctx->stream));
+    AA_HIP(hipMemcpyAsync(pinned + 8, extra_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+    AA_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(total, pinned, 8);
+    memcpy(extra_host, pinned + 8, 4);
+    return AMDARROW_OK;
+  }
   AA_TRY(ReadBack(ctx, r.block_offsets + r.nblocks, 8, total));
   return AMDARROW_OK;
 }
@@ -1054,13 +1065,19 @@ constexpr int kSideNull = kSlots, kSideFree = kSlots + 1;
 // expensive divergent probe loop of plain linear probing disappears.
 constexpr int kBucket = 4;
 constexpr int kBuckets = kSlots / kBucket;
+constexpr int kBucketBits = 10;  // second bucket: the next kBucketBits bits of the tag
+static_assert(kBuckets == 1 << kBucketBits, "bucket index width");
 
 __device__ __forceinline__ int MatchBucket(const uint4& b, uint32_t h) {
   return b.x == h ? 0 : b.y == h ? 1 : b.z == h ? 2 : b.w == h ? 3 : -1;
 }
 // Slow path: (re)read buckets until the key is found or inserted.  Returns slot or -1 (full).
-__device__ __forceinline__ int ProbeInsert(unsigned int* s_tag, unsigned int* s_groups, uint32_t h, uint32_t bucket) {
-  for (int probes = 0; probes < kBuckets; ++probes) {
+// Probe order of a key: its first bucket, its second bucket, then linearly on from the second.
+// Entries of a bucket fill from index 0 and are never removed, so every inserter of a key
+// targets the same entry and the loser of a CAS race re-reads the bucket.
+__device__ __forceinline__ int ProbeInsert(unsigned int* s_tag, unsigned int* s_groups, uint32_t h, uint32_t b1, uint32_t b2) {
+  uint32_t bucket = b1;
+  for (int probes = 0; probes <= kBuckets; ++probes) {
     for (;;) {
       const uint4 b = *reinterpret_cast<const uint4*>(&s_tag[bucket * kBucket]);
       int j = MatchBucket(b, h);
@@ -1073,11 +1090,72 @@ __device__ __forceinline__ int ProbeInsert(unsigned int* s_tag, unsigned int* s_
       if (old == h) return static_cast<int>(bucket * kBucket + j);
       // another key took the free entry: look at the bucket again
     }
-    bucket = (bucket + 1) & (kBuckets - 1);
+    bucket = probes == 0 ? b2 : (bucket + 1) & (kBuckets - 1);
   }
   return -1;
 }
 
+constexpr int kAggUnroll = 4;                  // records per lane and step
+constexpr int kAggStep = 64 * kAggUnroll;      // records per wave and step
+
+// Issue the (unconditional, clamped) streaming loads of one step: records [i0, i0 + kAggStep) of `seg`.
+__device__ __forceinline__ void AggLoad(uint4 (&rec)[kAggUnroll], const uint4* seg, uint32_t i0, uint32_t cnt, int lane) {
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+  const uint32_t last = cnt ? cnt - 1 : 0;
+#pragma unroll
+  for (int u = 0; u < kAggUnroll; ++u) {
+    const uint32_t i = i0 + lane + 64 * u;
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(&seg[i < cnt ? i : last]));
+    rec[u] = make_uint4(v.x, v.y, v.z, v.w);
+  }
+}
+
+// Fold one step into the LDS table.  Returns false when the table overflowed.
+__device__ __forceinline__ bool AggFold(const uint4 (&rec)[kAggUnroll], uint32_t i0, uint32_t cnt, int lane, int acc_double,
+                                        unsigned int* s_tag, unsigned long long* s_sum, uint32_t* s_first,
+                                        unsigned int* s_cnt, unsigned int* s_groups) {
+  bool ok = true;
+  uint32_t h[kAggUnroll];
+  int slot[kAggUnroll];
+  uint4 home1[kAggUnroll], home2[kAggUnroll];
+#pragma unroll
+  for (int u = 0; u < kAggUnroll; ++u) {
+    h[u] = Fmix32(rec[u].x);
+    home1[u] = *reinterpret_cast<const uint4*>(&s_tag[(h[u] & (kBuckets - 1)) * kBucket]);
+    home2[u] = *reinterpret_cast<const uint4*>(&s_tag[((h[u] >> kBucketBits) & (kBuckets - 1)) * kBucket]);
+  }
+#pragma unroll
+  for (int u = 0; u < kAggUnroll; ++u) {
+    if (i0 + lane + 64 * u >= cnt) { slot[u] = -2; continue; }
+    if (rec[u].y & kRecKeyNull) slot[u] = kSideNull;
+    else if (h[u] == kTagFree) slot[u] = kSideFree;
+    else {
+      const uint32_t b1 = h[u] & (kBuckets - 1), b2 = (h[u] >> kBucketBits) & (kBuckets - 1);
+      const int j1 = MatchBucket(home1[u], h[u]), j2 = MatchBucket(home2[u], h[u]);
+      if (j1 >= 0) slot[u] = static_cast<int>(b1 * kBucket) + j1;
+      else if (j2 >= 0) slot[u] = static_cast<int>(b2 * kBucket) + j2;
+      else slot[u] = ProbeInsert(s_tag, s_groups, h[u], b1, b2);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kAggUnroll; ++u) {
+    if (slot[u] == -2) continue;
+    if (slot[u] < 0) { ok = false; continue; }
+    const uint4 r = rec[u];
+    atomicMin(&s_first[slot[u]], r.y & kRecRowMask);
+    if (r.y & kRecValValid) {
+      const unsigned long long bits = (static_cast<unsigned long long>(r.w) << 32) | r.z;
+      if (acc_double) atomicAdd(reinterpret_cast<double*>(&s_sum[slot[u]]), __longlong_as_double(bits));
+      else atomicAdd(&s_sum[slot[u]], bits);
+      atomicAdd(&s_cnt[slot[u]], 1u);
+    }
+  }
+  return ok;
+}
+
+// A wave owns segments wave, wave + 16, ...; their fills are fetched once (one per lane) and
+// the steps are software-pipelined: the loads of step s + 1 are in flight while step s is
+// folded into LDS, so a wave never sits idle for a dependent fill -> records round trip.
 __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const uint4* regions, const uint32_t* counts,
                                                                         int nblocks, int64_t cap, int k_bits,
                                                                         int acc_double, GroupTable t,
@@ -1090,56 +1168,45 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
   __shared__ unsigned int s_groups;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = blockIdx.x;
+  constexpr int kWaves = kPartThreads / 64;
+  // fills of this wave's first 64 segments, fetched before the table is cleared
+  uint32_t my_cnt = 0;
+  {
+    const int b = wave + kWaves * lane;
+    if (b < nblocks) my_cnt = counts[int64_t(p) * nblocks + b];
+  }
   for (int s = tid; s < kSlots + 2; s += kPartThreads) { s_tag[s] = kTagFree; s_sum[s] = 0; s_first[s] = kNoRow; s_cnt[s] = 0; }
   if (tid == 0) s_groups = 0;
   __syncthreads();
   bool failed = false;
-  constexpr int kUnroll = 8;
-  for (int b = wave; b < nblocks; b += kPartThreads / 64) {
-    const uint32_t cnt = counts[int64_t(p) * nblocks + b];
-    const uint4* seg = regions + (int64_t(b) * kP + p) * cap;
-    for (uint32_t i0 = lane; i0 < cnt; i0 += 64 * kUnroll) {
-      uint4 rec[kUnroll];
-#pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
-        const uint32_t i = i0 + 64 * u;
-        using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
-        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(&seg[i < cnt ? i : cnt - 1]));
-        rec[u] = make_uint4(v.x, v.y, v.z, v.w);  // unconditional (clamped) and streamed once
-      }
-      uint32_t h[kUnroll];
-      int slot[kUnroll];
-      uint4 home[kUnroll];
-#pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
-        h[u] = Fmix32(rec[u].x);
-        slot[u] = static_cast<int>(h[u] & (kBuckets - 1));  // home bucket
-        home[u] = *reinterpret_cast<const uint4*>(&s_tag[slot[u] * kBucket]);
-      }
-#pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
-        if (i0 + 64 * u >= cnt) { slot[u] = -2; continue; }
-        if (rec[u].y & kRecKeyNull) slot[u] = kSideNull;
-        else if (h[u] == kTagFree) slot[u] = kSideFree;
-        else {
-          const int j = MatchBucket(home[u], h[u]);
-          if (j >= 0) slot[u] = slot[u] * kBucket + j;
-          else slot[u] = ProbeInsert(s_tag, &s_groups, h[u], static_cast<uint32_t>(slot[u]));
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
-        if (slot[u] == -2) continue;
-        if (slot[u] < 0) { failed = true; continue; }
-        const uint4 r = rec[u];
-        atomicMin(&s_first[slot[u]], r.y & kRecRowMask);
-        if (r.y & kRecValValid) {
-          const unsigned long long bits = (static_cast<unsigned long long>(r.w) << 32) | r.z;
-          if (acc_double) atomicAdd(reinterpret_cast<double*>(&s_sum[slot[u]]), __longlong_as_double(bits));
-          else atomicAdd(&s_sum[slot[u]], bits);
-          atomicAdd(&s_cnt[slot[u]], 1u);
-        }
-      }
+  for (int jb = 0; wave + kWaves * jb < nblocks; jb += 64) {
+    if (jb) {
+      const int b = wave + kWaves * (jb + lane);
+      my_cnt = b < nblocks ? counts[int64_t(p) * nblocks + b] : 0;
+    }
+    const int left = (nblocks - wave - kWaves * jb + kWaves - 1) / kWaves;
+    const int nseg = left < 64 ? left : 64;
+    const int64_t seg_stride = int64_t(kWaves) * kP * cap;
+    const uint4* seg = regions + (int64_t(wave + kWaves * jb) * kP + p) * cap;  // segment k: seg + k * seg_stride
+    int k = 0;
+    uint32_t i0 = 0, cnt = __shfl(my_cnt, 0);
+    uint4 ra[kAggUnroll], rb[kAggUnroll];
+    AggLoad(ra, seg, i0, cnt, lane);
+    for (;;) {
+      // step after (k, i0): the rest of the segment, else the next segment (a step of an empty
+      // or out-of-range segment loads one valid record and folds nothing)
+      int k2 = k;
+      uint32_t i2 = i0 + kAggStep, cnt2 = cnt;
+      if (i2 >= cnt) { k2 = k + 1; i2 = 0; cnt2 = k2 < nseg ? __shfl(my_cnt, k2) : 0; }
+      AggLoad(rb, seg + (k2 < nseg ? k2 : k) * seg_stride, i2, cnt2, lane);
+      failed |= !AggFold(ra, i0, cnt, lane, acc_double, s_tag, s_sum, s_first, s_cnt, &s_groups);
+      if (k2 >= nseg) break;
+      k = k2;
+      i0 = i2 + kAggStep; cnt = cnt2;
+      if (i0 >= cnt2) { k = k2 + 1; i0 = 0; cnt = k < nseg ? __shfl(my_cnt, k) : 0; }
+      AggLoad(ra, seg + (k < nseg ? k : k2) * seg_stride, i0, cnt, lane);
+      failed |= !AggFold(rb, i2, cnt2, lane, acc_double, s_tag, s_sum, s_first, s_cnt, &s_groups);
+      if (k >= nseg) break;
     }
   }
   if (failed) *overflow = 1;
@@ -1522,9 +1589,8 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
       AA_HIP(hipGetLastError());
     }
     int64_t G = 0;
-    AA_TRY(RankFirstRows(ctx, t, 0, r, &G, /*already_marked=*/path == 2));
     unsigned int overflow = 0;
-    AA_TRY(ReadBack(ctx, misc, 4, &overflow));
+    AA_TRY(RankFirstRows(ctx, t, 0, r, &G, /*already_marked=*/path == 2, misc, &overflow));
     if (overflow && fast) continue;  // capacity assumption failed: next (more general) path
     if (overflow || G > group_capacity)
       return SetError(AMDARROW_CAPACITY_ERROR,
@@ -1547,7 +1613,7 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
                      ks.col[0].bits, 0, ks.wide_null_slot ? -1 : ks.total_bits, wide, out_keys,
                      reinterpret_cast<uint64_t*>(out_key_validity), reinterpret_cast<unsigned long long*>(misc + 2));
   AA_HIP(hipGetLastError());
-  AA_HIP(hipStreamSynchronize(ctx->stream));
+  // no trailing synchronise: *out_num_groups is final, the output arrays are stream-ordered
   return AMDARROW_OK;
 }
 

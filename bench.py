@@ -33,6 +33,8 @@ from arrow1_amd import _abi, compute, device  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 SEED = 0x0ff1ce         # kRandomSeed, compute/kernels/test_util.h:123
 
+NUM_GROUPS = 1_000_000  # --groups
+
 WORKLOADS = {
     # name: (description, algorithmic bytes per row as a function of selectivity)
     "filter_groupby_sum_i64": "Filter(mask 50%) -> GroupBy{hash_sum,hash_count}(int64) by int32 key, 1M groups",
@@ -63,7 +65,7 @@ def make_inputs(workload, n, dev, rank, sel):
     d = {}
     if workload in ("filter_groupby_sum_i64",):
         vals = torch.randint(-100, 101, (n,), dtype=torch.int64, device=dev, generator=gen)
-        keys = torch.randint(0, 1_000_000, (n,), dtype=torch.int32, device=dev, generator=gen)
+        keys = torch.randint(0, NUM_GROUPS, (n,), dtype=torch.int32, device=dev, generator=gen)
         d["values"] = device.DeviceArray(_abi.INT64, vals.view(torch.uint8), None, n)
         d["keys"] = device.DeviceArray(_abi.INT32, keys.view(torch.uint8), None, n)
         d["mask"] = device.DeviceArray(_abi.BOOL, device_bitmap(n, sel, gen, dev), None, n)
@@ -84,7 +86,7 @@ def make_inputs(workload, n, dev, rank, sel):
         d["_keep"] = (vals,)
     elif workload == "hash_agg_f64":
         vals = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 1e3
-        keys = torch.randint(0, 1_000_000, (n,), dtype=torch.int32, device=dev, generator=gen)
+        keys = torch.randint(0, NUM_GROUPS, (n,), dtype=torch.int32, device=dev, generator=gen)
         d["values"] = device.DeviceArray(_abi.DOUBLE, vals.view(torch.uint8), device_bitmap(n, 0.99, gen, dev), n, 0, -1)
         d["keys"] = device.DeviceArray(_abi.INT32, keys.view(torch.uint8), None, n)
         d["_keep"] = (vals, keys)
@@ -143,7 +145,7 @@ def cpu_baseline(workload, sel):
         return None
     n = 8_000_000
     vals = orc.Arr(orc.INT64, rng.integers(-100, 101, n))
-    keys = orc.Arr(orc.INT32, rng.integers(0, 1_000_000, n))
+    keys = orc.Arr(orc.INT32, rng.integers(0, NUM_GROUPS, n))
     mask = orc.Arr(orc.BOOL, rng.random(n) < sel)
     t0 = time.time()
     reps = 0
@@ -165,8 +167,11 @@ def main():
     ap.add_argument("--workload", default="filter_groupby_sum_i64", choices=sorted(WORKLOADS))
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU")
     ap.add_argument("--selectivity", type=float, default=0.5)
+    ap.add_argument("--groups", type=int, default=1_000_000, help="distinct group keys (tuning aid; the headline is 1M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    global NUM_GROUPS
+    NUM_GROUPS = args.groups
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -227,7 +232,7 @@ def main():
                                             "compare_i64": "int64"}[args.workload],
             "data": "synthetic (device-generated, seed 0x0ff1ce + rank; HBM-resident before timing)",
             "config": {"workload": args.workload + ": " + WORKLOADS[args.workload], "rows_per_gpu": n,
-                       "selectivity": sel, "groups": 1_000_000, "sharding": "row-range, %d shard(s)" % world},
+                       "selectivity": sel, "groups": NUM_GROUPS, "sharding": "row-range, %d shard(s)" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "note": "algorithmic %.3f B/row x %d rows / HIP-event time per step (%.3f ms) on the kernel stream; "

@@ -197,7 +197,8 @@ int amdarrow_hash_finalize(amdarrow_ctx* ctx, int func, int value_type_id, int64
  *   out_keys (key type) + out_key_validity, out_first_rows (optional, may be NULL):
  *   row index, within this call's input, of the first selected row of each group --
  *   what a multi-GPU merge orders groups by.
- * *out_num_groups (host). */
+ * *out_num_groups (host) is final on return; the output ARRAYS are complete in stream order
+ * (synchronise the context, or consume them on the same stream). */
 int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values,
                             const amdarrow_array* keys, const amdarrow_array* mask,
                             int64_t group_capacity, void* out_sums, int64_t* out_counts,
