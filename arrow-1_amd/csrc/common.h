@@ -39,7 +39,9 @@ struct amdarrow_ctx {
   bool own_stream = false;
   void* scratch = nullptr;  // grow-only HBM arena for per-call temporaries
   size_t scratch_cap = 0;
-  void* pinned = nullptr;   // 4 KiB pinned host memory for small read-backs
+  void* pinned = nullptr;   // 4 KiB pinned, device-mapped host memory for small read-backs
+  void* pinned_dev = nullptr;  // the same memory as the device sees it (kernels may store status words there)
+  hipEvent_t status_event = nullptr;  // marks the kernel that stored them
   int num_cus = 256;
   int64_t bytes_allocated = 0;
   int64_t max_memory = 0;

@@ -171,7 +171,8 @@ __global__ __launch_bounds__(kThreads) void k_groupby_build(KeySpec ks, ValueCol
 // ---- first-appearance numbering -----------------------------------------------------------------
 // Set bit first_row for every group that needs an id.
 __global__ __launch_bounds__(kThreads) void k_mark_first(GroupTable t, int64_t nslots, int only_unassigned,
-                                                         unsigned long long* bitmap) {
+                                                         unsigned long long* bitmap, const unsigned int* skip_if) {
+  if (skip_if && *skip_if) return;  // the groups were marked by the kernel that built them
   for (int64_t s = int64_t(blockIdx.x) * kThreads + threadIdx.x; s < nslots; s += int64_t(gridDim.x) * kThreads) {
     const uint32_t fr = t.first[s];
     if (fr == kNoRow) continue;
@@ -197,7 +198,19 @@ __global__ __launch_bounds__(kThreads) void k_popc_blocks(const unsigned long lo
 }
 // prefix[w] = number of set bits in words [0, w)
 __global__ __launch_bounds__(kThreads) void k_word_prefix(const unsigned long long* bitmap, int64_t nwords,
-                                                          const int64_t* block_offsets, uint32_t* prefix) {
+                                                          const int64_t* block_offsets, uint32_t* prefix,
+                                                          unsigned int* status, unsigned int* host_status) {
+  // status words (see RankFirstRows): store the total, then mirror all of them into mapped host
+  // memory -- the host waits for an event behind this kernel instead of paying a copy launch.
+  if (status && blockIdx.x == 0 && threadIdx.x == 0) {
+    const long long total = block_offsets[gridDim.x];
+    *reinterpret_cast<long long*>(status + 6) = total;
+    if (host_status) {
+      for (int i = 0; i < 6; ++i) host_status[i] = status[i];
+      host_status[6] = static_cast<unsigned int>(total);
+      host_status[7] = static_cast<unsigned int>(static_cast<unsigned long long>(total) >> 32);
+    }
+  }
   __shared__ uint32_t s_wave[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t base = int64_t(blockIdx.x) * 1024;
@@ -224,8 +237,12 @@ struct EmitArgs {
   long long* counts;          // may be null
   uint32_t* first_rows;       // may be null
   uint32_t* wide_null_id;     // id of the null-key group of a single 64-bit key (kNoRow if none)
+  const unsigned int* skip_if; // optional device word: non-zero = the table is not valid, emit nothing
+  ulonglong4* packed;          // optional: ONE 32-byte record {key word, sum, count, first row} per id instead of
+                               // the four arrays above (one full-sector scattered store instead of four partial ones)
 };
 __global__ __launch_bounds__(kThreads) void k_emit_groups(EmitArgs a) {
+  if (a.skip_if && *a.skip_if) return;
   for (int64_t s = int64_t(blockIdx.x) * kThreads + threadIdx.x; s < a.nslots; s += int64_t(gridDim.x) * kThreads) {
     const uint32_t fr = a.t.first[s];
     if (fr == kNoRow) continue;
@@ -239,6 +256,10 @@ __global__ __launch_bounds__(kThreads) void k_emit_groups(EmitArgs a) {
     if (static_cast<uint64_t>(s) == T) { x = 0; *a.wide_null_id = id; }
     else if (static_cast<uint64_t>(s) == T + 1) x = Fmix64Inv(kEmpty);
     else x = Fmix64Inv(a.t.hkeys[s]);
+    if (a.packed) {
+      a.packed[id] = make_ulonglong4(x, a.t.sums[s], a.t.counts[s], fr);
+      continue;
+    }
     a.gx[id] = x;
     if (a.sums) a.sums[id] = a.t.sums[s];
     if (a.counts) a.counts[id] = static_cast<long long>(a.t.counts[s]);
@@ -250,7 +271,14 @@ __global__ __launch_bounds__(kThreads) void k_emit_groups(EmitArgs a) {
 __global__ __launch_bounds__(kThreads) void k_decode_keys(const unsigned long long* gx, int64_t G, int bits, int shift,
                                                           int null_bit /* <0: none */, uint32_t wide_null_id,
                                                           void* out_values, uint64_t* out_validity,
-                                                          unsigned long long* null_count) {
+                                                          unsigned long long* null_count,
+                                                          const unsigned int* status /* optional, see RankFirstRows */) {
+  if (status) {  // group count and wide-null id still live on the device; G is the capacity here
+    if (status[0]) return;
+    const long long total = *reinterpret_cast<const long long*>(status + 6);
+    if (total < G) G = total;
+    wide_null_id = status[4];
+  }
   const int lane = threadIdx.x & 63;
   const int64_t ground = (G + 63) & ~int64_t(63);
   for (int64_t g = int64_t(blockIdx.x) * kThreads + threadIdx.x; g < ground; g += int64_t(gridDim.x) * kThreads) {
@@ -279,6 +307,49 @@ __global__ __launch_bounds__(kThreads) void k_decode_keys(const unsigned long lo
       const int64_t live = G - g >= 64 ? 64 : G - g;
       const int nulls = static_cast<int>(live) - __popcll(vm);
       if (nulls) atomicAdd(null_count, static_cast<unsigned long long>(nulls));
+    }
+  }
+}
+
+// Packed group records (k_emit_groups) -> the caller's arrays, all coalesced; decodes the single
+// key column like k_decode_keys.  The group count comes from the status words (see RankFirstRows).
+__global__ __launch_bounds__(kThreads) void k_unpack_groups(const ulonglong4* packed, int64_t bound, int bits,
+                                                            int null_bit /* <0: none */, unsigned long long* out_sums,
+                                                            long long* out_counts, uint32_t* out_first_rows,
+                                                            void* out_keys, uint64_t* out_validity,
+                                                            const unsigned int* status) {
+  if (status[0]) return;
+  int64_t G = *reinterpret_cast<const long long*>(status + 6);
+  if (G > bound) G = bound;
+  const uint32_t wide_null_id = status[4];
+  const int lane = threadIdx.x & 63;
+  const int64_t ground = (G + 63) & ~int64_t(63);
+  for (int64_t g = int64_t(blockIdx.x) * kThreads + threadIdx.x; g < ground; g += int64_t(gridDim.x) * kThreads) {
+    bool valid = false;
+    uint64_t v = 0;
+    if (g < G) {
+      const ulonglong4 r = packed[g];
+      if (out_sums) out_sums[g] = r.y;
+      if (out_counts) out_counts[g] = static_cast<long long>(r.z);
+      if (out_first_rows) out_first_rows[g] = static_cast<uint32_t>(r.w);
+      const uint64_t x = r.x;
+      valid = (null_bit >= 0) ? !((x >> null_bit) & 1) : (static_cast<uint32_t>(g) != wide_null_id);
+      v = bits >= 64 ? x : (x & ((uint64_t(1) << bits) - 1));
+      if (!valid) v = 0;
+      switch (bits) {
+        case 1: break;  // packed below
+        case 8: reinterpret_cast<uint8_t*>(out_keys)[g] = static_cast<uint8_t>(v); break;
+        case 16: reinterpret_cast<uint16_t*>(out_keys)[g] = static_cast<uint16_t>(v); break;
+        case 32: reinterpret_cast<uint32_t*>(out_keys)[g] = static_cast<uint32_t>(v); break;
+        default: reinterpret_cast<uint64_t*>(out_keys)[g] = v; break;
+      }
+    }
+    // whole waves reach this point together (the loop bound is a multiple of 64)
+    const uint64_t vm = __ballot(valid);
+    const uint64_t bm = __ballot(v != 0);
+    if (lane == 0) {
+      out_validity[g >> 6] = vm;
+      if (bits == 1) reinterpret_cast<uint64_t*>(out_keys)[g >> 6] = bm;
     }
   }
 }
@@ -428,30 +499,40 @@ static RankMem BindRank(char* base, const size_t off[4], int64_t n_rows) {
   r.block_offsets = reinterpret_cast<int64_t*>(base + off[3]);
   return r;
 }
-// `extra_dev` (optional): a second device word fetched in the same round trip as the total.
+constexpr size_t kStatusOffset = 256;  // status words inside the pinned block (ReadBack uses its head)
+// Wait for the status words queued by RankFirstRows(status_dev != nullptr).
+static int AwaitStatus(amdarrow_ctx* ctx, unsigned int (&status)[8]) {
+  AA_HIP(hipEventSynchronize(ctx->status_event));
+  memcpy(status, static_cast<const char*>(ctx->pinned) + kStatusOffset, sizeof(status));
+  return AMDARROW_OK;
+}
+
+// mark_mode: 0 = clear the bitmap and mark every group's first row here; 1 = already marked by
+// the kernel that built the table; 2 = bitmap already cleared, mark here unless status[1] is
+// set on the device (then the partition path built the table and marked on the way); 3 = bitmap
+// already cleared, mark here.
+// `status_dev` (optional): 8 device words {overflow, local-abort, null count x2, wide-null id, -,
+// total lo, total hi}; k_word_prefix stores the total there and mirrors the words into mapped
+// host memory.  With status_dev the caller collects them with AwaitStatus (after queueing
+// whatever else does not need them on the host).
 static int RankFirstRows(amdarrow_ctx* ctx, const GroupTable& t, int only_unassigned, const RankMem& r, int64_t* total,
-                         bool already_marked = false, const unsigned int* extra_dev = nullptr,
-                         unsigned int* extra_host = nullptr) {
+                         int mark_mode = 0, unsigned int* status_dev = nullptr) {
   const int64_t nslots = static_cast<int64_t>(t.mask) + 3;
-  if (!already_marked) {
-  AA_HIP(hipMemsetAsync(r.bitmap, 0, 8 * r.nwords, ctx->stream));
-  hipLaunchKernelGGL(k_mark_first, dim3(GridFor(nslots, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, t,
-                     nslots, only_unassigned, r.bitmap);
+  if (mark_mode != 1) {
+    if (mark_mode == 0) AA_HIP(hipMemsetAsync(r.bitmap, 0, 8 * r.nwords, ctx->stream));
+    hipLaunchKernelGGL(k_mark_first, dim3(GridFor(nslots, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, t,
+                       nslots, only_unassigned, r.bitmap, mark_mode == 2 ? status_dev + 1 : nullptr);
   }
   hipLaunchKernelGGL(k_popc_blocks, dim3(static_cast<unsigned>(r.nblocks)), dim3(kThreads), 0, ctx->stream, r.bitmap,
                      r.nwords, r.block_counts);
   AA_HIP(hipGetLastError());
   AA_TRY(LaunchScanU32(ctx, r.block_counts, r.nblocks, r.block_offsets));
   hipLaunchKernelGGL(k_word_prefix, dim3(static_cast<unsigned>(r.nblocks)), dim3(kThreads), 0, ctx->stream, r.bitmap,
-                     r.nwords, r.block_offsets, r.prefix);
+                     r.nwords, r.block_offsets, r.prefix, status_dev,
+                     status_dev ? reinterpret_cast<unsigned int*>(static_cast<char*>(ctx->pinned_dev) + kStatusOffset) : nullptr);
   AA_HIP(hipGetLastError());
-  if (extra_dev) {  // one synchronisation for both words
-    char* pinned = static_cast<char*>(ctx->pinned);
-    AA_HIP(hipMemcpyAsync(pinned, r.block_offsets + r.nblocks, 8, hipMemcpyDeviceToHost, ctx->stream));
-    AA_HIP(hipMemcpyAsync(pinned + 8, extra_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
-    AA_HIP(hipStreamSynchronize(ctx->stream));
-    memcpy(total, pinned, 8);
-    memcpy(extra_host, pinned + 8, 4);
+  if (status_dev) {
+    AA_HIP(hipEventRecord(ctx->status_event, ctx->stream));
     return AMDARROW_OK;
   }
   AA_TRY(ReadBack(ctx, r.block_offsets + r.nblocks, 8, total));
@@ -753,7 +834,9 @@ __device__ __forceinline__ void LoadTile(const FastArgs& a, int64_t tile0, int64
 // partition, then copy every partition's run to the tail of this workgroup's private region.
 // The loads of tile i+1 are issued before the copy-out of tile i, so HBM latency hides behind it.
 __global__ __launch_bounds__(kDThreads) void k_part_scatter_direct(FastArgs a, int64_t cap, uint4* regions,
-                                                                   uint32_t* counts, unsigned int* overflow) {
+                                                                   uint32_t* counts, unsigned int* overflow,
+                                                                   const unsigned int* run_if) {
+  if (run_if && !*run_if) return;  // the local path already built the table
   __shared__ unsigned int s_cnt[2][kP];
   __shared__ uint32_t s_off[kP];
   __shared__ uint32_t s_cur[kP];
@@ -995,7 +1078,8 @@ __device__ __forceinline__ void FastFinishTile(ScatterShared& sh, int buf, int64
 // current tile goes through its LDS phases.
 template <bool MASK, bool VVALID>
 __global__ __launch_bounds__(kDThreads) void k_part_scatter_fast(FastArgs a, int64_t cap, uint4* regions, uint32_t* counts,
-                                                                 unsigned int* overflow) {
+                                                                 unsigned int* overflow, const unsigned int* run_if) {
+  if (run_if && !*run_if) return;  // the local path already built the table
   __shared__ ScatterShared sh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < kP) { sh.cnt[0][tid] = 0; sh.cnt[1][tid] = 0; sh.cur[tid] = 0; sh.carry_cnt[tid] = 0; sh.wcnt[tid] = 0; }
@@ -1075,7 +1159,8 @@ __device__ __forceinline__ int MatchBucket(const uint4& b, uint32_t h) {
 // Probe order of a key: its first bucket, its second bucket, then linearly on from the second.
 // Entries of a bucket fill from index 0 and are never removed, so every inserter of a key
 // targets the same entry and the loser of a CAS race re-reads the bucket.
-__device__ __forceinline__ int ProbeInsert(unsigned int* s_tag, unsigned int* s_groups, uint32_t h, uint32_t b1, uint32_t b2) {
+__device__ __forceinline__ int ProbeInsert(unsigned int* s_tag, unsigned int* s_groups, uint32_t h, uint32_t b1, uint32_t b2,
+                                           unsigned int limit) {
   uint32_t bucket = b1;
   for (int probes = 0; probes <= kBuckets; ++probes) {
     for (;;) {
@@ -1084,7 +1169,7 @@ __device__ __forceinline__ int ProbeInsert(unsigned int* s_tag, unsigned int* s_
       if (j >= 0) return static_cast<int>(bucket * kBucket + j);
       j = MatchBucket(b, kTagFree);
       if (j < 0) break;  // bucket full: next bucket
-      if (*s_groups >= kSlotLimit) return -1;
+      if (*s_groups >= limit) return -1;
       const unsigned int old = atomicCAS(&s_tag[bucket * kBucket + j], kTagFree, h);
       if (old == kTagFree) { atomicAdd(s_groups, 1u); return static_cast<int>(bucket * kBucket + j); }
       if (old == h) return static_cast<int>(bucket * kBucket + j);
@@ -1111,9 +1196,9 @@ __device__ __forceinline__ void AggLoad(uint4 (&rec)[kAggUnroll], const uint4* s
 }
 
 // Fold one step into the LDS table.  Returns false when the table overflowed.
-__device__ __forceinline__ bool AggFold(const uint4 (&rec)[kAggUnroll], uint32_t i0, uint32_t cnt, int lane, int acc_double,
+__device__ __forceinline__ bool AggFold(const uint4 (&rec)[kAggUnroll], const bool (&live)[kAggUnroll], int acc_double,
                                         unsigned int* s_tag, unsigned long long* s_sum, uint32_t* s_first,
-                                        unsigned int* s_cnt, unsigned int* s_groups) {
+                                        unsigned int* s_cnt, unsigned int* s_groups, unsigned int limit = kSlotLimit) {
   bool ok = true;
   uint32_t h[kAggUnroll];
   int slot[kAggUnroll];
@@ -1126,7 +1211,7 @@ __device__ __forceinline__ bool AggFold(const uint4 (&rec)[kAggUnroll], uint32_t
   }
 #pragma unroll
   for (int u = 0; u < kAggUnroll; ++u) {
-    if (i0 + lane + 64 * u >= cnt) { slot[u] = -2; continue; }
+    if (!live[u]) { slot[u] = -2; continue; }
     if (rec[u].y & kRecKeyNull) slot[u] = kSideNull;
     else if (h[u] == kTagFree) slot[u] = kSideFree;
     else {
@@ -1134,7 +1219,7 @@ __device__ __forceinline__ bool AggFold(const uint4 (&rec)[kAggUnroll], uint32_t
       const int j1 = MatchBucket(home1[u], h[u]), j2 = MatchBucket(home2[u], h[u]);
       if (j1 >= 0) slot[u] = static_cast<int>(b1 * kBucket) + j1;
       else if (j2 >= 0) slot[u] = static_cast<int>(b2 * kBucket) + j2;
-      else slot[u] = ProbeInsert(s_tag, s_groups, h[u], b1, b2);
+      else slot[u] = ProbeInsert(s_tag, s_groups, h[u], b1, b2, limit);
     }
   }
 #pragma unroll
@@ -1153,6 +1238,15 @@ __device__ __forceinline__ bool AggFold(const uint4 (&rec)[kAggUnroll], uint32_t
   return ok;
 }
 
+__device__ __forceinline__ bool AggFoldStep(const uint4 (&rec)[kAggUnroll], uint32_t i0, uint32_t cnt, int lane,
+                                            int acc_double, unsigned int* s_tag, unsigned long long* s_sum,
+                                            uint32_t* s_first, unsigned int* s_cnt, unsigned int* s_groups) {
+  bool live[kAggUnroll];
+#pragma unroll
+  for (int u = 0; u < kAggUnroll; ++u) live[u] = i0 + lane + 64 * u < cnt;
+  return AggFold(rec, live, acc_double, s_tag, s_sum, s_first, s_cnt, s_groups);
+}
+
 // A wave owns segments wave, wave + 16, ...; their fills are fetched once (one per lane) and
 // the steps are software-pipelined: the loads of step s + 1 are in flight while step s is
 // folded into LDS, so a wave never sits idle for a dependent fill -> records round trip.
@@ -1160,12 +1254,13 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
                                                                         int nblocks, int64_t cap, int k_bits,
                                                                         int acc_double, GroupTable t,
                                                                         unsigned long long* first_bitmap,
-                                                                        unsigned int* overflow) {
+                                                                        unsigned int* overflow, const unsigned int* run_if) {
   __shared__ __attribute__((aligned(16))) unsigned int s_tag[kSlots + 4];
   __shared__ unsigned long long s_sum[kSlots + 2];
   __shared__ uint32_t s_first[kSlots + 2];
   __shared__ unsigned int s_cnt[kSlots + 2];
   __shared__ unsigned int s_groups;
+  if (run_if && !*run_if) return;  // the local path already built the table
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = blockIdx.x;
   constexpr int kWaves = kPartThreads / 64;
@@ -1199,13 +1294,13 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
       uint32_t i2 = i0 + kAggStep, cnt2 = cnt;
       if (i2 >= cnt) { k2 = k + 1; i2 = 0; cnt2 = k2 < nseg ? __shfl(my_cnt, k2) : 0; }
       AggLoad(rb, seg + (k2 < nseg ? k2 : k) * seg_stride, i2, cnt2, lane);
-      failed |= !AggFold(ra, i0, cnt, lane, acc_double, s_tag, s_sum, s_first, s_cnt, &s_groups);
+      failed |= !AggFoldStep(ra, i0, cnt, lane, acc_double, s_tag, s_sum, s_first, s_cnt, &s_groups);
       if (k2 >= nseg) break;
       k = k2;
       i0 = i2 + kAggStep; cnt = cnt2;
       if (i0 >= cnt2) { k = k2 + 1; i0 = 0; cnt = k < nseg ? __shfl(my_cnt, k) : 0; }
       AggLoad(ra, seg + (k < nseg ? k : k2) * seg_stride, i0, cnt, lane);
-      failed |= !AggFold(rb, i2, cnt2, lane, acc_double, s_tag, s_sum, s_first, s_cnt, &s_groups);
+      failed |= !AggFoldStep(rb, i2, cnt2, lane, acc_double, s_tag, s_sum, s_first, s_cnt, &s_groups);
       if (k >= nseg) break;
     }
   }
@@ -1244,6 +1339,205 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
   if (p == 0 && tid < 2) {
     const int64_t T = int64_t(kP) * kSlots;
     t.hkeys[T + tid] = kEmpty; t.first[T + tid] = kNoRow; t.sums[T + tid] = 0; t.counts[T + tid] = 0;
+  }
+}
+
+
+// ---- local path: per-workgroup LDS pre-aggregation ----------------------------------------------------
+// When a workgroup's row range holds few distinct keys (low-cardinality or clustered keys) the
+// records never need to leave the CU: every workgroup folds its rows straight into the LDS table
+// of k_part_aggregate_direct and the (small) tables are merged into the global table afterwards.
+// The attempt is optimistic: a workgroup whose table exceeds kLocalLimit raises ITS OWN flag word
+// and stops (a flag shared by all workgroups costs ~30 ns per store: same-address device-scope
+// stores are serialised at the memory side -- 130 us when every wave of a doomed attempt raises
+// it).  The first kernel behind ORs the flags into status[1]; the merge kernels then turn into
+// no-ops and the partition path (already queued, gated on the same word) takes over.  No host
+// round trip is spent on the decision.
+struct LocalStage { unsigned int* tag; uint32_t* first; unsigned long long* sum; unsigned int* cnt; };
+constexpr int kStageSlots = kSlots + 2;
+// The local attempt gives up at half load: beyond it the inserts crawl (long probe chains, CAS
+// races of 16 waves) and a doomed attempt must fail fast, it is pure overhead for the partition path.
+#ifndef LOCAL_LIMIT
+#define LOCAL_LIMIT (kSlots / 2)
+#endif
+constexpr unsigned int kLocalLimit = LOCAL_LIMIT;
+static size_t LocalStageBytes(int nblocks) { return size_t(20) * kStageSlots * nblocks; }
+
+struct LocalShared {
+  __attribute__((aligned(16))) unsigned int tag[kSlots + 4];
+  unsigned long long sum[kSlots + 2];
+  uint32_t first[kSlots + 2];
+  unsigned int cnt[kSlots + 2];
+  unsigned int groups;
+  unsigned int stop;  // some wave of this workgroup gave up
+};
+__device__ __forceinline__ void LocalInit(LocalShared& sh, int tid) {
+  for (int s = tid; s < kSlots + 2; s += kDThreads) { sh.tag[s] = kTagFree; sh.sum[s] = 0; sh.first[s] = kNoRow; sh.cnt[s] = 0; }
+  if (tid == 0) { sh.groups = 0; sh.stop = 0; }
+  __syncthreads();
+}
+__device__ __forceinline__ void LocalGiveUp(LocalShared& sh, unsigned int* wg_flags) {
+  if ((threadIdx.x & 63) == 0) { sh.stop = 1; wg_flags[blockIdx.x] = 1; }
+}
+__device__ __forceinline__ void LocalWriteOut(const LocalShared& sh, const LocalStage& st, int tid) {
+  const int64_t base = int64_t(blockIdx.x) * kStageSlots;
+  for (int s = tid; s < kStageSlots; s += kDThreads) {
+    st.tag[base + s] = s < kSlots ? sh.tag[s] : 0u;
+    st.first[base + s] = sh.first[s];
+    st.sum[base + s] = sh.sum[s];
+    st.cnt[base + s] = sh.cnt[s];
+  }
+}
+// Fold the 7 x 64 rows a wave holds of one fast-layout tile (see FastLoadTile).
+template <bool VVALID>
+__device__ __forceinline__ bool LocalFoldFast(LocalShared& sh, int64_t tile0, int wave, int lane, int acc_double,
+                                              const uint32_t (&kx)[kFSteps], const uint64_t (&kv)[kFSteps], uint64_t mword,
+                                              uint64_t vword) {
+  const int64_t wrow0 = tile0 + wave * (kFSteps * 64);
+  bool ok = true;
+#pragma unroll
+  for (int g = 0; g < kFSteps; g += kAggUnroll) {
+    uint4 rec[kAggUnroll];
+    bool live[kAggUnroll];
+#pragma unroll
+    for (int u = 0; u < kAggUnroll; ++u) {
+      const int j = g + u;
+      live[u] = false;
+      rec[u] = make_uint4(0, 0, 0, 0);
+      if (j < kFSteps) {
+        live[u] = (__shfl(mword, j, 64) >> lane) & 1;
+        const bool valid = VVALID ? ((__shfl(vword, j, 64) >> lane) & 1) != 0 : true;
+        const uint32_t row = static_cast<uint32_t>(wrow0 + j * 64 + lane);
+        rec[u] = make_uint4(kx[j], row | (valid ? kRecValValid : 0u), static_cast<uint32_t>(kv[j]),
+                            static_cast<uint32_t>(kv[j] >> 32));
+      }
+    }
+    ok &= AggFold(rec, live, acc_double, sh.tag, sh.sum, sh.first, sh.cnt, &sh.groups, kLocalLimit);
+  }
+  return ok;
+}
+
+template <bool MASK, bool VVALID>
+__global__ __launch_bounds__(kDThreads) void k_local_aggregate_fast(FastArgs a, int acc_double, LocalStage st,
+                                                                    unsigned int* wg_flags) {
+  __shared__ LocalShared sh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  LocalInit(sh, tid);
+  const int64_t lo = int64_t(blockIdx.x) * a.rows_per_block;
+  const int64_t hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
+  const uint32_t* keys = reinterpret_cast<const uint32_t*>(a.k_data) + a.k_off;
+  const uint64_t* vals = reinterpret_cast<const uint64_t*>(a.v.data) + a.v.off;
+  uint32_t kxA[kFSteps], kxB[kFSteps];
+  uint64_t kvA[kFSteps], kvB[kFSteps];
+  RawBits mA{}, vA{}, mB{}, vB{};
+  auto words = [&](int64_t t0, const RawBits& mraw, const RawBits& vraw, uint64_t* mword, uint64_t* vword) {
+    const int64_t mrow = t0 + wave * (kFSteps * 64) + 64 * (lane & 7);
+    const int64_t left = hi - mrow;
+    const int nbits = left >= 64 ? 64 : (left > 0 ? static_cast<int>(left) : 0);
+    const int64_t mrow_c = nbits > 0 ? mrow : hi - 1;
+    const uint64_t live = nbits == 0 ? 0 : (nbits < 64 ? (uint64_t(1) << nbits) - 1 : ~uint64_t(0));
+    *mword = MASK ? (CombineBits(a.m_data, a.m_off + mrow_c, nbits > 0 ? nbits : 1, mraw) & live) : live;
+    *vword = VVALID ? (CombineBits(a.v.valid, a.v.off + mrow_c, nbits > 0 ? nbits : 1, vraw) & live) : live;
+  };
+  uint64_t mw, vw;
+  volatile unsigned int* stop = &sh.stop;
+  if (lo < hi) FastLoadTile<MASK, VVALID>(a, keys, vals, lo, hi, wave, lane, kxA, kvA, mA, vA);
+  for (int64_t tile0 = lo; tile0 < hi; tile0 += 2 * kFRows) {
+    const bool has_b = tile0 + kFRows < hi;
+    if (has_b) FastLoadTile<MASK, VVALID>(a, keys, vals, tile0 + kFRows, hi, wave, lane, kxB, kvB, mB, vB);
+    if (*stop) break;
+    words(tile0, mA, vA, &mw, &vw);
+    if (__any(!LocalFoldFast<VVALID>(sh, tile0, wave, lane, acc_double, kxA, kvA, mw, vw))) { LocalGiveUp(sh, wg_flags); break; }
+    if (!has_b) break;
+    if (tile0 + 2 * kFRows < hi) FastLoadTile<MASK, VVALID>(a, keys, vals, tile0 + 2 * kFRows, hi, wave, lane, kxA, kvA, mA, vA);
+    if (*stop) break;
+    words(tile0 + kFRows, mB, vB, &mw, &vw);
+    if (__any(!LocalFoldFast<VVALID>(sh, tile0 + kFRows, wave, lane, acc_double, kxB, kvB, mw, vw))) { LocalGiveUp(sh, wg_flags); break; }
+  }
+  __syncthreads();
+  if (*stop) return;  // a stale staging table is never read: the merge is gated on the flags
+  LocalWriteOut(sh, st, tid);
+}
+
+// Any key width <= 32 bits, key / value / mask validity, every value type (LoadTile).
+__global__ __launch_bounds__(kDThreads) void k_local_aggregate(FastArgs a, int acc_double, LocalStage st,
+                                                               unsigned int* wg_flags) {
+  __shared__ LocalShared sh;
+  const int tid = threadIdx.x, lane = tid & 63;
+  LocalInit(sh, tid);
+  const int64_t lo = int64_t(blockIdx.x) * a.rows_per_block;
+  const int64_t hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
+  constexpr int kIters = kDRows / kDThreads;
+  static_assert(kIters % kAggUnroll == 0, "tile rows per thread");
+  volatile unsigned int* stop = &sh.stop;
+  TileRegs t;
+  if (lo < hi) LoadTile(a, lo, hi, tid, lane, &t);
+  for (int64_t tile0 = lo; tile0 < hi; tile0 += kDRows) {
+    const TileRegs c = t;
+    if (tile0 + kDRows < hi) LoadTile(a, tile0 + kDRows, hi, tid, lane, &t);
+    if (*stop) break;
+    bool ok = true;
+#pragma unroll
+    for (int g = 0; g < kIters; g += kAggUnroll) {
+      uint4 rec[kAggUnroll];
+      bool live[kAggUnroll];
+#pragma unroll
+      for (int u = 0; u < kAggUnroll; ++u) {
+        live[u] = c.sel[g + u];
+        rec[u] = make_uint4(c.x[g + u], c.flags[g + u], static_cast<uint32_t>(c.val[g + u]),
+                            static_cast<uint32_t>(c.val[g + u] >> 32));
+      }
+      ok &= AggFold(rec, live, acc_double, sh.tag, sh.sum, sh.first, sh.cnt, &sh.groups, kLocalLimit);
+    }
+    if (__any(!ok)) { LocalGiveUp(sh, wg_flags); break; }
+  }
+  __syncthreads();
+  if (*stop) return;
+  LocalWriteOut(sh, st, tid);
+}
+
+// Zero the first-row bitmap, the status words and the per-workgroup flags in one launch.
+__global__ __launch_bounds__(kThreads) void k_prepare(unsigned long long* bitmap, int64_t nwords, unsigned int* status,
+                                                      unsigned int* wg_flags, int nflags) {
+  for (int64_t w = int64_t(blockIdx.x) * kThreads + threadIdx.x; w < nwords; w += int64_t(gridDim.x) * kThreads) bitmap[w] = 0;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < 8) status[threadIdx.x] = threadIdx.x == 4 ? kNoRow : 0u;
+    for (int i = threadIdx.x; i < nflags; i += kThreads) wg_flags[i] = 0;
+  }
+}
+
+// OR the workgroup flags into *summary (status[1]); reset the global table -- only when the
+// local path went through.
+__global__ __launch_bounds__(kThreads) void k_clear_table_unless(GroupTable t, int64_t nslots, const unsigned int* wg_flags,
+                                                                 int nflags, unsigned int* summary) {
+  int mine = 0;
+  for (int i = threadIdx.x; i < nflags; i += kThreads) mine |= wg_flags[i] != 0;
+  const int any = __syncthreads_or(mine);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *summary = any ? 1u : 0u;
+  if (any) return;
+  for (int64_t s = int64_t(blockIdx.x) * kThreads + threadIdx.x; s < nslots; s += int64_t(gridDim.x) * kThreads) {
+    t.hkeys[s] = kEmpty; t.first[s] = kNoRow; t.sums[s] = 0; t.counts[s] = 0;
+  }
+}
+
+// Merge the staged workgroup tables into the global table (global atomics, few entries).
+__global__ __launch_bounds__(kThreads) void k_local_merge(LocalStage st, int64_t nentries, int k_bits, int acc_double,
+                                                          GroupTable t, const unsigned int* skip_if, unsigned int* overflow) {
+  if (*skip_if) return;
+  for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < nentries; i += int64_t(gridDim.x) * kThreads) {
+    const uint32_t fr = st.first[i];
+    if (fr == kNoRow) continue;  // free slot
+    const int s = static_cast<int>(i % kStageSlots);
+    const uint64_t x = s == kSideNull ? (uint64_t(1) << k_bits)
+                     : s == kSideFree ? uint64_t(Fmix32Inv(kTagFree)) : uint64_t(Fmix32Inv(st.tag[i]));
+    const int64_t idx = FindOrInsert(t, Fmix64(x), true);
+    if (idx < 0) { *overflow = 1; continue; }
+    atomicMin(&t.first[idx], fr);
+    const unsigned int c = st.cnt[i];
+    if (c) {
+      Accumulate(&t.sums[idx], st.sum[i], acc_double != 0);
+      atomicAdd(&t.counts[idx], static_cast<unsigned long long>(c));
+    }
   }
 }
 
@@ -1401,7 +1695,7 @@ int amdarrow_grouper_uniques(amdarrow_grouper* g, int k, void* out_values, uint8
   const int null_bit = g->spec.wide_null_slot ? -1 : g->spec.total_bits + k;
   hipLaunchKernelGGL(k_decode_keys, dim3(GridFor(g->num_groups, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream,
                      g->gx, static_cast<int64_t>(g->num_groups), c.bits, c.shift, null_bit, wide, out_values,
-                     reinterpret_cast<uint64_t*>(out_validity), nulls);
+                     reinterpret_cast<uint64_t*>(out_validity), nulls, nullptr);
   AA_HIP(hipGetLastError());
   unsigned long long nn = 0;
   AA_TRY(ReadBack(ctx, nulls, 8, &nn));
@@ -1495,12 +1789,13 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
   // path 2: one-pass partition into private regions; 1: exact two-pass partition; 0: generic
   // global table.  Each falls back to the next when its capacity assumption fails.
   const bool fast_ok = ks.total_bits <= 32 && n >= (int64_t(1) << 18) && n < (int64_t(1) << 30);
-  int path = fast_ok ? 2 : 0;
+  int path = fast_ok ? 3 : 0;  // 3 = local pre-aggregation with the partition path queued behind it
   if (const char* env = getenv("AMDARROW_GROUPBY_PATH")) path = std::min(path, atoi(env));
   GroupTable t{};
   RankMem r{};
   unsigned long long* gx = nullptr;
-  unsigned int* misc = nullptr;  // [0] overflow, [2..3] null_count, [4] wide_null_id
+  unsigned int* misc = nullptr;  // status words, see RankFirstRows; [64..] one flag per workgroup of the local path
+  constexpr int kMaxFlags = 1024;
   for (;; --path) {
     const bool fast = path > 0;
     const uint64_t T = fast ? uint64_t(kP) * kSlots
@@ -1510,12 +1805,12 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
     CarveTable(&c, T, false, &tm);
     size_t roff[4];
     CarveRank(&c, n, roff);
-    const size_t off_gx = c.Take(8 * static_cast<size_t>(group_capacity));
-    const size_t off_misc = c.Take(256);
+    const size_t off_gx = c.Take(32 * static_cast<size_t>(group_capacity));  // packed group records
+    const size_t off_misc = c.Take(256 + 4 * kMaxFlags);
     // partition scratch
     int nblocks = 0;
     int64_t rows_per_block = 0, cap = 0, hist_n = 0;
-    if (path == 2) {
+    if (path >= 2) {
       nblocks = static_cast<int>(std::min<int64_t>(ctx->num_cus, (n + kDRows - 1) / kDRows));
       rows_per_block = (((n + nblocks - 1) / nblocks + kDRows - 1) / kDRows) * kDRows;
       const double mean = static_cast<double>(rows_per_block) / kP;
@@ -1530,7 +1825,7 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
     const size_t off_hist = c.Take(4 * hist_n);
     const size_t off_sums = c.Take(4 * scan_nb);
     const size_t off_sumoff = c.Take(8 * (scan_nb + 1));
-    const size_t rec_bytes = path == 2 ? 16 * static_cast<size_t>(cap) * kP * nblocks
+    const size_t rec_bytes = path >= 2 ? std::max(16 * static_cast<size_t>(cap) * kP * nblocks, LocalStageBytes(nblocks))
                            : path == 1 ? 16 * static_cast<size_t>(n) : 0;
     const size_t off_rec = c.Take(rec_bytes);
     void* base;
@@ -1540,8 +1835,11 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
     r = BindRank(b, roff, n);
     gx = reinterpret_cast<unsigned long long*>(b + off_gx);
     misc = reinterpret_cast<unsigned int*>(b + off_misc);
-    AA_HIP(hipMemsetAsync(misc, 0, 16, ctx->stream));
-    AA_HIP(hipMemsetAsync(misc + 4, 0xFF, 4, ctx->stream));
+    unsigned int* wg_flags = misc + 64;
+    if (nblocks > kMaxFlags) return SetError(AMDARROW_INVALID, "group-by: more workgroups than flag words");
+    hipLaunchKernelGGL(k_prepare, dim3(GridFor(r.nwords, kThreads, ctx->num_cus * 4)), dim3(kThreads), 0, ctx->stream, r.bitmap,
+                       r.nwords, misc, wg_flags, nblocks);
+    AA_HIP(hipGetLastError());
 
     if (fast) {
       auto* hist = reinterpret_cast<uint32_t*>(b + off_hist);
@@ -1554,22 +1852,45 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
       fa.m_data = m_data; fa.m_valid = m_valid; fa.m_off = m_off;
       fa.n = n; fa.nblocks = nblocks; fa.rows_per_block = rows_per_block;
       const int acc_double = values && IsFloat(values->type_id) ? 1 : 0;
-      if (path == 2) {
+      if (path >= 2) {
         const bool headline_shape = ks.total_bits == 32 && !keys->validity && values && BitWidth(values->type_id) == 64 &&
                                     !m_valid;
+        const bool M = m_data != nullptr, V = values && values->validity != nullptr;
+        const unsigned int* run_if = nullptr;
+        if (path == 3) {
+          // optimistic local pre-aggregation; everything after it is gated on misc[1] on the device
+          char* sb = reinterpret_cast<char*>(records);
+          const size_t ne = static_cast<size_t>(kStageSlots) * nblocks;
+          LocalStage st;
+          st.sum = reinterpret_cast<unsigned long long*>(sb);
+          st.tag = reinterpret_cast<unsigned int*>(sb + 8 * ne);
+          st.first = reinterpret_cast<uint32_t*>(sb + 12 * ne);
+          st.cnt = reinterpret_cast<unsigned int*>(sb + 16 * ne);
+          unsigned int* abort_flag = misc + 1;  // written by k_clear_table_unless (OR of the workgroup flags)
+#define AA_LOCAL(MM, VV) hipLaunchKernelGGL((k_local_aggregate_fast<MM, VV>), dim3(nblocks), dim3(kDThreads), 0, ctx->stream, fa, acc_double, st, wg_flags)
+          if (!headline_shape) hipLaunchKernelGGL(k_local_aggregate, dim3(nblocks), dim3(kDThreads), 0, ctx->stream, fa, acc_double, st, wg_flags);
+          else if (M && V) AA_LOCAL(true, true); else if (M) AA_LOCAL(true, false); else if (V) AA_LOCAL(false, true); else AA_LOCAL(false, false);
+#undef AA_LOCAL
+          AA_HIP(hipGetLastError());
+          const int64_t nslots = static_cast<int64_t>(T) + 2;
+          hipLaunchKernelGGL(k_clear_table_unless, dim3(GridFor(nslots, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0,
+                             ctx->stream, t, nslots, wg_flags, nblocks, abort_flag);
+          hipLaunchKernelGGL(k_local_merge, dim3(GridFor(static_cast<int64_t>(ne), kThreads, ctx->num_cus * 8)), dim3(kThreads),
+                             0, ctx->stream, st, static_cast<int64_t>(ne), ks.total_bits, acc_double, t, abort_flag, misc);
+          AA_HIP(hipGetLastError());
+          run_if = abort_flag;
+        }
         if (headline_shape) {
-          const bool M = m_data != nullptr, V = values->validity != nullptr;
-#define AA_FAST(MM, VV) hipLaunchKernelGGL((k_part_scatter_fast<MM, VV>), dim3(nblocks), dim3(kDThreads), 0, ctx->stream, fa, cap, records, hist, misc)
+#define AA_FAST(MM, VV) hipLaunchKernelGGL((k_part_scatter_fast<MM, VV>), dim3(nblocks), dim3(kDThreads), 0, ctx->stream, fa, cap, records, hist, misc, run_if)
           if (M && V) AA_FAST(true, true); else if (M) AA_FAST(true, false); else if (V) AA_FAST(false, true); else AA_FAST(false, false);
 #undef AA_FAST
         } else {
           hipLaunchKernelGGL(k_part_scatter_direct, dim3(nblocks), dim3(kDThreads), 0, ctx->stream, fa, cap, records, hist,
-                             misc);
+                             misc, run_if);
         }
         AA_HIP(hipGetLastError());
-        AA_HIP(hipMemsetAsync(r.bitmap, 0, 8 * r.nwords, ctx->stream));
         hipLaunchKernelGGL(k_part_aggregate_direct, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nblocks,
-                           cap, ks.total_bits, acc_double, t, r.bitmap, misc);
+                           cap, ks.total_bits, acc_double, t, r.bitmap, misc, run_if);
         AA_HIP(hipGetLastError());
       } else {
         AA_HIP(hipMemsetAsync(hist + hist_n - 1, 0, 4, ctx->stream));
@@ -1589,30 +1910,36 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
       AA_HIP(hipGetLastError());
     }
     int64_t G = 0;
-    unsigned int overflow = 0;
-    AA_TRY(RankFirstRows(ctx, t, 0, r, &G, /*already_marked=*/path == 2, misc, &overflow));
-    if (overflow && fast) continue;  // capacity assumption failed: next (more general) path
+    AA_TRY(RankFirstRows(ctx, t, 0, r, &G, /*mark_mode=*/path == 3 ? 2 : path == 2 ? 1 : 3, misc));
+    // Emit and decode are queued BEFORE the group count is known on the host (they take it from
+    // the status words and are bounded by group_capacity), so the one host round trip of the
+    // call overlaps with them instead of sitting between two kernels.
+    EmitArgs e{};
+    e.t = t; e.nslots = static_cast<int64_t>(t.mask) + 3; e.bitmap = r.bitmap; e.prefix = r.prefix;
+    e.capacity = group_capacity; e.id_base = 0; e.only_unassigned = 0;
+    e.packed = reinterpret_cast<ulonglong4*>(gx); e.wide_null_id = misc + 4; e.skip_if = misc;
+    hipLaunchKernelGGL(k_emit_groups, dim3(GridFor(e.nslots, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, e);
+    AA_HIP(hipGetLastError());
+    const int64_t bound = group_capacity < n ? group_capacity : n;
+    hipLaunchKernelGGL(k_unpack_groups, dim3(GridFor(bound, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream,
+                       e.packed, bound, ks.col[0].bits, ks.wide_null_slot ? -1 : ks.total_bits,
+                       static_cast<unsigned long long*>(out_sums), reinterpret_cast<long long*>(out_counts), out_first_rows,
+                       out_keys, reinterpret_cast<uint64_t*>(out_key_validity), misc);
+    AA_HIP(hipGetLastError());
+    unsigned int status[8] = {0};
+    AA_TRY(AwaitStatus(ctx, status));
+    memcpy(&G, status + 6, 8);
+    const unsigned int overflow = status[0];
+    if (overflow && fast) {  // capacity assumption failed: next (more general) path
+      if (path == 3) path = 2;  // the partition attempt was part of path 3
+      continue;
+    }
     if (overflow || G > group_capacity)
       return SetError(AMDARROW_CAPACITY_ERROR,
                       "group-by: more than group_capacity = " + std::to_string(group_capacity) + " groups");
     *out_num_groups = G;
     break;
   }
-  const int64_t G = *out_num_groups;
-  if (G == 0) return AMDARROW_OK;
-  EmitArgs e{};
-  e.t = t; e.nslots = static_cast<int64_t>(t.mask) + 3; e.bitmap = r.bitmap; e.prefix = r.prefix;
-  e.capacity = group_capacity; e.id_base = 0; e.only_unassigned = 0;
-  e.gx = gx; e.sums = static_cast<unsigned long long*>(out_sums); e.counts = reinterpret_cast<long long*>(out_counts);
-  e.first_rows = out_first_rows; e.wide_null_id = misc + 4;
-  hipLaunchKernelGGL(k_emit_groups, dim3(GridFor(e.nslots, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, e);
-  AA_HIP(hipGetLastError());
-  unsigned int wide = kNoRow;
-  if (ks.wide_null_slot) AA_TRY(ReadBack(ctx, misc + 4, 4, &wide));
-  hipLaunchKernelGGL(k_decode_keys, dim3(GridFor(G, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, gx, G,
-                     ks.col[0].bits, 0, ks.wide_null_slot ? -1 : ks.total_bits, wide, out_keys,
-                     reinterpret_cast<uint64_t*>(out_key_validity), reinterpret_cast<unsigned long long*>(misc + 2));
-  AA_HIP(hipGetLastError());
   // no trailing synchronise: *out_num_groups is final, the output arrays are stream-ordered
   return AMDARROW_OK;
 }

@@ -71,8 +71,11 @@ int amdarrow_ctx_create(int device, void* stream, int private_stream, amdarrow_c
     if (e != hipSuccess) { delete ctx; return HipError(e, "hipStreamCreate", __FILE__, __LINE__); }
     ctx->own_stream = true;
   }
-  hipError_t e = hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault);
+  hipError_t e = hipHostMalloc(&ctx->pinned, 4096, hipHostMallocMapped);
   if (e != hipSuccess) { delete ctx; return HipError(e, "hipHostMalloc", __FILE__, __LINE__); }
+  e = hipHostGetDevicePointer(&ctx->pinned_dev, ctx->pinned, 0);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->status_event, hipEventDisableTiming);
+  if (e != hipSuccess) { (void)hipHostFree(ctx->pinned); delete ctx; return HipError(e, "hipEventCreate", __FILE__, __LINE__); }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
   *out_ctx = ctx;
@@ -84,6 +87,7 @@ int amdarrow_ctx_destroy(amdarrow_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->status_event) (void)hipEventDestroy(ctx->status_event);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   for (auto& kv : ctx->allocs) (void)hipFree(kv.first);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

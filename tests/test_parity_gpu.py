@@ -425,10 +425,11 @@ def test_sharded_groupby_merge_on_gpu(gpu, oracle):
     tdist.destroy_process_group()
 
 
-@pytest.mark.parametrize("path", ["2", "1", "0"])
+@pytest.mark.parametrize("path", ["3", "2", "1", "0"])
 def test_filter_groupby_every_path(gpu, oracle, path, monkeypatch):
-    """AMDARROW_GROUPBY_PATH caps the strategy: 2 one-pass partition, 1 two-pass partition,
-    0 generic global table.  All three must give the reference's rows."""
+    """AMDARROW_GROUPBY_PATH caps the strategy: 3 local LDS pre-aggregation with the one-pass
+    partition queued behind it (default), 2 one-pass partition, 1 two-pass partition, 0 generic
+    global table.  All must give the reference's rows."""
     monkeypatch.setenv("AMDARROW_GROUPBY_PATH", path)
     rng = np.random.default_rng(13)
     n = 400_000
@@ -451,3 +452,43 @@ def test_filter_groupby_skewed_keys_overflow_one_pass_regions(gpu, oracle):
     v, k, m = R(rng, INT64, n, .01, 0), Arr(INT32, keys), R(rng, BOOL, n, 0.0, 0)
     for x, y in zip(oracle.filter_groupby_sum(v, k, m), gpu.filter_groupby_sum(v, k, m)):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("shape", ["mask", "mask+value-nulls", "no-mask", "value-nulls", "key-nulls", "int16-keys"])
+def test_filter_groupby_local_path_low_cardinality(gpu, oracle, shape):
+    """Few distinct keys per row range: the workgroup-local LDS tables hold every group, the
+    partition kernels behind them are no-ops.  Covers the four specialisations of the headline
+    shape (mask / value validity present or not) and the generic loader."""
+    rng = np.random.default_rng(21)
+    n = 700_000
+    kt = INT16 if shape == "int16-keys" else INT32
+    v = R(rng, INT64, n, .05 if "value-nulls" in shape else 0.0, 2, lo=-2**62, hi=2**62)
+    k = R(rng, kt, n, .02 if shape == "key-nulls" else 0.0, 1, lo=-300, hi=300)
+    m = Arr(BOOL, np.ones(n, bool)) if shape in ("no-mask", "value-nulls") else R(rng, BOOL, n, 0.0, 3)
+    for x, y in zip(oracle.filter_groupby_sum(v, k, m), gpu.filter_groupby_sum(v, k, m)):
+        assert np.array_equal(x, y), shape
+
+
+def test_filter_groupby_local_path_clustered_keys(gpu, oracle):
+    """Sorted keys: many groups overall (150 k) but only a few per row range, so the local path
+    succeeds with a large merged table; and one hot key everywhere (all lanes on one LDS slot)."""
+    rng = np.random.default_rng(22)
+    n = 1_500_000
+    keys = np.sort(rng.integers(0, 150_000, n)).astype(np.int32)
+    v, k, m = R(rng, INT64, n, .0, 0, lo=-2**62, hi=2**62), Arr(INT32, keys), R(rng, BOOL, n, 0.0, 0)
+    for x, y in zip(oracle.filter_groupby_sum(v, k, m), gpu.filter_groupby_sum(v, k, m)):
+        assert np.array_equal(x, y)
+    k = Arr(INT32, np.full(n, 42, np.int32))
+    for x, y in zip(oracle.filter_groupby_sum(v, k, m), gpu.filter_groupby_sum(v, k, m)):
+        assert np.array_equal(x, y)
+
+
+def test_filter_groupby_local_path_double_sums(gpu, oracle):
+    rng = np.random.default_rng(23)
+    n = 500_000
+    v, k, m = R(rng, DOUBLE, n, .01, 2), R(rng, INT32, n, 0.0, 1, lo=0, hi=999), R(rng, BOOL, n, 0.0, 3)
+    for x, y in zip(oracle.filter_groupby_sum(v, k, m), gpu.filter_groupby_sum(v, k, m)):
+        if x.dtype == np.float64:
+            assert x.shape == y.shape and np.allclose(x, y, rtol=F64_RTOL)
+        else:
+            assert np.array_equal(x, y)
