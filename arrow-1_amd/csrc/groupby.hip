@@ -942,18 +942,30 @@ __device__ __forceinline__ uint64_t CombineBits(const uint8_t* bm, int64_t pos, 
 // Tile geometry of the fast scatter: 7 steps of 64 rows per wave (7168 rows per tile), which
 // leaves LDS room for the per-partition carry buffers below.
 constexpr int kFSteps = 7;
-constexpr int kFRows = kFSteps * kDThreads;  // 7168
+// SC_THREADS = 512 runs two workgroups per CU on half-size tiles (staging in rounds of kFStage
+// records).  Measured: slower (578 vs 466 us) -- the per-tile work of the 512 partition counters
+// (scan, carry flush) is paid twice as often and outweighs the overlap.  -DSC_PHASES adds
+// per-phase cycle counters (AMDARROW_PHASES=1 prints them per call); at 1024 threads a tile costs
+// ~20 k cycles: 36 % waiting at the first barrier for the prefetched loads and the previous
+// tile's stores to retire, 16 % scan + carry flush, 10 % stage, 12 % copy-out.
+#ifndef SC_THREADS
+#define SC_THREADS 1024
+#endif
+constexpr int kFThreads = SC_THREADS;
+constexpr int kFRows = kFSteps * kFThreads;  // 3584 rows per tile
+constexpr int kFStage = SC_THREADS == 512 ? 2304 : kFRows;  // staged records per round: one round up to 64 % selectivity
+constexpr int kLRows = kFSteps * kDThreads;  // 7168: tile of the 1024-thread local-aggregate kernel (same row mapping)
 constexpr int kSector = 4;                   // records per 64-byte sector
 
 struct ScatterShared {
   unsigned int cnt[2][kP];
   uint32_t off[kP];
-  uint32_t cur[kP];         // records already written to this workgroup's region of partition p (multiple of 4)
+  uint32_t cur[2][kP];      // records already written to this workgroup's region of partition p (multiple of 4)
   uint32_t wcnt[kP];        // records of (carry + this tile) that go out this tile (multiple of 4); bit 31 = overflow
-  uint32_t carry_cnt[kP];   // 0..3 records waiting for their sector to fill
+  uint32_t carry_cnt[2][kP];  // 0..3 records waiting for their sector to fill; [buf] = before this tile, [buf ^ 1] = after it
   uint32_t scan[8];
   uint4 carry[kP][kSector - 1];
-  uint4 rec[kFRows];
+  uint4 rec[kFStage];
 };
 
 template <bool MASK, bool VVALID>
@@ -995,19 +1007,31 @@ __device__ __forceinline__ void FastRankTile(ScatterShared& sh, int buf, int lan
 // sectors only: up to 3 trailing records per partition wait in an LDS carry buffer for the
 // next tile, so HBM never sees a partially written sector (partial sectors evicted from L2
 // made the region stores cost as much as the rest of the kernel).
+#ifdef SC_PHASES
+__device__ unsigned long long g_phase_cycles[16];
+#define PH(i) do { const unsigned long long _n = __builtin_readcyclecounter(); ph_acc[i] += _n - ph_last; ph_last = _n; } while (0)
+#define PH_ARGS , unsigned long long (&ph_acc)[16], unsigned long long& ph_last
+#define PH_PASS , ph_acc, ph_last
+#else
+#define PH(i)
+#define PH_ARGS
+#define PH_PASS
+#endif
 template <bool VVALID>
 __device__ __forceinline__ void FastFinishTile(ScatterShared& sh, int buf, int64_t tile0, int64_t cap, int nblocks,
                                                uint4* __restrict__ regions, int tid, int wave, int lane,
                                                const uint32_t (&kx)[kFSteps], const uint64_t (&kv)[kFSteps],
                                                uint64_t vword, const uint32_t (&rpart)[kFSteps],
-                                               const uint32_t (&rrank)[kFSteps], const bool (&sel)[kFSteps]) {
+                                               const uint32_t (&rrank)[kFSteps], const bool (&sel)[kFSteps] PH_ARGS) {
   const int64_t wrow0 = tile0 + wave * (kFSteps * 64);
   using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
   // this workgroup's regions as one buffer: 32-bit offsets, cache policy per store (aux)
   uint4* const block_base = regions + int64_t(blockIdx.x) * kP * cap;
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc(block_base, 0, static_cast<int>(kP * cap * 16), 0x00020000);
+  PH(1);
   LdsBarrier();
+  PH(2);
   uint32_t c = 0, incl = 0;
   if (tid < kP) {
     c = sh.cnt[buf][tid];
@@ -1015,61 +1039,80 @@ __device__ __forceinline__ void FastFinishTile(ScatterShared& sh, int buf, int64
     if (lane == 63) sh.scan[wave] = incl;
   }
   LdsBarrier();
+  PH(3);
   if (tid < kP) {
+    // all eight wave totals in two reads (a loop over `wave` dependent reads took 7 LDS round trips)
+    const uint4 s0 = *reinterpret_cast<const uint4*>(&sh.scan[0]), s1 = *reinterpret_cast<const uint4*>(&sh.scan[4]);
+    const uint32_t tot[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
     uint32_t woff = 0;
-    for (int w = 0; w < wave; ++w) woff += sh.scan[w];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) woff += w < wave ? tot[w] : 0u;
     sh.off[tid] = woff + incl - c;
     sh.cnt[buf ^ 1][tid] = 0;
     // sectors that become complete with this tile; the old carry leads them out
-    const uint32_t cc = sh.carry_cnt[tid];
+    const uint32_t cc = sh.carry_cnt[buf][tid];
     const uint32_t w = (cc + c) & ~uint32_t(kSector - 1);
-    const uint32_t cur = sh.cur[tid];
+    const uint32_t cur = sh.cur[buf][tid];
     const bool ovf = cur + w > cap;
     sh.wcnt[tid] = w | (ovf ? 0x80000000u : 0u);
-    if (w > 0 && !ovf) {
+    // the state after this tile is known now: no trailing phase (and barrier) to update it
+    sh.carry_cnt[buf ^ 1][tid] = cc + c - w;
+    sh.cur[buf ^ 1][tid] = cur + w;
+    if (w > 0 && !ovf && cc > 0) {
       uint4* dst = regions + (int64_t(blockIdx.x) * kP + tid) * cap + cur;
-      for (uint32_t k = 0; k < cc; ++k) dst[k] = sh.carry[tid][k];
+      const uint4 c0 = sh.carry[tid][0], c1 = sh.carry[tid][1], c2 = sh.carry[tid][2];  // read together
+      dst[0] = c0;
+      if (cc > 1) dst[1] = c1;
+      if (cc > 2) dst[2] = c2;
     }
   }
   LdsBarrier();
-#pragma unroll
-  for (int j = 0; j < kFSteps; ++j) {
-    // the shuffle must run with the whole wave active (the source lane may be unselected)
-    const bool vvalid = VVALID ? ((__shfl(vword, j, 64) >> lane) & 1) : true;
-    if (sel[j]) {
-      const uint64_t v = vvalid ? kv[j] : 0;
-      uint4 q;
-      q.x = kx[j];
-      q.y = static_cast<uint32_t>(wrow0 + j * 64 + lane) | (vvalid ? kRecValValid : 0u);
-      q.z = static_cast<uint32_t>(v); q.w = static_cast<uint32_t>(v >> 32);
-      sh.rec[sh.off[rpart[j]] + rrank[j]] = q;
-    }
-  }
-  LdsBarrier();
+  PH(4);
   const uint32_t total = sh.off[kP - 1] + sh.cnt[buf][kP - 1];
-  for (uint32_t i = tid; i < total; i += kDThreads) {
-    const uint4 q = sh.rec[i];
-    const uint32_t p = Fmix32(q.x) >> (32 - kPBits);
-    const uint32_t k = sh.carry_cnt[p] + (i - sh.off[p]);  // position in (old carry + this tile's run)
-    const uint32_t w = sh.wcnt[p];
-    if (k < (w & 0x7FFFFFFFu)) {
-      if (!(w >> 31)) {
-        const uint32_t voff = static_cast<uint32_t>((int64_t(p) * cap + sh.cur[p] + k) * 16);
-        u32x4 v = {q.x, q.y, q.z, q.w};
-        // nt: the region lines are written once and read once by another CU -- streaming them past
-        // the L2 replacement queue measured 10 % faster than default-policy stores (sc1 write-through: 45 % slower)
-        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 2);
+  // The staging buffer holds kFStage records; a denser tile goes out in several rounds.
+  for (uint32_t base = 0; base < total; base += kFStage) {
+    if (base) LdsBarrier();  // the previous round's copy-out has read the buffer
+#pragma unroll
+    for (int j = 0; j < kFSteps; ++j) {
+      // the shuffle must run with the whole wave active (the source lane may be unselected)
+      const bool vvalid = VVALID ? ((__shfl(vword, j, 64) >> lane) & 1) : true;
+      if (sel[j]) {
+        const uint32_t at = sh.off[rpart[j]] + rrank[j] - base;
+        if (at < static_cast<uint32_t>(kFStage)) {
+          const uint64_t v = vvalid ? kv[j] : 0;
+          uint4 q;
+          q.x = kx[j];
+          q.y = static_cast<uint32_t>(wrow0 + j * 64 + lane) | (vvalid ? kRecValValid : 0u);
+          q.z = static_cast<uint32_t>(v); q.w = static_cast<uint32_t>(v >> 32);
+          sh.rec[at] = q;
+        }
       }
-    } else {
-      sh.carry[p][k - (w & 0x7FFFFFFFu)] = q;  // < 3 by construction
+    }
+    PH(5);
+    LdsBarrier();
+    PH(6);
+    const uint32_t round = total - base < static_cast<uint32_t>(kFStage) ? total - base : static_cast<uint32_t>(kFStage);
+    for (uint32_t i = tid; i < round; i += kFThreads) {
+      const uint4 q = sh.rec[i];
+      const uint32_t p = Fmix32(q.x) >> (32 - kPBits);
+      const uint32_t k = sh.carry_cnt[buf][p] + (base + i - sh.off[p]);  // position in (old carry + this tile's run)
+      const uint32_t w = sh.wcnt[p];
+      if (k < (w & 0x7FFFFFFFu)) {
+        if (!(w >> 31)) {
+          const uint32_t voff = static_cast<uint32_t>((int64_t(p) * cap + sh.cur[buf][p] + k) * 16);
+          u32x4 v = {q.x, q.y, q.z, q.w};
+          // nt: the region lines are written once and read once by another CU -- streaming them past
+          // the L2 replacement queue measured 10 % faster than default-policy stores (sc1 write-through: 45 % slower)
+          __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 2);
+        }
+      } else {
+        sh.carry[p][k - (w & 0x7FFFFFFFu)] = q;  // < 3 by construction
+      }
     }
   }
-  LdsBarrier();
-  if (tid < kP) {
-    const uint32_t w = sh.wcnt[tid] & 0x7FFFFFFFu;
-    sh.carry_cnt[tid] = sh.carry_cnt[tid] + sh.cnt[buf][tid] - w;
-    sh.cur[tid] += w;
-  }
+  PH(7);
+  // No barrier here: the next tile's rank phase only touches cnt[buf ^ 1] (cleared above), and three
+  // barriers separate this copy-out from the next writes to rec / carry / wcnt.
 }
 
 // Specialisation of k_part_scatter_direct for the headline shape: 32-bit keys without nulls and
@@ -1077,12 +1120,12 @@ __device__ __forceinline__ void FastFinishTile(ScatterShared& sh, int buf, int64
 // unconditional, and TWO register sets so that the next tile's loads are in flight while the
 // current tile goes through its LDS phases.
 template <bool MASK, bool VVALID>
-__global__ __launch_bounds__(kDThreads) void k_part_scatter_fast(FastArgs a, int64_t cap, uint4* regions, uint32_t* counts,
+__global__ __launch_bounds__(kFThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_part_scatter_fast(FastArgs a, int64_t cap, uint4* regions, uint32_t* counts,
                                                                  unsigned int* overflow, const unsigned int* run_if) {
   if (run_if && !*run_if) return;  // the local path already built the table
   __shared__ ScatterShared sh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < kP) { sh.cnt[0][tid] = 0; sh.cnt[1][tid] = 0; sh.cur[tid] = 0; sh.carry_cnt[tid] = 0; sh.wcnt[tid] = 0; }
+  if (tid < kP) { sh.cnt[0][tid] = 0; sh.cnt[1][tid] = 0; sh.cur[0][tid] = 0; sh.carry_cnt[0][tid] = 0; sh.wcnt[tid] = 0; }
   __syncthreads();
   const int64_t lo = int64_t(blockIdx.x) * a.rows_per_block;
   const int64_t hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
@@ -1109,23 +1152,35 @@ __global__ __launch_bounds__(kDThreads) void k_part_scatter_fast(FastArgs a, int
   uint32_t rpart[kFSteps], rrank[kFSteps];
   bool sel[kFSteps];
   uint64_t mw, vw;
+  int fin = 0;  // which copy of cur / carry_cnt holds the state after the last tile
+#ifdef SC_PHASES
+  unsigned long long ph_acc[16] = {0};
+  unsigned long long ph_last = __builtin_readcyclecounter();
+#endif
   if (lo < hi) FastLoadTile<MASK, VVALID>(a, keys, vals, lo, hi, wave, lane, kxA, kvA, mA, vA);
   for (int64_t tile0 = lo; tile0 < hi; tile0 += 2 * kFRows) {
     const bool has_b = tile0 + kFRows < hi;
     words(tile0, mA, vA, &mw, &vw);
     FastRankTile(sh, 0, lane, kxA, mw, rpart, rrank, sel);
+    PH(0);
     if (has_b) FastLoadTile<MASK, VVALID>(a, keys, vals, tile0 + kFRows, hi, wave, lane, kxB, kvB, mB, vB);
-    FastFinishTile<VVALID>(sh, 0, tile0, cap, a.nblocks, regions, tid, wave, lane, kxA, kvA, vw, rpart, rrank, sel);
+    FastFinishTile<VVALID>(sh, 0, tile0, cap, a.nblocks, regions, tid, wave, lane, kxA, kvA, vw, rpart, rrank, sel PH_PASS);
+    fin = 1;
     if (!has_b) break;
     words(tile0 + kFRows, mB, vB, &mw, &vw);
     FastRankTile(sh, 1, lane, kxB, mw, rpart, rrank, sel);
+    PH(0);
     if (tile0 + 2 * kFRows < hi) FastLoadTile<MASK, VVALID>(a, keys, vals, tile0 + 2 * kFRows, hi, wave, lane, kxA, kvA, mA, vA);
-    FastFinishTile<VVALID>(sh, 1, tile0 + kFRows, cap, a.nblocks, regions, tid, wave, lane, kxB, kvB, vw, rpart, rrank, sel);
+    FastFinishTile<VVALID>(sh, 1, tile0 + kFRows, cap, a.nblocks, regions, tid, wave, lane, kxB, kvB, vw, rpart, rrank, sel PH_PASS);
+    fin = 0;
   }
+#ifdef SC_PHASES
+  if (tid == 0) for (int i = 0; i < 16; ++i) atomicAdd(&g_phase_cycles[i], ph_acc[i]);
+#endif
   __syncthreads();
   if (tid < kP) {
     // flush the last (partial) sector of every partition and publish the region fill
-    const uint32_t cc = sh.carry_cnt[tid], cur = sh.cur[tid];
+    const uint32_t cc = sh.carry_cnt[fin][tid], cur = sh.cur[fin][tid];
     bool over = (sh.wcnt[tid] >> 31) != 0 || cur + cc > cap;
     if (!over) {
       uint4* dst = regions + (int64_t(blockIdx.x) * kP + tid) * cap + cur;
@@ -1442,17 +1497,17 @@ __global__ __launch_bounds__(kDThreads) void k_local_aggregate_fast(FastArgs a, 
   uint64_t mw, vw;
   volatile unsigned int* stop = &sh.stop;
   if (lo < hi) FastLoadTile<MASK, VVALID>(a, keys, vals, lo, hi, wave, lane, kxA, kvA, mA, vA);
-  for (int64_t tile0 = lo; tile0 < hi; tile0 += 2 * kFRows) {
-    const bool has_b = tile0 + kFRows < hi;
-    if (has_b) FastLoadTile<MASK, VVALID>(a, keys, vals, tile0 + kFRows, hi, wave, lane, kxB, kvB, mB, vB);
+  for (int64_t tile0 = lo; tile0 < hi; tile0 += 2 * kLRows) {
+    const bool has_b = tile0 + kLRows < hi;
+    if (has_b) FastLoadTile<MASK, VVALID>(a, keys, vals, tile0 + kLRows, hi, wave, lane, kxB, kvB, mB, vB);
     if (*stop) break;
     words(tile0, mA, vA, &mw, &vw);
     if (__any(!LocalFoldFast<VVALID>(sh, tile0, wave, lane, acc_double, kxA, kvA, mw, vw))) { LocalGiveUp(sh, wg_flags); break; }
     if (!has_b) break;
-    if (tile0 + 2 * kFRows < hi) FastLoadTile<MASK, VVALID>(a, keys, vals, tile0 + 2 * kFRows, hi, wave, lane, kxA, kvA, mA, vA);
+    if (tile0 + 2 * kLRows < hi) FastLoadTile<MASK, VVALID>(a, keys, vals, tile0 + 2 * kLRows, hi, wave, lane, kxA, kvA, mA, vA);
     if (*stop) break;
-    words(tile0 + kFRows, mB, vB, &mw, &vw);
-    if (__any(!LocalFoldFast<VVALID>(sh, tile0 + kFRows, wave, lane, acc_double, kxB, kvB, mw, vw))) { LocalGiveUp(sh, wg_flags); break; }
+    words(tile0 + kLRows, mB, vB, &mw, &vw);
+    if (__any(!LocalFoldFast<VVALID>(sh, tile0 + kLRows, wave, lane, acc_double, kxB, kvB, mw, vw))) { LocalGiveUp(sh, wg_flags); break; }
   }
   __syncthreads();
   if (*stop) return;  // a stale staging table is never read: the merge is gated on the flags
@@ -1791,6 +1846,7 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
   const bool fast_ok = ks.total_bits <= 32 && n >= (int64_t(1) << 18) && n < (int64_t(1) << 30);
   int path = fast_ok ? 3 : 0;  // 3 = local pre-aggregation with the partition path queued behind it
   if (const char* env = getenv("AMDARROW_GROUPBY_PATH")) path = std::min(path, atoi(env));
+  const bool headline_shape = ks.total_bits == 32 && !keys->validity && values && BitWidth(values->type_id) == 64 && !m_valid;
   GroupTable t{};
   RankMem r{};
   unsigned long long* gx = nullptr;
@@ -1808,11 +1864,15 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
     const size_t off_gx = c.Take(32 * static_cast<size_t>(group_capacity));  // packed group records
     const size_t off_misc = c.Take(256 + 4 * kMaxFlags);
     // partition scratch
-    int nblocks = 0;
-    int64_t rows_per_block = 0, cap = 0, hist_n = 0;
+    int nblocks = 0, nblocks_local = 0;
+    int64_t rows_per_block = 0, rows_per_block_local = 0, cap = 0, hist_n = 0;
     if (path >= 2) {
-      nblocks = static_cast<int>(std::min<int64_t>(ctx->num_cus, (n + kDRows - 1) / kDRows));
-      rows_per_block = (((n + nblocks - 1) / nblocks + kDRows - 1) / kDRows) * kDRows;
+      // the specialised scatter runs two 512-thread workgroups per CU on 3584-row tiles
+      const int64_t tile = headline_shape ? kFRows : kDRows;
+      nblocks = static_cast<int>(std::min<int64_t>(ctx->num_cus * (headline_shape ? 1024 / kFThreads : 1), (n + tile - 1) / tile));
+      rows_per_block = (((n + nblocks - 1) / nblocks + tile - 1) / tile) * tile;
+      nblocks_local = static_cast<int>(std::min<int64_t>(ctx->num_cus, (n + kDRows - 1) / kDRows));
+      rows_per_block_local = (((n + nblocks_local - 1) / nblocks_local + kDRows - 1) / kDRows) * kDRows;
       const double mean = static_cast<double>(rows_per_block) / kP;
       cap = (static_cast<int64_t>(mean * 1.25 + 8.0 * std::sqrt(mean) + 16.0) + 3) & ~int64_t(3);  // whole 64-byte sectors
       hist_n = int64_t(kP) * nblocks;
@@ -1825,7 +1885,7 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
     const size_t off_hist = c.Take(4 * hist_n);
     const size_t off_sums = c.Take(4 * scan_nb);
     const size_t off_sumoff = c.Take(8 * (scan_nb + 1));
-    const size_t rec_bytes = path >= 2 ? std::max(16 * static_cast<size_t>(cap) * kP * nblocks, LocalStageBytes(nblocks))
+    const size_t rec_bytes = path >= 2 ? std::max(16 * static_cast<size_t>(cap) * kP * nblocks, LocalStageBytes(nblocks_local))
                            : path == 1 ? 16 * static_cast<size_t>(n) : 0;
     const size_t off_rec = c.Take(rec_bytes);
     void* base;
@@ -1836,9 +1896,9 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
     gx = reinterpret_cast<unsigned long long*>(b + off_gx);
     misc = reinterpret_cast<unsigned int*>(b + off_misc);
     unsigned int* wg_flags = misc + 64;
-    if (nblocks > kMaxFlags) return SetError(AMDARROW_INVALID, "group-by: more workgroups than flag words");
+    if (nblocks > kMaxFlags || nblocks_local > kMaxFlags) return SetError(AMDARROW_INVALID, "group-by: more workgroups than flag words");
     hipLaunchKernelGGL(k_prepare, dim3(GridFor(r.nwords, kThreads, ctx->num_cus * 4)), dim3(kThreads), 0, ctx->stream, r.bitmap,
-                       r.nwords, misc, wg_flags, nblocks);
+                       r.nwords, misc, wg_flags, nblocks_local > nblocks ? nblocks_local : nblocks);
     AA_HIP(hipGetLastError());
 
     if (fast) {
@@ -1853,35 +1913,35 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
       fa.n = n; fa.nblocks = nblocks; fa.rows_per_block = rows_per_block;
       const int acc_double = values && IsFloat(values->type_id) ? 1 : 0;
       if (path >= 2) {
-        const bool headline_shape = ks.total_bits == 32 && !keys->validity && values && BitWidth(values->type_id) == 64 &&
-                                    !m_valid;
         const bool M = m_data != nullptr, V = values && values->validity != nullptr;
         const unsigned int* run_if = nullptr;
         if (path == 3) {
           // optimistic local pre-aggregation; everything after it is gated on misc[1] on the device
           char* sb = reinterpret_cast<char*>(records);
-          const size_t ne = static_cast<size_t>(kStageSlots) * nblocks;
+          FastArgs fl = fa;
+          fl.nblocks = nblocks_local; fl.rows_per_block = rows_per_block_local;
+          const size_t ne = static_cast<size_t>(kStageSlots) * nblocks_local;
           LocalStage st;
           st.sum = reinterpret_cast<unsigned long long*>(sb);
           st.tag = reinterpret_cast<unsigned int*>(sb + 8 * ne);
           st.first = reinterpret_cast<uint32_t*>(sb + 12 * ne);
           st.cnt = reinterpret_cast<unsigned int*>(sb + 16 * ne);
           unsigned int* abort_flag = misc + 1;  // written by k_clear_table_unless (OR of the workgroup flags)
-#define AA_LOCAL(MM, VV) hipLaunchKernelGGL((k_local_aggregate_fast<MM, VV>), dim3(nblocks), dim3(kDThreads), 0, ctx->stream, fa, acc_double, st, wg_flags)
-          if (!headline_shape) hipLaunchKernelGGL(k_local_aggregate, dim3(nblocks), dim3(kDThreads), 0, ctx->stream, fa, acc_double, st, wg_flags);
+#define AA_LOCAL(MM, VV) hipLaunchKernelGGL((k_local_aggregate_fast<MM, VV>), dim3(nblocks_local), dim3(kDThreads), 0, ctx->stream, fl, acc_double, st, wg_flags)
+          if (!headline_shape) hipLaunchKernelGGL(k_local_aggregate, dim3(nblocks_local), dim3(kDThreads), 0, ctx->stream, fl, acc_double, st, wg_flags);
           else if (M && V) AA_LOCAL(true, true); else if (M) AA_LOCAL(true, false); else if (V) AA_LOCAL(false, true); else AA_LOCAL(false, false);
 #undef AA_LOCAL
           AA_HIP(hipGetLastError());
           const int64_t nslots = static_cast<int64_t>(T) + 2;
           hipLaunchKernelGGL(k_clear_table_unless, dim3(GridFor(nslots, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0,
-                             ctx->stream, t, nslots, wg_flags, nblocks, abort_flag);
+                             ctx->stream, t, nslots, wg_flags, nblocks_local, abort_flag);
           hipLaunchKernelGGL(k_local_merge, dim3(GridFor(static_cast<int64_t>(ne), kThreads, ctx->num_cus * 8)), dim3(kThreads),
                              0, ctx->stream, st, static_cast<int64_t>(ne), ks.total_bits, acc_double, t, abort_flag, misc);
           AA_HIP(hipGetLastError());
           run_if = abort_flag;
         }
         if (headline_shape) {
-#define AA_FAST(MM, VV) hipLaunchKernelGGL((k_part_scatter_fast<MM, VV>), dim3(nblocks), dim3(kDThreads), 0, ctx->stream, fa, cap, records, hist, misc, run_if)
+#define AA_FAST(MM, VV) hipLaunchKernelGGL((k_part_scatter_fast<MM, VV>), dim3(nblocks), dim3(kFThreads), 0, ctx->stream, fa, cap, records, hist, misc, run_if)
           if (M && V) AA_FAST(true, true); else if (M) AA_FAST(true, false); else if (V) AA_FAST(false, true); else AA_FAST(false, false);
 #undef AA_FAST
         } else {
@@ -1928,6 +1988,18 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
     AA_HIP(hipGetLastError());
     unsigned int status[8] = {0};
     AA_TRY(AwaitStatus(ctx, status));
+#ifdef SC_PHASES
+    if (getenv("AMDARROW_PHASES")) {
+      unsigned long long ph[16];
+      AA_HIP(hipStreamSynchronize(ctx->stream));
+      AA_HIP(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase_cycles), sizeof(ph)));
+      unsigned long long z[16] = {0};
+      AA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)));
+      fprintf(stderr, "phases(kcycles/wg):");
+      for (int i = 0; i < 9; ++i) fprintf(stderr, " %d:%.1f", i, double(ph[i]) / nblocks / 1e3);
+      fprintf(stderr, "\n");
+    }
+#endif
     memcpy(&G, status + 6, 8);
     const unsigned int overflow = status[0];
     if (overflow && fast) {  // capacity assumption failed: next (more general) path
