@@ -28,7 +28,7 @@ namespace amdarrow {
 
 constexpr int kThreads = 256;
 constexpr int kCTile = 2048;   // classify tile: 256 threads x 8
-constexpr int kRTile = 4096;   // radix tile: 256 threads x 16
+constexpr int kRTile = 4096;   // radix tile: 16 keys per lane of a 256-thread block
 
 struct SortChunk {
   const void* values; const uint8_t* valid; int64_t off; int64_t length;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kThreads) void k_sort_count(const SortChunk* chunks
 // directly the global output position (sortable rows first, then NaNs, then nulls).
 template <typename KeyT>
 __global__ __launch_bounds__(kThreads) void k_sort_partition(const SortChunk* chunks, int nchunks, int type_id, int64_t ntiles,
-                                                             const int64_t* offsets, KeyT key_mask, KeyT flip, KeyT* keys,
+                                                             const uint32_t* offsets, KeyT key_mask, KeyT flip, KeyT* keys,
                                                              uint32_t* idx, uint64_t* out_indices) {
   __shared__ uint32_t s_wave[3][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kThreads) void k_sort_partition(const SortChunk* ch
     for (int k = 0; k < 3; ++k) {
       uint32_t w_off = 0;
       for (int w = 0; w < wave; ++w) w_off += s_wave[k][w];
-      base[k] = offsets[k * ntiles + tile] + w_off;
+      base[k] = int64_t(offsets[k * ntiles + tile]) + w_off;
     }
 #pragma unroll
     for (int j = 0; j < kIters; ++j) {
@@ -330,6 +330,185 @@ __global__ __launch_bounds__(kThreads) void k_radix_scatter(const KeyT* keys_in,
   }
 }
 
+// ---- one-sweep pass ---------------------------------------------------------------------------------
+// One kernel per digit: a block takes the next tile (ticket), counts its digits, publishes the
+// counts, ranks and stages its keys in LDS, and only then needs the number of equal digits in
+// ALL earlier tiles -- obtained by decoupled look-back over the published counts (chained scan:
+// a tile adds predecessors' aggregates until it meets one whose inclusive prefix is known).
+// The keys are read once per pass; the separate block-histogram read and the device-wide scan of
+// 256 x nblocks counters of the three-kernel variant are gone.
+// lookback word: bits 31..30 = 0 nothing yet, 1 aggregate of this tile, 2 inclusive prefix;
+// bits 29..0 = count (n < 2^30).  Tile = workgroup id: workgroups are dispatched in id order, so
+// every tile a block waits for is already running.  (An atomic ticket would make that a
+// guarantee, but one same-address device-scope atomic per tile is serialised at ~40 ns -- the
+// whole pass then runs at ticket speed: 1.02 ms for 24 k tiles, 3.5 ms for 49 k.)  The wait is
+// bounded by kSpinLimit; if it ever expires the pass reports it and the host redoes the sort
+// with the three-kernel passes, which need no inter-block ordering.
+constexpr uint32_t kLbAggregate = 1u << 30, kLbInclusive = 2u << 30, kLbValue = (1u << 30) - 1;
+constexpr int kLbWindow = 8;
+constexpr int kSpinLimit = 1 << 18;  // polls of one predecessor word (~0.3 s) before the pass gives up
+
+// dbase[pass][d] = number of keys whose digit `pass` is < d (exclusive scan of the global histogram)
+__global__ __launch_bounds__(kThreads) void k_digit_bases(const unsigned int* ghist, uint32_t* dbase) {
+  __shared__ uint32_t s_scan[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t c = ghist[blockIdx.x * 256 + tid];
+  const uint32_t incl = WaveInclusiveScan(c);
+  if (lane == 63) s_scan[wave] = incl;
+  __syncthreads();
+  uint32_t woff = 0;
+  for (int w = 0; w < wave; ++w) woff += s_scan[w];
+  dbase[blockIdx.x * 256 + tid] = woff + incl - c;
+}
+
+constexpr int kOThreads = 256;            // one-sweep block
+constexpr int kOWaves = kOThreads / 64;
+
+template <typename KeyT, bool LAST>
+__global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_in, const uint32_t* idx_in, int64_t n, int shift,
+                                                              const uint32_t* dbase /* [256] of this pass */,
+                                                              uint32_t* lookback /* [nblocks][256], zeroed */,
+                                                              unsigned int* error, KeyT* keys_out,
+                                                              uint32_t* idx_out, uint64_t* out64) {
+  constexpr int kIters = kRTile / kOThreads;  // 8; wave w owns keys [w*512, (w+1)*512) of the tile, in order
+  __shared__ uint32_t s_whist[kOWaves][256];  // per-wave digit counts, then per-wave running local positions
+  __shared__ uint32_t s_dstart[256];          // first local position of each digit
+  __shared__ uint32_t s_gbase[256];           // global position of this tile's run of each digit
+  __shared__ uint32_t s_scan[4];
+  __shared__ KeyT s_keys[kRTile];
+  __shared__ uint32_t s_idx[kRTile];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < kOWaves * 256; i += kOThreads) (&s_whist[0][0])[i] = 0;
+  __syncthreads();
+  const uint32_t tile = blockIdx.x;
+  const int64_t base = int64_t(tile) * kRTile;
+  const int64_t left = n - base;
+  const uint32_t count = left >= kRTile ? kRTile : static_cast<uint32_t>(left);
+
+  KeyT key[kIters];
+  uint32_t idx[kIters];
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+    key[j] = 0; idx[j] = 0;
+    if (li < count) {
+      key[j] = keys_in[base + li];
+      idx[j] = idx_in[base + li];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+    if (li < count) atomicAdd(&s_whist[wave][(key[j] >> shift) & 255], 1u);
+  }
+  __syncthreads();
+  uint32_t tot = 0;
+  if (tid < 256) {  // thread d: totals of digit d -> publish; exclusive scan over digits, per-wave bases
+    uint32_t c[kOWaves];
+#pragma unroll
+    for (int w = 0; w < kOWaves; ++w) { c[w] = s_whist[w][tid]; tot += c[w]; }
+    __hip_atomic_store(&lookback[int64_t(tile) * 256 + tid], tot | (tile == 0 ? kLbInclusive : kLbAggregate), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t incl = WaveInclusiveScan(tot);
+    if (lane == 63) s_scan[wave] = incl;
+    // only waves 0..3 are in here: a named barrier would do; the block barrier below is shared with the rest
+    uint32_t run = 0;
+#pragma unroll
+    for (int w = 0; w < kOWaves; ++w) { const uint32_t cw = c[w]; c[w] = run; run += cw; }
+    // positions relative to the digit start; the start itself is added after the barrier
+#pragma unroll
+    for (int w = 0; w < kOWaves; ++w) s_whist[w][tid] = c[w];
+    s_dstart[tid] = incl - tot;  // within this wave of digits; completed below
+  }
+  __syncthreads();
+  if (tid < 256) {
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_scan[w];
+    const uint32_t dstart = s_dstart[tid] + woff;
+    s_dstart[tid] = dstart;
+#pragma unroll
+    for (int w = 0; w < kOWaves; ++w) s_whist[w][tid] += dstart;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+    const bool live = li < count;
+    const uint32_t d = (key[j] >> shift) & 255;
+    // match-any on the 8 digit bits among live lanes
+    uint64_t m = __ballot(live);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const uint64_t bb = __ballot((d >> b) & 1);
+      m &= ((d >> b) & 1) ? bb : ~bb;
+    }
+    if (live) {
+      const uint32_t rank = RankBelowLane(m);
+      const uint32_t old = s_whist[wave][d];
+      __builtin_amdgcn_wave_barrier();
+      if (rank == 0) s_whist[wave][d] = old + __popcll(m);
+      const uint32_t lpos = old + rank;
+      s_keys[lpos] = key[j];
+      s_idx[lpos] = idx[j];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  bool gave_up = false;
+  if (tid < 256) {  // thread d: keys with digit d in all earlier tiles
+    uint32_t excl = 0;
+    if (tile > 0) {
+      // A window of kLbWindow predecessors per round trip: the words of one round are loaded
+      // back to back and consumed nearest-first; the walk stops at the first inclusive word and
+      // re-polls from the first word that is not published yet.
+      int64_t j = int64_t(tile) - 1;
+      int spins = 0;
+      for (bool done = false; !done;) {
+        uint32_t v[kLbWindow];
+#pragma unroll
+        for (int s = 0; s < kLbWindow; ++s) {
+          const int64_t t = j - s;
+          v[s] = t >= 0 ? __hip_atomic_load(&lookback[t * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kLbInclusive;
+        }
+        int consumed = kLbWindow;
+#pragma unroll
+        for (int s = 0; s < kLbWindow; ++s) {
+          if (consumed != kLbWindow) continue;         // stopped at an earlier word of this window
+          if ((v[s] >> 30) == 0) { consumed = s; continue; }  // not published yet: poll again from here
+          excl += v[s] & kLbValue;
+          if ((v[s] >> 30) == 2) { done = true; consumed = s + 1; }
+        }
+        j -= consumed;
+        if (!done && consumed != kLbWindow) {
+          // never in a correct run (see header); the host checks the word.  Once one tile gave up
+          // the others follow quickly instead of each waiting out its own bound.
+          if (++spins >= kSpinLimit ||
+              ((spins & 1023) == 0 && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gave_up = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      __hip_atomic_store(&lookback[int64_t(tile) * 256 + tid], ((excl + tot) & kLbValue) | kLbInclusive, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_gbase[tid] = dbase[tid] + excl;
+  }
+  if (__syncthreads_or(gave_up)) return;  // positions unknown: write nothing
+  for (uint32_t i = tid; i < count; i += kOThreads) {
+    const KeyT k = s_keys[i];
+    const uint32_t d = (k >> shift) & 255;
+    const uint32_t gpos = s_gbase[d] + (i - s_dstart[d]);
+    if (LAST) {
+      out64[gpos] = s_idx[i];
+    } else {
+      keys_out[gpos] = k;
+      idx_out[gpos] = s_idx[i];
+    }
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void k_widen_indices(const uint32_t* idx, int64_t n, uint64_t* out) {
   for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < n; i += int64_t(gridDim.x) * kThreads) out[i] = idx[i];
 }
@@ -346,7 +525,7 @@ int ScanU32InPlace(amdarrow_ctx* ctx, uint32_t* data, int64_t n, uint32_t* sums,
 
 template <typename KeyT>
 static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks, int type_id, int order, int64_t n,
-                    uint64_t* out) {
+                    uint64_t* out, bool allow_onesweep = true) {
   constexpr int kPasses = sizeof(KeyT);
   const int key_bits = BitWidth(type_id);
   const KeyT key_mask = key_bits >= static_cast<int>(8 * sizeof(KeyT)) ? ~KeyT(0) : ((KeyT(1) << key_bits) - 1);
@@ -365,12 +544,11 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   const int64_t ntiles = tiles;
   const int64_t nblocks = (n + kRTile - 1) / kRTile;
   const int64_t hist_n = 256 * nblocks;
-  const int64_t scan_nb = (hist_n + 2047) / 2048;
+  const int64_t scan_nb = (std::max<int64_t>(hist_n, 3 * ntiles) + 2047) / 2048;
 
   Carver cv;
   const size_t o_chunks = cv.Take(sizeof(SortChunk) * nchunks);
   const size_t o_counts = cv.Take(4 * 3 * ntiles);
-  const size_t o_offsets = cv.Take(8 * (3 * ntiles + 1));
   const size_t o_keys_a = cv.Take(sizeof(KeyT) * n);
   const size_t o_keys_b = cv.Take(sizeof(KeyT) * n);
   const size_t o_idx_a = cv.Take(4 * n);
@@ -379,12 +557,14 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   const size_t o_bhist = cv.Take(4 * hist_n);
   const size_t o_sums = cv.Take(4 * scan_nb);
   const size_t o_sumoff = cv.Take(8 * (scan_nb + 1));
+  const size_t o_dbase = cv.Take(4 * 256 * kPasses);
+  const size_t o_ctl = cv.Take(256);  // [15] error word of the one-sweep passes
+  const size_t o_lookback = cv.Take(4 * static_cast<size_t>(hist_n) * kPasses);
   void* base;
   AA_TRY(Scratch(ctx, cv.off, &base));
   char* b = static_cast<char*>(base);
   auto* d_chunks = reinterpret_cast<SortChunk*>(b + o_chunks);
   auto* counts = reinterpret_cast<uint32_t*>(b + o_counts);
-  auto* offsets = reinterpret_cast<int64_t*>(b + o_offsets);
   KeyT* keys_a = reinterpret_cast<KeyT*>(b + o_keys_a);
   KeyT* keys_b = reinterpret_cast<KeyT*>(b + o_keys_b);
   uint32_t* idx_a = reinterpret_cast<uint32_t*>(b + o_idx_a);
@@ -393,6 +573,9 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   auto* bhist = reinterpret_cast<uint32_t*>(b + o_bhist);
   auto* sums = reinterpret_cast<uint32_t*>(b + o_sums);
   auto* sumoff = reinterpret_cast<int64_t*>(b + o_sumoff);
+  auto* dbase = reinterpret_cast<uint32_t*>(b + o_dbase);
+  auto* ctl = reinterpret_cast<unsigned int*>(b + o_ctl);
+  auto* lookback = reinterpret_cast<uint32_t*>(b + o_lookback);
 
   AA_HIP(hipMemcpyAsync(d_chunks, hc.data(), sizeof(SortChunk) * nchunks, hipMemcpyHostToDevice, ctx->stream));
   AA_HIP(hipStreamSynchronize(ctx->stream));  // hc is pageable host memory
@@ -402,12 +585,13 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   hipLaunchKernelGGL((k_sort_count<KeyT>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, d_chunks, nchunks, type_id, ntiles,
                      counts);
   AA_HIP(hipGetLastError());
-  AA_TRY(LaunchScanU32(ctx, counts, 3 * ntiles, offsets));
+  AA_TRY(ScanU32InPlace(ctx, counts, 3 * ntiles, sums, sumoff));  // counts -> offsets (rows < 2^32)
   hipLaunchKernelGGL((k_sort_partition<KeyT>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, d_chunks, nchunks, type_id, ntiles,
-                     offsets, key_mask, flip, keys_a, idx_a, out);
+                     counts, key_mask, flip, keys_a, idx_a, out);
   AA_HIP(hipGetLastError());
-  int64_t n0 = 0;
-  AA_TRY(ReadBack(ctx, offsets + ntiles, 8, &n0));  // start of the NaN region = number of sortable rows
+  uint32_t n0_32 = 0;
+  AA_TRY(ReadBack(ctx, counts + ntiles, 4, &n0_32));  // start of the NaN region = number of sortable rows
+  const int64_t n0 = n0_32;
   if (n0 == 0) return AMDARROW_OK;
 
   // 2. histograms of every digit; skip digits on which all keys agree
@@ -433,9 +617,30 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   // 3. LSD passes
   const int64_t nb0 = (n0 + kRTile - 1) / kRTile;
   const int64_t hn0 = 256 * nb0;
+  const bool onesweep = allow_onesweep && n0 < (int64_t(1) << 30) && !getenv("AMDARROW_SORT_THREE_KERNEL");
+  if (onesweep) {
+    hipLaunchKernelGGL(k_digit_bases, dim3(kPasses), dim3(kThreads), 0, ctx->stream, ghist, dbase);
+    AA_HIP(hipGetLastError());
+    AA_HIP(hipMemsetAsync(ctl, 0, 256, ctx->stream));
+    AA_HIP(hipMemsetAsync(lookback, 0, 4 * static_cast<size_t>(hn0) * active.size(), ctx->stream));
+  }
   for (size_t a = 0; a < active.size(); ++a) {
     const int shift = 8 * active[a];
     const bool last = a + 1 == active.size();
+    if (onesweep) {
+      uint32_t* lb = lookback + static_cast<size_t>(hn0) * a;
+      const uint32_t* db = dbase + 256 * active[a];
+      if (last)
+        hipLaunchKernelGGL((k_radix_onesweep<KeyT, true>), dim3(static_cast<unsigned>(nb0)), dim3(kOThreads), 0, ctx->stream,
+                           keys_a, idx_a, n0, shift, db, lb, ctl + 15, keys_b, idx_b, out);
+      else
+        hipLaunchKernelGGL((k_radix_onesweep<KeyT, false>), dim3(static_cast<unsigned>(nb0)), dim3(kOThreads), 0, ctx->stream,
+                           keys_a, idx_a, n0, shift, db, lb, ctl + 15, keys_b, idx_b, out);
+      AA_HIP(hipGetLastError());
+      std::swap(keys_a, keys_b);
+      std::swap(idx_a, idx_b);
+      continue;
+    }
     hipLaunchKernelGGL((k_radix_block_hist<KeyT>), dim3(static_cast<unsigned>(nb0)), dim3(kThreads), 0, ctx->stream, keys_a, n0,
                        shift, nb0, bhist);
     AA_HIP(hipGetLastError());
@@ -449,6 +654,11 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
     AA_HIP(hipGetLastError());
     std::swap(keys_a, keys_b);
     std::swap(idx_a, idx_b);
+  }
+  if (onesweep) {
+    unsigned int err = 0;
+    AA_TRY(ReadBack(ctx, ctl + 15, 4, &err));
+    if (err) return SortImpl<KeyT>(ctx, chunks, nchunks, type_id, order, n, out, /*allow_onesweep=*/false);
   }
   return AMDARROW_OK;
 }
