@@ -64,6 +64,12 @@ struct Carver {
   }
 };
 
+// Status words: kernels store small results (a total, an overflow flag) at pinned_dev +
+// kStatusOffset, the host records status_event behind that kernel, queues whatever does not need
+// the value, and only then waits for the event -- the round trip overlaps with the queued work.
+// (ReadBack uses the head of the same pinned block.)
+constexpr size_t kStatusOffset = 256;
+
 // Copy `nbytes` (<= 4096) from device to the pinned word and wait for it.
 int ReadBack(amdarrow_ctx* ctx, const void* dev, size_t nbytes, void* host_out);
 

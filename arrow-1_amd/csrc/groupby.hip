@@ -499,7 +499,6 @@ static RankMem BindRank(char* base, const size_t off[4], int64_t n_rows) {
   r.block_offsets = reinterpret_cast<int64_t*>(base + off[3]);
   return r;
 }
-constexpr size_t kStatusOffset = 256;  // status words inside the pinned block (ReadBack uses its head)
 // Wait for the status words queued by RankFirstRows(status_dev != nullptr).
 static int AwaitStatus(amdarrow_ctx* ctx, unsigned int (&status)[8]) {
   AA_HIP(hipEventSynchronize(ctx->status_event));

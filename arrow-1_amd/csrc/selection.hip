@@ -15,6 +15,8 @@
 // Values are loaded only for selected rows, so a 10 % filter does not read 100 % of HBM.
 #include "common.h"
 
+#include <cstring>
+
 namespace amdarrow {
 
 constexpr int kTile = 4096;     // rows per tile = 64 bitmap words
@@ -59,33 +61,57 @@ __global__ __launch_bounds__(kThreads) void k_filter_tile_counts(const uint8_t* 
 }
 
 // Single-workgroup exclusive scan: offsets[i] = sum(counts[0..i)), offsets[n] = total.
-// Each thread owns ceil(n/1024) consecutive entries: one pass to sum them, one block scan
-// of the 1024 partial sums, one pass to write the prefixes.
-__global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* counts, int64_t n, int64_t* offsets) {
+// Rounds of 8192 entries: a thread owns 8 consecutive ones (two 16-byte loads, one 64-byte run
+// of int64 stores), the 1024 partial sums are scanned across the block.  `host_total`
+// (optional, mapped host memory) receives the total as well, see StatusWords in common.h.
+__global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* counts, int64_t n, int64_t* offsets,
+                                                     long long* host_total) {
+  constexpr int kPer = 8;
   __shared__ uint64_t s_wave[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t per = (n + 1023) / 1024;
-  const int64_t lo = per * tid;
-  const int64_t hi = lo + per < n ? lo + per : n;
-  uint64_t sum = 0;
-  for (int64_t i = lo; i < hi; ++i) sum += counts[i];
-  uint64_t incl = sum;
+  uint64_t carry = 0;  // identical in every thread
+  for (int64_t base = 0; base < n; base += 1024 * kPer) {
+    const int64_t i0 = base + int64_t(tid) * kPer;
+    uint32_t v[kPer];
+    if (i0 + kPer <= n && (reinterpret_cast<uintptr_t>(counts + i0) & 15) == 0) {
+      const uint4 a = *reinterpret_cast<const uint4*>(counts + i0), b = *reinterpret_cast<const uint4*>(counts + i0 + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint64_t t = __shfl_up(incl, d, 64);
-    if (lane >= d) incl += t;
+      for (int k = 0; k < kPer; ++k) v[k] = i0 + k < n ? counts[i0 + k] : 0u;
+    }
+    uint64_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) sum += v[k];
+    uint64_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint64_t t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint64_t wave_off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const uint64_t x = s_wave[w]; if (w < wave) wave_off += x; total += x; }
+    uint64_t run = carry + wave_off + incl - sum;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      if (i0 + k < n) offsets[i0 + k] = static_cast<int64_t>(run);
+      run += v[k];
+    }
+    carry += total;
+    __syncthreads();
   }
-  if (lane == 63) s_wave[wave] = incl;
-  __syncthreads();
-  uint64_t wave_off = 0, total = 0;
-  for (int w = 0; w < 16; ++w) { if (w < wave) wave_off += s_wave[w]; total += s_wave[w]; }
-  uint64_t run = wave_off + incl - sum;
-  for (int64_t i = lo; i < hi; ++i) { offsets[i] = static_cast<int64_t>(run); run += counts[i]; }
-  if (tid == 0) offsets[n] = static_cast<int64_t>(total);
+  if (tid == 0) {
+    offsets[n] = static_cast<int64_t>(carry);
+    if (host_total) *host_total = static_cast<long long>(carry);
+  }
 }
 
 int LaunchScanU32(amdarrow_ctx* ctx, const uint32_t* counts, int64_t n, int64_t* offsets) {
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, counts, n, offsets);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, counts, n, offsets,
+                     static_cast<long long*>(nullptr));
   AA_HIP(hipGetLastError());
   return AMDARROW_OK;
 }
@@ -163,18 +189,31 @@ __global__ __launch_bounds__(kThreads) void k_filter_compact(FilterArgs a) {
     // ---- gather selected values (loads only where the value is copied) ----
     constexpr int kIters = kTile / kThreads;  // 16
     T vals[kIters];
+    if (!IOTA && !kBits && count * 8 >= kTile) {
+      // dense tile: every 64-byte sector holds a selected row anyway, so load all rows --
+      // 16 independent loads in flight instead of 16 branches around one load each
 #pragma unroll
-    for (int j = 0; j < kIters; ++j) {
-      const int word = j * 4 + wave;
-      const bool s = (s_sel[word] >> lane) & 1;
-      const int64_t row = row0 + word * 64 + lane;
-      T v = 0;
-      if (s) {
-        if (IOTA) v = static_cast<T>(row);
-        else if (kBits) v = static_cast<T>((s_bvals[word] >> lane) & 1);
-        else v = values[a.v_off + row];
+      for (int j = 0; j < kIters; ++j) {
+        const int64_t row = row0 + (j * 4 + wave) * 64 + lane;
+        vals[j] = values[a.v_off + (row < a.length ? row : a.length - 1)];
       }
-      vals[j] = v;
+#pragma unroll
+      for (int j = 0; j < kIters; ++j)
+        if (!((s_sel[j * 4 + wave] >> lane) & 1)) vals[j] = 0;  // emitted-null slots carry 0
+    } else {
+#pragma unroll
+      for (int j = 0; j < kIters; ++j) {
+        const int word = j * 4 + wave;
+        const bool s = (s_sel[word] >> lane) & 1;
+        const int64_t row = row0 + word * 64 + lane;
+        T v = 0;
+        if (s) {
+          if (IOTA) v = static_cast<T>(row);
+          else if (kBits) v = static_cast<T>((s_bvals[word] >> lane) & 1);
+          else v = values[a.v_off + row];
+        }
+        vals[j] = v;
+      }
     }
 #pragma unroll
     for (int j = 0; j < kIters; ++j) {
@@ -342,8 +381,12 @@ static int RunCompaction(amdarrow_ctx* ctx, FilterArgs a, int width_bytes /*0 = 
   hipLaunchKernelGGL(k_filter_tile_counts, dim3(GridFor(a.ntiles, 4, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream,
                      a.f_data, a.f_valid, a.f_off, a.emit_null, a.length, a.ntiles, counts);
   AA_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, counts, a.ntiles, offsets);
+  // the total goes to mapped host memory; an event behind the scan lets the host pick it up
+  // while the compaction (queued right behind) is still running
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, counts, a.ntiles, offsets,
+                     reinterpret_cast<long long*>(static_cast<char*>(ctx->pinned_dev) + kStatusOffset));
   AA_HIP(hipGetLastError());
+  AA_HIP(hipEventRecord(ctx->status_event, ctx->stream));
   // bitmaps are merged with atomicOr at tile edges: start from zero (also zeroes the tails)
   const size_t bm_bytes = static_cast<size_t>((BytesForBits(a.out_capacity) + 7) & ~int64_t(7));
   if (a.has_validity) AA_HIP(hipMemsetAsync(a.out_validity, 0, bm_bytes, ctx->stream));
@@ -361,7 +404,8 @@ static int RunCompaction(amdarrow_ctx* ctx, FilterArgs a, int width_bytes /*0 = 
     }
   }
   AA_TRY(rc);
-  AA_TRY(ReadBack(ctx, offsets + a.ntiles, 8, total));
+  AA_HIP(hipEventSynchronize(ctx->status_event));
+  memcpy(total, static_cast<const char*>(ctx->pinned) + kStatusOffset, 8);
   if (*total > a.out_capacity)
     return SetError(AMDARROW_CAPACITY_ERROR, "filter: selection of " + std::to_string(*total) +
                                                  " rows exceeds out_capacity " + std::to_string(a.out_capacity));
