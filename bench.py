@@ -34,12 +34,14 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 SEED = 0x0ff1ce         # kRandomSeed, compute/kernels/test_util.h:123
 
 NUM_GROUPS = 1_000_000  # --groups
+NUM_CHUNKS = 1  # --chunks (sort workloads)
 
 WORKLOADS = {
     # name: (description, algorithmic bytes per row as a function of selectivity)
     "filter_groupby_sum_i64": "Filter(mask 50%) -> GroupBy{hash_sum,hash_count}(int64) by int32 key, 1M groups",
     "filter_i64": "Filter int64 + validity (p_null .01), Bernoulli(s) mask, DROP",
     "take_i64": "Take int64 + validity by uint32 indices (monotonic = GetTakeIndices(mask))",
+    "take_random_i64": "Take int64 + validity by uint32 indices (uniform random, M = s*N of them)",
     "sort_u64": "sort_indices uint64 full range",
     "sort_f64": "sort_indices float64 U[0,1) + 0.1% NaN + 1% null",
     "hash_agg_f64": "GroupBy sum/count over float64 (p_null .01), 1M int32 keys",
@@ -70,7 +72,7 @@ def make_inputs(workload, n, dev, rank, sel):
         d["keys"] = device.DeviceArray(_abi.INT32, keys.view(torch.uint8), None, n)
         d["mask"] = device.DeviceArray(_abi.BOOL, device_bitmap(n, sel, gen, dev), None, n)
         d["_keep"] = (vals, keys)
-    elif workload in ("filter_i64", "take_i64"):
+    elif workload in ("filter_i64", "take_i64", "take_random_i64"):
         vals = torch.randint(-100, 101, (n,), dtype=torch.int64, device=dev, generator=gen)
         d["values"] = device.DeviceArray(_abi.INT64, vals.view(torch.uint8), device_bitmap(n, 0.99, gen, dev), n, 0, -1)
         d["mask"] = device.DeviceArray(_abi.BOOL, device_bitmap(n, sel, gen, dev), None, n)
@@ -103,7 +105,7 @@ def make_inputs(workload, n, dev, rank, sel):
 
 def bytes_per_row(workload, sel):
     return {"filter_groupby_sum_i64": 12.125, "filter_i64": 8.25 + 8.125 * sel, "take_i64": 20.25 * sel,
-            "sort_u64": 16.0, "sort_f64": 16.0, "hash_agg_f64": 12.125, "compare_i64": 16.25}[workload]
+            "take_random_i64": 20.25 * sel, "sort_u64": 16.0, "sort_f64": 16.0, "hash_agg_f64": 12.125, "compare_i64": 16.25}[workload]
 
 
 def make_step(workload, ctx, inp, sel, world, rank):
@@ -125,8 +127,21 @@ def make_step(workload, ctx, inp, sel, world, rank):
     if workload == "take_i64":
         idx = compute.take_indices(ctx, inp["mask"])
         return lambda: compute.take(ctx, inp["values"], idx)
+    if workload == "take_random_i64":
+        m = int(inp["values"].length * sel)
+        gen = torch.Generator(device=inp["values"].values.device)
+        gen.manual_seed(SEED + 77 + rank)
+        ridx = torch.randint(0, inp["values"].length, (m,), dtype=torch.int64, device=inp["values"].values.device,
+                             generator=gen).to(torch.int32)  # values < 2^31: same bits as uint32
+        idx = device.DeviceArray(_abi.UINT32, ridx.view(torch.uint8), None, m)
+        inp["_keep_idx"] = ridx
+        return lambda: compute.take(ctx, inp["values"], idx)
     if workload in ("sort_u64", "sort_f64"):
-        return lambda: compute.sort_indices(ctx, inp["values"])
+        chunks = inp["values"]
+        if NUM_CHUNKS > 1:  # the same rows as NUM_CHUNKS equal slices: a ChunkedArray (vector_sort.cc:657-832)
+            per = (chunks.length + NUM_CHUNKS - 1) // NUM_CHUNKS
+            chunks = [chunks.slice(i * per, min(per, chunks.length - i * per)) for i in range(NUM_CHUNKS)]
+        return lambda: compute.sort_indices(ctx, chunks)
     if workload == "compare_i64":
         return lambda: compute.compare(ctx, _abi.GT, inp["a"], inp["b"])
     raise SystemExit("unknown workload " + workload)
@@ -141,22 +156,63 @@ def cpu_baseline(workload, sel):
     kind = "reference" if orc.have_ref() else "port"
     api = orc.Api("ref" if kind == "reference" else "orc")
     rng = np.random.default_rng(SEED)
-    if workload != "filter_groupby_sum_i64":
+    n = {"sort_u64": 2_000_000, "sort_f64": 2_000_000}.get(workload, 8_000_000)
+
+    def nullable(type_id, data, p_null):
+        return orc.Arr(type_id, data, rng.random(len(data)) >= p_null)
+
+    if workload == "filter_groupby_sum_i64":
+        vals = orc.Arr(orc.INT64, rng.integers(-100, 101, n))
+        keys = orc.Arr(orc.INT32, rng.integers(0, NUM_GROUPS, n))
+        mask = orc.Arr(orc.BOOL, rng.random(n) < sel)
+        call = lambda: api.filter_groupby_sum(vals, keys, mask)  # noqa: E731
+        what = "Filter+Filter+GroupBy{hash_sum,hash_count}, 1M keys, mask %.0f%%" % (sel * 100)
+    elif workload == "hash_agg_f64":
+        vals = nullable(orc.DOUBLE, rng.random(n) * 1e3, 0.01)
+        keys = orc.Arr(orc.INT32, rng.integers(0, NUM_GROUPS, n))
+        mask = orc.Arr(orc.BOOL, np.ones(n, bool))
+        call = lambda: api.filter_groupby_sum(vals, keys, mask)  # noqa: E731
+        what = "GroupBy{hash_sum,hash_count} float64, 1M keys (through an all-true Filter)"
+    elif workload == "filter_i64":
+        vals = nullable(orc.INT64, rng.integers(-100, 101, n), 0.01)
+        mask = orc.Arr(orc.BOOL, rng.random(n) < sel)
+        call = lambda: api.filter(vals, mask)  # noqa: E731
+        what = "filter int64+validity, mask %.0f%%" % (sel * 100)
+    elif workload in ("take_i64", "take_random_i64"):
+        vals = nullable(orc.INT64, rng.integers(-100, 101, n), 0.01)
+        if workload == "take_i64":
+            idx = api.take_indices(orc.Arr(orc.BOOL, rng.random(n) < sel))
+            idx = orc.Arr(orc.UINT32, idx.values)
+        else:
+            idx = orc.Arr(orc.UINT32, rng.integers(0, n, int(n * sel)))
+        call = lambda: api.take(vals, idx)  # noqa: E731
+        what = "take int64+validity by %d uint32 indices" % idx.length
+    elif workload == "sort_u64":
+        vals = orc.Arr(orc.UINT64, rng.integers(0, 2**64, n, dtype=np.uint64))
+        call = lambda: api.sort_indices([vals])  # noqa: E731
+        what = "sort_indices uint64"
+    elif workload == "sort_f64":
+        data = rng.random(n)
+        data[rng.random(n) < 0.001] = np.nan
+        vals = nullable(orc.DOUBLE, data, 0.01)
+        call = lambda: api.sort_indices([vals])  # noqa: E731
+        what = "sort_indices float64 (0.1% NaN, 1% null)"
+    elif workload == "compare_i64":
+        a, b = orc.Arr(orc.INT64, rng.integers(-100, 101, n)), orc.Arr(orc.INT64, rng.integers(-100, 101, n))
+        call = lambda: api.compare(orc.GT, a, b)  # noqa: E731
+        what = "greater(int64, int64)"
+    else:
         return None
-    n = 8_000_000
-    vals = orc.Arr(orc.INT64, rng.integers(-100, 101, n))
-    keys = orc.Arr(orc.INT32, rng.integers(0, NUM_GROUPS, n))
-    mask = orc.Arr(orc.BOOL, rng.random(n) < sel)
     t0 = time.time()
     reps = 0
     while True:
-        api.filter_groupby_sum(vals, keys, mask)
+        call()
         reps += 1
         if time.time() - t0 > 10.0 or reps >= 20:
             break
     dt = (time.time() - t0) / reps
     return {"value": n / dt, "unit": "rows/s", "cores": 1, "kind": kind,
-            "sample": "%d rows (same generator family, 1M keys, mask %.0f%%), %d reps of Filter+Filter+GroupBy{hash_sum,hash_count}" % (n, sel * 100, reps)}
+            "sample": "%d rows (same generator family), %d reps of %s" % (n, reps, what)}
 
 
 def main():
@@ -168,10 +224,12 @@ def main():
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU")
     ap.add_argument("--selectivity", type=float, default=0.5)
     ap.add_argument("--groups", type=int, default=1_000_000, help="distinct group keys (tuning aid; the headline is 1M)")
+    ap.add_argument("--chunks", type=int, default=1, help="sort workloads: present the rows as this many equal chunks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
-    global NUM_GROUPS
+    global NUM_GROUPS, NUM_CHUNKS
     NUM_GROUPS = args.groups
+    NUM_CHUNKS = args.chunks
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -228,7 +286,7 @@ def main():
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"filter_groupby_sum_i64": "int64", "filter_i64": "u64", "take_i64": "u64",
-                                            "sort_u64": "u64", "sort_f64": "f64", "hash_agg_f64": "f64",
+                                            "take_random_i64": "u64", "sort_u64": "u64", "sort_f64": "f64", "hash_agg_f64": "f64",
                                             "compare_i64": "int64"}[args.workload],
             "data": "synthetic (device-generated, seed 0x0ff1ce + rank; HBM-resident before timing)",
             "config": {"workload": args.workload + ": " + WORKLOADS[args.workload], "rows_per_gpu": n,
