@@ -215,6 +215,23 @@ def cpu_baseline(workload, sel):
             "sample": "%d rows (same generator family), %d reps of %s" % (n, reps, what)}
 
 
+def pmc_traffic(workload):
+    """HBM bytes per step from the committed rocprofv3 --pmc summary of this very command
+    (profiles/run_pmc.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 correction applied
+    there): sum over the kernels of one step.  None when no summary is committed for the workload."""
+    if workload != "filter_groupby_sum_i64":
+        return None, None
+    path = os.path.join(ROOT, "profiles", "r01_headline_hbm_pmc.txt")
+    if not os.path.exists(path):
+        return None, None
+    total_kb = 0.0
+    for line in open(path):
+        parts = line.split()
+        if "avg" in parts and ("FETCH_SIZE" in parts or "WRITE_SIZE" in parts):
+            total_kb += float(parts[parts.index("avg") + 1])
+    return total_kb * 1024.0, os.path.relpath(path, ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -296,6 +313,10 @@ def main():
                          "note": "algorithmic %.3f B/row x %d rows / HIP-event time per step (%.3f ms) on the kernel stream; "
                                  "whole step (all kernels of the op), rank 0" % (bpr, n, step_s * 1e3)},
         }
+        traffic, src = pmc_traffic(args.workload)
+        if traffic is not None and n == 100_000_000 and NUM_GROUPS == 1_000_000 and sel == 0.5:
+            out["roofline"]["traffic"] = traffic
+            out["roofline"]["note"] += "; traffic = FETCH_SIZE + WRITE_SIZE bytes per step over all kernels of the op, from %s" % src
         if hasattr(res, "num_groups"):
             out["config"]["result_groups"] = int(res.num_groups)
         if not args.no_cpu_baseline and world == 1:

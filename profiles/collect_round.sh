@@ -1,0 +1,20 @@
+#!/bin/bash
+# Usage (GPU box, repo root): bash profiles/collect_round.sh <round-tag, e.g. r01>
+# For every bench workload: rocprofv3 --kernel-trace --stats of `python3 bench.py --workload W`
+# -> gpurun_out/round_<tag>/<W>_kernel_stats.csv + <W>_bench.json (the JSON line of the same run);
+# then the two --pmc passes (FETCH_SIZE / WRITE_SIZE, kernel trace only) of the headline.
+# Copy gpurun_out/round_<tag>/* into profiles/ afterwards (gpurun_out/ is scratch).
+export TMPDIR=/tmp
+R=$PWD
+tag=$1
+out=$R/gpurun_out/round_$tag
+mkdir -p $out
+for w in filter_groupby_sum_i64 hash_agg_f64 filter_i64 take_i64 take_random_i64 sort_u64 sort_f64 compare_i64; do
+  rm -rf $R/gpurun_out/tmp_prof
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/tmp_prof -- python3 bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > $out/${w}.log 2>&1
+  cp $(ls $R/gpurun_out/tmp_prof/*/*kernel_stats.csv | head -1) $out/${tag}_${w}_kernel_stats.csv
+  grep -h '^{' $out/${w}.log > $out/${tag}_${w}_bench.json
+  echo "$w: $(cut -c95-200 $out/${tag}_${w}_bench.json)"
+done
+bash profiles/run_pmc.sh $tag filter_groupby_sum_i64 > $out/${tag}_headline_hbm_pmc.txt 2>&1
+cat $out/${tag}_headline_hbm_pmc.txt
