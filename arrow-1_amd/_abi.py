@@ -13,6 +13,8 @@ COUNT_NON_NULL, COUNT_NULL = 0, 1
 EQ, NE, GT, GE, LT, LE = range(6)
 ADD, SUB, MUL, DIV, ADD_CHECKED, SUB_CHECKED, MUL_CHECKED, DIV_CHECKED = range(8)
 HASH_SUM, HASH_COUNT, HASH_MEAN = 0, 1, 2
+INVERT, AND, AND_NOT, OR, XOR, AND_KLEENE, AND_NOT_KLEENE, OR_KLEENE = range(8)
+SCALAR_NONE, SCALAR_FALSE, SCALAR_TRUE, SCALAR_NULL = -1, 0, 1, 2
 
 STATUS_NAMES = {0: "OK", 1: "OutOfMemory", 2: "KeyError", 3: "TypeError", 4: "Invalid", 6: "CapacityError",
                 7: "IndexError", 9: "UnknownError", 10: "NotImplemented"}
@@ -55,6 +57,10 @@ SYMBOLS = {
     "amdarrow_sort_indices": (C.c_int, [_P, _A, C.c_int, C.c_int, _P]),
     "amdarrow_compare": (C.c_int, [_P, C.c_int, _A, _P, _A, _P, _P, _P, _O]),
     "amdarrow_arith": (C.c_int, [_P, C.c_int, _A, _P, _A, _P, _P, _P, _O]),
+    "amdarrow_boolean": (C.c_int, [_P, C.c_int, _A, C.c_int, _A, C.c_int, _P, _P, _O]),
+    "amdarrow_validity_test": (C.c_int, [_P, C.c_int, _A, _P, _O]),
+    "amdarrow_is_nan": (C.c_int, [_P, _A, _P, _P, _O]),
+    "amdarrow_fill_null": (C.c_int, [_P, _A, _P, _P, _P, _O]),
     "amdarrow_grouper_create": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(_P)]),
     "amdarrow_grouper_destroy": (C.c_int, [_P]),
     "amdarrow_grouper_consume": (C.c_int, [_P, _A, _P]),

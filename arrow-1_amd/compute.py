@@ -123,6 +123,70 @@ def arith(ctx, op, lhs, rhs):
     return _binary(ctx, ctx.lib.amdarrow_arith, op, lhs, rhs, None)
 
 
+def _finish(ot, out_v, out_b, out):
+    """DeviceArray of a scalar kernel whose validity buffer may be absent (has_validity == 0): the
+    buffer (all ones then) stays reachable as .validity_buffer."""
+    d = DeviceArray(ot, out_v, out_b if out.has_validity else None, out.length, 0, out.null_count)
+    d.validity_buffer = out_b
+    return d
+
+
+def boolean(ctx, op, lhs, rhs=None):
+    """invert / and / and_not / or / xor / and_kleene / and_not_kleene / or_kleene --
+    scalar_boolean.cc:521-542.  lhs / rhs: a boolean DeviceArray, or a scalar: False, True, None (null)."""
+    arr = lhs if isinstance(lhs, DeviceArray) else rhs
+    n, dev = arr.length, arr.values.device
+    keep = []
+
+    def operand(x):
+        if isinstance(x, DeviceArray):
+            c = x.c()
+            keep.append(c)
+            return C.byref(c), _abi.SCALAR_NONE
+        return None, (_abi.SCALAR_NULL if x is None else int(bool(x)))
+
+    la, ls = operand(lhs)
+    ra, rs = (None, _abi.SCALAR_TRUE) if op == _abi.INVERT else operand(rhs)
+    out_v = alloc_bytes((n + 7) // 8, dev)
+    out_b = alloc_bytes((n + 7) // 8, dev)
+    out = COut()
+    check(ctx.lib, ctx.lib.amdarrow_boolean(ctx.handle, op, la, ls, ra, rs, _ptr(out_v), _ptr(out_b), C.byref(out)))
+    return _finish(BOOL, out_v, out_b, out)
+
+
+def is_valid(ctx, a, is_null=False):
+    """is_valid / is_null -- scalar_validity.cc:34-82 (result never null)."""
+    out_v = alloc_bytes((a.length + 7) // 8, a.values.device)
+    out = COut()
+    c = a.c()
+    check(ctx.lib, ctx.lib.amdarrow_validity_test(ctx.handle, 1 if is_null else 0, C.byref(c), _ptr(out_v), C.byref(out)))
+    return DeviceArray(BOOL, out_v, None, out.length, 0, 0)
+
+
+def is_null(ctx, a):
+    return is_valid(ctx, a, is_null=True)
+
+
+def is_nan(ctx, a):
+    """is_nan -- scalar_validity.cc:84-89, 111-126."""
+    n, dev = a.length, a.values.device
+    out_v, out_b, out = alloc_bytes((n + 7) // 8, dev), alloc_bytes((n + 7) // 8, dev), COut()
+    c = a.c()
+    check(ctx.lib, ctx.lib.amdarrow_is_nan(ctx.handle, C.byref(c), _ptr(out_v), _ptr(out_b), C.byref(out)))
+    return _finish(BOOL, out_v, out_b, out)
+
+
+def fill_null(ctx, a, fill):
+    """fill_null(values, scalar) -- scalar_fill_null.cc:44-147.  fill: a value of a's type or None (null scalar)."""
+    n, dev, t = a.length, a.values.device, a.type_id
+    out_v, out_b, out = alloc_bytes(_values_bytes(t, n), dev), alloc_bytes((n + 7) // 8, dev), COut()
+    c = a.c()
+    keep = None if fill is None else np.array([fill], dtype=np.uint8 if t == BOOL else NP_OF[t])
+    fp = None if fill is None else keep.ctypes.data_as(C.c_void_p)
+    check(ctx.lib, ctx.lib.amdarrow_fill_null(ctx.handle, C.byref(c), fp, _ptr(out_v), _ptr(out_b), C.byref(out)))
+    return _finish(t, out_v, out_b, out)
+
+
 def hash_aggregate(ctx, func, values, ids, num_groups, count_mode=0):
     """One HashAggregateKernel (hash_sum / hash_count / hash_mean) over (values, ids, num_groups).
     `ids`: torch.int32/uint32 tensor on the device."""

@@ -39,7 +39,7 @@ struct amdarrow_ctx {
   bool own_stream = false;
   void* scratch = nullptr;  // grow-only HBM arena for per-call temporaries
   size_t scratch_cap = 0;
-  void* pinned = nullptr;   // 4 KiB pinned, device-mapped host memory for small read-backs
+  void* pinned = nullptr;   // 8 KiB pinned, device-mapped host memory: [0, 4096) ReadBack, [4096, ..) status words
   void* pinned_dev = nullptr;  // the same memory as the device sees it (kernels may store status words there)
   hipEvent_t status_event = nullptr;  // marks the kernel that stored them
   int num_cus = 256;
@@ -68,10 +68,23 @@ struct Carver {
 // kStatusOffset, the host records status_event behind that kernel, queues whatever does not need
 // the value, and only then waits for the event -- the round trip overlaps with the queued work.
 // (ReadBack uses the head of the same pinned block.)
-constexpr size_t kStatusOffset = 256;
+constexpr size_t kStatusOffset = 4096;  // behind the 4 KiB ReadBack area
 
 // Copy `nbytes` (<= 4096) from device to the pinned word and wait for it.
 int ReadBack(amdarrow_ctx* ctx, const void* dev, size_t nbytes, void* host_out);
+
+// Slotted counters.  A device-scope atomic on ONE address is serialised at the memory side
+// (~30 ns each on MI355X: 2048 workgroups adding to one word cost 60 us, more than the kernels
+// that did it), so global sums go to kCounterSlots copies, each in its own 128-byte line, picked
+// by the workgroup id; the host adds them up after ONE 4 KiB read-back.  Up to kCounterStride
+// counters per slot.
+constexpr int kCounterSlots = 32;
+constexpr int kCounterStride = 16;  // unsigned long long per slot = 128 bytes
+constexpr size_t kCounterBytes = size_t(kCounterSlots) * kCounterStride * 8;
+// Zero the block (asynchronously); `base` is kCounterBytes of device memory.
+int ClearCounters(amdarrow_ctx* ctx, unsigned long long* base);
+// Sum counter `k` (k < ncounters <= kCounterStride) over the slots into out[k].
+int ReadCounters(amdarrow_ctx* ctx, const unsigned long long* base, int ncounters, unsigned long long* out);
 
 // Single-workgroup exclusive scan of u32 counts into int64 offsets (offsets[n] = total).
 int LaunchScanU32(amdarrow_ctx* ctx, const uint32_t* counts, int64_t n, int64_t* offsets);
@@ -124,6 +137,10 @@ __device__ __forceinline__ uint64_t LoadBits64(const uint8_t* __restrict__ bm, i
 __device__ __forceinline__ uint64_t LoadBitsOrOnes(const uint8_t* __restrict__ bm, int64_t pos, int nbits) {
   if (bm == nullptr) return nbits < 64 ? (uint64_t(1) << nbits) - 1 : ~uint64_t(0);
   return LoadBits64(bm, pos, nbits);
+}
+// This workgroup's copy of the slotted counters (see ClearCounters / ReadCounters).
+__device__ __forceinline__ unsigned long long* CounterSlot(unsigned long long* base) {
+  return base + (blockIdx.x & (kCounterSlots - 1)) * kCounterStride;
 }
 __device__ __forceinline__ bool GetBit(const uint8_t* __restrict__ bm, int64_t pos) {
   return (bm[pos >> 3] >> (pos & 7)) & 1;

@@ -42,6 +42,20 @@ int ReadBack(amdarrow_ctx* ctx, const void* dev, size_t nbytes, void* host_out) 
   return AMDARROW_OK;
 }
 
+int ClearCounters(amdarrow_ctx* ctx, unsigned long long* base) {
+  AA_HIP(hipMemsetAsync(base, 0, kCounterBytes, ctx->stream));
+  return AMDARROW_OK;
+}
+int ReadCounters(amdarrow_ctx* ctx, const unsigned long long* base, int ncounters, unsigned long long* out) {
+  unsigned long long host[kCounterSlots * kCounterStride];
+  AA_TRY(ReadBack(ctx, base, kCounterBytes, host));
+  for (int k = 0; k < ncounters; ++k) {
+    out[k] = 0;
+    for (int s = 0; s < kCounterSlots; ++s) out[k] += host[s * kCounterStride + k];
+  }
+  return AMDARROW_OK;
+}
+
 }  // namespace amdarrow
 
 using namespace amdarrow;
@@ -71,7 +85,7 @@ int amdarrow_ctx_create(int device, void* stream, int private_stream, amdarrow_c
     if (e != hipSuccess) { delete ctx; return HipError(e, "hipStreamCreate", __FILE__, __LINE__); }
     ctx->own_stream = true;
   }
-  hipError_t e = hipHostMalloc(&ctx->pinned, 4096, hipHostMallocMapped);
+  hipError_t e = hipHostMalloc(&ctx->pinned, 8192, hipHostMallocMapped);
   if (e != hipSuccess) { delete ctx; return HipError(e, "hipHostMalloc", __FILE__, __LINE__); }
   e = hipHostGetDevicePointer(&ctx->pinned_dev, ctx->pinned, 0);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->status_event, hipEventDisableTiming);

@@ -166,7 +166,10 @@ static int Propagate(amdarrow_ctx* ctx, const amdarrow_array* lhs, const amdarro
   else if (nw == 0) out->null_count = 0;                   // :433-439
   else if (nw == 1) out->null_count = with_nulls[0]->null_count;  // PropagateSingle :350-380
   else out->null_count = -1;                               // PropagateMultiple :382-408
-  if (n == 0) return AMDARROW_OK;
+  if (n == 0) {  // a zero-length call runs no batch: the empty result keeps kUnknownNullCount
+    out->null_count = -1;
+    return AMDARROW_OK;
+  }
   const uint8_t* a = nw > 0 ? with_nulls[0]->validity : nullptr;
   const int64_t a_off = nw > 0 ? with_nulls[0]->offset : 0;
   const uint8_t* b = nw > 1 ? with_nulls[1]->validity : nullptr;
@@ -200,6 +203,123 @@ static Operand MakeOperand(const amdarrow_array* a, const void* scalar, int type
   if (a) { o.data = a->values; o.off = a->offset; }
   else memcpy(&o.scalar, scalar, type == AMDARROW_BOOL ? 1 : BitWidth(type) / 8);
   return o;
+}
+
+// ---- mask-building scalars ----------------------------------------------------------------
+// Boolean kernels (compute/kernels/scalar_boolean.cc), is_valid / is_null / is_nan
+// (scalar_validity.cc), fill_null (scalar_fill_null.cc).  Bitmap work: one 64-bit output word per
+// lane, inputs funnel-shifted from arbitrary bit offsets; 2 x N/8 bytes in, N/8 out per operand.
+struct BoolSrc { const uint8_t* data; const uint8_t* valid; int64_t off; int scalar; };  // scalar < 0: array
+
+__device__ __forceinline__ void FetchBool(const BoolSrc& s, int64_t row, int nbits, uint64_t live, uint64_t* d, uint64_t* v) {
+  if (s.scalar < 0) {
+    *d = LoadBits64(s.data, s.off + row, nbits);
+    *v = s.valid ? LoadBits64(s.valid, s.off + row, nbits) : live;
+  } else {
+    *d = s.scalar == AMDARROW_SCALAR_TRUE ? live : 0;
+    *v = s.scalar == AMDARROW_SCALAR_NULL ? 0 : live;
+  }
+}
+
+enum { kDataPlain = 0, kDataKleene, kDataZero, kDataOnes, kDataCopy, kDataCopyInverted, kDataFill };
+enum { kValidNone = 0, kValidKleene, kValidCopy, kValidDecides };
+
+// `arr` = the array operand the copy / decides modes refer to (0 = left, 1 = right).
+// null_count (optional, slotted counters of common.h): [0] null slots of the result, [1] / [2] null slots of the left / right array
+// operand -- one pass also answers ArrayData::GetNullCount() for inputs whose count is unknown.
+__global__ __launch_bounds__(kThreads) void k_boolean(int op, int data_mode, int valid_mode, int arr, BoolSrc l, BoolSrc r,
+                                                      int64_t n, uint64_t* out_bits, uint64_t* out_valid,
+                                                      unsigned long long* null_count) {
+  const int64_t nwords = (n + 63) >> 6;
+  unsigned long long nulls = 0, lnulls = 0, rnulls = 0;
+  for (int64_t w = int64_t(blockIdx.x) * kThreads + threadIdx.x; w < nwords; w += int64_t(gridDim.x) * kThreads) {
+    const int64_t row = w << 6;
+    const int64_t left = n - row;
+    const int nbits = left >= 64 ? 64 : static_cast<int>(left);
+    const uint64_t live = nbits < 64 ? (uint64_t(1) << nbits) - 1 : ~uint64_t(0);
+    uint64_t ld, lv, rd, rv;
+    FetchBool(l, row, nbits, live, &ld, &lv);
+    FetchBool(r, row, nbits, live, &rd, &rv);
+    if (l.scalar < 0) lnulls += __popcll(~lv & live);
+    if (r.scalar < 0) rnulls += __popcll(~rv & live);
+    const bool or_type = op == AMDARROW_OR || op == AMDARROW_OR_KLEENE;
+    const bool not_rhs = op == AMDARROW_AND_NOT || op == AMDARROW_AND_NOT_KLEENE;
+    uint64_t data = 0, valid = live;
+    switch (data_mode) {
+      case kDataPlain:
+        if (op == AMDARROW_INVERT) data = ~ld;                       // CopyFromInverted :103-106
+        else if (op == AMDARROW_XOR) data = ld ^ rd;                 // :349-356
+        else if (or_type) data = ld | rd;                            // :224-231
+        else data = ld & (not_rhs ? ~rd : rd);                       // :132-139, :380-387
+        break;
+      case kDataKleene: {                                            // ComputeKleene :34-91
+        const uint64_t rdd = not_rhs ? ~rd : rd;
+        const uint64_t lt = lv & ld, lf = lv & ~ld, rt = rv & rdd, rf = rv & ~rdd;
+        if (or_type) { data = lt | rt; valid = lt | rt | (lf & rf); }      // :311-319
+        else { data = lt & rt; valid = lf | rf | (lt & rt); }              // :211-217, :447-453
+        break;
+      }
+      case kDataZero: data = 0; break;
+      case kDataOnes: data = live; break;
+      case kDataCopy: data = arr ? rd : ld; break;
+      case kDataFill: data = (lv & ld) | (rd & ~lv); break;  // fill_null on bits: rd = the fill bit replicated
+      default: data = ~(arr ? rd : ld); break;
+    }
+    data &= live;
+    if (valid_mode == kValidCopy) valid = arr ? rv : lv;
+    else if (valid_mode == kValidDecides) valid = (arr ? rv : lv) & (or_type ? data : ~data);  // :178-190, :282-293, :417-430
+    valid &= live;
+    if (out_bits) out_bits[w] = data;
+    if (out_valid) out_valid[w] = valid;
+    nulls += __popcll(~valid & live);
+  }
+  if (null_count) {
+    nulls = WaveReduceSum64(nulls);
+    lnulls = WaveReduceSum64(lnulls);
+    rnulls = WaveReduceSum64(rnulls);
+    if ((threadIdx.x & 63) == 0) {
+      unsigned long long* slot = CounterSlot(null_count);
+      if (nulls) atomicAdd(&slot[0], nulls);
+      if (lnulls) atomicAdd(&slot[1], lnulls);
+      if (rnulls) atomicAdd(&slot[2], rnulls);
+    }
+  }
+}
+
+// is_valid (func 0) / is_null (func 1): the validity bitmap or its complement; constant when `valid` is null.
+__global__ __launch_bounds__(kThreads) void k_validity_test(int func, const uint8_t* valid, int64_t off, int64_t n,
+                                                            uint64_t* out_bits) {
+  const int64_t nwords = (n + 63) >> 6;
+  for (int64_t w = int64_t(blockIdx.x) * kThreads + threadIdx.x; w < nwords; w += int64_t(gridDim.x) * kThreads) {
+    const int64_t row = w << 6;
+    const int64_t left = n - row;
+    const int nbits = left >= 64 ? 64 : static_cast<int>(left);
+    const uint64_t live = nbits < 64 ? (uint64_t(1) << nbits) - 1 : ~uint64_t(0);
+    const uint64_t v = LoadBitsOrOnes(valid, off + row, nbits);
+    out_bits[w] = (func == 0 ? v : ~v) & live;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_is_nan(const T* values, int64_t off, int64_t n, uint64_t* out_bits) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nround = (n + 63) & ~int64_t(63);
+  for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < nround; i += int64_t(gridDim.x) * kThreads) {
+    bool v = false;
+    if (i < n) { const T x = values[off + i]; v = x != x; }
+    const uint64_t m = __ballot(v);
+    if (lane == 0) out_bits[i >> 6] = m;
+  }
+}
+
+// fill_null on fixed-width values of W bytes: out[i] = valid ? in[i] : fill (valid == nullptr: plain copy)
+template <typename U>
+__global__ __launch_bounds__(kThreads) void k_fill_null(const U* values, const uint8_t* valid, int64_t off, int64_t n, U fill,
+                                                        U* out) {
+  for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < n; i += int64_t(gridDim.x) * kThreads) {
+    const bool ok = valid ? GetBit(valid, off + i) : true;
+    out[i] = ok ? values[off + i] : fill;
+  }
 }
 
 }  // namespace amdarrow
@@ -278,6 +398,185 @@ int amdarrow_arith(amdarrow_ctx* ctx, int op, const amdarrow_array* lhs, const v
     AA_TRY(ReadBack(ctx, err_word, 8, &e));
     if (e) return SetError(AMDARROW_INVALID, (e & 3) == kErrDivZero ? "divide by zero" : "overflow");
   }
+  return AMDARROW_OK;
+}
+
+// ---- SURVEY 8f.1 entry points ------------------------------------------------------------------------
+static int AllValid(amdarrow_ctx* ctx, int64_t n, uint8_t* out_validity) {  // ones for n bits, tail zero
+  if (n == 0 || !out_validity) return AMDARROW_OK;
+  hipLaunchKernelGGL(k_validity, dim3(GridFor((n + 63) / 64, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream,
+                     static_cast<const uint8_t*>(nullptr), int64_t(0), static_cast<const uint8_t*>(nullptr), int64_t(0), 0, n,
+                     reinterpret_cast<uint64_t*>(out_validity));
+  AA_HIP(hipGetLastError());
+  return AMDARROW_OK;
+}
+
+int amdarrow_boolean(amdarrow_ctx* ctx, int op, const amdarrow_array* lhs, int lhs_scalar, const amdarrow_array* rhs,
+                     int rhs_scalar, uint8_t* out_bits, uint8_t* out_validity, amdarrow_out* out) {
+  if (op < AMDARROW_INVERT || op > AMDARROW_OR_KLEENE) return SetError(AMDARROW_KEY_ERROR, "boolean: no such function");
+  if (op == AMDARROW_INVERT) { rhs = nullptr; rhs_scalar = AMDARROW_SCALAR_TRUE; }
+  if (!lhs && !rhs) return SetError(AMDARROW_INVALID, "boolean: need at least one array operand");
+  if ((lhs && lhs->type_id != AMDARROW_BOOL) || (rhs && rhs->type_id != AMDARROW_BOOL))
+    return SetError(AMDARROW_NOT_IMPLEMENTED, "boolean: operands must be boolean");
+  if (lhs && rhs && lhs->length != rhs->length)
+    return SetError(AMDARROW_INVALID, "Array arguments must all be the same length");  // compute/exec.cc:190-192
+  if ((!lhs && (lhs_scalar < 0 || lhs_scalar > 2)) || (!rhs && (rhs_scalar < 0 || rhs_scalar > 2)))
+    return SetError(AMDARROW_INVALID, "boolean: bad scalar state");
+  const int64_t n = lhs ? lhs->length : rhs->length;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  BoolSrc l{lhs ? static_cast<const uint8_t*>(lhs->values) : nullptr, lhs ? lhs->validity : nullptr, lhs ? lhs->offset : 0,
+            lhs ? -1 : lhs_scalar};
+  BoolSrc r{rhs ? static_cast<const uint8_t*>(rhs->values) : nullptr, rhs ? rhs->validity : nullptr, rhs ? rhs->offset : 0,
+            rhs ? -1 : rhs_scalar};
+  const int grid = GridFor((n + 63) / 64, kThreads, ctx->num_cus * 8);
+  const size_t bm_bytes = static_cast<size_t>((n + 7) / 8);
+  if (op <= AMDARROW_XOR) {  // INTERSECTION kernels
+    if ((!lhs && lhs_scalar == AMDARROW_SCALAR_NULL) || (op != AMDARROW_INVERT && !rhs && rhs_scalar == AMDARROW_SCALAR_NULL)) {
+      // a null scalar: every slot null, the zero-filled data bitmap stays untouched (exec.cc:326-348)
+      out->length = n; out->has_validity = 1; out->null_count = n ? n : -1;
+      if (n) {
+        AA_HIP(hipMemsetAsync(out_bits, 0, bm_bytes, ctx->stream));
+        AA_HIP(hipMemsetAsync(out_validity, 0, bm_bytes, ctx->stream));
+      }
+      return AMDARROW_OK;
+    }
+    AA_TRY(Propagate(ctx, lhs, rhs, n, out_validity, out));
+    if (n == 0) return AMDARROW_OK;
+    hipLaunchKernelGGL(k_boolean, dim3(grid), dim3(kThreads), 0, ctx->stream, op, kDataPlain, kValidNone, 0, l, r, n,
+                       reinterpret_cast<uint64_t*>(out_bits), static_cast<uint64_t*>(nullptr),
+                       static_cast<unsigned long long*>(nullptr));
+    AA_HIP(hipGetLastError());
+    return AMDARROW_OK;
+  }
+  // Kleene kernels compute validity themselves (COMPUTED_PREALLOCATE, scalar_boolean.cc:531-541)
+  out->length = n; out->has_validity = 0; out->null_count = 0;
+  if (n == 0) return AMDARROW_OK;  // SimpleBinary returns at once, codegen_internal.h:474
+  // ArrayData::GetNullCount() of an input: the stored count, or (count unknown) whatever the
+  // kernel itself counts on the way -- no extra pass, one read-back of three counters.
+  auto known_no_nulls = [](const amdarrow_array* a) { return a->validity == nullptr || a->null_count == 0; };
+  int data_mode, valid_mode, arr = 0;
+  bool decide_validity_from_counts = false;  // has_validity = (an array operand has nulls)
+  if (lhs && rhs) {
+    if (known_no_nulls(lhs) && known_no_nulls(rhs)) { data_mode = kDataPlain; valid_mode = kValidNone; }  // :205-209
+    else { data_mode = kDataKleene; valid_mode = kValidKleene; decide_validity_from_counts = true; }
+    // (with unknown counts that turn out to be zero the Kleene formula yields the plain result
+    // and an all-ones validity: only the has_validity flag is left to decide)
+  } else {
+    arr = lhs ? 0 : 1;
+    const amdarrow_array* a = lhs ? lhs : rhs;
+    int sc = lhs ? rhs_scalar : lhs_scalar;
+    bool invert_array = false;
+    if (op == AMDARROW_AND_NOT_KLEENE) {
+      if (!lhs) invert_array = true;                                   // KleeneAndNot(scalar, array) :396-431
+      else if (sc != AMDARROW_SCALAR_NULL) sc = sc == AMDARROW_SCALAR_TRUE ? AMDARROW_SCALAR_FALSE : AMDARROW_SCALAR_TRUE;  // :433-436
+    }
+    const int absorbing = op == AMDARROW_OR_KLEENE ? AMDARROW_SCALAR_TRUE : AMDARROW_SCALAR_FALSE;
+    if (sc == absorbing) {
+      data_mode = op == AMDARROW_OR_KLEENE ? kDataOnes : kDataZero;
+      valid_mode = kValidNone;
+    } else {
+      data_mode = invert_array ? kDataCopyInverted : kDataCopy;
+      if (sc != AMDARROW_SCALAR_NULL) {
+        valid_mode = known_no_nulls(a) ? kValidNone : kValidCopy;
+        decide_validity_from_counts = valid_mode == kValidCopy;
+      } else {
+        valid_mode = kValidDecides;
+      }
+    }
+  }
+  unsigned long long* counters = nullptr;
+  if (valid_mode != kValidNone) {
+    void* base;
+    AA_TRY(Scratch(ctx, kCounterBytes, &base));
+    counters = static_cast<unsigned long long*>(base);
+    AA_TRY(ClearCounters(ctx, counters));
+  }
+  hipLaunchKernelGGL(k_boolean, dim3(grid), dim3(kThreads), 0, ctx->stream, op, data_mode, valid_mode, arr, l, r, n,
+                     reinterpret_cast<uint64_t*>(out_bits), reinterpret_cast<uint64_t*>(out_validity), counters);
+  AA_HIP(hipGetLastError());
+  if (valid_mode != kValidNone) {
+    unsigned long long c[3] = {0, 0, 0};
+    AA_TRY(ReadCounters(ctx, counters, 3, c));
+    auto stored_nulls = [](const amdarrow_array* a) { return a && a->validity && a->null_count > 0; };
+    const bool input_nulls = c[1] > 0 || c[2] > 0 || stored_nulls(lhs) || stored_nulls(rhs);  // GetNullCount trusts a stored count
+    if (!decide_validity_from_counts || input_nulls) {
+      out->has_validity = 1;
+      out->null_count = static_cast<int64_t>(c[0]);
+    }  // else: no input has a null -> the reference drops the buffer; out_validity already holds all ones
+  }
+  return AMDARROW_OK;
+}
+
+int amdarrow_validity_test(amdarrow_ctx* ctx, int func, const amdarrow_array* a, uint8_t* out_bits, amdarrow_out* out) {
+  if (func != 0 && func != 1) return SetError(AMDARROW_KEY_ERROR, "validity_test: 0 = is_valid, 1 = is_null");
+  out->length = a->length; out->has_validity = 0; out->null_count = 0;  // OUTPUT_NOT_NULL, scalar_validity.cc:100
+  if (a->length == 0) return AMDARROW_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  hipLaunchKernelGGL(k_validity_test, dim3(GridFor((a->length + 63) / 64, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0,
+                     ctx->stream, func, MayHaveNulls(a) ? a->validity : nullptr, a->offset, a->length,
+                     reinterpret_cast<uint64_t*>(out_bits));
+  AA_HIP(hipGetLastError());
+  return AMDARROW_OK;
+}
+
+int amdarrow_is_nan(amdarrow_ctx* ctx, const amdarrow_array* a, uint8_t* out_bits, uint8_t* out_validity, amdarrow_out* out) {
+  if (a->type_id != AMDARROW_FLOAT && a->type_id != AMDARROW_DOUBLE)
+    return SetError(AMDARROW_NOT_IMPLEMENTED, "is_nan: floating point only");  // scalar_validity.cc:111-126
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  AA_TRY(Propagate(ctx, a, nullptr, a->length, out_validity, out));
+  if (a->length == 0) return AMDARROW_OK;
+  const int grid = GridFor(a->length, kThreads, ctx->num_cus * 8);
+  if (a->type_id == AMDARROW_FLOAT)
+    hipLaunchKernelGGL(k_is_nan<float>, dim3(grid), dim3(kThreads), 0, ctx->stream, static_cast<const float*>(a->values),
+                       a->offset, a->length, reinterpret_cast<uint64_t*>(out_bits));
+  else
+    hipLaunchKernelGGL(k_is_nan<double>, dim3(grid), dim3(kThreads), 0, ctx->stream, static_cast<const double*>(a->values),
+                       a->offset, a->length, reinterpret_cast<uint64_t*>(out_bits));
+  AA_HIP(hipGetLastError());
+  return AMDARROW_OK;
+}
+
+int amdarrow_fill_null(amdarrow_ctx* ctx, const amdarrow_array* a, const void* fill, void* out_values, uint8_t* out_validity,
+                       amdarrow_out* out) {
+  const int bw = BitWidth(a->type_id);
+  if (bw < 0) return SetError(AMDARROW_NOT_IMPLEMENTED, "fill_null: type");
+  const int64_t n = a->length;
+  out->length = n; out->has_validity = 0; out->null_count = 0;
+  if (n == 0) return AMDARROW_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  const bool may = MayHaveNulls(a);
+  const bool replace = may && fill != nullptr;  // scalar_fill_null.cc:55, :107
+  const uint8_t* valid = replace ? a->validity : nullptr;
+  if (bw == 1) {
+    // bits: out = valid ? data : fill (scalar_fill_null.cc:100-139)
+    const int fill_bit = fill && *static_cast<const uint8_t*>(fill) != 0;
+    BoolSrc src{static_cast<const uint8_t*>(a->values), valid, a->offset, -1};
+    BoolSrc fs{nullptr, nullptr, 0, fill_bit ? AMDARROW_SCALAR_TRUE : AMDARROW_SCALAR_FALSE};
+    hipLaunchKernelGGL(k_boolean, dim3(GridFor((n + 63) / 64, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream,
+                       AMDARROW_AND, kDataFill, kValidNone, 0, src, fs, n, reinterpret_cast<uint64_t*>(out_values),
+                       static_cast<uint64_t*>(nullptr), static_cast<unsigned long long*>(nullptr));
+  } else {
+    const int grid = GridFor(n, kThreads, ctx->num_cus * 8);
+    uint64_t f = 0;
+    if (fill) memcpy(&f, fill, bw / 8);
+#define AA_FILL(U) hipLaunchKernelGGL(k_fill_null<U>, dim3(grid), dim3(kThreads), 0, ctx->stream, static_cast<const U*>(a->values), valid, a->offset, n, static_cast<U>(f), static_cast<U*>(out_values))
+    switch (bw) {
+      case 8: AA_FILL(uint8_t); break;
+      case 16: AA_FILL(uint16_t); break;
+      case 32: AA_FILL(uint32_t); break;
+      default: AA_FILL(uint64_t); break;
+    }
+#undef AA_FILL
+  }
+  AA_HIP(hipGetLastError());
+  if (replace || !may) return AllValid(ctx, n, out_validity);
+  // the result IS the input: validity normalised to offset 0, count as stored (ArrayData copy :84)
+  out->has_validity = 1;
+  out->null_count = a->null_count;
+  hipLaunchKernelGGL(k_validity, dim3(GridFor((n + 63) / 64, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream,
+                     a->validity, a->offset, static_cast<const uint8_t*>(nullptr), int64_t(0), 0, n,
+                     reinterpret_cast<uint64_t*>(out_validity));
+  AA_HIP(hipGetLastError());
   return AMDARROW_OK;
 }
 

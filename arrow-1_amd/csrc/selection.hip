@@ -250,7 +250,7 @@ struct TakeArgs {
   const void* i_data; const uint8_t* i_valid; int64_t i_off; int64_t n;
   int boundscheck;
   void* out_values; uint8_t* out_validity;
-  unsigned long long* valid_count;  // device
+  unsigned long long* valid_count;  // device, slotted counters (common.h), counter 0
   unsigned long long* err_pos;      // device, initialised to ~0
 };
 
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kThreads) void k_take(TakeArgs a) {
   }
   if (lane == 0 && my_valid) atomicAdd(&s_valid, my_valid);
   __syncthreads();
-  if (tid == 0 && s_valid) atomicAdd(a.valid_count, s_valid);
+  if (tid == 0 && s_valid) atomicAdd(CounterSlot(a.valid_count), s_valid);
 }
 
 // ---- CountSetBits / GetFilterOutputSize -------------------------------------------------------
@@ -332,21 +332,21 @@ __global__ __launch_bounds__(kThreads) void k_popcount(const uint8_t* a, int64_t
   acc = WaveReduceSum64(acc);
   if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&s_sum, acc);
   __syncthreads();
-  if (threadIdx.x == 0 && s_sum) atomicAdd(total, s_sum);
+  if (threadIdx.x == 0 && s_sum) atomicAdd(CounterSlot(total), s_sum);
 }
 
 static int PopcountImpl(amdarrow_ctx* ctx, const uint8_t* a, int64_t a_off, const uint8_t* b, int64_t b_off, int mode,
                         int64_t length, int64_t* out) {
   if (length <= 0) { *out = 0; return AMDARROW_OK; }
   void* base;
-  AA_TRY(Scratch(ctx, 256, &base));
+  AA_TRY(Scratch(ctx, kCounterBytes, &base));
   auto* total = static_cast<unsigned long long*>(base);
-  AA_HIP(hipMemsetAsync(total, 0, 8, ctx->stream));
+  AA_TRY(ClearCounters(ctx, total));
   const int grid = GridFor((length + 63) / 64, kThreads, ctx->num_cus * 8);
   hipLaunchKernelGGL(k_popcount, dim3(grid), dim3(kThreads), 0, ctx->stream, a, a_off, b, b_off, mode, length, total);
   AA_HIP(hipGetLastError());
   unsigned long long host = 0;
-  AA_TRY(ReadBack(ctx, total, 8, &host));
+  AA_TRY(ReadCounters(ctx, total, 1, &host));
   *out = static_cast<int64_t>(host);
   return AMDARROW_OK;
 }
@@ -525,17 +525,18 @@ int amdarrow_take(amdarrow_ctx* ctx, const amdarrow_array* values, const amdarro
 
   std::lock_guard<std::mutex> lock(ctx->mu);
   void* base;
-  AA_TRY(Scratch(ctx, 256, &base));
-  auto* counters = static_cast<unsigned long long*>(base);
-  AA_HIP(hipMemsetAsync(counters, 0, 8, ctx->stream));
-  AA_HIP(hipMemsetAsync(counters + 1, 0xFF, 8, ctx->stream));
+  AA_TRY(Scratch(ctx, kCounterBytes + 256, &base));
+  auto* counters = static_cast<unsigned long long*>(base);                    // valid rows, slotted
+  auto* err_pos = counters + kCounterSlots * kCounterStride;                  // first out-of-bounds position (atomicMin: rare)
+  AA_TRY(ClearCounters(ctx, counters));
+  AA_HIP(hipMemsetAsync(err_pos, 0xFF, 8, ctx->stream));
   TakeArgs a{};
   a.v_data = values->values; a.v_valid = values->validity; a.v_off = values->offset; a.v_len = values->length;
   a.v_may_null = ArgNullCount(values) != 0;
   a.i_data = indices->values; a.i_valid = indices->validity; a.i_off = indices->offset; a.n = indices->length;
   a.boundscheck = boundscheck;
   a.out_values = out_values; a.out_validity = out_validity;
-  a.valid_count = counters; a.err_pos = counters + 1;
+  a.valid_count = counters; a.err_pos = err_pos;
   const int grid = GridFor(a.n, kThreads, ctx->num_cus * 8);
   const int iw = BitWidth(it) / 8;
   const bool sgn = IsSignedInt(it);
@@ -560,7 +561,9 @@ int amdarrow_take(amdarrow_ctx* ctx, const amdarrow_array* values, const amdarro
 #undef AA_TAKE
   AA_HIP(hipGetLastError());
   unsigned long long host[2];
-  AA_TRY(ReadBack(ctx, counters, 16, host));
+  AA_HIP(hipMemcpyAsync(static_cast<char*>(ctx->pinned) + kStatusOffset, err_pos, 8, hipMemcpyDeviceToHost, ctx->stream));
+  AA_TRY(ReadCounters(ctx, counters, 1, host));  // synchronises the stream: the err_pos copy above has landed too
+  memcpy(&host[1], static_cast<const char*>(ctx->pinned) + kStatusOffset, 8);
   if (boundscheck && host[1] != ~0ull) {
     // Report the first offending index, as CheckIndexBounds does (util/int_util.cc:553-561)
     unsigned char raw[8] = {0};

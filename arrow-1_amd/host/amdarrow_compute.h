@@ -530,6 +530,9 @@ void RegisterVectorSelection(FunctionRegistry* registry);  // array_filter, filt
 void RegisterVectorSort(FunctionRegistry* registry);       // array_sort_indices, sort_indices
 void RegisterScalarComparison(FunctionRegistry* registry); // equal ... less_equal
 void RegisterScalarArithmetic(FunctionRegistry* registry); // add ... divide(_checked)
+void RegisterScalarBoolean(FunctionRegistry* registry);    // invert, and, and_not, or, xor, *_kleene
+void RegisterScalarValidity(FunctionRegistry* registry);   // is_valid, is_null, is_nan
+void RegisterScalarFillNull(FunctionRegistry* registry);   // fill_null
 void RegisterHashAggregateBasic(FunctionRegistry* registry);  // hash_count, hash_sum, hash_mean
 
 // Grouper / GroupBy (api_aggregate.h:313-403)

@@ -498,6 +498,9 @@ FunctionRegistry* GetFunctionRegistry() {  // registry.cc:115-150, hot-path subs
     auto r = FunctionRegistry::Make();
     internal::RegisterScalarArithmetic(r.get());
     internal::RegisterScalarComparison(r.get());
+    internal::RegisterScalarBoolean(r.get());
+    internal::RegisterScalarValidity(r.get());
+    internal::RegisterScalarFillNull(r.get());
     internal::RegisterVectorSelection(r.get());
     internal::RegisterVectorSort(r.get());
     internal::RegisterHashAggregateBasic(r.get());

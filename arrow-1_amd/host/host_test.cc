@@ -129,7 +129,9 @@ static int RunCpu() {
     FunctionRegistry* dev = GetFunctionRegistry();
     for (const char* n : {"filter", "array_filter", "take", "array_take", "sort_indices", "array_sort_indices", "equal", "not_equal",
                           "greater", "greater_equal", "less", "less_equal", "add", "subtract", "multiply", "divide", "add_checked",
-                          "subtract_checked", "multiply_checked", "divide_checked", "hash_sum", "hash_count", "hash_mean"})
+                          "subtract_checked", "multiply_checked", "divide_checked", "hash_sum", "hash_count", "hash_mean",
+                          "invert", "and", "and_not", "or", "xor", "and_kleene", "and_not_kleene", "or_kleene", "is_valid",
+                          "is_null", "is_nan", "fill_null"})
       CHECK(dev->GetFunction(n).ok());
     auto f = dev->GetFunction("hash_sum");
     CHECK((*f)->kind() == Function::HASH_AGGREGATE && (*f)->arity().num_args == 3);
@@ -406,6 +408,82 @@ static int RunGpu() {
       auto i2 = (*g)->Consume(*b2);
       CHECK_OK(i2.status());
       if (i2.ok()) CHECK(Same(Host<uint32_t>(pool, *i2->array()), {V(uint32_t, 2), V(uint32_t, 2)}));
+    }
+  }
+  {  // mask-building scalars: scalar_boolean_test.cc:58-155, scalar_validity_test.cc, scalar_fill_null_test.cc
+    auto left = DevBool(pool, {1, 1, 1, 0, 0, -1}), right = DevBool(pool, {1, 0, -1, 0, -1, -1});
+    struct BC { const char* name; std::vector<int> want; };
+    for (const BC& c : {BC{"and", {1, 0, -1, 0, -1, -1}}, BC{"or", {1, 1, -1, 0, -1, -1}}, BC{"xor", {0, 1, -1, 0, -1, -1}},
+                        BC{"and_kleene", {1, 0, -1, 0, 0, -1}}, BC{"or_kleene", {1, 1, 1, 0, -1, -1}}}) {
+      auto r = CallFunction(c.name, {Datum(left), Datum(right)}, &ctx);
+      CHECK_OK(r.status());
+      if (r.ok()) CHECK(HostBool(pool, *r->array()) == c.want);
+    }
+    auto inv = CallFunction("invert", {Datum(DevBool(pool, {1, 0, 1, -1, 0, 1, 0, -1}))}, &ctx);
+    CHECK_OK(inv.status());
+    if (inv.ok()) CHECK(HostBool(pool, *inv->array()) == std::vector<int>({0, 1, 0, -1, 1, 0, 1, -1}));
+    auto l9 = DevBool(pool, {1, 1, 1, 0, 0, 0, -1, -1, -1}), r9 = DevBool(pool, {1, 0, -1, 1, 0, -1, 1, 0, -1});
+    auto an = CallFunction("and_not", {Datum(l9), Datum(r9)}, &ctx);
+    CHECK_OK(an.status());
+    if (an.ok()) CHECK(HostBool(pool, *an->array()) == std::vector<int>({0, 1, -1, 0, 0, -1, -1, -1, -1}));
+    auto ank = CallFunction("and_not_kleene", {Datum(l9), Datum(r9)}, &ctx);
+    CHECK_OK(ank.status());
+    if (ank.ok()) CHECK(HostBool(pool, *ank->array()) == std::vector<int>({0, 1, -1, 0, 0, 0, 0, -1, -1}));
+    // a null scalar: Kleene logic keeps what the array decides alone (:178-190); "and" nulls everything
+    auto null_scalar = Datum(Scalar::MakeNull(boolean()));
+    auto ks = CallFunction("and_kleene", {Datum(left), null_scalar}, &ctx);
+    CHECK_OK(ks.status());
+    if (ks.ok()) CHECK(HostBool(pool, *ks->array()) == std::vector<int>({-1, -1, -1, 0, 0, -1}));
+    auto ps = CallFunction("and", {Datum(left), null_scalar}, &ctx);
+    CHECK_OK(ps.status());
+    if (ps.ok()) CHECK(HostBool(pool, *ps->array()) == std::vector<int>({-1, -1, -1, -1, -1, -1}));
+    auto no_nulls = CallFunction("or_kleene", {Datum(DevBool(pool, {1, 1, 0, 0})), Datum(DevBool(pool, {1, 0, 0, 1}))}, &ctx);
+    CHECK_OK(no_nulls.status());
+    if (no_nulls.ok()) CHECK(no_nulls->array()->buffers[0] == nullptr && HostBool(pool, *no_nulls->array()) == std::vector<int>({1, 1, 0, 1}));
+    CHECK(CallFunction("and", {Datum(left), Datum(Dev<int32_t>(pool, int32(), {V(int32_t, 1)}))}, &ctx).status().IsNotImplemented());
+    // is_valid / is_null / is_nan
+    auto v4 = Dev<int32_t>(pool, int32(), {N(int32_t), V(int32_t, 1), V(int32_t, 0), N(int32_t)});
+    auto iv = CallFunction("is_valid", {Datum(v4)}, &ctx);
+    CHECK_OK(iv.status());
+    if (iv.ok()) CHECK(iv->array()->buffers[0] == nullptr && HostBool(pool, *iv->array()) == std::vector<int>({0, 1, 1, 0}));
+    auto in = CallFunction("is_null", {Datum(v4)}, &ctx);
+    CHECK_OK(in.status());
+    if (in.ok()) CHECK(in->array()->null_count == 0 && HostBool(pool, *in->array()) == std::vector<int>({1, 0, 0, 1}));
+    const double nan = std::nan("");
+    auto nn = CallFunction("is_nan", {Datum(Dev<double>(pool, float64(), {V(double, 0.0), V(double, nan), V(double, 2.0), V(double, nan), V(double, 4.0), N(double)}))}, &ctx);
+    CHECK_OK(nn.status());
+    if (nn.ok()) CHECK(HostBool(pool, *nn->array()) == std::vector<int>({0, 1, 0, 1, 0, -1}));
+    CHECK(CallFunction("is_nan", {Datum(v4)}, &ctx).status().IsNotImplemented());
+    // fill_null
+    auto f5 = CallFunction("fill_null", {Datum(Dev<int32_t>(pool, int32(), {N(int32_t), V(int32_t, 4), N(int32_t), V(int32_t, 8)})),
+                                         Datum(Scalar::Make(int32(), int32_t(5)))}, &ctx);
+    CHECK_OK(f5.status());
+    if (f5.ok()) {
+      CHECK(f5->array()->null_count == 0 && f5->array()->buffers[0] == nullptr);  // FillNullSetsZeroNullCount :175-183
+      CHECK(Same(Host<int32_t>(pool, *f5->array()), {V(int32_t, 5), V(int32_t, 4), V(int32_t, 5), V(int32_t, 8)}));
+    }
+    auto fb = CallFunction("fill_null", {Datum(DevBool(pool, {1, -1, 0, -1})), Datum(Scalar::Make(boolean(), uint8_t(1)))}, &ctx);
+    CHECK_OK(fb.status());
+    if (fb.ok()) CHECK(HostBool(pool, *fb->array()) == std::vector<int>({1, 1, 0, 1}));
+    auto fn = CallFunction("fill_null", {Datum(Dev<int8_t>(pool, int8(), {V(int8_t, 1), N(int8_t), V(int8_t, 3), V(int8_t, 2)})),
+                                         Datum(Scalar::MakeNull(int8()))}, &ctx);
+    CHECK_OK(fn.status());
+    if (fn.ok()) CHECK(Same(Host<int8_t>(pool, *fn->array()), {V(int8_t, 1), N(int8_t), V(int8_t, 3), V(int8_t, 2)}));  // FillNullInvalidScalar :73-78
+    // the predicate pipeline these kernels exist for: filter(x, and_kleene(greater(x, 1), is_valid(y)))
+    auto x = Dev<int32_t>(pool, int32(), {V(int32_t, 0), V(int32_t, 2), V(int32_t, 3), N(int32_t), V(int32_t, 5)});
+    auto y = Dev<int32_t>(pool, int32(), {V(int32_t, 1), N(int32_t), V(int32_t, 1), V(int32_t, 1), V(int32_t, 1)});
+    auto gt = Compare(Datum(x), Datum(Scalar::Make(int32(), int32_t(1))), GREATER, &ctx);
+    CHECK_OK(gt.status());
+    auto yv = CallFunction("is_valid", {Datum(y)}, &ctx);
+    CHECK_OK(yv.status());
+    if (gt.ok() && yv.ok()) {
+      auto m = CallFunction("and_kleene", {Datum(*gt), Datum(*yv)}, &ctx);
+      CHECK_OK(m.status());
+      if (m.ok()) {
+        auto fr = Filter(Datum(x), *m, FilterOptions::Defaults(), &ctx);
+        CHECK_OK(fr.status());
+        if (fr.ok()) CHECK(Same(Host<int32_t>(pool, *fr->array()), {V(int32_t, 3), V(int32_t, 5)}));
+      }
     }
   }
   CHECK(pool->bytes_allocated() >= 0 && pool->max_memory() > 0);  // the MemoryPool counters (memory_pool.h:38-105)

@@ -147,6 +147,66 @@ Status ExecArith(KernelContext* ctx, const ExecBatch& batch, Datum* out) {
   return Status::OK();
 }
 
+// ---- mask-building scalars: scalar_boolean.cc / scalar_validity.cc / scalar_fill_null.cc ----
+int ScalarState(const Scalar& s) {
+  return !s.is_valid ? AMDARROW_SCALAR_NULL : (s.bits & 0xFF) ? AMDARROW_SCALAR_TRUE : AMDARROW_SCALAR_FALSE;
+}
+template <int kOp>
+Status ExecBoolean(KernelContext* ctx, const ExecBatch& batch, Datum* out) {
+  amdarrow_array l{}, r{};
+  const amdarrow_array* lp = nullptr;
+  const amdarrow_array* rp = nullptr;
+  int ls = AMDARROW_SCALAR_NONE, rs = AMDARROW_SCALAR_NONE;
+  int64_t length = 0;
+  if (batch[0].is_array()) { l = batch[0].array()->abi(); lp = &l; length = l.length; }
+  else ls = ScalarState(*batch[0].scalar());
+  if (kOp != AMDARROW_INVERT) {
+    if (batch[1].is_array()) { r = batch[1].array()->abi(); rp = &r; length = r.length; }
+    else rs = ScalarState(*batch[1].scalar());
+  }
+  AMD_ASSIGN_OR_RAISE(auto vbuf, ctx->AllocateBitmap(length));
+  AMD_ASSIGN_OR_RAISE(auto nbuf, ctx->AllocateBitmap(length));
+  amdarrow_out o;
+  const int rc = amdarrow_boolean(ctx->abi(), kOp, lp, ls, rp, rs, vbuf->mutable_data(), nbuf->mutable_data(), &o);
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  // the Kleene kernels drop the validity buffer where no slot can be null (scalar_boolean.cc:205-209 etc.)
+  *out = Datum(ArrayData::Make(boolean(), o.length, {o.has_validity ? nbuf : nullptr, vbuf}, o.null_count));
+  return Status::OK();
+}
+template <int kFunc>
+Status ExecValidityTest(KernelContext* ctx, const ExecBatch& batch, Datum* out) {
+  amdarrow_array a = batch[0].array()->abi();
+  AMD_ASSIGN_OR_RAISE(auto vbuf, ctx->AllocateBitmap(a.length));
+  amdarrow_out o;
+  const int rc = amdarrow_validity_test(ctx->abi(), kFunc, &a, vbuf->mutable_data(), &o);
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  *out = Datum(ArrayData::Make(boolean(), o.length, {nullptr, vbuf}, 0));  // OUTPUT_NOT_NULL (scalar_validity.cc:100)
+  return Status::OK();
+}
+Status ExecIsNan(KernelContext* ctx, const ExecBatch& batch, Datum* out) {
+  amdarrow_array a = batch[0].array()->abi();
+  AMD_ASSIGN_OR_RAISE(auto vbuf, ctx->AllocateBitmap(a.length));
+  AMD_ASSIGN_OR_RAISE(auto nbuf, ctx->AllocateBitmap(a.length));
+  amdarrow_out o;
+  const int rc = amdarrow_is_nan(ctx->abi(), &a, vbuf->mutable_data(), nbuf->mutable_data(), &o);
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  *out = Datum(ArrayData::Make(boolean(), o.length, {nbuf, vbuf}, o.null_count));
+  return Status::OK();
+}
+Status ExecFillNull(KernelContext* ctx, const ExecBatch& batch, Datum* out) {
+  const ArrayData& values = *batch[0].array();
+  const Scalar& fill = *batch[1].scalar();
+  amdarrow_array a = values.abi();
+  AMD_ASSIGN_OR_RAISE(auto vbuf, ctx->Allocate(ValueBytes(*values.type, a.length)));
+  AMD_ASSIGN_OR_RAISE(auto nbuf, ctx->AllocateBitmap(a.length));
+  amdarrow_out o;
+  const int rc = amdarrow_fill_null(ctx->abi(), &a, fill.is_valid ? &fill.bits : nullptr, vbuf->mutable_data(),
+                                    nbuf->mutable_data(), &o);
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  *out = Datum(ArrayData::Make(values.type, o.length, {o.has_validity ? nbuf : nullptr, vbuf}, o.null_count));
+  return Status::OK();
+}
+
 // ---- meta functions ------------------------------------------------------------------------------------
 // FilterMetaFunction (vector_selection.cc:1877-1903): array / chunked values with an array / chunked
 // boolean filter go to "array_filter" (chunk-wise through the executor); batches and tables are
@@ -380,6 +440,72 @@ void RegisterScalarArithmetic(FunctionRegistry* registry) {
   static const char* names[] = {"add", "subtract", "multiply", "divide",
                                 "add_checked", "subtract_checked", "multiply_checked", "divide_checked"};
   AddBinaryFunctions(registry, names, 8, false, [](int op) { return PickArith<0, 1, 2, 3, 4, 5, 6, 7>(op); });
+}
+
+template <int... kOps>
+ArrayKernelExec PickBoolean(int op) {
+  static const ArrayKernelExec table[] = {ExecBoolean<kOps>...};
+  return table[op];
+}
+// scalar_boolean.cc:521-542: invert, and, and_not, or, xor (INTERSECTION) and the Kleene variants
+// (COMPUTED_PREALLOCATE, cannot write into slices)
+void RegisterScalarBoolean(FunctionRegistry* registry) {
+  static const char* names[] = {"invert", "and", "and_not", "or", "xor", "and_kleene", "and_not_kleene", "or_kleene"};
+  for (int op = 0; op < 8; ++op) {
+    const int arity = op == AMDARROW_INVERT ? 1 : 2;
+    auto func = std::make_shared<ScalarFunction>(names[op], arity == 1 ? Arity::Unary() : Arity::Binary());
+    ScalarKernel k;
+    k.signature.in_types = std::vector<InputType>(arity, InputType::Exact(Type::BOOL));
+    k.signature.out_type = FixedOut(boolean());
+    k.exec = PickBoolean<0, 1, 2, 3, 4, 5, 6, 7>(op);
+    k.can_write_into_slices = false;
+    if (op >= AMDARROW_AND_KLEENE) k.null_handling = NullHandling::COMPUTED_PREALLOCATE;
+    (void)func->AddKernel(std::move(k));
+    (void)registry->AddFunction(std::move(func));
+  }
+}
+// scalar_validity.cc:171-182: is_valid / is_null over ANY type, is_nan over float32 / float64
+void RegisterScalarValidity(FunctionRegistry* registry) {
+  struct Def { const char* name; ArrayKernelExec exec; };
+  const Def defs[] = {{"is_valid", ExecValidityTest<0>}, {"is_null", ExecValidityTest<1>}};
+  for (const auto& d : defs) {
+    auto func = std::make_shared<ScalarFunction>(d.name, Arity::Unary());
+    ScalarKernel k;
+    k.signature.in_types = {InputType::Any()};
+    k.signature.out_type = FixedOut(boolean());
+    k.exec = d.exec;
+    k.null_handling = NullHandling::OUTPUT_NOT_NULL;
+    k.can_write_into_slices = false;
+    (void)func->AddKernel(std::move(k));
+    (void)registry->AddFunction(std::move(func));
+  }
+  auto func = std::make_shared<ScalarFunction>("is_nan", Arity::Unary());
+  for (Type::type t : {Type::FLOAT, Type::DOUBLE}) {
+    ScalarKernel k;
+    k.signature.in_types = {InputType::Exact(t)};
+    k.signature.out_type = FixedOut(boolean());
+    k.exec = ExecIsNan;
+    k.can_write_into_slices = false;
+    (void)func->AddKernel(std::move(k));
+  }
+  (void)registry->AddFunction(std::move(func));
+}
+// scalar_fill_null.cc:229-240: {Array(ty), Scalar(ty)} -> ty for numeric and boolean types
+void RegisterScalarFillNull(FunctionRegistry* registry) {
+  auto func = std::make_shared<ScalarFunction>("fill_null", Arity::Binary());
+  auto add = [&](Type::type t) {
+    ScalarKernel k;
+    k.signature.in_types = {InputType::Exact(t, ValueDescr::ARRAY), InputType::Exact(t, ValueDescr::SCALAR)};
+    k.signature.out_type = FirstArgOut();
+    k.exec = ExecFillNull;
+    k.null_handling = NullHandling::COMPUTED_NO_PREALLOCATE;
+    k.mem_allocation = MemAllocation::NO_PREALLOCATE;
+    k.can_write_into_slices = false;
+    (void)func->AddKernel(std::move(k));
+  };
+  for (Type::type t : kNumeric) add(t);
+  add(Type::BOOL);
+  (void)registry->AddFunction(std::move(func));
 }
 
 void RegisterHashAggregateBasic(FunctionRegistry* registry) {

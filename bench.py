@@ -46,6 +46,7 @@ WORKLOADS = {
     "sort_f64": "sort_indices float64 U[0,1) + 0.1% NaN + 1% null",
     "hash_agg_f64": "GroupBy sum/count over float64 (p_null .01), 1M int32 keys",
     "compare_i64": "greater(int64 array, int64 array)",
+    "mask_and_kleene": "and_kleene(boolean + validity, boolean + validity): the mask-building step of a predicate",
 }
 
 
@@ -92,6 +93,9 @@ def make_inputs(workload, n, dev, rank, sel):
         d["values"] = device.DeviceArray(_abi.DOUBLE, vals.view(torch.uint8), device_bitmap(n, 0.99, gen, dev), n, 0, -1)
         d["keys"] = device.DeviceArray(_abi.INT32, keys.view(torch.uint8), None, n)
         d["_keep"] = (vals, keys)
+    elif workload == "mask_and_kleene":
+        d["a"] = device.DeviceArray(_abi.BOOL, device_bitmap(n, 0.5, gen, dev), device_bitmap(n, 0.95, gen, dev), n, 0, -1)
+        d["b"] = device.DeviceArray(_abi.BOOL, device_bitmap(n, 0.5, gen, dev), device_bitmap(n, 0.95, gen, dev), n, 0, -1)
     elif workload == "compare_i64":
         a = torch.randint(-100, 101, (n,), dtype=torch.int64, device=dev, generator=gen)
         b = torch.randint(-100, 101, (n,), dtype=torch.int64, device=dev, generator=gen)
@@ -105,7 +109,8 @@ def make_inputs(workload, n, dev, rank, sel):
 
 def bytes_per_row(workload, sel):
     return {"filter_groupby_sum_i64": 12.125, "filter_i64": 8.25 + 8.125 * sel, "take_i64": 20.25 * sel,
-            "take_random_i64": 20.25 * sel, "sort_u64": 16.0, "sort_f64": 16.0, "hash_agg_f64": 12.125, "compare_i64": 16.25}[workload]
+            "take_random_i64": 20.25 * sel, "sort_u64": 16.0, "sort_f64": 16.0, "hash_agg_f64": 12.125, "compare_i64": 16.25,
+            "mask_and_kleene": 0.75}[workload]  # 2 x (data + validity) bits in, data + validity bits out
 
 
 def make_step(workload, ctx, inp, sel, world, rank):
@@ -144,6 +149,8 @@ def make_step(workload, ctx, inp, sel, world, rank):
         return lambda: compute.sort_indices(ctx, chunks)
     if workload == "compare_i64":
         return lambda: compute.compare(ctx, _abi.GT, inp["a"], inp["b"])
+    if workload == "mask_and_kleene":
+        return lambda: compute.boolean(ctx, _abi.AND_KLEENE, inp["a"], inp["b"])
     raise SystemExit("unknown workload " + workload)
 
 
@@ -197,6 +204,11 @@ def cpu_baseline(workload, sel):
         vals = nullable(orc.DOUBLE, data, 0.01)
         call = lambda: api.sort_indices([vals])  # noqa: E731
         what = "sort_indices float64 (0.1% NaN, 1% null)"
+    elif workload == "mask_and_kleene":
+        a = orc.Arr(orc.BOOL, rng.random(n) < .5, rng.random(n) < .95)
+        b = orc.Arr(orc.BOOL, rng.random(n) < .5, rng.random(n) < .95)
+        call = lambda: api.boolean(orc.AND_KLEENE, a, b)  # noqa: E731
+        what = "and_kleene(boolean, boolean), 5% nulls each"
     elif workload == "compare_i64":
         a, b = orc.Arr(orc.INT64, rng.integers(-100, 101, n)), orc.Arr(orc.INT64, rng.integers(-100, 101, n))
         call = lambda: api.compare(orc.GT, a, b)  # noqa: E731
@@ -304,7 +316,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"filter_groupby_sum_i64": "int64", "filter_i64": "u64", "take_i64": "u64",
                                             "take_random_i64": "u64", "sort_u64": "u64", "sort_f64": "f64", "hash_agg_f64": "f64",
-                                            "compare_i64": "int64"}[args.workload],
+                                            "compare_i64": "int64", "mask_and_kleene": "u64"}[args.workload],
             "data": "synthetic (device-generated, seed 0x0ff1ce + rank; HBM-resident before timing)",
             "config": {"workload": args.workload + ": " + WORKLOADS[args.workload], "rows_per_gpu": n,
                        "selectivity": sel, "groups": NUM_GROUPS, "sharding": "row-range, %d shard(s)" % world},

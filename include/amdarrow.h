@@ -188,6 +188,37 @@ int amdarrow_hash_finalize(amdarrow_ctx* ctx, int func, int value_type_id, int64
                            void* sums, const int64_t* counts, uint8_t* out_validity,
                            amdarrow_out* out);
 
+/* ---- mask-building scalars ------------------------------------------------------------
+ * Boolean kernels: compute/kernels/scalar_boolean.cc:30-566 (registered :521-542 as "invert", "and",
+ * "and_not", "or", "xor", "and_kleene", "and_not_kleene", "or_kleene").  Operand i is a boolean
+ * array or a scalar given by its state; at least one is an array; AMDARROW_INVERT ignores the right
+ * operand.  invert..xor: validity / null_count as amdarrow_compare (NullPropagator; a null scalar
+ * makes every slot null and leaves the data bits zero), data bits = the op on the DATA bits of
+ * every slot.  *_kleene: validity computed by the kernel (ComputeKleene :34-91 and the scalar
+ * special cases); out->has_validity = 0 (and out_validity all ones) exactly where the reference
+ * drops the buffer; otherwise out->null_count is exact.  out_bits / out_validity: BytesForBits(n)
+ * rounded up to 8 bytes, both required. */
+enum { AMDARROW_INVERT = 0, AMDARROW_AND, AMDARROW_AND_NOT, AMDARROW_OR, AMDARROW_XOR, AMDARROW_AND_KLEENE,
+       AMDARROW_AND_NOT_KLEENE, AMDARROW_OR_KLEENE };
+enum { AMDARROW_SCALAR_NONE = -1, AMDARROW_SCALAR_FALSE = 0, AMDARROW_SCALAR_TRUE = 1, AMDARROW_SCALAR_NULL = 2 };
+int amdarrow_boolean(amdarrow_ctx* ctx, int op, const amdarrow_array* lhs, int lhs_scalar, const amdarrow_array* rhs,
+                     int rhs_scalar, uint8_t* out_bits, uint8_t* out_validity, amdarrow_out* out);
+
+/* is_valid (func 0) / is_null (func 1): scalar_validity.cc:34-82, any type, result never null
+ * (NullHandling::OUTPUT_NOT_NULL :100); constant when the input cannot have nulls
+ * (ArrayData::MayHaveNulls). */
+int amdarrow_validity_test(amdarrow_ctx* ctx, int func, const amdarrow_array* array, uint8_t* out_bits, amdarrow_out* out);
+/* is_nan: scalar_validity.cc:84-89, 111-126 (float32 / float64; op on every slot, validity by
+ * NullPropagator). */
+int amdarrow_is_nan(amdarrow_ctx* ctx, const amdarrow_array* array, uint8_t* out_bits, uint8_t* out_validity,
+                    amdarrow_out* out);
+/* fill_null(values, scalar): scalar_fill_null.cc:44-147 (numeric and boolean).  fill = one value of
+ * values' type in HOST memory, or NULL for a null scalar.  values may have nulls and fill valid:
+ * null slots take the fill value, no validity, null_count 0; otherwise the result is the input
+ * (validity normalised to bit offset 0, null_count as stored). */
+int amdarrow_fill_null(amdarrow_ctx* ctx, const amdarrow_array* values, const void* fill, void* out_values,
+                       uint8_t* out_validity, amdarrow_out* out);
+
 /* Fused Filter -> GroupBy (BASELINE.json north_star / config 5 on one shard):
  *   Filter(values, mask, DROP), Filter(keys, mask, DROP), GroupBy({values}, {keys},
  *   {hash_sum, hash_count})  (vector_selection.cc:786-835 + hash_aggregate.cc:890-966)

@@ -487,6 +487,9 @@ static void propagate(const orc_array* a, const orc_array* b, int64_t len, uint8
   }
   out->length = len; out->has_validity = 1; /* validity_preallocated_ :690-693 */
   memset(out_validity, 0, bytes_for_bits(len));
+  /* a zero-length call runs no batch: the (empty) result keeps kUnknownNullCount (observed on
+   * the reference build for every INTERSECTION scalar kernel; exec.cc:704-716, :760-768) */
+  if (len == 0) { out->null_count = -1; return; }
   if (all_null) { out->null_count = len; return; }                     /* :326-348 */
   if (nw == 0) {                                                       /* :433-439 */
     out->null_count = 0;
@@ -622,6 +625,181 @@ int orc_arith(int op, const orc_array* lhs, const void* ls, const orc_array* rhs
     default: return fail(ORC_NOT_IMPLEMENTED, "arith: type");
   }
   if (err) return fail(ORC_INVALID, err);
+  return ORC_OK;
+}
+
+/* ---- 8f.1: boolean kernels, scalar_boolean.cc ------------------------------------------ */
+static int64_t exact_null_count(const orc_array* a) { /* ArrayData::GetNullCount */
+  if (!a->validity) return 0;
+  if (a->null_count >= 0) return a->null_count;
+  int64_t n = 0;
+  for (int64_t i = 0; i < a->length; ++i) n += !slot_valid(a, i);
+  return n;
+}
+static void all_valid(uint8_t* v, int64_t n) { for (int64_t i = 0; i < n; ++i) set_bit(v, i); }
+/* finish a Kleene result whose validity bits were computed into out_validity */
+static void kleene_done(int64_t n, const uint8_t* out_validity, orc_out* out) {
+  int64_t nulls = 0;
+  for (int64_t i = 0; i < n; ++i) nulls += !get_bit(out_validity, i);
+  out->has_validity = 1; out->null_count = nulls;
+}
+static void kleene_no_validity(int64_t n, uint8_t* out_validity, orc_out* out) {
+  all_valid(out_validity, n); /* buffers[0] = nullptr, null_count = 0 */
+  out->has_validity = 0; out->null_count = 0;
+}
+int orc_boolean(int op, const orc_array* lhs, int lsc, const orc_array* rhs, int rsc,
+                uint8_t* out_bits, uint8_t* out_validity, orc_out* out) {
+  if (op < ORC_INVERT || op > ORC_OR_KLEENE) return fail(ORC_KEY_ERROR, "boolean: no such function");
+  if (op == ORC_INVERT) { rhs = NULL; rsc = ORC_SCALAR_TRUE; }
+  if (!lhs && !rhs) return fail(ORC_INVALID, "boolean: need at least one array operand");
+  if ((lhs && lhs->type_id != ORC_BOOL) || (rhs && rhs->type_id != ORC_BOOL))
+    return fail(ORC_NOT_IMPLEMENTED, "boolean: operands must be boolean");
+  if (lhs && rhs && lhs->length != rhs->length)
+    return fail(ORC_INVALID, "Array arguments must all be the same length");
+  const int64_t n = lhs ? lhs->length : rhs->length;
+  memset(out_bits, 0, bytes_for_bits(n));
+  if (op <= ORC_XOR) {
+    /* INTERSECTION: a null scalar is NullGeneralization ALL_NULL (exec.cc:258-281) */
+    if ((!lhs && lsc == ORC_SCALAR_NULL) || (op != ORC_INVERT && !rhs && rsc == ORC_SCALAR_NULL)) {
+      out->length = n; out->has_validity = 1; out->null_count = n ? n : -1;
+      memset(out_validity, 0, bytes_for_bits(n));
+      return ORC_OK; /* Op::Call with an invalid scalar writes nothing (:122-130 etc.) */
+    }
+    propagate(lhs, rhs, n, out_validity, out);
+    for (int64_t i = 0; i < n; ++i) { /* the op on the data bits of every slot */
+      const int l = lhs ? bool_at(lhs, i) : lsc, r = rhs ? bool_at(rhs, i) : rsc;
+      int v;
+      switch (op) {
+        case ORC_INVERT: v = !l; break;           /* CopyFromInverted :103-106 */
+        case ORC_AND: v = l & r; break;           /* :132-139 */
+        case ORC_AND_NOT: v = l & !r; break;      /* :357-387 */
+        case ORC_OR: v = l | r; break;            /* :224-231 */
+        default: v = l ^ r; break;                /* :349-356 */
+      }
+      if (v) set_bit(out_bits, i);
+    }
+    return ORC_OK;
+  }
+  /* Kleene: and_not_kleene(x, y) = and_kleene(x, invert y) slot by slot (:389-458) */
+  out->length = n;
+  memset(out_validity, 0, bytes_for_bits(n));
+  if (n == 0) { out->has_validity = 0; out->null_count = 0; return ORC_OK; } /* SimpleBinary returns at once, codegen_internal.h:474 */
+  const int lnulls = lhs ? exact_null_count(lhs) > 0 : lsc == ORC_SCALAR_NULL;
+  const int rnulls = rhs ? exact_null_count(rhs) > 0 : rsc == ORC_SCALAR_NULL;
+  for (int64_t i = 0; i < n; ++i) {
+    int lv = lhs ? slot_valid(lhs, i) : lsc != ORC_SCALAR_NULL, ld = lhs ? bool_at(lhs, i) : lsc == ORC_SCALAR_TRUE;
+    int rv = rhs ? slot_valid(rhs, i) : rsc != ORC_SCALAR_NULL, rd = rhs ? bool_at(rhs, i) : rsc == ORC_SCALAR_TRUE;
+    if (op == ORC_AND_NOT_KLEENE) rd = !rd;
+    const int lt = lv & ld, lf = lv & !ld, rt = rv & rd, rf = rv & !rd;
+    int data, valid;
+    if (op == ORC_OR_KLEENE) { data = lt | rt; valid = lt | rt | (lf & rf); }   /* :311-319 */
+    else { data = lt & rt; valid = lf | rf | (lt & rt); }                      /* :211-217, :447-453 */
+    if (data) set_bit(out_bits, i);
+    if (valid) set_bit(out_validity, i);
+  }
+  /* Where the reference copies the data bitmap instead of computing it (scalar cases) the
+   * copied bits of NULL slots differ from lt&rt; restate those cases literally. */
+  const orc_array* arr = lhs ? lhs : rhs;
+  if (!lhs || !rhs) {
+    int sc = lhs ? rsc : lsc;                       /* the scalar operand */
+    const int scalar_is_left = !lhs;
+    int invert_array = 0;
+    if (op == ORC_AND_NOT_KLEENE) {
+      if (scalar_is_left) invert_array = 1;         /* KleeneAndNot(scalar, array) :396-431 */
+      else if (sc != ORC_SCALAR_NULL) sc = !sc;     /* KleeneAnd(array, InvertScalar) :433-436 */
+    }
+    const int absorbing = op == ORC_OR_KLEENE ? ORC_SCALAR_TRUE : ORC_SCALAR_FALSE;
+    memset(out_bits, 0, bytes_for_bits(n));
+    if (sc == absorbing) {                          /* all false / all true, no validity */
+      if (op == ORC_OR_KLEENE) for (int64_t i = 0; i < n; ++i) set_bit(out_bits, i);
+      kleene_no_validity(n, out_validity, out);
+      return ORC_OK;
+    }
+    for (int64_t i = 0; i < n; ++i)                 /* data = (inverted) copy of the array's data bits */
+      if (bool_at(arr, i) ^ invert_array) set_bit(out_bits, i);
+    if (sc != ORC_SCALAR_NULL) {                    /* neutral scalar: validity = the array's */
+      if (exact_null_count(arr) == 0) { kleene_no_validity(n, out_validity, out); return ORC_OK; }
+      memset(out_validity, 0, bytes_for_bits(n));
+      for (int64_t i = 0; i < n; ++i) if (slot_valid(arr, i)) set_bit(out_validity, i);
+      kleene_done(n, out_validity, out);
+      return ORC_OK;
+    }
+    /* null scalar: valid iff the array slot is valid and decides the result by itself */
+    memset(out_validity, 0, bytes_for_bits(n));
+    for (int64_t i = 0; i < n; ++i) {
+      const int d = bool_at(arr, i) ^ invert_array;  /* and: decides when false; or: when true */
+      const int decides = op == ORC_OR_KLEENE ? d : !d;
+      if (slot_valid(arr, i) && decides) set_bit(out_validity, i);
+    }
+    kleene_done(n, out_validity, out);
+    return ORC_OK;
+  }
+  if (!lnulls && !rnulls) {                         /* plain And/AndNot/Or on the data bits (:205-209) */
+    memset(out_bits, 0, bytes_for_bits(n));
+    for (int64_t i = 0; i < n; ++i) {
+      const int l = bool_at(lhs, i), r = bool_at(rhs, i);
+      const int v = op == ORC_OR_KLEENE ? (l | r) : op == ORC_AND_KLEENE ? (l & r) : (l & !r);
+      if (v) set_bit(out_bits, i);
+    }
+    kleene_no_validity(n, out_validity, out);
+    return ORC_OK;
+  }
+  kleene_done(n, out_validity, out);
+  return ORC_OK;
+}
+
+/* ---- is_valid / is_null / is_nan, scalar_validity.cc ------------------------------------- */
+int orc_validity_test(int func, const orc_array* a, uint8_t* out_bits, orc_out* out) {
+  const int64_t n = a->length;
+  out->length = n; out->has_validity = 0; out->null_count = 0; /* OUTPUT_NOT_NULL :100 */
+  memset(out_bits, 0, bytes_for_bits(n));
+  const int may_have_nulls = a->validity != NULL && a->null_count != 0; /* ArrayData::MayHaveNulls */
+  for (int64_t i = 0; i < n; ++i) {
+    const int valid = may_have_nulls ? slot_valid(a, i) : 1;
+    if (func == 0 ? valid : !valid) set_bit(out_bits, i);
+  }
+  return ORC_OK;
+}
+int orc_is_nan(const orc_array* a, uint8_t* out_bits, uint8_t* out_validity, orc_out* out) {
+  if (a->type_id != ORC_FLOAT && a->type_id != ORC_DOUBLE) return fail(ORC_NOT_IMPLEMENTED, "is_nan: floating point only");
+  const int64_t n = a->length;
+  propagate(a, NULL, n, out_validity, out);
+  memset(out_bits, 0, bytes_for_bits(n));
+  for (int64_t i = 0; i < n; ++i) {
+    const int v = a->type_id == ORC_FLOAT ? isnan(((const float*)a->values)[a->offset + i])
+                                          : isnan(((const double*)a->values)[a->offset + i]);
+    if (v) set_bit(out_bits, i);
+  }
+  return ORC_OK;
+}
+
+/* ---- fill_null, scalar_fill_null.cc:44-147 ---------------------------------------------- */
+int orc_fill_null(const orc_array* a, const void* fill, void* out_values, uint8_t* out_validity, orc_out* out) {
+  const int bw = orc_bit_width(a->type_id);
+  if (bw < 0) return fail(ORC_NOT_IMPLEMENTED, "fill_null: type");
+  const int64_t n = a->length;
+  const int may_have_nulls = a->validity != NULL && a->null_count != 0;
+  out->length = n;
+  memset(out_validity, 0, bytes_for_bits(n));
+  if (bw == 1) memset(out_values, 0, bytes_for_bits(n));
+  if (n == 0) { out->has_validity = 0; out->null_count = 0; return ORC_OK; } /* empty result of a zero-length call */
+  const int replace = may_have_nulls && fill != NULL; /* :55, :107 */
+  for (int64_t i = 0; i < n; ++i) {
+    const int take_fill = replace && !slot_valid(a, i);
+    if (bw == 1) {
+      const int v = take_fill ? (*(const uint8_t*)fill != 0) : bool_at(a, i);
+      if (v) set_bit((uint8_t*)out_values, i);
+    } else {
+      const size_t w = (size_t)bw / 8;
+      memcpy((uint8_t*)out_values + (size_t)i * w,
+             take_fill ? (const uint8_t*)fill : (const uint8_t*)a->values + (size_t)(a->offset + i) * w, w);
+    }
+  }
+  if (replace) { out->has_validity = 0; out->null_count = 0; all_valid(out_validity, n); return ORC_OK; }
+  /* *output = data :84 -- ArrayData::Make drops a validity buffer whose stored count is 0 (array/data.cc:50-60) */
+  out->has_validity = may_have_nulls;
+  out->null_count = may_have_nulls ? a->null_count : 0;
+  for (int64_t i = 0; i < n; ++i) if (!may_have_nulls || slot_valid(a, i)) set_bit(out_validity, i);
   return ORC_OK;
 }
 

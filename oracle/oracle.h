@@ -150,6 +150,40 @@ int orc_arith(int op, const orc_array* lhs, const void* lhs_scalar, const orc_ar
               const void* rhs_scalar, void* out_values, uint8_t* out_validity,
               orc_out* out);
 
+/* ---- mask-building scalars ------------------------------------------------
+ * Boolean kernels, scalar_boolean.cc:30-566.  Operand i is a boolean array (lhs / rhs
+ * non-NULL) or a scalar given by its state (ORC_SCALAR_FALSE / TRUE / NULL); at least one
+ * operand is an array; ORC_INVERT ignores the right operand.
+ *  - invert / and / and_not / or / xor (NullHandling::INTERSECTION, :524-529): validity and
+ *    out->null_count exactly as orc_compare (NullPropagator; a null scalar makes every slot
+ *    null, exec.cc:326-348); the data bits are the op on the DATA bits of every slot
+ *    (a null scalar leaves the zero-filled preallocated bitmap untouched).
+ *  - and_kleene / and_not_kleene / or_kleene (COMPUTED_PREALLOCATE, :531-541): the kernel
+ *    computes validity itself (ComputeKleene :34-91 and the scalar special cases); no
+ *    validity buffer (out->has_validity 0, null_count 0) exactly where the reference drops
+ *    it (both inputs without nulls; false / true scalar cases); otherwise out->null_count is
+ *    the exact number of null slots. */
+enum { ORC_INVERT = 0, ORC_AND, ORC_AND_NOT, ORC_OR, ORC_XOR, ORC_AND_KLEENE, ORC_AND_NOT_KLEENE, ORC_OR_KLEENE };
+enum { ORC_SCALAR_NONE = -1, ORC_SCALAR_FALSE = 0, ORC_SCALAR_TRUE = 1, ORC_SCALAR_NULL = 2 };
+int orc_boolean(int op, const orc_array* lhs, int lhs_scalar, const orc_array* rhs, int rhs_scalar,
+                uint8_t* out_bits, uint8_t* out_validity, orc_out* out);
+
+/* is_valid / is_null, scalar_validity.cc:34-82 (any type; OUTPUT_NOT_NULL): the validity
+ * bitmap (resp. its complement), all true (false) when the input cannot have nulls
+ * (ArrayData::MayHaveNulls: null_count != 0 and a validity buffer).  func 0 = is_valid,
+ * 1 = is_null. */
+int orc_validity_test(int func, const orc_array* a, uint8_t* out_bits, orc_out* out);
+/* is_nan, :84-89,111-126: float32/float64, ScalarUnary over EVERY slot, validity by
+ * NullPropagator as orc_compare with one operand. */
+int orc_is_nan(const orc_array* a, uint8_t* out_bits, uint8_t* out_validity, orc_out* out);
+
+/* fill_null(values, scalar), scalar_fill_null.cc:44-147 (numeric and boolean): when
+ * values may have nulls and the scalar is valid (fill != NULL, one value of values' type)
+ * every null slot takes the scalar and the result has no validity; otherwise the result IS
+ * the input (values and validity normalised to offset 0 here, null_count as stored). */
+int orc_fill_null(const orc_array* values, const void* fill, void* out_values, uint8_t* out_validity,
+                  orc_out* out);
+
 /* Headline composition (BASELINE.json config 5 on one shard): Filter(values, mask) and
  * Filter(keys, mask) with DROP, then GroupBy{hash_sum(values)} by keys
  * (vector_selection.cc:786-835 + hash_aggregate.cc:890-966).  Outputs in group order:

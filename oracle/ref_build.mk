@@ -62,7 +62,8 @@ SRCS := \
   $(A)/compute/kernels/aggregate_basic.cc $(A)/compute/kernels/codegen_internal.cc \
   $(A)/compute/kernels/hash_aggregate.cc $(A)/compute/kernels/scalar_arithmetic.cc \
   $(A)/compute/kernels/scalar_boolean.cc $(A)/compute/kernels/scalar_compare.cc \
-  $(A)/compute/kernels/scalar_validity.cc $(A)/compute/kernels/util_internal.cc \
+  $(A)/compute/kernels/scalar_validity.cc $(A)/compute/kernels/scalar_fill_null.cc \
+  $(A)/compute/kernels/util_internal.cc \
   $(A)/compute/kernels/vector_selection.cc $(A)/compute/kernels/vector_sort.cc \
   $(A)/compute/kernels/scalar_cast_boolean.cc $(A)/compute/kernels/scalar_cast_internal.cc \
   $(A)/compute/kernels/scalar_cast_numeric.cc

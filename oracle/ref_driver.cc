@@ -52,6 +52,7 @@ FunctionRegistry* HotPathRegistry() {
     compute::internal::RegisterScalarComparison(r.get());
     compute::internal::RegisterScalarBoolean(r.get());
     compute::internal::RegisterScalarValidity(r.get());
+    compute::internal::RegisterScalarFillNull(r.get());
     compute::internal::RegisterVectorSelection(r.get());
     compute::internal::RegisterVectorSort(r.get());
     compute::internal::RegisterScalarAggregateBasic(r.get());
@@ -296,6 +297,55 @@ int ref_compare(int op, const orc_array* lhs, const void* ls, const orc_array* r
 int ref_arith(int op, const orc_array* lhs, const void* ls, const orc_array* rhs, const void* rs,
               void* out_values, uint8_t* out_validity, orc_out* out) {
   return Binary(kArithNames[op], lhs, ls, rhs, rs, out_values, out_validity, out);
+}
+
+// ---- mask-building scalars -------------------------------------------------
+static const char* kBoolNames[] = {"invert", "and", "and_not", "or", "xor", "and_kleene", "and_not_kleene", "or_kleene"};
+
+static Datum BoolOperand(const orc_array* a, int state) {
+  if (a) return Datum(Wrap(a));
+  if (state == ORC_SCALAR_NULL) return Datum(std::make_shared<BooleanScalar>());
+  return Datum(std::make_shared<BooleanScalar>(state == ORC_SCALAR_TRUE));
+}
+
+int ref_boolean(int op, const orc_array* lhs, int lsc, const orc_array* rhs, int rsc, uint8_t* out_bits,
+                uint8_t* out_validity, orc_out* out) {
+  std::vector<Datum> args{BoolOperand(lhs, lsc)};
+  if (op != ORC_INVERT) args.push_back(BoolOperand(rhs, rsc));
+  auto res = CallFunction(kBoolNames[op], args, nullptr, Ctx());
+  if (!res.ok()) return Fail(res.status());
+  const ArrayData& d = *res->array();
+  Export(d, out_bits, out_validity, out);
+  if (op >= ORC_AND_KLEENE) {  // the Kleene kernels leave the count unknown: report it exactly
+    out->null_count = d.GetNullCount();
+    if (!out->has_validity)
+      for (int64_t i = 0; i < out->length; ++i) BitUtil::SetBit(out_validity, i);
+  }
+  return 0;
+}
+
+int ref_validity_test(int func, const orc_array* a, uint8_t* out_bits, orc_out* out) {
+  auto res = CallFunction(func == 0 ? "is_valid" : "is_null", {Datum(Wrap(a))}, nullptr, Ctx());
+  if (!res.ok()) return Fail(res.status());
+  Export(*res->array(), out_bits, nullptr, out);
+  return 0;
+}
+
+int ref_is_nan(const orc_array* a, uint8_t* out_bits, uint8_t* out_validity, orc_out* out) {
+  auto res = CallFunction("is_nan", {Datum(Wrap(a))}, nullptr, Ctx());
+  if (!res.ok()) return Fail(res.status());
+  Export(*res->array(), out_bits, out_validity, out);
+  return 0;
+}
+
+int ref_fill_null(const orc_array* a, const void* fill, void* out_values, uint8_t* out_validity, orc_out* out) {
+  Datum scalar = fill ? Datum(WrapScalar(a->type_id, fill)) : Datum(MakeNullScalar(TypeOf(a->type_id)));
+  auto res = CallFunction("fill_null", {Datum(Wrap(a)), scalar}, nullptr, Ctx());
+  if (!res.ok()) return Fail(res.status());
+  Export(*res->array(), out_values, out_validity, out);
+  if (!out->has_validity)
+    for (int64_t i = 0; i < out->length; ++i) BitUtil::SetBit(out_validity, i);
+  return 0;
 }
 
 // Filter(values, mask), Filter(keys, mask), GroupBy({values}, {keys}, {hash_sum})

@@ -94,6 +94,36 @@ def iter_cases():
         k = R(rng, orc.INT32, 3000, 0.05, 0, lo=0, hi=300)
         m = R(rng, BOOL, 3000, 0.0, 0)
         yield ("filter_groupby_sum", {}, [v, k, m])
+    # ---- mask-building scalars (scalar_boolean_test.cc / scalar_validity_test.cc /
+    # scalar_fill_null_test.cc have no randomized array-array tests; same matrix as compare) ----
+    # Kleene kernels with nulls on inputs sliced at a bit offset that is not a multiple of 64
+    # AND longer than 128 rows hit a reference defect (ComputeKleene writes one whole output
+    # word per visited word although Bitmap::VisitWords starts with a partial word,
+    # scalar_boolean.cc:47-60 + util/bitmap.h:167-175): those shapes are left out.
+    for (n, lo, ro) in [(100, 3, 6), (128, 0, 5), (333, 0, 0), (333, 64, 128)]:
+        for (p1, p2) in [(0.0, 0.0), (0.3, 0.0), (0.0, 0.3), (0.3, 0.3), (1.0, 0.2)]:
+            a = R(rng, BOOL, n, p1, lo)
+            b = R(rng, BOOL, n, p2, ro)
+            for op in range(8):
+                yield ("boolean", dict(op=op), [a, b] if op else [a])
+                if op:
+                    for sc in (False, True, None):
+                        yield ("boolean", dict(op=op, rhs_scalar=sc, has_rhs_scalar=True), [a])
+                        yield ("boolean", dict(op=op, lhs_scalar=sc, has_lhs_scalar=True), [b])
+    for t in [BOOL, orc.UINT8, orc.INT32, orc.INT64, orc.DOUBLE]:
+        for null_prob in [0.0, 0.2, 1.0]:
+            for off, nc in [(0, None), (5, None), (5, -1)]:
+                a = R(rng, t, 300, null_prob, off, null_count=nc, force_validity=(nc == -1))
+                yield ("is_valid", {}, [a])
+                yield ("is_null", {}, [a])
+                for fill in ([None, True, False] if t == BOOL else [None, 5]):
+                    yield ("fill_null", dict(fill=fill), [a])
+    for t in [FLOAT, DOUBLE]:
+        for null_prob in [0.0, 0.2]:
+            a = R(rng, t, 300, null_prob, 3)
+            d = a.data.copy()
+            d[::7] = np.nan
+            yield ("is_nan", {}, [Arr(t, d, a.valid, 3, 300)])
 
 
 def run_case(api, op, params, arrs):
@@ -124,6 +154,20 @@ def run_case(api, op, params, arrs):
             return res(api.compare(params["op"], arrs[0], rhs))
         if op == "arith":
             return res(api.arith(params["op"], arrs[0], arrs[1]))
+        if op == "boolean":
+            if params.get("has_lhs_scalar"):
+                return res(api.boolean(params["op"], params["lhs_scalar"], arrs[0]))
+            if params.get("has_rhs_scalar"):
+                return res(api.boolean(params["op"], arrs[0], params["rhs_scalar"]))
+            return res(api.boolean(params["op"], arrs[0], arrs[1] if len(arrs) > 1 else None))
+        if op == "is_valid":
+            return res(api.is_valid(arrs[0]))
+        if op == "is_null":
+            return res(api.is_null(arrs[0]))
+        if op == "is_nan":
+            return res(api.is_nan(arrs[0]))
+        if op == "fill_null":
+            return res(api.fill_null(arrs[0], params["fill"]))
         if op == "filter_groupby_sum":
             s, c, k, kv = api.filter_groupby_sum(*arrs)
             return {"sums": s.view(np.uint8), "counts": c, "keys": k.view(np.uint8), "key_valid": kv}

@@ -66,6 +66,32 @@ class GpuApi:
         f = lambda x: up(x) if isinstance(x, orc.Arr) else x  # noqa: E731
         return self._wrap(lambda: down(compute.arith(self.ctx, op, f(lhs), f(rhs))))
 
+    # ---- mask-building scalars ----
+    @staticmethod
+    def _down_full(d):
+        """like down(), with the validity bits the library wrote even when has_validity == 0"""
+        r = down(d)
+        vb = getattr(d, "validity_buffer", None)
+        if vb is not None:
+            r.validity_bits = vb[:(d.length + 7) // 8].cpu().numpy().copy()
+        return r
+
+    def boolean(self, op, lhs, rhs=None):
+        f = lambda x: up(x) if isinstance(x, orc.Arr) else x  # noqa: E731
+        return self._wrap(lambda: self._down_full(compute.boolean(self.ctx, op, f(lhs), f(rhs))))
+
+    def is_valid(self, a):
+        return self._wrap(lambda: down(compute.is_valid(self.ctx, up(a))))
+
+    def is_null(self, a):
+        return self._wrap(lambda: down(compute.is_null(self.ctx, up(a))))
+
+    def is_nan(self, a):
+        return self._wrap(lambda: self._down_full(compute.is_nan(self.ctx, up(a))))
+
+    def fill_null(self, a, fill):
+        return self._wrap(lambda: self._down_full(compute.fill_null(self.ctx, up(a), fill)))
+
     def group_ids(self, key_batches):
         g = compute.Grouper(self.ctx, [k.type_id for k in key_batches[0]])
         try:

@@ -14,6 +14,8 @@ TYPE_GROUPS = {"numeric": NUMERIC, "integral": INTS, "real": [FLOAT, DOUBLE], "b
                "int64": [orc.INT64], "int32": [orc.INT32]}
 CMP = {"equal": orc.EQ, "not_equal": orc.NE, "greater": orc.GT, "greater_equal": orc.GE, "less": orc.LT,
        "less_equal": orc.LE}
+BOOL_OPS = {"invert": orc.INVERT, "and": orc.AND, "and_not": orc.AND_NOT, "or": orc.OR, "xor": orc.XOR,
+            "and_kleene": orc.AND_KLEENE, "and_not_kleene": orc.AND_NOT_KLEENE, "or_kleene": orc.OR_KLEENE}
 ARITH = {"add": orc.ADD, "subtract": orc.SUB, "multiply": orc.MUL, "divide": orc.DIV, "add_checked": orc.ADD_C,
          "subtract_checked": orc.SUB_C, "multiply_checked": orc.MUL_C, "divide_checked": orc.DIV_C}
 
@@ -178,4 +180,39 @@ def run_all(api, skip_grouper_multi_batch=False):
                         continue
                     r = api.arith(ARITH[opname], lhs, rhs)
                     check("%s t=%d %s %s" % (grp["source"], t, opname, c), logical(r.values, r.validity()), expect(t, c["expected"]))
+    # ---- mask-building scalars ----
+    def lv(r):
+        return logical(r.values, r.validity() if r.has_validity else np.ones(r.length, bool))
+
+    for c in lit.get("boolean", []):
+        op = BOOL_OPS[c["op"]]
+        left = arr(BOOL, c["left"])
+        r = api.boolean(op, left) if op == orc.INVERT else api.boolean(op, left, arr(BOOL, c["right"]))
+        check("%s" % c["source"], lv(r), expect(BOOL, c["expected"]))
+        if c["op"] in lit["boolean_scalar_equivalence"]["ops"]:
+            n = len(c["left"])
+            for sc in (None, True, False):  # CheckBooleanScalarArrayBinary :37-55
+                const = Arr(BOOL, np.full(n, bool(sc)), None if sc is not None else np.zeros(n, bool))
+                check("%s scalar(%s), array" % (c["source"], sc), lv(api.boolean(op, sc, left)), lv(api.boolean(op, const, left)))
+                check("%s array, scalar(%s)" % (c["source"], sc), lv(api.boolean(op, left, sc)), lv(api.boolean(op, left, const)))
+    for grp in lit.get("validity", []):
+        for t in TYPE_GROUPS[grp["types"]]:
+            for c in grp["cases"]:
+                f = api.is_valid if grp["func"] == "is_valid" else api.is_null
+                r = f(arr(t, c["in"]))
+                if r.has_validity or r.null_count != 0:
+                    fails.append("%s: the result must not carry nulls" % grp["source"])
+                check("%s %s" % (grp["source"], c), lv(r), expect(BOOL, c["out"]))
+    if "is_nan" in lit:
+        grp = lit["is_nan"]
+        for t in TYPE_GROUPS[grp["types"]]:
+            for c in grp["cases"]:
+                check("%s t=%d %s" % (grp["source"], t, c), lv(api.is_nan(arr(t, c["in"]))), expect(BOOL, c["out"]))
+    for grp in lit.get("fill_null", []):
+        for t in TYPE_GROUPS[grp["types"]]:
+            for c in grp["cases"]:
+                r = api.fill_null(arr(t, c["in"]), grp["fill"])
+                check("%s t=%d %s" % (grp["source"], t, c), lv(r), expect(t, c["out"]))
+                if grp["fill"] is not None and r.length and (r.has_validity or r.null_count != 0):
+                    fails.append("%s: null_count must be 0 (FillNullSetsZeroNullCount :175-183)" % grp["source"])
     return fails

@@ -21,6 +21,8 @@ INTS = [UINT8, INT8, UINT16, INT16, UINT32, INT32, UINT64, INT64]
 DROP, EMIT_NULL = 0, 1
 ASC, DESC = 0, 1
 EQ, NE, GT, GE, LT, LE = range(6)
+INVERT, AND, AND_NOT, OR, XOR, AND_KLEENE, AND_NOT_KLEENE, OR_KLEENE = range(8)
+SCALAR_NONE, SCALAR_FALSE, SCALAR_TRUE, SCALAR_NULL = -1, 0, 1, 2
 ADD, SUB, MUL, DIV, ADD_C, SUB_C, MUL_C, DIV_C = range(8)
 OK, KEY_ERROR, TYPE_ERROR, INVALID, INDEX_ERROR, NOT_IMPLEMENTED = 0, 2, 3, 4, 7, 10
 
@@ -283,6 +285,60 @@ class Api:
 
     def arith(self, op, lhs, rhs):
         return self._binary("arith", op, lhs, rhs, None)
+
+    # ---- mask-building scalars ----
+    def boolean(self, op, lhs, rhs=None):
+        """lhs / rhs: Arr(BOOL) or a scalar state: False, True or None (= null scalar)."""
+        def operand(x):
+            if isinstance(x, Arr):
+                c = x.c()
+                return C.byref(c), SCALAR_NONE, c
+            return None, (SCALAR_NULL if x is None else int(bool(x))), None
+        arr = lhs if isinstance(lhs, Arr) else rhs
+        n = arr.length
+        la, ls, k1 = operand(lhs)
+        ra, rs, k2 = operand(rhs) if op != INVERT else (None, SCALAR_TRUE, None)
+        ov = np.zeros(n // 8 + 16, np.uint8)
+        ob = np.zeros(n // 8 + 16, np.uint8)
+        out = COut()
+        self._check(self._f("boolean")(op, la, ls, ra, rs, ov.ctypes.data_as(C.c_void_p),
+                                       ob.ctypes.data_as(C.c_void_p), C.byref(out)))
+        return self._result(BOOL, ov, ob, out)
+
+    def _validity_test(self, func, a):
+        ov = np.zeros(a.length // 8 + 16, np.uint8)
+        out = COut()
+        c = a.c()
+        self._check(self._f("validity_test")(func, C.byref(c), ov.ctypes.data_as(C.c_void_p), C.byref(out)))
+        return self._result(BOOL, ov, np.zeros(a.length // 8 + 16, np.uint8), out)
+
+    def is_valid(self, a):
+        return self._validity_test(0, a)
+
+    def is_null(self, a):
+        return self._validity_test(1, a)
+
+    def is_nan(self, a):
+        ov = np.zeros(a.length // 8 + 16, np.uint8)
+        ob = np.zeros(a.length // 8 + 16, np.uint8)
+        out = COut()
+        c = a.c()
+        self._check(self._f("is_nan")(C.byref(c), ov.ctypes.data_as(C.c_void_p), ob.ctypes.data_as(C.c_void_p),
+                                      C.byref(out)))
+        return self._result(BOOL, ov, ob, out)
+
+    def fill_null(self, a, fill):
+        """fill: a python/numpy scalar of a's type, or None for a null scalar."""
+        n = a.length
+        ov = np.zeros((n + 64) * 8 + 16, np.uint8)
+        ob = np.zeros(n // 8 + 16, np.uint8)
+        out = COut()
+        c = a.c()
+        keep = None if fill is None else np.array([fill], dtype=np.uint8 if a.type_id == BOOL else NP_OF[a.type_id])
+        fp = None if fill is None else keep.ctypes.data_as(C.c_void_p)
+        self._check(self._f("fill_null")(C.byref(c), fp, ov.ctypes.data_as(C.c_void_p), ob.ctypes.data_as(C.c_void_p),
+                                         C.byref(out)))
+        return self._result(a.type_id, ov, ob, out)
 
     def filter_groupby_sum(self, values, keys, mask):
         n = values.length

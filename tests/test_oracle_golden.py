@@ -86,3 +86,35 @@ def test_edge_cases(oracle):
     # unchecked add wraps (SafeSignedAdd), int MIN / -1 unchecked -> 0
     assert oracle.arith(orc.ADD, orc.Arr(orc.INT8, [127]), orc.Arr(orc.INT8, [1])).values.tolist() == [-128]
     assert oracle.arith(orc.DIV, orc.Arr(orc.INT8, [-128]), orc.Arr(orc.INT8, [-1])).values.tolist() == [0]
+
+
+def test_mask_scalars_match_live_reference(oracle, reference):
+    """SURVEY 8f.1 kernels (boolean / is_valid / is_null / is_nan / fill_null) on a fresh seed,
+    every operand shape incl. null scalars, unknown null counts and empty inputs.  Kleene
+    kernels with nulls are checked where the reference itself is sound: bit offsets that are
+    multiples of 64 or at most 128 rows (see golden_io.iter_cases)."""
+    rng = np.random.default_rng(20260102)
+    R = orc.random_arr
+    for n, lo, ro in [(0, 0, 0), (1, 2, 1), (77, 3, 9), (128, 5, 0), (500, 0, 0), (500, 64, 192)]:
+        for p1, p2 in [(0, 0), (.3, 0), (0, .3), (.3, .3), (1.0, .3)]:
+            for nc in (None, -1):
+                a = R(rng, orc.BOOL, n, p1, lo, null_count=nc, force_validity=(nc == -1))
+                b = R(rng, orc.BOOL, n, p2, ro, null_count=nc, force_validity=(nc == -1))
+                for op in range(8):
+                    assert oracle.boolean(op, a, b).same(reference.boolean(op, a, b)), (op, n, p1, p2)
+                    for sc in (False, True, None):
+                        assert oracle.boolean(op, a, sc).same(reference.boolean(op, a, sc)), (op, sc)
+                        if op != orc.INVERT:
+                            assert oracle.boolean(op, sc, b).same(reference.boolean(op, sc, b)), (op, sc)
+        for t in [orc.BOOL, orc.INT8, orc.UINT16, orc.INT32, orc.INT64, orc.FLOAT, orc.DOUBLE]:
+            for p in (0, .2, 1.0):
+                v = R(rng, t, n, p, lo)
+                assert oracle.is_valid(v).same(reference.is_valid(v))
+                assert oracle.is_null(v).same(reference.is_null(v))
+                for fill in (None, 1, 0):
+                    assert oracle.fill_null(v, fill).same(reference.fill_null(v, fill)), (t, p, fill)
+                if t in (orc.FLOAT, orc.DOUBLE):
+                    d = v.data.copy()
+                    d[::5] = np.nan
+                    w = orc.Arr(t, d, v.valid, lo, n)
+                    assert oracle.is_nan(w).same(reference.is_nan(w))

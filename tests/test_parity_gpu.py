@@ -492,3 +492,47 @@ def test_filter_groupby_local_path_double_sums(gpu, oracle):
             assert x.shape == y.shape and np.allclose(x, y, rtol=F64_RTOL)
         else:
             assert np.array_equal(x, y)
+
+
+def test_mask_scalars_random(gpu, oracle):
+    """boolean kernels (all eight, array / scalar / null-scalar operands, unknown null
+    counts, ragged lengths around the 64-bit word grid), is_valid / is_null / is_nan, fill_null."""
+    rng = np.random.default_rng(31)
+    for n, lo, ro in [(0, 0, 0), (1, 2, 1), (63, 3, 9), (64, 0, 0), (65, 7, 0), (4097, 5, 13), (100_000, 1, 66)]:
+        for p1, p2 in [(0, 0), (.3, 0), (0, .3), (.3, .3), (1.0, .3)]:
+            for nc in (None, -1):
+                a = R(rng, BOOL, n, p1, lo, null_count=nc, force_validity=(nc == -1))
+                b = R(rng, BOOL, n, p2, ro, null_count=nc, force_validity=(nc == -1))
+                for op in range(8):
+                    assert gpu.boolean(op, a, b).same(oracle.boolean(op, a, b)), (op, n, p1, p2, nc)
+                    for sc in (False, True, None):
+                        assert gpu.boolean(op, a, sc).same(oracle.boolean(op, a, sc)), (op, sc, n, p1)
+                        if op != orc.INVERT:
+                            assert gpu.boolean(op, sc, b).same(oracle.boolean(op, sc, b)), (op, sc, n, p2)
+        for t in [BOOL] + NUMERIC:
+            for p in (0, .2, 1.0):
+                v = R(rng, t, n, p, lo)
+                assert gpu.is_valid(v).same(oracle.is_valid(v))
+                assert gpu.is_null(v).same(oracle.is_null(v))
+                for fill in (None, 1, 0):
+                    assert gpu.fill_null(v, fill).same(oracle.fill_null(v, fill)), (t, n, p, fill)
+                if t in (FLOAT, DOUBLE):
+                    d = v.data.copy()
+                    d[::5] = np.nan
+                    w = Arr(t, d, v.valid, lo, n)
+                    assert gpu.is_nan(w).same(oracle.is_nan(w))
+
+
+def test_mask_scalars_errors(gpu, oracle):
+    a, b = R(np.random.default_rng(1), BOOL, 10, 0, 0), R(np.random.default_rng(2), BOOL, 11, 0, 0)
+    i = R(np.random.default_rng(3), INT32, 10, 0, 0)
+    for api in (gpu, oracle):
+        with pytest.raises(orc.StatusError) as e:
+            api.boolean(orc.AND, a, b)
+        assert e.value.code == 4 and "same length" in e.value.msg
+        with pytest.raises(orc.StatusError) as e:
+            api.boolean(orc.OR_KLEENE, a, i)
+        assert e.value.code == 10
+        with pytest.raises(orc.StatusError) as e:
+            api.is_nan(i)
+        assert e.value.code == 10
