@@ -29,6 +29,10 @@ class COut(C.Structure):
     _fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("has_validity", C.c_int32)]
 
 
+class CAgg(C.Structure):
+    _fields_ = [("valid_count", C.c_int64), ("sum", C.c_uint64), ("min", C.c_uint64), ("max", C.c_uint64)]
+
+
 # every symbol include/amdarrow.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 _A = C.POINTER(CArray)
@@ -61,6 +65,7 @@ SYMBOLS = {
     "amdarrow_validity_test": (C.c_int, [_P, C.c_int, _A, _P, _O]),
     "amdarrow_is_nan": (C.c_int, [_P, _A, _P, _P, _O]),
     "amdarrow_fill_null": (C.c_int, [_P, _A, _P, _P, _P, _O]),
+    "amdarrow_aggregate": (C.c_int, [_P, _A, _P]),
     "amdarrow_grouper_create": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(_P)]),
     "amdarrow_grouper_destroy": (C.c_int, [_P]),
     "amdarrow_grouper_consume": (C.c_int, [_P, _A, _P]),

@@ -187,6 +187,15 @@ def fill_null(ctx, a, fill):
     return _finish(t, out_v, out_b, out)
 
 
+def aggregate(ctx, a):
+    """count / sum / min / max of one array in one pass -- aggregate_basic_internal.h:54-330.
+    -> (valid_count, sum_bits, min_bits, max_bits): 64-bit patterns in the accumulator family."""
+    out = _abi.CAgg()
+    c = a.c()
+    check(ctx.lib, ctx.lib.amdarrow_aggregate(ctx.handle, C.byref(c), C.byref(out)))
+    return out.valid_count, out.sum, out.min, out.max
+
+
 def hash_aggregate(ctx, func, values, ids, num_groups, count_mode=0):
     """One HashAggregateKernel (hash_sum / hash_count / hash_mean) over (values, ids, num_groups).
     `ids`: torch.int32/uint32 tensor on the device."""

@@ -92,7 +92,8 @@ class Result {
 
 // ---- types (arrow/type_fwd.h:277-313; only the primitive types on the path) -------------------------
 struct Type {
-  enum type { NA = 0, BOOL = 1, UINT8, INT8, UINT16, INT16, UINT32, INT32, UINT64, INT64, HALF_FLOAT, FLOAT, DOUBLE };
+  enum type { NA = 0, BOOL = 1, UINT8, INT8, UINT16, INT16, UINT32, INT32, UINT64, INT64, HALF_FLOAT, FLOAT, DOUBLE,
+              STRUCT };  // STRUCT: only as the type of min_max's {min, max} result scalar
 };
 class DataType {
  public:
@@ -116,6 +117,7 @@ std::shared_ptr<DataType> uint64();
 std::shared_ptr<DataType> int64();
 std::shared_ptr<DataType> float32();
 std::shared_ptr<DataType> float64();
+std::shared_ptr<DataType> struct_();  // field list carried by the StructScalar itself
 std::shared_ptr<DataType> TypeFromId(Type::type id);
 bool is_integer(Type::type id);
 bool is_signed_integer(Type::type id);
@@ -190,6 +192,9 @@ struct Scalar {
   std::shared_ptr<DataType> type;
   bool is_valid = true;
   uint64_t bits = 0;  // raw value bits (little endian, low bytes)
+  // StructScalar (scalar.h): min_max returns {min, max}
+  std::vector<std::shared_ptr<Scalar>> fields;
+  std::vector<std::string> field_names;
   template <typename T>
   static std::shared_ptr<Scalar> Make(std::shared_ptr<DataType> t, T v) {
     auto s = std::make_shared<Scalar>();
@@ -289,6 +294,12 @@ struct SortOptions : public FunctionOptions {
   explicit SortOptions(std::vector<SortKey> sort_keys = {}) : sort_keys(std::move(sort_keys)) {}
   static SortOptions Defaults() { return SortOptions(); }
   std::vector<SortKey> sort_keys;
+};
+struct MinMaxOptions : public FunctionOptions {  // api_aggregate.h:78-90
+  enum Mode { SKIP = 0, EMIT_NULL };
+  explicit MinMaxOptions(Mode m = SKIP) : null_handling(m) {}
+  static MinMaxOptions Defaults() { return MinMaxOptions(); }
+  Mode null_handling;
 };
 struct CountOptions : public FunctionOptions {
   enum Mode { COUNT_NON_NULL = 0, COUNT_NULL };
@@ -413,6 +424,13 @@ struct VectorKernel : ArrayKernel {
   bool output_chunked = true;
 };
 struct KernelState { virtual ~KernelState() = default; };
+// ScalarAggregateKernel (kernel.h:634-679): one state per batch, merged into the first, finalized once
+struct ScalarAggregateKernel : Kernel {
+  std::function<Result<std::unique_ptr<KernelState>>(KernelContext*, const std::shared_ptr<DataType>&, const FunctionOptions*)> init;
+  std::function<Status(KernelContext*, KernelState*, const ExecBatch&)> consume;
+  std::function<Status(KernelContext*, KernelState&&, KernelState*)> merge;
+  std::function<Status(KernelContext*, KernelState*, Datum*)> finalize;
+};
 struct HashAggregateKernel : Kernel {  // kernel.h:681-721 (first constructor's order: init, consume, merge, finalize)
   std::function<Result<std::unique_ptr<KernelState>>(KernelContext*, const std::shared_ptr<DataType>&, const FunctionOptions*)> init;
   std::function<Status(KernelContext*, KernelState*, const ExecBatch&)> consume;  // {argument, group ids, num_groups}
@@ -484,6 +502,19 @@ class VectorFunction : public Function {
  private:
   std::vector<VectorKernel> kernels_;
 };
+class ScalarAggregateFunction : public Function {
+ public:
+  ScalarAggregateFunction(std::string name, Arity arity, FunctionDoc doc = {}, const FunctionOptions* default_options = nullptr)
+      : Function(std::move(name), SCALAR_AGGREGATE, arity, std::move(doc), default_options) {}
+  Status AddKernel(ScalarAggregateKernel kernel);
+  int num_kernels() const override { return static_cast<int>(kernels_.size()); }
+  Result<const ScalarAggregateKernel*> DispatchExact(const std::vector<ValueDescr>& values) const;
+  // ScalarAggExecutor (exec.cc:802-903): consume every batch into a fresh state, merge, finalize -> a scalar
+  Result<Datum> Execute(const std::vector<Datum>& args, const FunctionOptions* options, ExecContext* ctx) const override;
+
+ private:
+  std::vector<ScalarAggregateKernel> kernels_;
+};
 class HashAggregateFunction : public Function {
  public:
   HashAggregateFunction(std::string name, Arity arity, FunctionDoc doc = {}, const FunctionOptions* default_options = nullptr)
@@ -533,6 +564,7 @@ void RegisterScalarArithmetic(FunctionRegistry* registry); // add ... divide(_ch
 void RegisterScalarBoolean(FunctionRegistry* registry);    // invert, and, and_not, or, xor, *_kleene
 void RegisterScalarValidity(FunctionRegistry* registry);   // is_valid, is_null, is_nan
 void RegisterScalarFillNull(FunctionRegistry* registry);   // fill_null
+void RegisterScalarAggregateBasic(FunctionRegistry* registry);  // count, sum, mean, min_max
 void RegisterHashAggregateBasic(FunctionRegistry* registry);  // hash_count, hash_sum, hash_mean
 
 // Grouper / GroupBy (api_aggregate.h:313-403)

@@ -36,16 +36,17 @@ int DataType::bit_width() const {
 }
 std::string DataType::ToString() const {
   static const char* names[] = {"null", "bool", "uint8", "int8", "uint16", "int16", "uint32", "int32", "uint64", "int64",
-                                "halffloat", "float", "double"};
+                                "halffloat", "float", "double", "struct"};
   return names[id_];
 }
 std::shared_ptr<DataType> TypeFromId(Type::type id) {
-  static std::shared_ptr<DataType> types[13];
+  static std::shared_ptr<DataType> types[14];
   static std::once_flag once;
-  std::call_once(once, [] { for (int i = 0; i < 13; ++i) types[i] = std::make_shared<DataType>(static_cast<Type::type>(i)); });
+  std::call_once(once, [] { for (int i = 0; i < 14; ++i) types[i] = std::make_shared<DataType>(static_cast<Type::type>(i)); });
   return types[id];
 }
 std::shared_ptr<DataType> boolean() { return TypeFromId(Type::BOOL); }
+std::shared_ptr<DataType> struct_() { return TypeFromId(Type::STRUCT); }
 std::shared_ptr<DataType> uint8() { return TypeFromId(Type::UINT8); }
 std::shared_ptr<DataType> int8() { return TypeFromId(Type::INT8); }
 std::shared_ptr<DataType> uint16() { return TypeFromId(Type::UINT16); }
@@ -370,6 +371,14 @@ Result<const VectorKernel*> VectorFunction::DispatchExact(const std::vector<Valu
   AMD_RETURN_NOT_OK(CheckArity(static_cast<int>(v.size())));
   return Dispatch(name_, kernels_, v);
 }
+Status ScalarAggregateFunction::AddKernel(ScalarAggregateKernel kernel) {
+  kernels_.push_back(std::move(kernel));
+  return Status::OK();
+}
+Result<const ScalarAggregateKernel*> ScalarAggregateFunction::DispatchExact(const std::vector<ValueDescr>& v) const {
+  AMD_RETURN_NOT_OK(CheckArity(static_cast<int>(v.size())));
+  return Dispatch(name_, kernels_, v);
+}
 Result<const HashAggregateKernel*> HashAggregateFunction::DispatchExact(const std::vector<ValueDescr>& v) const {
   AMD_RETURN_NOT_OK(CheckArity(static_cast<int>(v.size())));
   return Dispatch(name_, kernels_, v);
@@ -455,6 +464,31 @@ Result<Datum> VectorFunction::Execute(const std::vector<Datum>& args, const Func
   return WrapResults(args, std::move(outputs), out_type, ctx->memory_pool());
 }
 
+// ScalarAggExecutor (exec.cc:802-903)
+Result<Datum> ScalarAggregateFunction::Execute(const std::vector<Datum>& args, const FunctionOptions* options, ExecContext* ctx) const {
+  AMD_RETURN_NOT_OK(CheckArity(static_cast<int>(args.size())));
+  std::vector<ValueDescr> descrs;
+  for (const auto& a : args) {
+    if (!a.is_arraylike()) return Status::NotImplemented("Unsupported Datum kind for aggregate function " + name_);
+    descrs.push_back(a.descr());
+  }
+  AMD_ASSIGN_OR_RAISE(const ScalarAggregateKernel* kernel, DispatchExact(descrs));
+  KernelContext kctx(ctx);
+  const FunctionOptions* opts = options ? options : default_options_;
+  kctx.SetOptions(opts);
+  AMD_ASSIGN_OR_RAISE(auto state, kernel->init(&kctx, descrs[0].type, opts));
+  AMD_ASSIGN_OR_RAISE(auto it, detail::ExecBatchIterator::Make(args, ctx->exec_chunksize()));
+  ExecBatch batch;
+  while (it->Next(&batch)) {
+    AMD_ASSIGN_OR_RAISE(auto batch_state, kernel->init(&kctx, descrs[0].type, opts));  // :861-866
+    AMD_RETURN_NOT_OK(kernel->consume(&kctx, batch_state.get(), batch));
+    AMD_RETURN_NOT_OK(kernel->merge(&kctx, std::move(*batch_state), state.get()));
+  }
+  Datum out;
+  AMD_RETURN_NOT_OK(kernel->finalize(&kctx, state.get(), &out));
+  return out;
+}
+
 Result<Datum> HashAggregateFunction::Execute(const std::vector<Datum>&, const FunctionOptions*, ExecContext*) const {
   return Status::NotImplemented("Direct execution of HASH_AGGREGATE functions");  // function.cc:193-195
 }
@@ -501,6 +535,7 @@ FunctionRegistry* GetFunctionRegistry() {  // registry.cc:115-150, hot-path subs
     internal::RegisterScalarBoolean(r.get());
     internal::RegisterScalarValidity(r.get());
     internal::RegisterScalarFillNull(r.get());
+    internal::RegisterScalarAggregateBasic(r.get());
     internal::RegisterVectorSelection(r.get());
     internal::RegisterVectorSort(r.get());
     internal::RegisterHashAggregateBasic(r.get());

@@ -131,7 +131,7 @@ static int RunCpu() {
                           "greater", "greater_equal", "less", "less_equal", "add", "subtract", "multiply", "divide", "add_checked",
                           "subtract_checked", "multiply_checked", "divide_checked", "hash_sum", "hash_count", "hash_mean",
                           "invert", "and", "and_not", "or", "xor", "and_kleene", "and_not_kleene", "or_kleene", "is_valid",
-                          "is_null", "is_nan", "fill_null"})
+                          "is_null", "is_nan", "fill_null", "count", "sum", "mean", "min_max"})
       CHECK(dev->GetFunction(n).ok());
     auto f = dev->GetFunction("hash_sum");
     CHECK((*f)->kind() == Function::HASH_AGGREGATE && (*f)->arity().num_args == 3);
@@ -485,6 +485,65 @@ static int RunGpu() {
         if (fr.ok()) CHECK(Same(Host<int32_t>(pool, *fr->array()), {V(int32_t, 3), V(int32_t, 5)}));
       }
     }
+  }
+  {  // scalar aggregates: aggregate_test.cc:178-212 SimpleSum, :399-418 SimpleMean, :334-343 SimpleCount, :556-611 MinMax
+    auto v7 = Dev<int32_t>(pool, int32(), {V(int32_t, 1), N(int32_t), V(int32_t, 3), N(int32_t), V(int32_t, 3), N(int32_t), V(int32_t, 7)});
+    auto sum = CallFunction("sum", {Datum(v7)}, &ctx);
+    CHECK_OK(sum.status());
+    if (sum.ok()) CHECK(sum->is_scalar() && sum->scalar()->is_valid && sum->scalar()->type->id() == Type::INT64 && static_cast<int64_t>(sum->scalar()->bits) == 14);
+    auto chunked = std::make_shared<ChunkedArray>(std::vector<std::shared_ptr<ArrayData>>{Dev<int32_t>(pool, int32(), {V(int32_t, 0), V(int32_t, 1), V(int32_t, 2)}),
+                                                                                          Dev<int32_t>(pool, int32(), {}),
+                                                                                          Dev<int32_t>(pool, int32(), {V(int32_t, 3), V(int32_t, 4), V(int32_t, 5)})}, int32());
+    auto csum = CallFunction("sum", {Datum(chunked)}, &ctx);
+    CHECK_OK(csum.status());
+    if (csum.ok()) CHECK(static_cast<int64_t>(csum->scalar()->bits) == 15);
+    auto nsum = CallFunction("sum", {Datum(Dev<int32_t>(pool, int32(), {N(int32_t)}))}, &ctx);
+    CHECK_OK(nsum.status());
+    if (nsum.ok()) CHECK(!nsum->scalar()->is_valid);  // no valid value -> null (SumImpl::Finalize :80-87)
+    auto fsum = CallFunction("sum", {Datum(Dev<float>(pool, float32(), {V(float, 0.5f), V(float, 1.25f), N(float)}))}, &ctx);
+    CHECK_OK(fsum.status());
+    if (fsum.ok()) { double d; memcpy(&d, &fsum->scalar()->bits, 8); CHECK(fsum->scalar()->type->id() == Type::DOUBLE && d == 1.75); }
+    auto bsum = CallFunction("sum", {Datum(DevBool(pool, {1, 0, 1, 1, -1}))}, &ctx);
+    CHECK_OK(bsum.status());
+    if (bsum.ok()) CHECK(bsum->scalar()->type->id() == Type::UINT64 && bsum->scalar()->bits == 3);
+    auto mean = CallFunction("mean", {Datum(Dev<int8_t>(pool, int8(), {V(int8_t, 1), V(int8_t, 2), V(int8_t, 3), V(int8_t, 4), V(int8_t, 5), V(int8_t, 6), V(int8_t, 7), V(int8_t, 8)}))}, &ctx);
+    CHECK_OK(mean.status());
+    if (mean.ok()) { double d; memcpy(&d, &mean->scalar()->bits, 8); CHECK(d == 4.5); }
+    auto bmean = CallFunction("mean", {Datum(DevBool(pool, {1, -1, 0, 1, 1}))}, &ctx);
+    CHECK_OK(bmean.status());
+    if (bmean.ok()) { double d; memcpy(&d, &bmean->scalar()->bits, 8); CHECK(d == 0.75); }
+    CountOptions count_nulls(CountOptions::COUNT_NULL);
+    auto c1 = CallFunction("count", {Datum(v7)}, &ctx);
+    auto c2 = CallFunction("count", {Datum(v7)}, &count_nulls, &ctx);
+    CHECK_OK(c1.status());
+    CHECK_OK(c2.status());
+    if (c1.ok() && c2.ok()) CHECK(static_cast<int64_t>(c1->scalar()->bits) == 4 && static_cast<int64_t>(c2->scalar()->bits) == 3);
+    // min_max: SKIP / EMIT_NULL, NaN ignored, merged across batches of 2 rows
+    auto f5 = Dev<double>(pool, float64(), {V(double, 5), V(double, std::nan("")), V(double, 2), N(double), V(double, 4)});
+    ctx.set_exec_chunksize(2);
+    auto mm = CallFunction("min_max", {Datum(f5)}, &ctx);
+    ctx.set_exec_chunksize(kDefaultExecChunksize);
+    CHECK_OK(mm.status());
+    if (mm.ok()) {
+      const Scalar& st = *mm->scalar();
+      CHECK(st.type->id() == Type::STRUCT && st.fields.size() == 2 && st.field_names == std::vector<std::string>({"min", "max"}));
+      double mn, mx;
+      memcpy(&mn, &st.fields[0]->bits, 8); memcpy(&mx, &st.fields[1]->bits, 8);
+      CHECK(st.fields[0]->is_valid && mn == 2 && mx == 5);
+    }
+    MinMaxOptions emit(MinMaxOptions::EMIT_NULL);
+    auto mme = CallFunction("min_max", {Datum(f5)}, &emit, &ctx);
+    CHECK_OK(mme.status());
+    if (mme.ok()) CHECK(!mme->scalar()->fields[0]->is_valid && !mme->scalar()->fields[1]->is_valid);
+    auto mi = CallFunction("min_max", {Datum(Dev<int16_t>(pool, int16(), {V(int16_t, 5), V(int16_t, -1), V(int16_t, 2), V(int16_t, 3), V(int16_t, 4)}))}, &ctx);
+    CHECK_OK(mi.status());
+    if (mi.ok()) CHECK(static_cast<int16_t>(mi->scalar()->fields[0]->bits) == -1 && static_cast<int16_t>(mi->scalar()->fields[1]->bits) == 5);
+    auto mb = CallFunction("min_max", {Datum(DevBool(pool, {1, -1, 0, 1}))}, &ctx);
+    CHECK_OK(mb.status());
+    if (mb.ok()) CHECK(mb->scalar()->fields[0]->bits == 0 && mb->scalar()->fields[1]->bits == 1);
+    auto me = CallFunction("min_max", {Datum(Dev<int16_t>(pool, int16(), {}))}, &ctx);
+    CHECK_OK(me.status());
+    if (me.ok()) CHECK(!me->scalar()->fields[0]->is_valid);
   }
   CHECK(pool->bytes_allocated() >= 0 && pool->max_memory() > 0);  // the MemoryPool counters (memory_pool.h:38-105)
   printf("host_test gpu: %d checks, %d failures\n", g_checks, g_failures);

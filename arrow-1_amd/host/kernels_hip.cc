@@ -9,6 +9,8 @@
 
 #include "amdarrow_compute.h"
 
+#include <cmath>
+
 namespace amdarrow {
 namespace compute {
 namespace internal {
@@ -204,6 +206,113 @@ Status ExecFillNull(KernelContext* ctx, const ExecBatch& batch, Datum* out) {
                                     nbuf->mutable_data(), &o);
   if (rc != AMDARROW_OK) return Status::FromAbi(rc);
   *out = Datum(ArrayData::Make(values.type, o.length, {o.has_validity ? nbuf : nullptr, vbuf}, o.null_count));
+  return Status::OK();
+}
+
+// ---- scalar aggregates: aggregate_basic.cc:58-130, aggregate_basic_internal.h:54-330 ----
+// One amdarrow_aggregate call per batch yields everything a Consume of count / sum / mean / min_max needs.
+struct AggState : KernelState {
+  Type::type in_type = Type::NA;
+  int64_t length = 0, valid = 0;  // rows seen, non-null rows
+  uint64_t sum = 0, min = 0, max = 0;
+  bool any = false;               // a batch has been consumed (min / max hold real identities)
+};
+enum AggFamily { kFamUnsigned, kFamSigned, kFamFloat };
+AggFamily FamilyOf(Type::type t) { return is_floating(t) ? kFamFloat : is_signed_integer(t) ? kFamSigned : kFamUnsigned; }
+double AsDouble(uint64_t b) { double d; __builtin_memcpy(&d, &b, 8); return d; }
+uint64_t FromDouble(double d) { uint64_t b; __builtin_memcpy(&b, &d, 8); return b; }
+
+Result<std::unique_ptr<KernelState>> AggInit(KernelContext*, const std::shared_ptr<DataType>& type, const FunctionOptions*) {
+  auto st = std::unique_ptr<AggState>(new AggState());
+  st->in_type = type->id();
+  return std::unique_ptr<KernelState>(std::move(st));
+}
+Status AggConsume(KernelContext* ctx, KernelState* state, const ExecBatch& batch) {
+  auto* st = static_cast<AggState*>(state);
+  amdarrow_array a = batch[0].array()->abi();
+  amdarrow_agg r;
+  const int rc = amdarrow_aggregate(ctx->abi(), &a, &r);
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  st->length = a.length; st->valid = r.valid_count; st->sum = r.sum; st->min = r.min; st->max = r.max; st->any = true;
+  return Status::OK();
+}
+// MergeFrom: SumImpl :73-78 (count, sum +=), MinMaxState::operator+= (:150-157, :173-180, :196-203), CountImpl :69-74
+Status AggMerge(KernelContext*, KernelState&& src, KernelState* dst) {
+  auto& o = static_cast<AggState&>(src);
+  auto* st = static_cast<AggState*>(dst);
+  if (!o.any) return Status::OK();
+  if (!st->any) { const Type::type t = st->in_type; *st = o; st->in_type = t; return Status::OK(); }
+  st->length += o.length;
+  st->valid += o.valid;
+  switch (FamilyOf(st->in_type)) {
+    case kFamFloat:
+      st->sum = FromDouble(AsDouble(st->sum) + AsDouble(o.sum));
+      st->min = FromDouble(std::fmin(AsDouble(st->min), AsDouble(o.min)));
+      st->max = FromDouble(std::fmax(AsDouble(st->max), AsDouble(o.max)));
+      break;
+    case kFamSigned:
+      st->sum += o.sum;
+      st->min = static_cast<uint64_t>(std::min(static_cast<int64_t>(st->min), static_cast<int64_t>(o.min)));
+      st->max = static_cast<uint64_t>(std::max(static_cast<int64_t>(st->max), static_cast<int64_t>(o.max)));
+      break;
+    default:
+      st->sum += o.sum;
+      st->min = std::min(st->min, o.min);
+      st->max = std::max(st->max, o.max);
+      break;
+  }
+  return Status::OK();
+}
+std::shared_ptr<DataType> AccumulatorType(Type::type t) {  // FindAccumulatorType, aggregate_internal.h:29-50
+  return is_floating(t) ? float64() : is_signed_integer(t) ? int64() : uint64();
+}
+Status SumFinalize(KernelContext*, KernelState* state, Datum* out) {  // SumImpl::Finalize :80-87
+  auto* st = static_cast<AggState*>(state);
+  auto type = AccumulatorType(st->in_type);
+  *out = st->valid == 0 ? Datum(Scalar::MakeNull(type)) : Datum(Scalar::Make(type, st->sum));
+  return Status::OK();
+}
+Status MeanFinalize(KernelContext*, KernelState* state, Datum* out) {  // MeanImpl::Finalize :94-102
+  auto* st = static_cast<AggState*>(state);
+  if (st->valid == 0) { *out = Datum(Scalar::MakeNull(float64())); return Status::OK(); }
+  double sum;
+  switch (FamilyOf(st->in_type)) {
+    case kFamFloat: sum = AsDouble(st->sum); break;
+    case kFamSigned: sum = static_cast<double>(static_cast<int64_t>(st->sum)); break;
+    default: sum = static_cast<double>(st->sum); break;
+  }
+  *out = Datum(Scalar::Make(float64(), sum / static_cast<double>(st->valid)));
+  return Status::OK();
+}
+Status CountFinalize(KernelContext* ctx, KernelState* state, Datum* out) {  // CountImpl::Finalize :76-89
+  auto* st = static_cast<AggState*>(state);
+  const auto* opts = static_cast<const CountOptions*>(ctx->options());
+  const bool nulls = opts && opts->count_mode == CountOptions::COUNT_NULL;
+  *out = Datum(Scalar::Make(int64(), nulls ? st->length - st->valid : st->valid));
+  return Status::OK();
+}
+// value bits in the accumulator family -> a scalar of the INPUT type (MinMaxImpl::Finalize :254-267)
+std::shared_ptr<Scalar> NarrowScalar(Type::type t, uint64_t bits) {
+  auto type = TypeFromId(t);
+  if (t == Type::FLOAT) return Scalar::Make(type, static_cast<float>(AsDouble(bits)));
+  if (t == Type::DOUBLE) return Scalar::Make(type, AsDouble(bits));
+  const int bw = type->bit_width();
+  return Scalar::Make(type, bw >= 64 ? bits : (bits & ((uint64_t(1) << (bw == 1 ? 8 : bw)) - 1)));
+}
+Status MinMaxFinalize(KernelContext* ctx, KernelState* state, Datum* out) {
+  auto* st = static_cast<AggState*>(state);
+  const auto* opts = static_cast<const MinMaxOptions*>(ctx->options());
+  const bool emit_null = opts && opts->null_handling == MinMaxOptions::EMIT_NULL;
+  auto s = std::make_shared<Scalar>();
+  s->type = struct_();
+  s->field_names = {"min", "max"};
+  const bool has_nulls = st->length - st->valid > 0;
+  if (st->valid == 0 || (has_nulls && emit_null)) {
+    s->fields = {Scalar::MakeNull(TypeFromId(st->in_type)), Scalar::MakeNull(TypeFromId(st->in_type))};
+  } else {
+    s->fields = {NarrowScalar(st->in_type, st->min), NarrowScalar(st->in_type, st->max)};
+  }
+  *out = Datum(s);
   return Status::OK();
 }
 
@@ -506,6 +615,34 @@ void RegisterScalarFillNull(FunctionRegistry* registry) {
   for (Type::type t : kNumeric) add(t);
   add(Type::BOOL);
   (void)registry->AddFunction(std::move(func));
+}
+
+// aggregate_basic.cc:143-330: count over any type; sum / mean / min_max over boolean and numeric types
+void RegisterScalarAggregateBasic(FunctionRegistry* registry) {
+  static CountOptions count_defaults = CountOptions::Defaults();
+  static MinMaxOptions minmax_defaults = MinMaxOptions::Defaults();
+  struct Def { const char* name; const FunctionOptions* opts; bool any_type; std::function<Status(KernelContext*, KernelState*, Datum*)> finalize; };
+  const Def defs[] = {{"count", &count_defaults, true, CountFinalize}, {"sum", nullptr, false, SumFinalize},
+                      {"mean", nullptr, false, MeanFinalize}, {"min_max", &minmax_defaults, false, MinMaxFinalize}};
+  for (const auto& d : defs) {
+    auto f = std::make_shared<ScalarAggregateFunction>(d.name, Arity::Unary(), FunctionDoc{}, d.opts);
+    auto add = [&](InputType in) {
+      ScalarAggregateKernel k;
+      k.signature.in_types = {std::move(in)};
+      k.init = AggInit;
+      k.consume = AggConsume;
+      k.merge = AggMerge;
+      k.finalize = d.finalize;
+      (void)f->AddKernel(std::move(k));
+    };
+    if (d.any_type) {
+      add(InputType::Primitive());  // the fixed-width types of this backend
+    } else {
+      add(InputType::Exact(Type::BOOL));
+      for (Type::type t : kNumeric) add(InputType::Exact(t));
+    }
+    (void)registry->AddFunction(std::move(f));
+  }
 }
 
 void RegisterHashAggregateBasic(FunctionRegistry* registry) {

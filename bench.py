@@ -46,6 +46,7 @@ WORKLOADS = {
     "sort_f64": "sort_indices float64 U[0,1) + 0.1% NaN + 1% null",
     "hash_agg_f64": "GroupBy sum/count over float64 (p_null .01), 1M int32 keys",
     "compare_i64": "greater(int64 array, int64 array)",
+    "agg_f64": "count + sum + min_max of float64 + validity (one pass feeds the four scalar aggregates)",
     "mask_and_kleene": "and_kleene(boolean + validity, boolean + validity): the mask-building step of a predicate",
 }
 
@@ -93,6 +94,10 @@ def make_inputs(workload, n, dev, rank, sel):
         d["values"] = device.DeviceArray(_abi.DOUBLE, vals.view(torch.uint8), device_bitmap(n, 0.99, gen, dev), n, 0, -1)
         d["keys"] = device.DeviceArray(_abi.INT32, keys.view(torch.uint8), None, n)
         d["_keep"] = (vals, keys)
+    elif workload == "agg_f64":
+        vals = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 1e3
+        d["values"] = device.DeviceArray(_abi.DOUBLE, vals.view(torch.uint8), device_bitmap(n, 0.99, gen, dev), n, 0, -1)
+        d["_keep"] = (vals,)
     elif workload == "mask_and_kleene":
         d["a"] = device.DeviceArray(_abi.BOOL, device_bitmap(n, 0.5, gen, dev), device_bitmap(n, 0.95, gen, dev), n, 0, -1)
         d["b"] = device.DeviceArray(_abi.BOOL, device_bitmap(n, 0.5, gen, dev), device_bitmap(n, 0.95, gen, dev), n, 0, -1)
@@ -110,7 +115,7 @@ def make_inputs(workload, n, dev, rank, sel):
 def bytes_per_row(workload, sel):
     return {"filter_groupby_sum_i64": 12.125, "filter_i64": 8.25 + 8.125 * sel, "take_i64": 20.25 * sel,
             "take_random_i64": 20.25 * sel, "sort_u64": 16.0, "sort_f64": 16.0, "hash_agg_f64": 12.125, "compare_i64": 16.25,
-            "mask_and_kleene": 0.75}[workload]  # 2 x (data + validity) bits in, data + validity bits out
+            "mask_and_kleene": 0.75, "agg_f64": 8.125}[workload]  # 2 x (data + validity) bits in, data + validity bits out
 
 
 def make_step(workload, ctx, inp, sel, world, rank):
@@ -149,6 +154,8 @@ def make_step(workload, ctx, inp, sel, world, rank):
         return lambda: compute.sort_indices(ctx, chunks)
     if workload == "compare_i64":
         return lambda: compute.compare(ctx, _abi.GT, inp["a"], inp["b"])
+    if workload == "agg_f64":
+        return lambda: compute.aggregate(ctx, inp["values"])
     if workload == "mask_and_kleene":
         return lambda: compute.boolean(ctx, _abi.AND_KLEENE, inp["a"], inp["b"])
     raise SystemExit("unknown workload " + workload)
@@ -204,6 +211,10 @@ def cpu_baseline(workload, sel):
         vals = nullable(orc.DOUBLE, data, 0.01)
         call = lambda: api.sort_indices([vals])  # noqa: E731
         what = "sort_indices float64 (0.1% NaN, 1% null)"
+    elif workload == "agg_f64":
+        vals = nullable(orc.DOUBLE, rng.random(n) * 1e3, 0.01)
+        call = lambda: api.aggregate(vals)  # noqa: E731
+        what = "count + sum + min_max of float64 (three CallFunctions on the reference)"
     elif workload == "mask_and_kleene":
         a = orc.Arr(orc.BOOL, rng.random(n) < .5, rng.random(n) < .95)
         b = orc.Arr(orc.BOOL, rng.random(n) < .5, rng.random(n) < .95)
@@ -316,7 +327,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"filter_groupby_sum_i64": "int64", "filter_i64": "u64", "take_i64": "u64",
                                             "take_random_i64": "u64", "sort_u64": "u64", "sort_f64": "f64", "hash_agg_f64": "f64",
-                                            "compare_i64": "int64", "mask_and_kleene": "u64"}[args.workload],
+                                            "compare_i64": "int64", "mask_and_kleene": "u64", "agg_f64": "f64"}[args.workload],
             "data": "synthetic (device-generated, seed 0x0ff1ce + rank; HBM-resident before timing)",
             "config": {"workload": args.workload + ": " + WORKLOADS[args.workload], "rows_per_gpu": n,
                        "selectivity": sel, "groups": NUM_GROUPS, "sharding": "row-range, %d shard(s)" % world},

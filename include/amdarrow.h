@@ -219,6 +219,22 @@ int amdarrow_is_nan(amdarrow_ctx* ctx, const amdarrow_array* array, uint8_t* out
 int amdarrow_fill_null(amdarrow_ctx* ctx, const amdarrow_array* values, const void* fill, void* out_values,
                        uint8_t* out_validity, amdarrow_out* out);
 
+/* ---- scalar aggregates ----------------------------------------------------------------
+ * One Consume of count / sum / mean / min_max over an array: compute/kernels/aggregate_basic.cc:58-130,
+ * aggregate_basic_internal.h:54-330 (CountImpl, SumImpl, MeanImpl, MinMaxImpl, BooleanMinMaxImpl).
+ * valid_count = length - null count; sum / min / max over the valid slots as 64-bit patterns in the
+ * accumulator family of the input type (FindAccumulatorType, aggregate_internal.h:29-50): uint64 for
+ * unsigned and boolean (sum = true count, min / max = 0 / 1), int64 for signed (sums wrap), double
+ * for float32 / float64 (min / max by fmin / fmax: NaN ignored).  No valid slot leaves the identities
+ * (sum 0, min = type max / +inf / true, max = type min / -inf / false); the caller turns that into
+ * the null scalars of SumImpl / MeanImpl / MinMaxImpl::Finalize and applies MinMaxOptions.  `out` is
+ * HOST memory. */
+typedef struct amdarrow_agg {
+  int64_t valid_count;
+  uint64_t sum, min, max;
+} amdarrow_agg;
+int amdarrow_aggregate(amdarrow_ctx* ctx, const amdarrow_array* array, amdarrow_agg* out);
+
 /* Fused Filter -> GroupBy (BASELINE.json north_star / config 5 on one shard):
  *   Filter(values, mask, DROP), Filter(keys, mask, DROP), GroupBy({values}, {keys},
  *   {hash_sum, hash_count})  (vector_selection.cc:786-835 + hash_aggregate.cc:890-966)

@@ -803,6 +803,102 @@ int orc_fill_null(const orc_array* a, const void* fill, void* out_values, uint8_
   return ORC_OK;
 }
 
+/* ---- 8f.2: scalar aggregates, aggregate_basic_internal.h / aggregate_internal.h ---------- */
+typedef struct { double sum[64]; uint64_t mask; int root; } pairwise; /* SumArray state :80-103 */
+static void pw_reduce(pairwise* p, double block_sum) {
+  int lvl = 0; uint64_t m = 1;
+  p->sum[lvl] += block_sum; p->mask ^= m;
+  while ((p->mask & m) == 0) {
+    block_sum = p->sum[lvl]; p->sum[lvl] = 0; ++lvl; m <<= 1;
+    p->sum[lvl] += block_sum; p->mask ^= m;
+  }
+  if (lvl > p->root) p->root = lvl;
+}
+static double value_as_double(const orc_array* a, int64_t i) {
+  return a->type_id == ORC_FLOAT ? (double)((const float*)a->values)[a->offset + i] : ((const double*)a->values)[a->offset + i];
+}
+int orc_aggregate(const orc_array* a, orc_agg* out) {
+  const int t = a->type_id;
+  if (orc_bit_width(t) < 0) return fail(ORC_NOT_IMPLEMENTED, "No sum implemented");
+  const int64_t n = a->length;
+  const int is_f = t == ORC_FLOAT || t == ORC_DOUBLE;
+  const int is_signed = t == ORC_INT8 || t == ORC_INT16 || t == ORC_INT32 || t == ORC_INT64;
+  int64_t valid = 0;
+  for (int64_t i = 0; i < n; ++i) valid += slot_valid(a, i);
+  out->valid_count = valid;
+  /* sum */
+  if (is_f) {
+    pairwise p; memset(&p, 0, sizeof(p));
+    double s = 0;
+    if (valid > 0) {
+      int64_t i = 0;
+      while (i < n) { /* VisitSetBitRunsVoid: maximal runs of valid slots */
+        while (i < n && !slot_valid(a, i)) ++i;
+        int64_t j = i;
+        while (j < n && slot_valid(a, j)) ++j;
+        int64_t k = i;
+        for (; k + 16 <= j; k += 16) { double b = 0; for (int q = 0; q < 16; ++q) b += value_as_double(a, k + q); pw_reduce(&p, b); }
+        if (k < j) { double b = 0; for (; k < j; ++k) b += value_as_double(a, k); pw_reduce(&p, b); }
+        i = j;
+      }
+      for (int l = 1; l <= p.root; ++l) p.sum[l] += p.sum[l - 1];
+      s = p.sum[p.root];
+    }
+    memcpy(&out->sum, &s, 8);
+  } else {
+    uint64_t s = 0; /* signed sums wrap the same way in two's complement */
+    for (int64_t i = 0; i < n; ++i) if (slot_valid(a, i)) {
+      switch (t) {
+        case ORC_BOOL: s += (uint64_t)bool_at(a, i); break;
+        case ORC_UINT8: s += ((const uint8_t*)a->values)[a->offset + i]; break;
+        case ORC_INT8: s += (uint64_t)(int64_t)((const int8_t*)a->values)[a->offset + i]; break;
+        case ORC_UINT16: s += ((const uint16_t*)a->values)[a->offset + i]; break;
+        case ORC_INT16: s += (uint64_t)(int64_t)((const int16_t*)a->values)[a->offset + i]; break;
+        case ORC_UINT32: s += ((const uint32_t*)a->values)[a->offset + i]; break;
+        case ORC_INT32: s += (uint64_t)(int64_t)((const int32_t*)a->values)[a->offset + i]; break;
+        case ORC_UINT64: s += ((const uint64_t*)a->values)[a->offset + i]; break;
+        default: s += (uint64_t)((const int64_t*)a->values)[a->offset + i]; break;
+      }
+    }
+    out->sum = s;
+  }
+  /* min / max over valid slots */
+  if (is_f) {
+    double mn = INFINITY, mx = -INFINITY;
+    for (int64_t i = 0; i < n; ++i) if (slot_valid(a, i)) { const double v = value_as_double(a, i); mn = fmin(mn, v); mx = fmax(mx, v); }
+    memcpy(&out->min, &mn, 8); memcpy(&out->max, &mx, 8);
+  } else if (t == ORC_BOOL) {
+    uint64_t mn = 1, mx = 0;
+    for (int64_t i = 0; i < n; ++i) if (slot_valid(a, i)) { const uint64_t v = (uint64_t)bool_at(a, i); if (v < mn) mn = v; if (v > mx) mx = v; }
+    out->min = mn; out->max = mx;
+  } else if (is_signed) {
+    const int bw = orc_bit_width(t);
+    int64_t mn = bw == 64 ? INT64_MAX : ((int64_t)1 << (bw - 1)) - 1, mx = bw == 64 ? INT64_MIN : -((int64_t)1 << (bw - 1));
+    for (int64_t i = 0; i < n; ++i) if (slot_valid(a, i)) {
+      int64_t v;
+      switch (t) { case ORC_INT8: v = ((const int8_t*)a->values)[a->offset + i]; break;
+        case ORC_INT16: v = ((const int16_t*)a->values)[a->offset + i]; break;
+        case ORC_INT32: v = ((const int32_t*)a->values)[a->offset + i]; break;
+        default: v = ((const int64_t*)a->values)[a->offset + i]; break; }
+      if (v < mn) mn = v; if (v > mx) mx = v;
+    }
+    out->min = (uint64_t)mn; out->max = (uint64_t)mx;
+  } else {
+    const int bw = orc_bit_width(t);
+    uint64_t mn = bw == 64 ? UINT64_MAX : ((uint64_t)1 << bw) - 1, mx = 0;
+    for (int64_t i = 0; i < n; ++i) if (slot_valid(a, i)) {
+      uint64_t v;
+      switch (t) { case ORC_UINT8: v = ((const uint8_t*)a->values)[a->offset + i]; break;
+        case ORC_UINT16: v = ((const uint16_t*)a->values)[a->offset + i]; break;
+        case ORC_UINT32: v = ((const uint32_t*)a->values)[a->offset + i]; break;
+        default: v = ((const uint64_t*)a->values)[a->offset + i]; break; }
+      if (v < mn) mn = v; if (v > mx) mx = v;
+    }
+    out->min = mn; out->max = mx;
+  }
+  return ORC_OK;
+}
+
 /* ---- headline composition: Filter -> GroupBy{hash_sum} ------------------------------- */
 int64_t orc_filter_groupby_sum(const orc_array* values, const orc_array* keys, const orc_array* mask,
                                void* out_sums, int64_t* out_counts, void* out_keys,

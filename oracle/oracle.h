@@ -184,6 +184,25 @@ int orc_is_nan(const orc_array* a, uint8_t* out_bits, uint8_t* out_validity, orc
 int orc_fill_null(const orc_array* values, const void* fill, void* out_values, uint8_t* out_validity,
                   orc_out* out);
 
+/* ---- scalar aggregates over ONE array (one Consume) -----------------------
+ * count / sum / mean / min_max, aggregate_basic.cc:58-130, aggregate_basic_internal.h:54-330.
+ *  valid_count : length - GetNullCount()                       (CountImpl :62-67)
+ *  sum         : SumImpl::Consume (:61-71) -- boolean: true count among valid slots (uint64);
+ *                integers: wrap-around sum in int64 / uint64 (FindAccumulatorType); float /
+ *                double: the reference's non-recursive PAIRWISE summation over the valid runs
+ *                in blocks of 16 (aggregate_internal.h:66-139), as double bits
+ *  min / max   : MinMaxImpl::Consume (:222-246) over valid slots, in the accumulator family
+ *                (int64 / uint64 / double bits; boolean 0 / 1); floats by fmin / fmax (NaN
+ *                ignored; all-NaN input leaves +inf / -inf); no valid slot leaves the
+ *                identities (type max / min, +inf / -inf, true / false).
+ * mean = double(sum) / valid_count, null results and MinMaxOptions::EMIT_NULL are decided by
+ * the caller from valid_count and length (MeanImpl :86-97, MinMaxImpl::Finalize :254-267). */
+typedef struct {
+  int64_t valid_count;
+  uint64_t sum, min, max;
+} orc_agg;
+int orc_aggregate(const orc_array* a, orc_agg* out);
+
 /* Headline composition (BASELINE.json config 5 on one shard): Filter(values, mask) and
  * Filter(keys, mask) with DROP, then GroupBy{hash_sum(values)} by keys
  * (vector_selection.cc:786-835 + hash_aggregate.cc:890-966).  Outputs in group order:

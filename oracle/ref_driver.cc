@@ -348,6 +348,64 @@ int ref_fill_null(const orc_array* a, const void* fill, void* out_values, uint8_
   return 0;
 }
 
+// ---- scalar aggregates: count / sum / min_max through CallFunction ----------------
+static uint64_t ScalarBits64(const Scalar& s) {  // widened to the accumulator family
+  if (!s.is_valid) return 0;
+  switch (s.type->id()) {
+    case Type::BOOL: return checked_cast<const BooleanScalar&>(s).value ? 1 : 0;
+    case Type::UINT8: return checked_cast<const UInt8Scalar&>(s).value;
+    case Type::UINT16: return checked_cast<const UInt16Scalar&>(s).value;
+    case Type::UINT32: return checked_cast<const UInt32Scalar&>(s).value;
+    case Type::UINT64: return checked_cast<const UInt64Scalar&>(s).value;
+    case Type::INT8: return static_cast<uint64_t>(static_cast<int64_t>(checked_cast<const Int8Scalar&>(s).value));
+    case Type::INT16: return static_cast<uint64_t>(static_cast<int64_t>(checked_cast<const Int16Scalar&>(s).value));
+    case Type::INT32: return static_cast<uint64_t>(static_cast<int64_t>(checked_cast<const Int32Scalar&>(s).value));
+    case Type::INT64: return static_cast<uint64_t>(checked_cast<const Int64Scalar&>(s).value);
+    case Type::FLOAT: { double d = checked_cast<const FloatScalar&>(s).value; uint64_t b; std::memcpy(&b, &d, 8); return b; }
+    case Type::DOUBLE: { double d = checked_cast<const DoubleScalar&>(s).value; uint64_t b; std::memcpy(&b, &d, 8); return b; }
+    default: return 0;
+  }
+}
+// Outputs follow orc_aggregate; where the reference returns a null scalar (no valid slot) the
+// field is left at the identity orc_aggregate documents, so both sides compare equal.
+int ref_aggregate(const orc_array* a, orc_agg* out) {
+  Datum arr(Wrap(a));
+  CountOptions copts(CountOptions::COUNT_NON_NULL);
+  auto c = CallFunction("count", {arr}, &copts, Ctx());
+  if (!c.ok()) return Fail(c.status());
+  out->valid_count = checked_cast<const Int64Scalar&>(*c->scalar()).value;
+  auto s = CallFunction("sum", {arr}, nullptr, Ctx());
+  if (!s.ok()) return Fail(s.status());
+  out->sum = ScalarBits64(*s->scalar());
+  MinMaxOptions mopts(MinMaxOptions::SKIP);
+  auto m = CallFunction("min_max", {arr}, &mopts, Ctx());
+  if (!m.ok()) return Fail(m.status());
+  const auto& st = checked_cast<const StructScalar&>(*m->scalar());
+  if (st.value[0]->is_valid) {
+    out->min = ScalarBits64(*st.value[0]);
+    out->max = ScalarBits64(*st.value[1]);
+  } else {  // identities of MinMaxState (:140-219)
+    const int bw = BitWidth(a->type_id);
+    switch (a->type_id) {
+      case ORC_BOOL: out->min = 1; out->max = 0; break;
+      case ORC_FLOAT: case ORC_DOUBLE: {
+        const double pinf = std::numeric_limits<double>::infinity(), ninf = -pinf;
+        std::memcpy(&out->min, &pinf, 8); std::memcpy(&out->max, &ninf, 8);
+        break;
+      }
+      case ORC_INT8: case ORC_INT16: case ORC_INT32: case ORC_INT64:
+        out->min = static_cast<uint64_t>(bw == 64 ? INT64_MAX : (int64_t(1) << (bw - 1)) - 1);
+        out->max = static_cast<uint64_t>(bw == 64 ? INT64_MIN : -(int64_t(1) << (bw - 1)));
+        break;
+      default:
+        out->min = bw == 64 ? UINT64_MAX : (uint64_t(1) << bw) - 1;
+        out->max = 0;
+        break;
+    }
+  }
+  return 0;
+}
+
 // Filter(values, mask), Filter(keys, mask), GroupBy({values}, {keys}, {hash_sum})
 int64_t ref_filter_groupby_sum(const orc_array* values, const orc_array* keys, const orc_array* mask,
                                void* out_sums, int64_t* out_counts, void* out_keys,

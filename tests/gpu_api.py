@@ -92,6 +92,10 @@ class GpuApi:
     def fill_null(self, a, fill):
         return self._wrap(lambda: self._down_full(compute.fill_null(self.ctx, up(a), fill)))
 
+    def aggregate(self, a):
+        r = self._wrap(lambda: compute.aggregate(self.ctx, up(a)))
+        return orc.agg_to_dict(a.type_id, *r)
+
     def group_ids(self, key_batches):
         g = compute.Grouper(self.ctx, [k.type_id for k in key_batches[0]])
         try:

@@ -215,4 +215,29 @@ def run_all(api, skip_grouper_multi_batch=False):
                 check("%s t=%d %s" % (grp["source"], t, c), lv(r), expect(t, c["out"]))
                 if grp["fill"] is not None and r.length and (r.has_validity or r.null_count != 0):
                     fails.append("%s: null_count must be 0 (FillNullSetsZeroNullCount :175-183)" % grp["source"])
+    # ---- scalar aggregates; the Finalize rules (aggregate_basic_internal.h:73-97, 254-267)
+    # are applied here exactly as the host layer applies them on top of one amdarrow_aggregate call ----
+    for grp in lit.get("aggregate", []):
+        for t in TYPE_GROUPS[grp["types"]]:
+            for c in grp["cases"]:
+                a = arr(t, c["in"])
+                r = api.aggregate(a)
+                n, vc = a.length, r["valid_count"]
+                name = "%s t=%d %s" % (grp["source"], t, c)
+                if "sum" in c:
+                    got = None if vc == 0 else r["sum"]
+                    if got != (None if c["sum"] is None else type(got)(c["sum"]) if got is not None else c["sum"]):
+                        fails.append("%s: sum %s" % (name, got))
+                if "mean" in c:
+                    got = None if vc == 0 else float(r["sum"]) / vc
+                    if got != c["mean"]:
+                        fails.append("%s: mean %s" % (name, got))
+                if "count" in c and [vc, n - vc] != c["count"]:
+                    fails.append("%s: count %s" % (name, [vc, n - vc]))
+                for key, emit_null in (("min_max", False), ("min_max_emit_null", True)):
+                    if key in c:
+                        got = None if vc == 0 or (emit_null and vc < n) else [r["min"], r["max"]]
+                        want = None if c[key] is None else [_num(x) if not isinstance(x, bool) else int(x) for x in c[key]]
+                        if got != want:
+                            fails.append("%s: %s %s" % (name, key, got))
     return fails

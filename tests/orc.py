@@ -88,6 +88,20 @@ class Arr:
         return self.valid[self.offset:self.offset + self.length]
 
 
+class CAgg(C.Structure):
+    _fields_ = [("valid_count", C.c_int64), ("sum", C.c_uint64), ("min", C.c_uint64), ("max", C.c_uint64)]
+
+
+def agg_to_dict(type_id, valid_count, s, mn, mx):
+    def conv(bits):
+        if type_id in (FLOAT, DOUBLE):
+            return float(np.array([bits], np.uint64).view(np.float64)[0])
+        if type_id in (INT8, INT16, INT32, INT64):
+            return int(np.array([bits], np.uint64).view(np.int64)[0])
+        return int(bits)
+    return {"valid_count": int(valid_count), "sum": conv(s), "min": conv(mn), "max": conv(mx)}
+
+
 class Result:
     def __init__(self, values, validity_bits, out, type_id):
         self.values, self.validity_bits, self.type_id = values, validity_bits, type_id
@@ -339,6 +353,15 @@ class Api:
         self._check(self._f("fill_null")(C.byref(c), fp, ov.ctypes.data_as(C.c_void_p), ob.ctypes.data_as(C.c_void_p),
                                          C.byref(out)))
         return self._result(a.type_id, ov, ob, out)
+
+    # ---- scalar aggregates ----
+    def aggregate(self, a):
+        """-> dict(valid_count, sum, min, max) in the accumulator family of a's type
+        (python int for integers / boolean, float for floating point)."""
+        out = CAgg()
+        c = a.c()
+        self._check(self._f("aggregate")(C.byref(c), C.byref(out)))
+        return agg_to_dict(a.type_id, out.valid_count, out.sum, out.min, out.max)
 
     def filter_groupby_sum(self, values, keys, mask):
         n = values.length

@@ -118,3 +118,15 @@ def test_mask_scalars_match_live_reference(oracle, reference):
                     d[::5] = np.nan
                     w = orc.Arr(t, d, v.valid, lo, n)
                     assert oracle.is_nan(w).same(reference.is_nan(w))
+
+
+def test_scalar_aggregates_match_live_reference(oracle, reference):
+    """SURVEY 8f.2 on a fresh seed: the restatement reproduces the reference bit for bit,
+    including its pairwise float summation (aggregate_internal.h:66-139)."""
+    rng = np.random.default_rng(20260103)
+    R = orc.random_arr
+    for t in [orc.BOOL] + orc.NUMERIC:
+        for n, p, off in [(0, 0, 0), (1, 0, 0), (17, .3, 2), (1000, 0, 0), (4099, .05, 5), (4099, 1.0, 0)]:
+            a = R(rng, t, n, p, off)
+            x, y = reference.aggregate(a), oracle.aggregate(a)
+            assert all(x[k] == y[k] or (x[k] != x[k] and y[k] != y[k]) for k in x), (t, n, p, x, y)

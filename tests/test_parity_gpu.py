@@ -38,7 +38,7 @@ def test_committed_reference_outputs(gpu):
                 np.array_equal(got["msg"], want["msg"])
             msg = "error differs: %s vs %s" % (bytes(got.get("msg", b"")), bytes(want.get("msg", b"")))
         else:
-            is_f64 = op in ("hash_aggregate", "filter_groupby_sum") and arrs[0].type_id in (FLOAT, DOUBLE)
+            is_f64 = op in ("hash_aggregate", "filter_groupby_sum", "aggregate") and arrs[0].type_id in (FLOAT, DOUBLE)
             ok, msg = golden_io.same_output(got, want, float_tol=is_f64)
         if not ok:
             bad.append("case %d %s %s: %s" % (i, op, params, msg))
@@ -536,3 +536,35 @@ def test_mask_scalars_errors(gpu, oracle):
         with pytest.raises(orc.StatusError) as e:
             api.is_nan(i)
         assert e.value.code == 10
+
+
+@pytest.mark.parametrize("t", [BOOL] + NUMERIC)
+def test_scalar_aggregates_random(gpu, oracle, t):
+    """count / sum / min / max of one array.  Integers and booleans bit-exact (sums
+    wrap); float sums within 1e-13 of the sum of magnitudes (tree order vs the reference's pairwise
+    blocks); float min / max equal as values, NaN ignored, all-NaN / no valid slot -> identities."""
+    rng = np.random.default_rng(41 + t)
+    for n, p, off in [(0, 0, 0), (1, 0, 0), (63, .1, 5), (64, 0, 0), (1000, .5, 3), (100_000, .01, 7), (1_000_003, 0, 1),
+                      (1_000_003, .2, 9), (5000, 1.0, 0)]:
+        lo, hi = (None, None) if t not in (orc.INT64, orc.UINT64) else ((-2**62, 2**62) if t == orc.INT64 else (0, 2**62))
+        a = R(rng, t, n, p, off, lo=lo, hi=hi)
+        if t in (FLOAT, DOUBLE) and n > 10:
+            d = a.data.copy()
+            d[3::101] = np.nan
+            a = Arr(t, d, a.valid, off, n)
+        g, o = gpu.aggregate(a), oracle.aggregate(a)
+        assert g["valid_count"] == o["valid_count"], (t, n, p)
+        if t in (FLOAT, DOUBLE):
+            v = a.values()[a.validity()] if a.valid is not None else a.values()
+            mag = float(np.nansum(np.abs(v.astype(np.float64)))) if len(v) else 0.0
+            if np.isnan(o["sum"]):
+                assert np.isnan(g["sum"])
+            else:
+                assert abs(g["sum"] - o["sum"]) <= 1e-13 * mag + 1e-300, (t, n, p, g, o)
+            assert g["min"] == o["min"] and g["max"] == o["max"], (t, n, p, g, o)
+        else:
+            assert g == o, (t, n, p, g, o)
+    if t in (FLOAT, DOUBLE):  # all NaN: fmin / fmax never replace the identities (:197-200)
+        a = Arr(t, np.full(100, np.nan))
+        g = gpu.aggregate(a)
+        assert g["min"] == np.inf and g["max"] == -np.inf and np.isnan(g["sum"]) and g["valid_count"] == 100
