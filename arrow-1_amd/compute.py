@@ -281,6 +281,9 @@ class GroupByResult:
         return self.counts[:self.num_groups * 8].cpu().numpy().view(np.int64).copy()
 
     def keys_numpy(self):
+        if self.key_type == BOOL:  # bit-packed
+            raw = self.keys[:(self.num_groups + 7) // 8].cpu().numpy()
+            return np.unpackbits(raw, bitorder="little")[:self.num_groups].astype(bool)
         w = bit_width(self.key_type) // 8
         return self.keys[:self.num_groups * w].cpu().numpy().view(NP_OF[self.key_type]).copy()
 
@@ -299,7 +302,7 @@ class GroupByBuffers:
         self.cap = group_capacity
         self.sums = alloc_bytes(group_capacity * 8, device)
         self.counts = alloc_bytes(group_capacity * 8, device)
-        self.keys = alloc_bytes(group_capacity * bit_width(key_type) // 8, device)
+        self.keys = alloc_bytes(((group_capacity * bit_width(key_type) + 63) // 64) * 8, device)  # whole 8-byte words
         self.key_validity = alloc_bytes((group_capacity + 7) // 8, device)
         self.first_rows = alloc_bytes(group_capacity * 4, device)
 

@@ -187,11 +187,8 @@ __global__ __launch_bounds__(256) void k_aggregate_final(const AggPartial* parti
   }
 }
 
-}  // namespace amdarrow
-
-using namespace amdarrow;
-
-extern "C" int amdarrow_aggregate(amdarrow_ctx* ctx, const amdarrow_array* a, amdarrow_agg* out) {
+// The body of amdarrow_aggregate; the caller holds ctx->mu (group-by uses it to range-compress int64 keys).
+int AggregateLocked(amdarrow_ctx* ctx, const amdarrow_array* a, amdarrow_agg* out) {
   const int t = a->type_id;
   const int bw = BitWidth(t);
   if (bw < 0) return SetError(AMDARROW_NOT_IMPLEMENTED, "No sum implemented");  // SumLikeInit::Visit(const DataType&) :108
@@ -213,7 +210,6 @@ extern "C" int amdarrow_aggregate(amdarrow_ctx* ctx, const amdarrow_array* a, am
   }
   out->valid_count = 0; out->sum = 0; out->min = min_id; out->max = max_id;
   if (a->length == 0) return AMDARROW_OK;
-  std::lock_guard<std::mutex> lock(ctx->mu);
   const int64_t items = kind == kAggBool ? (a->length + 63) / 64 : a->length;
   const int nblocks = GridFor(items, kAggThreads, ctx->num_cus * 2);
   void* base;
@@ -255,4 +251,11 @@ extern "C" int amdarrow_aggregate(amdarrow_ctx* ctx, const amdarrow_array* a, am
   out->min = host.min;
   out->max = host.max;
   return AMDARROW_OK;
+}
+
+}  // namespace amdarrow
+
+extern "C" int amdarrow_aggregate(amdarrow_ctx* ctx, const amdarrow_array* a, amdarrow_agg* out) {
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  return amdarrow::AggregateLocked(ctx, a, out);
 }

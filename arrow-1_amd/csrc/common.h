@@ -86,6 +86,9 @@ int ClearCounters(amdarrow_ctx* ctx, unsigned long long* base);
 // Sum counter `k` (k < ncounters <= kCounterStride) over the slots into out[k].
 int ReadCounters(amdarrow_ctx* ctx, const unsigned long long* base, int ncounters, unsigned long long* out);
 
+// amdarrow_aggregate without taking ctx->mu (aggregate.hip).
+int AggregateLocked(amdarrow_ctx* ctx, const amdarrow_array* a, amdarrow_agg* out);
+
 // Single-workgroup exclusive scan of u32 counts into int64 offsets (offsets[n] = total).
 int LaunchScanU32(amdarrow_ctx* ctx, const uint32_t* counts, int64_t n, int64_t* offsets);
 // Device-wide in-place exclusive scan of u32 (total < 2^32).  sums: ceil(n/2048) u32,

@@ -313,7 +313,9 @@ __global__ __launch_bounds__(kThreads) void k_decode_keys(const unsigned long lo
 
 // Packed group records (k_emit_groups) -> the caller's arrays, all coalesced; decodes the single
 // key column like k_decode_keys.  The group count comes from the status words (see RankFirstRows).
-__global__ __launch_bounds__(kThreads) void k_unpack_groups(const ulonglong4* packed, int64_t bound, int bits,
+// out_bits / bias: a range-compressed int64 key column comes back as x + bias in 64 bits.
+__global__ __launch_bounds__(kThreads) void k_unpack_groups(const ulonglong4* packed, int64_t bound, int bits, int out_bits,
+                                                            unsigned long long bias,
                                                             int null_bit /* <0: none */, unsigned long long* out_sums,
                                                             long long* out_counts, uint32_t* out_first_rows,
                                                             void* out_keys, uint64_t* out_validity,
@@ -335,8 +337,9 @@ __global__ __launch_bounds__(kThreads) void k_unpack_groups(const ulonglong4* pa
       const uint64_t x = r.x;
       valid = (null_bit >= 0) ? !((x >> null_bit) & 1) : (static_cast<uint32_t>(g) != wide_null_id);
       v = bits >= 64 ? x : (x & ((uint64_t(1) << bits) - 1));
+      v += bias;
       if (!valid) v = 0;
-      switch (bits) {
+      switch (out_bits) {
         case 1: break;  // packed below
         case 8: reinterpret_cast<uint8_t*>(out_keys)[g] = static_cast<uint8_t>(v); break;
         case 16: reinterpret_cast<uint16_t*>(out_keys)[g] = static_cast<uint16_t>(v); break;
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(kThreads) void k_unpack_groups(const ulonglong4* pa
     const uint64_t bm = __ballot(v != 0);
     if (lane == 0) {
       out_validity[g >> 6] = vm;
-      if (bits == 1) reinterpret_cast<uint64_t*>(out_keys)[g >> 6] = bm;
+      if (out_bits == 1) reinterpret_cast<uint64_t*>(out_keys)[g >> 6] = bm;
     }
   }
 }
@@ -558,6 +561,8 @@ constexpr uint32_t kRecKeyNull = 0x80000000u, kRecValValid = 0x40000000u, kRecRo
 
 struct FastArgs {
   const void* k_data; const uint8_t* k_valid; int64_t k_off; int k_bits;
+  int k_load_bits;    // width of the key column in memory (== k_bits, or 64 for a range-compressed int64 column)
+  uint64_t k_bias;    // subtracted from a 64-bit key: x = key - min(key) fits k_bits = 32
   ValueCol v; int has_values;
   const uint8_t* m_data; const uint8_t* m_valid; int64_t m_off;
   int64_t n; int64_t rows_per_block; int nblocks;
@@ -568,12 +573,6 @@ __device__ __forceinline__ bool FastSelected(const FastArgs& a, int64_t row) {
   if (!GetBit(a.m_data, a.m_off + row)) return false;
   return !a.m_valid || GetBit(a.m_valid, a.m_off + row);
 }
-// x as EncodeKey builds it for one key column of <= 32 bits: value bits, null flag at bit k_bits
-__device__ __forceinline__ uint64_t FastKey(const FastArgs& a, int64_t row, bool* is_null) {
-  *is_null = a.k_valid && !GetBit(a.k_valid, a.k_off + row);
-  return *is_null ? (uint64_t(1) << a.k_bits) : LoadBitsOfWidth(a.k_data, a.k_off + row, a.k_bits);
-}
-
 // Selection mask of the 64 consecutive rows starting at `row0` (one word per wave, every
 // lane loads the same address): bit i set <=> row0 + i is selected and < hi.
 __device__ __forceinline__ uint64_t FastMaskWord(const FastArgs& a, int64_t row0, int64_t hi) {
@@ -588,9 +587,11 @@ __device__ __forceinline__ uint64_t FastMaskWord(const FastArgs& a, int64_t row0
   return w;
 }
 __device__ __forceinline__ uint64_t FastKeyBits(const FastArgs& a, int64_t row) {
-  switch (a.k_bits) {
+  switch (a.k_load_bits) {
+    case 1: return GetBit(reinterpret_cast<const uint8_t*>(a.k_data), a.k_off + row);
     case 8: return reinterpret_cast<const uint8_t*>(a.k_data)[a.k_off + row];
     case 16: return reinterpret_cast<const uint16_t*>(a.k_data)[a.k_off + row];
+    case 64: return reinterpret_cast<const uint64_t*>(a.k_data)[a.k_off + row] - a.k_bias;
     default: return reinterpret_cast<const uint32_t*>(a.k_data)[a.k_off + row];
   }
 }
@@ -1833,6 +1834,23 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
   KeySpec ks;
   AA_TRY(MakeKeySpec(1, keys, nullptr, &ks));
   std::lock_guard<std::mutex> lock(ctx->mu);
+  const KeySpec ks_generic = ks;  // as the reference encodes the column; used by the generic path
+  // An int64 / uint64 key column whose values span less than 2^32 (ids, dates, small integers --
+  // most integer key columns) is range-compressed onto 32 bits: x = key - min.  One extra pass over
+  // the keys (min / max) buys the partitioned LDS paths instead of the global-atomic table.
+  int k_load_bits = ks.col[0].bits;
+  uint64_t k_bias = 0;
+  if (ks.total_bits == 64 && (keys->type_id == AMDARROW_INT64 || keys->type_id == AMDARROW_UINT64) &&
+      n >= (int64_t(1) << 18) && n < (int64_t(1) << 30) && !getenv("AMDARROW_GROUPBY_NO_RANGE_COMPRESSION")) {
+    amdarrow_agg kr;
+    AA_TRY(AggregateLocked(ctx, keys, &kr));
+    if (kr.valid_count > 0 && kr.max - kr.min < 0xFFFFFFFFull) {  // (wrap-around difference: exact for both signednesses)
+      k_bias = kr.min;
+      ks.total_bits = 32;
+      ks.col[0].bits = 32;
+      ks.wide_null_slot = 0;
+    }
+  }
 
   ValueCol v{};
   if (values) v = ValueCol{values->values, values->validity, values->offset, values->type_id};
@@ -1845,7 +1863,8 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
   const bool fast_ok = ks.total_bits <= 32 && n >= (int64_t(1) << 18) && n < (int64_t(1) << 30);
   int path = fast_ok ? 3 : 0;  // 3 = local pre-aggregation with the partition path queued behind it
   if (const char* env = getenv("AMDARROW_GROUPBY_PATH")) path = std::min(path, atoi(env));
-  const bool headline_shape = ks.total_bits == 32 && !keys->validity && values && BitWidth(values->type_id) == 64 && !m_valid;
+  const bool headline_shape = ks.total_bits == 32 && k_load_bits == 32 && !keys->validity && values &&
+                              BitWidth(values->type_id) == 64 && !m_valid;
   GroupTable t{};
   RankMem r{};
   unsigned long long* gx = nullptr;
@@ -1907,6 +1926,7 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
       auto* records = reinterpret_cast<uint4*>(b + off_rec);
       FastArgs fa{};
       fa.k_data = keys->values; fa.k_valid = keys->validity; fa.k_off = keys->offset; fa.k_bits = ks.total_bits;
+      fa.k_load_bits = k_load_bits; fa.k_bias = k_bias;
       fa.v = v; fa.has_values = values ? 1 : 0;
       fa.m_data = m_data; fa.m_valid = m_valid; fa.m_off = m_off;
       fa.n = n; fa.nblocks = nblocks; fa.rows_per_block = rows_per_block;
@@ -1964,8 +1984,8 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
       }
     } else {
       AA_TRY(ClearTable(ctx, t, false));
-      hipLaunchKernelGGL(k_groupby_build, dim3(GridFor(n, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, ks,
-                         v, values ? 1 : 0, m_data, m_valid, m_off, n, t, misc);
+      hipLaunchKernelGGL(k_groupby_build, dim3(GridFor(n, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream,
+                         ks_generic, v, values ? 1 : 0, m_data, m_valid, m_off, n, t, misc);
       AA_HIP(hipGetLastError());
     }
     int64_t G = 0;
@@ -1980,9 +2000,10 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
     hipLaunchKernelGGL(k_emit_groups, dim3(GridFor(e.nslots, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, e);
     AA_HIP(hipGetLastError());
     const int64_t bound = group_capacity < n ? group_capacity : n;
+    const KeySpec& ku = fast ? ks : ks_generic;  // how x was built on this path
     hipLaunchKernelGGL(k_unpack_groups, dim3(GridFor(bound, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream,
-                       e.packed, bound, ks.col[0].bits, ks.wide_null_slot ? -1 : ks.total_bits,
-                       static_cast<unsigned long long*>(out_sums), reinterpret_cast<long long*>(out_counts), out_first_rows,
+                       e.packed, bound, ku.col[0].bits, ks_generic.col[0].bits, fast ? k_bias : 0ull,
+                       ku.wide_null_slot ? -1 : ku.total_bits, static_cast<unsigned long long*>(out_sums), reinterpret_cast<long long*>(out_counts), out_first_rows,
                        out_keys, reinterpret_cast<uint64_t*>(out_key_validity), misc);
     AA_HIP(hipGetLastError());
     unsigned int status[8] = {0};

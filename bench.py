@@ -35,6 +35,7 @@ SEED = 0x0ff1ce         # kRandomSeed, compute/kernels/test_util.h:123
 
 NUM_GROUPS = 1_000_000  # --groups
 NUM_CHUNKS = 1  # --chunks (sort workloads)
+KEY_BITS = 32   # --key-bits (headline workload: 64 = int64 key column)
 
 WORKLOADS = {
     # name: (description, algorithmic bytes per row as a function of selectivity)
@@ -69,9 +70,12 @@ def make_inputs(workload, n, dev, rank, sel):
     d = {}
     if workload in ("filter_groupby_sum_i64",):
         vals = torch.randint(-100, 101, (n,), dtype=torch.int64, device=dev, generator=gen)
-        keys = torch.randint(0, NUM_GROUPS, (n,), dtype=torch.int32, device=dev, generator=gen)
+        kdt, kid = (torch.int64, _abi.INT64) if KEY_BITS == 64 else (torch.int32, _abi.INT32)
+        keys = torch.randint(0, NUM_GROUPS, (n,), dtype=kdt, device=dev, generator=gen)
+        if KEY_BITS == 64:
+            keys += 1_700_000_000_000  # e.g. millisecond timestamps / large ids: wide values, narrow range
         d["values"] = device.DeviceArray(_abi.INT64, vals.view(torch.uint8), None, n)
-        d["keys"] = device.DeviceArray(_abi.INT32, keys.view(torch.uint8), None, n)
+        d["keys"] = device.DeviceArray(kid, keys.view(torch.uint8), None, n)
         d["mask"] = device.DeviceArray(_abi.BOOL, device_bitmap(n, sel, gen, dev), None, n)
         d["_keep"] = (vals, keys)
     elif workload in ("filter_i64", "take_i64", "take_random_i64"):
@@ -121,7 +125,7 @@ def bytes_per_row(workload, sel):
 def make_step(workload, ctx, inp, sel, world, rank):
     """Returns a zero-argument callable running ONE step on this rank's shard."""
     if workload == "filter_groupby_sum_i64":
-        bufs = compute.GroupByBuffers(ctx.device, 1 << 21, _abi.INT32)
+        bufs = compute.GroupByBuffers(ctx.device, 1 << 21, _abi.INT64 if KEY_BITS == 64 else _abi.INT32)
         if world == 1:
             return lambda: compute.filter_groupby(ctx, inp["values"], inp["keys"], inp["mask"], buffers=bufs)
         from arrow1_amd import dist as adist
@@ -264,10 +268,12 @@ def main():
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU")
     ap.add_argument("--selectivity", type=float, default=0.5)
     ap.add_argument("--groups", type=int, default=1_000_000, help="distinct group keys (tuning aid; the headline is 1M)")
+    ap.add_argument("--key-bits", type=int, default=32, choices=[32, 64], help="headline workload: width of the key column")
     ap.add_argument("--chunks", type=int, default=1, help="sort workloads: present the rows as this many equal chunks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
-    global NUM_GROUPS, NUM_CHUNKS
+    global NUM_GROUPS, NUM_CHUNKS, KEY_BITS
+    KEY_BITS = args.key_bits
     NUM_GROUPS = args.groups
     NUM_CHUNKS = args.chunks
 

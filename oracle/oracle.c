@@ -907,8 +907,9 @@ int64_t orc_filter_groupby_sum(const orc_array* values, const orc_array* keys, c
   const int vw = orc_bit_width(values->type_id) / 8, kw = orc_bit_width(keys->type_id) / 8;
   orc_out o1, o2;
   const int64_t m = orc_filter_output_size(mask, ORC_DROP);
-  uint8_t* fv = (uint8_t*)malloc((size_t)(m ? m : 1) * vw);
-  uint8_t* fk = (uint8_t*)malloc((size_t)(m ? m : 1) * kw);
+  /* boolean columns are bit-packed (bit width 1 -> vw / kw == 0) */
+  uint8_t* fv = (uint8_t*)calloc(vw ? (size_t)(m ? m : 1) * vw : (size_t)bytes_for_bits(m) + 8, 1);
+  uint8_t* fk = (uint8_t*)calloc(kw ? (size_t)(m ? m : 1) * kw : (size_t)bytes_for_bits(m) + 8, 1);
   uint8_t* fvv = (uint8_t*)malloc((size_t)bytes_for_bits(m) + 1);
   uint8_t* fkv = (uint8_t*)malloc((size_t)bytes_for_bits(m) + 1);
   (void)n;

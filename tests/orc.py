@@ -378,8 +378,8 @@ class Api:
         kt = keys.type_id
         acc = np.float64 if values.type_id in (FLOAT, DOUBLE) else (
             np.int64 if values.type_id in (INT8, INT16, INT32, INT64) else np.uint64)
-        return (sums[:ng].view(acc).copy(), counts[:ng].copy(),
-                okeys[:ng * bit_width(kt) // 8].view(NP_OF[kt]).copy(), unpack(okv, ng))
+        okey = unpack(okeys, ng) if kt == BOOL else okeys[:ng * bit_width(kt) // 8].view(NP_OF[kt]).copy()
+        return (sums[:ng].view(acc).copy(), counts[:ng].copy(), okey, unpack(okv, ng))
 
 
 def have_ref():

@@ -568,3 +568,34 @@ def test_scalar_aggregates_random(gpu, oracle, t):
         a = Arr(t, np.full(100, np.nan))
         g = gpu.aggregate(a)
         assert g["min"] == np.inf and g["max"] == -np.inf and np.isnan(g["sum"]) and g["valid_count"] == 100
+
+
+@pytest.mark.parametrize("kt", [INT64, orc.UINT64, BOOL])
+def test_filter_groupby_wide_and_boolean_keys_on_partitioned_path(gpu, oracle, kt, monkeypatch):
+    """int64 / uint64 key columns whose values span < 2^32 are range-compressed (key - min) onto the
+    partitioned LDS paths; a wider span, and the switch off, use the generic table.  Boolean keys
+    (bit-packed) also take the partitioned path."""
+    rng = np.random.default_rng(51)
+    n = 600_000
+    cases = []
+    if kt == BOOL:
+        cases.append(R(rng, BOOL, n, .02, 3))
+    else:
+        base = -2**40 if kt == INT64 else 2**50
+        cases.append(Arr(kt, base + rng.integers(0, 50_000, n), rng.random(n) > .03))           # compressible, nulls
+        cases.append(Arr(kt, base + rng.integers(0, 2**32 - 2, n, dtype=np.int64)))              # just compressible
+        cases.append(Arr(kt, (rng.integers(0, 2, n) * (2**33) + rng.integers(0, 1000, n)) + (0 if kt != INT64 else -5)))  # too wide
+    for k in cases:
+        for vt in (INT64, DOUBLE):
+            v, m = R(rng, vt, n, .01, 2), R(rng, BOOL, n, 0.0, 1)
+            want = oracle.filter_groupby_sum(v, k, m)
+            for env in (None, "1"):
+                if env:
+                    monkeypatch.setenv("AMDARROW_GROUPBY_NO_RANGE_COMPRESSION", env)
+                else:
+                    monkeypatch.delenv("AMDARROW_GROUPBY_NO_RANGE_COMPRESSION", raising=False)
+                for x, y in zip(want, gpu.filter_groupby_sum(v, k, m)):
+                    if x.dtype == np.float64:
+                        assert x.shape == y.shape and np.allclose(x, y, rtol=F64_RTOL)
+                    else:
+                        assert np.array_equal(x, y), (kt, vt, env)
