@@ -170,8 +170,27 @@ __global__ __launch_bounds__(kThreads) void k_groupby_build(KeySpec ks, ValueCol
 
 // ---- first-appearance numbering -----------------------------------------------------------------
 // Set bit first_row for every group that needs an id.
+// scratch of the heavy-hitter path (see "heavy hitters" below)
+struct HotMem {
+  uint32_t* cand;          // [nwg][kHotPerWg] tags reported by the local attempt
+  unsigned int* cand_n;    // [nwg] how many; bit 31: the null key is hot in this row range
+  uint32_t* tags;          // [kHotCap] the hot set
+  unsigned int* count;     // [0] keys in the set, [1] null key is hot
+  unsigned long long* part_sum;  // [nwg][kHotCap + 1] partial sums (index kHotCap: the null key)
+  unsigned int* part_cnt;        // [nwg][kHotCap + 1]
+  uint32_t* part_first;          // [nwg][kHotCap + 1]
+  uint8_t* alt_mask;       // selection mask without the hot rows, bit offset 0
+};
+__device__ void InjectHotGroups(const HotMem& hot, int nwg, int k_bits, int acc_double, const GroupTable& t,
+                                unsigned long long* bitmap, int64_t gtid, int64_t gthreads);
 __global__ __launch_bounds__(kThreads) void k_mark_first(GroupTable t, int64_t nslots, int only_unassigned,
-                                                         unsigned long long* bitmap, const unsigned int* skip_if) {
+                                                         unsigned long long* bitmap, const unsigned int* skip_if,
+                                                         HotMem hot, const unsigned int* use_hot, int nwg,
+                                                         int k_bits, int acc_double) {
+  // heavy hitters kept out of the partitions join the table here (see "heavy hitters" below)
+  if (use_hot && *use_hot)
+    InjectHotGroups(hot, nwg, k_bits, acc_double, t, bitmap, int64_t(blockIdx.x) * kThreads + threadIdx.x,
+                    int64_t(gridDim.x) * kThreads);
   if (skip_if && *skip_if) return;  // the groups were marked by the kernel that built them
   for (int64_t s = int64_t(blockIdx.x) * kThreads + threadIdx.x; s < nslots; s += int64_t(gridDim.x) * kThreads) {
     const uint32_t fr = t.first[s];
@@ -517,13 +536,16 @@ static int AwaitStatus(amdarrow_ctx* ctx, unsigned int (&status)[8]) {
 // total lo, total hi}; k_word_prefix stores the total there and mirrors the words into mapped
 // host memory.  With status_dev the caller collects them with AwaitStatus (after queueing
 // whatever else does not need them on the host).
+struct HotInject { HotMem hot; int nwg, k_bits, acc_double; };  // heavy hitters to add while marking (mode 2)
 static int RankFirstRows(amdarrow_ctx* ctx, const GroupTable& t, int only_unassigned, const RankMem& r, int64_t* total,
-                         int mark_mode = 0, unsigned int* status_dev = nullptr) {
+                         int mark_mode = 0, unsigned int* status_dev = nullptr, const HotInject* inject = nullptr) {
   const int64_t nslots = static_cast<int64_t>(t.mask) + 3;
   if (mark_mode != 1) {
     if (mark_mode == 0) AA_HIP(hipMemsetAsync(r.bitmap, 0, 8 * r.nwords, ctx->stream));
     hipLaunchKernelGGL(k_mark_first, dim3(GridFor(nslots, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, t,
-                       nslots, only_unassigned, r.bitmap, mark_mode == 2 ? status_dev + 1 : nullptr);
+                       nslots, only_unassigned, r.bitmap, mark_mode == 2 ? status_dev + 1 : nullptr,
+                       inject ? inject->hot : HotMem{}, inject ? status_dev + 5 : nullptr, inject ? inject->nwg : 0,
+                       inject ? inject->k_bits : 0, inject ? inject->acc_double : 0);
   }
   hipLaunchKernelGGL(k_popc_blocks, dim3(static_cast<unsigned>(r.nblocks)), dim3(kThreads), 0, ctx->stream, r.bitmap,
                      r.nwords, r.block_counts);
@@ -835,8 +857,9 @@ __device__ __forceinline__ void LoadTile(const FastArgs& a, int64_t tile0, int64
 // The loads of tile i+1 are issued before the copy-out of tile i, so HBM latency hides behind it.
 __global__ __launch_bounds__(kDThreads) void k_part_scatter_direct(FastArgs a, int64_t cap, uint4* regions,
                                                                    uint32_t* counts, unsigned int* overflow,
-                                                                   const unsigned int* run_if) {
+                                                                   const unsigned int* run_if, const unsigned int* skip_if) {
   if (run_if && !*run_if) return;  // the local path already built the table
+  if (skip_if && *skip_if) return;  // the launch on the mask without the hot rows does the work
   __shared__ unsigned int s_cnt[2][kP];
   __shared__ uint32_t s_off[kP];
   __shared__ uint32_t s_cur[kP];
@@ -1121,8 +1144,10 @@ __device__ __forceinline__ void FastFinishTile(ScatterShared& sh, int buf, int64
 // current tile goes through its LDS phases.
 template <bool MASK, bool VVALID>
 __global__ __launch_bounds__(kFThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_part_scatter_fast(FastArgs a, int64_t cap, uint4* regions, uint32_t* counts,
-                                                                 unsigned int* overflow, const unsigned int* run_if) {
+                                                                 unsigned int* overflow, const unsigned int* run_if,
+                                                                 const unsigned int* skip_if) {
   if (run_if && !*run_if) return;  // the local path already built the table
+  if (skip_if && *skip_if) return;  // the launch on the mask without the hot rows does the work
   __shared__ ScatterShared sh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < kP) { sh.cnt[0][tid] = 0; sh.cnt[1][tid] = 0; sh.cur[0][tid] = 0; sh.carry_cnt[0][tid] = 0; sh.wcnt[tid] = 0; }
@@ -1443,6 +1468,231 @@ __device__ __forceinline__ void LocalWriteOut(const LocalShared& sh, const Local
     st.cnt[base + s] = sh.cnt[s];
   }
 }
+
+// ---- heavy hitters -------------------------------------------------------------------------------------
+// With one workgroup per partition in the aggregate, a key that carries 1 % / 10 % / 40 % of the
+// rows used to cost 3.5 / 15 / 53 ms per 100 M rows (uniform: 0.85 ms): its partition overflows the
+// fixed regions (two-pass fallback) and ONE workgroup then folds all of its records.  So hot keys
+// never reach the partitions:
+//   1. the optimistic local attempt (above) already counts keys per row range; when it gives up,
+//      every workgroup reports the keys it saw >= kHotMin times among its first ~2-4 k selected rows
+//      (frequency >~ 0.1 %); the null key counts as a key
+//   2. block 0 of k_clear_table_unless deduplicates the candidates into the hot set (<= kHotCap)
+//   3. k_hot_aggregate: every workgroup folds the hot rows of its row range into an LDS table
+//      indexed by the hot set and writes a copy of the selection mask without them
+//   4. the scatter runs on that mask (second launch gated on status[5]; the first, on the caller's
+//      mask, is gated off) -- partitions see a uniform remainder
+//   5. k_hot_inject (inside k_mark_first's launch) merges the per-workgroup partials and puts each
+//      hot group into a free slot of its partition's slice of the table, marking its first row.
+// Nothing here costs a host round trip; with no hot key steps 3-5 are two empty launches.
+constexpr int kHotPerWg = 32;     // candidates one workgroup may report
+constexpr int kHotCap = 2048;     // keys in the hot set
+constexpr unsigned int kHotMin = 4;
+constexpr int kHotMapSlots = 4096;  // LDS open-addressing map tag -> hot index (load <= 50 %)
+
+
+// Called by every thread of a local-aggregate workgroup that gave up.
+__device__ __forceinline__ void ReportHotCandidates(LocalShared& sh, const HotMem& hot, int tid) {
+  __shared__ unsigned int s_n;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  for (int s = tid; s < kSlots; s += kDThreads) {
+    if (sh.tag[s] != kTagFree && sh.cnt[s] >= kHotMin) {
+      const unsigned int i = atomicAdd(&s_n, 1u);
+      if (i < kHotPerWg) hot.cand[int64_t(blockIdx.x) * kHotPerWg + i] = sh.tag[s];
+    }
+  }
+  __syncthreads();
+  if (tid == 0)
+    hot.cand_n[blockIdx.x] = (s_n < kHotPerWg ? s_n : kHotPerWg) | (sh.cnt[kSideNull] >= kHotMin ? 0x80000000u : 0u);
+}
+
+// Block 0 of k_clear_table_unless, when the local attempt was given up: candidates -> hot set.
+__device__ __forceinline__ void BuildHotSet(const HotMem& hot, int nwg, unsigned int* use_hot) {
+  __shared__ uint32_t s_set[kHotMapSlots];
+  __shared__ unsigned int s_count, s_null;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < kHotMapSlots; i += blockDim.x) s_set[i] = kTagFree;
+  if (tid == 0) { s_count = 0; s_null = 0; }
+  __syncthreads();
+  for (int w = tid; w < nwg; w += blockDim.x) {
+    const unsigned int cn = hot.cand_n[w];
+    if (cn >> 31) s_null = 1;
+    const unsigned int n = cn & 0x7FFFFFFFu;
+    for (unsigned int i = 0; i < n && i < static_cast<unsigned int>(kHotPerWg); ++i) {
+      const uint32_t tag = hot.cand[int64_t(w) * kHotPerWg + i];
+      if (tag == kTagFree) continue;  // (the one key whose tag is the free marker stays cold)
+      uint32_t slot = tag & (kHotMapSlots - 1);
+      for (int probes = 0; probes < kHotMapSlots; ++probes) {
+        const uint32_t old = atomicCAS(&s_set[slot], kTagFree, tag);
+        if (old == kTagFree) {
+          const unsigned int idx = atomicAdd(&s_count, 1u);
+          if (idx < static_cast<unsigned int>(kHotCap)) hot.tags[idx] = tag;
+          break;
+        }
+        if (old == tag) break;
+        slot = (slot + 1) & (kHotMapSlots - 1);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned int n = s_count < static_cast<unsigned int>(kHotCap) ? s_count : kHotCap;
+    hot.count[0] = n;
+    hot.count[1] = s_null;
+    *use_hot = (n > 0 || s_null) ? 1u : 0u;
+  }
+}
+
+// Step 3.  One workgroup per row range of the local attempt (same geometry).
+__global__ __launch_bounds__(kDThreads) void k_hot_aggregate(FastArgs a, int acc_double, HotMem hot, const unsigned int* use_hot) {
+  if (!*use_hot) return;
+  __shared__ uint32_t s_map_tag[kHotMapSlots];
+  __shared__ unsigned short s_map_idx[kHotMapSlots];
+  __shared__ unsigned long long s_sum[kHotCap + 1];
+  __shared__ unsigned int s_cnt[kHotCap + 1];
+  __shared__ uint32_t s_first[kHotCap + 1];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned int nhot = hot.count[0];
+  const bool null_hot = hot.count[1] != 0;
+  for (int i = tid; i < kHotMapSlots; i += kDThreads) s_map_tag[i] = kTagFree;
+  for (int i = tid; i <= kHotCap; i += kDThreads) { s_sum[i] = 0; s_cnt[i] = 0; s_first[i] = kNoRow; }
+  __syncthreads();
+  for (unsigned int h = tid; h < nhot; h += kDThreads) {  // tags are distinct: plain linear-probing insert
+    const uint32_t tag = hot.tags[h];
+    uint32_t slot = tag & (kHotMapSlots - 1);
+    while (atomicCAS(&s_map_tag[slot], kTagFree, tag) != kTagFree) slot = (slot + 1) & (kHotMapSlots - 1);
+    s_map_idx[slot] = static_cast<unsigned short>(h);
+  }
+  __syncthreads();
+  const int64_t lo = int64_t(blockIdx.x) * a.rows_per_block;
+  const int64_t hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
+  unsigned long long* alt = reinterpret_cast<unsigned long long*>(hot.alt_mask);
+  // A wave takes 4 x 64 consecutive rows per step: the four mask words and (unconditional, clamped)
+  // key loads are issued together; values are loaded only for hot rows.
+  constexpr int kU = 4;
+  const int wave = tid >> 6;
+  const int64_t stride = int64_t(kDThreads / 64) * (64 * kU);
+  uint64_t mw[kU], mw_next[kU];
+  uint32_t kx[kU], kx_next[kU];
+  int64_t base0 = lo + int64_t(wave) * (64 * kU);
+  auto load = [&](int64_t b0, uint64_t (&m)[kU], uint32_t (&k)[kU]) {
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t row = b0 + 64 * u + lane;
+      k[u] = static_cast<uint32_t>(FastKeyBits(a, row < hi ? row : hi - 1));
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) m[u] = FastMaskWord(a, b0 + 64 * u, hi);
+  };
+  if (base0 < hi) load(base0, mw, kx);
+  for (; base0 < hi; base0 += stride) {
+    // the next step's keys and mask words are requested before this step is folded
+    const int64_t next = base0 + stride;
+    load(next < hi ? next : base0, mw_next, kx_next);
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t row0 = base0 + 64 * u;
+      if (row0 >= hi) break;  // wave-uniform
+      const int64_t row = row0 + lane;
+      bool keep = (mw[u] >> lane) & 1;
+      if (keep) {
+        const bool kn = a.k_valid && !GetBit(a.k_valid, a.k_off + row);
+        int h = -1;
+        if (kn) {
+          if (null_hot) h = kHotCap;
+        } else {
+          const uint32_t tag = Fmix32(kx[u]);
+          uint32_t slot = tag & (kHotMapSlots - 1);
+          for (;;) {
+            const uint32_t t = s_map_tag[slot];
+            if (t == tag) { h = s_map_idx[slot]; break; }
+            if (t == kTagFree) break;
+            slot = (slot + 1) & (kHotMapSlots - 1);
+          }
+        }
+        if (h >= 0) {
+          keep = false;
+          atomicMin(&s_first[h], static_cast<uint32_t>(row));
+          if (a.has_values && (!a.v.valid || GetBit(a.v.valid, a.v.off + row))) {
+            bool is_double;
+            const uint64_t bits = LoadAccum(a.v, row, &is_double);
+            if (acc_double) atomicAdd(reinterpret_cast<double*>(&s_sum[h]), __longlong_as_double(bits));
+            else atomicAdd(&s_sum[h], static_cast<unsigned long long>(bits));
+            atomicAdd(&s_cnt[h], 1u);
+          }
+        }
+      }
+      const uint64_t out = __ballot(keep);
+      if (lane == 0) alt[row0 >> 6] = out;
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) { mw[u] = mw_next[u]; kx[u] = kx_next[u]; }
+  }
+  __syncthreads();
+  const int64_t base = int64_t(blockIdx.x) * (kHotCap + 1);
+  for (int i = tid; i <= kHotCap; i += kDThreads) {
+    hot.part_sum[base + i] = s_sum[i];
+    hot.part_cnt[base + i] = s_cnt[i];
+    hot.part_first[base + i] = s_first[i];
+  }
+}
+
+// Step 5: hot group h -> a free slot of its partition's slice.  Called grid-stride from k_mark_first.
+__device__ __forceinline__ void InjectHot(const HotMem& hot, int nwg, int k_bits, int acc_double, const GroupTable& t,
+                                          unsigned long long* bitmap, int64_t gtid, int64_t gthreads) {
+  const unsigned int nhot = hot.count[0];
+  const bool null_hot = hot.count[1] != 0;
+  // one WAVE per hot key: the lanes split the workgroups' partials, a butterfly folds them
+  const int lane = static_cast<int>(gtid & 63);
+  for (int64_t h = gtid >> 6; h <= kHotCap; h += gthreads >> 6) {
+    if (h < kHotCap ? h >= nhot : !null_hot) continue;  // wave-uniform
+    unsigned long long sum = 0;
+    double dsum = 0.0;
+    unsigned long long cnt = 0;
+    uint32_t first = kNoRow;
+    for (int w = lane; w < nwg; w += 64) {
+      const int64_t i = int64_t(w) * (kHotCap + 1) + h;
+      const uint32_t f = hot.part_first[i];
+      if (f == kNoRow) continue;
+      first = f < first ? f : first;
+      cnt += hot.part_cnt[i];
+      if (acc_double) dsum += __longlong_as_double(hot.part_sum[i]);
+      else sum += hot.part_sum[i];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const uint32_t of = __shfl_xor(first, d, 64);
+      first = of < first ? of : first;
+      cnt += __shfl_xor(cnt, d, 64);
+      sum += __shfl_xor(sum, d, 64);
+      dsum += __longlong_as_double(__shfl_xor(static_cast<unsigned long long>(__double_as_longlong(dsum)), d, 64));
+    }
+    if (lane != 0) continue;
+    if (first == kNoRow) continue;  // no selected row carried this key
+    const uint32_t tag = h < kHotCap ? hot.tags[h] : 0u;
+    const uint64_t x = h < kHotCap ? uint64_t(Fmix32Inv(tag)) : (uint64_t(1) << k_bits);
+    const uint32_t p = h < kHotCap ? (tag >> (32 - kPBits)) : 0u;  // the null key lives in partition 0
+    const int64_t g0 = int64_t(p) * kSlots;
+    const unsigned long long hk = Fmix64(x);
+    for (int probes = 0; probes < kSlots; ++probes) {
+      const int64_t s = g0 + ((tag + probes) & (kSlots - 1));
+      if (atomicCAS(&t.hkeys[s], static_cast<unsigned long long>(kEmpty), hk) == kEmpty) {
+        t.first[s] = first;
+        t.sums[s] = acc_double ? static_cast<unsigned long long>(__double_as_longlong(dsum)) : sum;
+        t.counts[s] = cnt;
+        atomicOr(&bitmap[first >> 6], 1ull << (first & 63));
+        break;
+      }
+    }
+  }
+}
+
+__device__ void InjectHotGroups(const HotMem& hot, int nwg, int k_bits, int acc_double, const GroupTable& t,
+                                unsigned long long* bitmap, int64_t gtid, int64_t gthreads) {
+  InjectHot(hot, nwg, k_bits, acc_double, t, bitmap, gtid, gthreads);
+}
+
 // Fold the 7 x 64 rows a wave holds of one fast-layout tile (see FastLoadTile).
 template <bool VVALID>
 __device__ __forceinline__ bool LocalFoldFast(LocalShared& sh, int64_t tile0, int wave, int lane, int acc_double,
@@ -1474,7 +1724,7 @@ __device__ __forceinline__ bool LocalFoldFast(LocalShared& sh, int64_t tile0, in
 
 template <bool MASK, bool VVALID>
 __global__ __launch_bounds__(kDThreads) void k_local_aggregate_fast(FastArgs a, int acc_double, LocalStage st,
-                                                                    unsigned int* wg_flags) {
+                                                                    unsigned int* wg_flags, HotMem hot) {
   __shared__ LocalShared sh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   LocalInit(sh, tid);
@@ -1510,13 +1760,16 @@ __global__ __launch_bounds__(kDThreads) void k_local_aggregate_fast(FastArgs a, 
     if (__any(!LocalFoldFast<VVALID>(sh, tile0 + kLRows, wave, lane, acc_double, kxB, kvB, mw, vw))) { LocalGiveUp(sh, wg_flags); break; }
   }
   __syncthreads();
-  if (*stop) return;  // a stale staging table is never read: the merge is gated on the flags
+  if (*stop) {  // a stale staging table is never read: the merge is gated on the flags
+    ReportHotCandidates(sh, hot, tid);
+    return;
+  }
   LocalWriteOut(sh, st, tid);
 }
 
 // Any key width <= 32 bits, key / value / mask validity, every value type (LoadTile).
 __global__ __launch_bounds__(kDThreads) void k_local_aggregate(FastArgs a, int acc_double, LocalStage st,
-                                                               unsigned int* wg_flags) {
+                                                               unsigned int* wg_flags, HotMem hot) {
   __shared__ LocalShared sh;
   const int tid = threadIdx.x, lane = tid & 63;
   LocalInit(sh, tid);
@@ -1547,29 +1800,36 @@ __global__ __launch_bounds__(kDThreads) void k_local_aggregate(FastArgs a, int a
     if (__any(!ok)) { LocalGiveUp(sh, wg_flags); break; }
   }
   __syncthreads();
-  if (*stop) return;
+  if (*stop) {
+    ReportHotCandidates(sh, hot, tid);
+    return;
+  }
   LocalWriteOut(sh, st, tid);
 }
 
 // Zero the first-row bitmap, the status words and the per-workgroup flags in one launch.
 __global__ __launch_bounds__(kThreads) void k_prepare(unsigned long long* bitmap, int64_t nwords, unsigned int* status,
-                                                      unsigned int* wg_flags, int nflags) {
+                                                      unsigned int* wg_flags, int nflags, unsigned int* hot_cand_n) {
   for (int64_t w = int64_t(blockIdx.x) * kThreads + threadIdx.x; w < nwords; w += int64_t(gridDim.x) * kThreads) bitmap[w] = 0;
   if (blockIdx.x == 0) {
     if (threadIdx.x < 8) status[threadIdx.x] = threadIdx.x == 4 ? kNoRow : 0u;
-    for (int i = threadIdx.x; i < nflags; i += kThreads) wg_flags[i] = 0;
+    for (int i = threadIdx.x; i < nflags; i += kThreads) { wg_flags[i] = 0; if (hot_cand_n) hot_cand_n[i] = 0; }
   }
 }
 
 // OR the workgroup flags into *summary (status[1]); reset the global table -- only when the
 // local path went through.
 __global__ __launch_bounds__(kThreads) void k_clear_table_unless(GroupTable t, int64_t nslots, const unsigned int* wg_flags,
-                                                                 int nflags, unsigned int* summary) {
+                                                                 int nflags, unsigned int* summary, HotMem hot,
+                                                                 unsigned int* use_hot) {
   int mine = 0;
   for (int i = threadIdx.x; i < nflags; i += kThreads) mine |= wg_flags[i] != 0;
   const int any = __syncthreads_or(mine);
   if (blockIdx.x == 0 && threadIdx.x == 0) *summary = any ? 1u : 0u;
-  if (any) return;
+  if (any) {
+    if (blockIdx.x == 0) BuildHotSet(hot, nflags, use_hot);  // heavy hitters seen by the workgroups that gave up
+    return;
+  }
   for (int64_t s = int64_t(blockIdx.x) * kThreads + threadIdx.x; s < nslots; s += int64_t(gridDim.x) * kThreads) {
     t.hkeys[s] = kEmpty; t.first[s] = kNoRow; t.sums[s] = 0; t.counts[s] = 0;
   }
@@ -1906,9 +2166,28 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
     const size_t rec_bytes = path >= 2 ? std::max(16 * static_cast<size_t>(cap) * kP * nblocks, LocalStageBytes(nblocks_local))
                            : path == 1 ? 16 * static_cast<size_t>(n) : 0;
     const size_t off_rec = c.Take(rec_bytes);
+    // heavy-hitter scratch (path 3 only)
+    const int nwg_hot = path == 3 ? nblocks_local : 0;
+    const size_t off_hot_cand = c.Take(4 * size_t(nwg_hot) * kHotPerWg);
+    const size_t off_hot_candn = c.Take(4 * size_t(kMaxFlags));
+    const size_t off_hot_tags = c.Take(4 * size_t(kHotCap));
+    const size_t off_hot_count = c.Take(256);
+    const size_t off_hot_psum = c.Take(8 * size_t(nwg_hot) * (kHotCap + 1));
+    const size_t off_hot_pcnt = c.Take(4 * size_t(nwg_hot) * (kHotCap + 1));
+    const size_t off_hot_pfirst = c.Take(4 * size_t(nwg_hot) * (kHotCap + 1));
+    const size_t off_hot_mask = c.Take(path == 3 ? static_cast<size_t>(n / 8 + 64) : 0);
     void* base;
     AA_TRY(Scratch(ctx, c.off, &base));
     char* b = static_cast<char*>(base);
+    HotMem hot{};
+    hot.cand = reinterpret_cast<uint32_t*>(b + off_hot_cand);
+    hot.cand_n = reinterpret_cast<unsigned int*>(b + off_hot_candn);
+    hot.tags = reinterpret_cast<uint32_t*>(b + off_hot_tags);
+    hot.count = reinterpret_cast<unsigned int*>(b + off_hot_count);
+    hot.part_sum = reinterpret_cast<unsigned long long*>(b + off_hot_psum);
+    hot.part_cnt = reinterpret_cast<unsigned int*>(b + off_hot_pcnt);
+    hot.part_first = reinterpret_cast<uint32_t*>(b + off_hot_pfirst);
+    hot.alt_mask = reinterpret_cast<uint8_t*>(b + off_hot_mask);
     t = BindTable(b, tm, T, false);
     r = BindRank(b, roff, n);
     gx = reinterpret_cast<unsigned long long*>(b + off_gx);
@@ -1916,7 +2195,8 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
     unsigned int* wg_flags = misc + 64;
     if (nblocks > kMaxFlags || nblocks_local > kMaxFlags) return SetError(AMDARROW_INVALID, "group-by: more workgroups than flag words");
     hipLaunchKernelGGL(k_prepare, dim3(GridFor(r.nwords, kThreads, ctx->num_cus * 4)), dim3(kThreads), 0, ctx->stream, r.bitmap,
-                       r.nwords, misc, wg_flags, nblocks_local > nblocks ? nblocks_local : nblocks);
+                       r.nwords, misc, wg_flags, nblocks_local > nblocks ? nblocks_local : nblocks,
+                       path == 3 ? hot.cand_n : static_cast<unsigned int*>(nullptr));
     AA_HIP(hipGetLastError());
 
     if (fast) {
@@ -1946,26 +2226,38 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
           st.first = reinterpret_cast<uint32_t*>(sb + 12 * ne);
           st.cnt = reinterpret_cast<unsigned int*>(sb + 16 * ne);
           unsigned int* abort_flag = misc + 1;  // written by k_clear_table_unless (OR of the workgroup flags)
-#define AA_LOCAL(MM, VV) hipLaunchKernelGGL((k_local_aggregate_fast<MM, VV>), dim3(nblocks_local), dim3(kDThreads), 0, ctx->stream, fl, acc_double, st, wg_flags)
-          if (!headline_shape) hipLaunchKernelGGL(k_local_aggregate, dim3(nblocks_local), dim3(kDThreads), 0, ctx->stream, fl, acc_double, st, wg_flags);
+#define AA_LOCAL(MM, VV) hipLaunchKernelGGL((k_local_aggregate_fast<MM, VV>), dim3(nblocks_local), dim3(kDThreads), 0, ctx->stream, fl, acc_double, st, wg_flags, hot)
+          if (!headline_shape) hipLaunchKernelGGL(k_local_aggregate, dim3(nblocks_local), dim3(kDThreads), 0, ctx->stream, fl, acc_double, st, wg_flags, hot);
           else if (M && V) AA_LOCAL(true, true); else if (M) AA_LOCAL(true, false); else if (V) AA_LOCAL(false, true); else AA_LOCAL(false, false);
 #undef AA_LOCAL
           AA_HIP(hipGetLastError());
           const int64_t nslots = static_cast<int64_t>(T) + 2;
           hipLaunchKernelGGL(k_clear_table_unless, dim3(GridFor(nslots, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0,
-                             ctx->stream, t, nslots, wg_flags, nblocks_local, abort_flag);
+                             ctx->stream, t, nslots, wg_flags, nblocks_local, abort_flag, hot, misc + 5);
           hipLaunchKernelGGL(k_local_merge, dim3(GridFor(static_cast<int64_t>(ne), kThreads, ctx->num_cus * 8)), dim3(kThreads),
                              0, ctx->stream, st, static_cast<int64_t>(ne), ks.total_bits, acc_double, t, abort_flag, misc);
           AA_HIP(hipGetLastError());
+          // heavy hitters found by the workgroups that gave up: fold their rows here, hand the
+          // scatter a mask without them (no-op when status[5] is 0)
+          hipLaunchKernelGGL(k_hot_aggregate, dim3(nblocks_local), dim3(kDThreads), 0, ctx->stream, fl, acc_double, hot, misc + 5);
+          AA_HIP(hipGetLastError());
           run_if = abort_flag;
         }
+        const unsigned int* use_hot = path == 3 ? misc + 5 : nullptr;
+        FastArgs fh = fa;  // the same scatter on the mask k_hot_aggregate wrote
+        fh.m_data = hot.alt_mask; fh.m_valid = nullptr; fh.m_off = 0;
         if (headline_shape) {
-#define AA_FAST(MM, VV) hipLaunchKernelGGL((k_part_scatter_fast<MM, VV>), dim3(nblocks), dim3(kFThreads), 0, ctx->stream, fa, cap, records, hist, misc, run_if)
-          if (M && V) AA_FAST(true, true); else if (M) AA_FAST(true, false); else if (V) AA_FAST(false, true); else AA_FAST(false, false);
+#define AA_FAST(MM, VV, ARGS, RUN, SKIP) hipLaunchKernelGGL((k_part_scatter_fast<MM, VV>), dim3(nblocks), dim3(kFThreads), 0, ctx->stream, ARGS, cap, records, hist, misc, RUN, SKIP)
+          if (M && V) AA_FAST(true, true, fa, run_if, use_hot); else if (M) AA_FAST(true, false, fa, run_if, use_hot);
+          else if (V) AA_FAST(false, true, fa, run_if, use_hot); else AA_FAST(false, false, fa, run_if, use_hot);
+          if (use_hot) { if (V) AA_FAST(true, true, fh, use_hot, nullptr); else AA_FAST(true, false, fh, use_hot, nullptr); }
 #undef AA_FAST
         } else {
           hipLaunchKernelGGL(k_part_scatter_direct, dim3(nblocks), dim3(kDThreads), 0, ctx->stream, fa, cap, records, hist,
-                             misc, run_if);
+                             misc, run_if, use_hot);
+          if (use_hot)
+            hipLaunchKernelGGL(k_part_scatter_direct, dim3(nblocks), dim3(kDThreads), 0, ctx->stream, fh, cap, records, hist,
+                               misc, use_hot, static_cast<const unsigned int*>(nullptr));
         }
         AA_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_part_aggregate_direct, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nblocks,
@@ -1989,7 +2281,8 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
       AA_HIP(hipGetLastError());
     }
     int64_t G = 0;
-    AA_TRY(RankFirstRows(ctx, t, 0, r, &G, /*mark_mode=*/path == 3 ? 2 : path == 2 ? 1 : 3, misc));
+    const HotInject inject{hot, nblocks_local, ks.total_bits, values && IsFloat(values->type_id) ? 1 : 0};
+    AA_TRY(RankFirstRows(ctx, t, 0, r, &G, /*mark_mode=*/path == 3 ? 2 : path == 2 ? 1 : 3, misc, path == 3 ? &inject : nullptr));
     // Emit and decode are queued BEFORE the group count is known on the host (they take it from
     // the status words and are bounded by group_capacity), so the one host round trip of the
     // call overlaps with them instead of sitting between two kernels.

@@ -35,6 +35,7 @@ SEED = 0x0ff1ce         # kRandomSeed, compute/kernels/test_util.h:123
 
 NUM_GROUPS = 1_000_000  # --groups
 NUM_CHUNKS = 1  # --chunks (sort workloads)
+HOT_FRAC = 0.0  # --hot-frac (headline workload: this share of the rows carries ONE key)
 KEY_BITS = 32   # --key-bits (headline workload: 64 = int64 key column)
 
 WORKLOADS = {
@@ -72,6 +73,8 @@ def make_inputs(workload, n, dev, rank, sel):
         vals = torch.randint(-100, 101, (n,), dtype=torch.int64, device=dev, generator=gen)
         kdt, kid = (torch.int64, _abi.INT64) if KEY_BITS == 64 else (torch.int32, _abi.INT32)
         keys = torch.randint(0, NUM_GROUPS, (n,), dtype=kdt, device=dev, generator=gen)
+        if HOT_FRAC > 0:  # a heavy hitter among many distinct keys (skew)
+            keys[torch.rand(n, device=dev, generator=gen) < HOT_FRAC] = 7
         if KEY_BITS == 64:
             keys += 1_700_000_000_000  # e.g. millisecond timestamps / large ids: wide values, narrow range
         d["values"] = device.DeviceArray(_abi.INT64, vals.view(torch.uint8), None, n)
@@ -268,11 +271,13 @@ def main():
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU")
     ap.add_argument("--selectivity", type=float, default=0.5)
     ap.add_argument("--groups", type=int, default=1_000_000, help="distinct group keys (tuning aid; the headline is 1M)")
+    ap.add_argument("--hot-frac", type=float, default=0.0, help="headline workload: share of rows that carry one hot key")
     ap.add_argument("--key-bits", type=int, default=32, choices=[32, 64], help="headline workload: width of the key column")
     ap.add_argument("--chunks", type=int, default=1, help="sort workloads: present the rows as this many equal chunks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
-    global NUM_GROUPS, NUM_CHUNKS, KEY_BITS
+    global NUM_GROUPS, NUM_CHUNKS, KEY_BITS, HOT_FRAC
+    HOT_FRAC = args.hot_frac
     KEY_BITS = args.key_bits
     NUM_GROUPS = args.groups
     NUM_CHUNKS = args.chunks

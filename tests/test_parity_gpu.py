@@ -599,3 +599,37 @@ def test_filter_groupby_wide_and_boolean_keys_on_partitioned_path(gpu, oracle, k
                         assert x.shape == y.shape and np.allclose(x, y, rtol=F64_RTOL)
                     else:
                         assert np.array_equal(x, y), (kt, vt, env)
+
+
+@pytest.mark.parametrize("shape", ["one-hot-40%", "zipf", "hot-null-key", "hot+value-nulls+double", "int16-keys-hot"])
+def test_filter_groupby_heavy_hitters(gpu, oracle, shape):
+    """Skewed keys among many distinct ones: the heavy hitters are folded in LDS next to the
+    scatter (k_hot_aggregate) and injected into the table afterwards; the partitions only see the
+    uniform remainder.  Results must be the reference's rows, first-appearance order included."""
+    rng = np.random.default_rng(61)
+    n = 3_000_000
+    base = rng.integers(0, 400_000, n)
+    vt, kt, key_valid = INT64, INT32, None
+    if shape == "one-hot-40%":
+        base[rng.random(n) < 0.4] = 7
+    elif shape == "zipf":
+        z = rng.zipf(1.3, n)
+        base = np.where(z < 400_000, z, base)
+    elif shape == "hot-null-key":
+        key_valid = rng.random(n) > 0.3
+    elif shape == "hot+value-nulls+double":
+        base[rng.random(n) < 0.25] = 123_456
+        base[rng.random(n) < 0.10] = 9
+        vt = DOUBLE
+    else:
+        kt = INT16
+        base = rng.integers(-30_000, 30_000, n)
+        base[rng.random(n) < 0.5] = -77
+    v = R(rng, vt, n, .05 if "value-nulls" in shape else 0.01, 2)
+    k = Arr(kt, base, key_valid)
+    m = R(rng, BOOL, n, 0.0, 3)
+    for x, y in zip(oracle.filter_groupby_sum(v, k, m), gpu.filter_groupby_sum(v, k, m)):
+        if x.dtype == np.float64:
+            assert x.shape == y.shape and np.allclose(x, y, rtol=1e-9), shape  # hot sums: other order
+        else:
+            assert np.array_equal(x, y), shape
