@@ -1222,6 +1222,9 @@ __global__ __launch_bounds__(kFThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
 // two side slots.  Per step a lane takes 4 records: 4 unconditional 16-byte loads, then the
 // 4 first probes are issued together; only mismatches enter the probe loop.
 constexpr uint32_t kTagFree = 0xFFFFFFFFu;
+// status[0]: why a partitioned attempt failed
+constexpr unsigned int kOverflowRegion = 1;  // a (workgroup, partition) region was too small: the exact two-pass variant helps
+constexpr unsigned int kOverflowTable = 2;   // a partition holds more groups than LDS slots: only the generic table helps
 constexpr int kSideNull = kSlots, kSideFree = kSlots + 1;
 
 // The LDS table is bucketised: 1024 buckets of 4 tags (one ds_read_b128 fetches a bucket).  At
@@ -1340,6 +1343,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
   __shared__ uint32_t s_first[kSlots + 2];
   __shared__ unsigned int s_cnt[kSlots + 2];
   __shared__ unsigned int s_groups;
+  __shared__ unsigned int s_abort;
   if (run_if && !*run_if) return;  // the local path already built the table
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = blockIdx.x;
@@ -1351,9 +1355,16 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
     if (b < nblocks) my_cnt = counts[int64_t(p) * nblocks + b];
   }
   for (int s = tid; s < kSlots + 2; s += kPartThreads) { s_tag[s] = kTagFree; s_sum[s] = 0; s_first[s] = kNoRow; s_cnt[s] = 0; }
-  if (tid == 0) s_groups = 0;
+  if (tid == 0) { s_groups = 0; s_abort = 0; }
   __syncthreads();
   bool failed = false;
+  // A table that overflows (more groups in the partition than LDS slots) dooms the attempt: the
+  // wave raises kOverflowTable, its workgroup stops at the next step and every other workgroup at
+  // its next segment, so a hopeless attempt costs ~0.1 ms instead of a full pass.
+  volatile unsigned int* abort_lds = &s_abort;
+  auto give_up = [&]() {
+    if (lane == 0) { *abort_lds = 1; __hip_atomic_store(overflow, kOverflowTable, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  };
   for (int jb = 0; wave + kWaves * jb < nblocks; jb += 64) {
     if (jb) {
       const int b = wave + kWaves * (jb + lane);
@@ -1375,17 +1386,22 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
       if (i2 >= cnt) { k2 = k + 1; i2 = 0; cnt2 = k2 < nseg ? __shfl(my_cnt, k2) : 0; }
       AggLoad(rb, seg + (k2 < nseg ? k2 : k) * seg_stride, i2, cnt2, lane);
       failed |= !AggFoldStep(ra, i0, cnt, lane, acc_double, s_tag, s_sum, s_first, s_cnt, &s_groups);
+      if (__any(failed)) { give_up(); break; }
+      if (*abort_lds || (i2 == 0 && (k2 & 3) == 0 && __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
       if (k2 >= nseg) break;
       k = k2;
       i0 = i2 + kAggStep; cnt = cnt2;
       if (i0 >= cnt2) { k = k2 + 1; i0 = 0; cnt = k < nseg ? __shfl(my_cnt, k) : 0; }
       AggLoad(ra, seg + (k < nseg ? k : k2) * seg_stride, i0, cnt, lane);
       failed |= !AggFoldStep(rb, i2, cnt2, lane, acc_double, s_tag, s_sum, s_first, s_cnt, &s_groups);
+      if (__any(failed)) { give_up(); break; }
+      if (*abort_lds) break;
       if (k >= nseg) break;
     }
+    if (*abort_lds) break;
   }
-  if (failed) *overflow = 1;
   __syncthreads();
+  if (*abort_lds || __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // nothing reads the table
   const int64_t g0 = int64_t(p) * kSlots;
   for (int s = tid; s < kSlots; s += kPartThreads) {
     const unsigned int tag = s_tag[s];
@@ -1485,62 +1501,95 @@ __device__ __forceinline__ void LocalWriteOut(const LocalShared& sh, const Local
 //   5. k_hot_inject (inside k_mark_first's launch) merges the per-workgroup partials and puts each
 //      hot group into a free slot of its partition's slice of the table, marking its first row.
 // Nothing here costs a host round trip; with no hot key steps 3-5 are two empty launches.
-constexpr int kHotPerWg = 32;     // candidates one workgroup may report
+constexpr int kHotPerWg = 128;    // candidates one workgroup may report
 constexpr int kHotCap = 2048;     // keys in the hot set
 constexpr unsigned int kHotMin = 4;
 constexpr int kHotMapSlots = 4096;  // LDS open-addressing map tag -> hot index (load <= 50 %)
 
 
-// Called by every thread of a local-aggregate workgroup that gave up.
+// Called by every thread of a local-aggregate workgroup that gave up.  Reports the MOST frequent
+// keys of the sample (power-of-two count classes, from the top until kHotPerWg would be exceeded):
+// slot order is the same in every workgroup, so "the first kHotPerWg found" would drop the same
+// keys everywhere, however hot.
 __device__ __forceinline__ void ReportHotCandidates(LocalShared& sh, const HotMem& hot, int tid) {
-  __shared__ unsigned int s_n;
+  __shared__ unsigned int s_n, s_class[33], s_min_class;
   if (tid == 0) s_n = 0;
+  if (tid < 33) s_class[tid] = 0;
   __syncthreads();
+  for (int s = tid; s < kSlots; s += kDThreads)
+    if (sh.tag[s] != kTagFree && sh.cnt[s] >= kHotMin) atomicAdd(&s_class[32 - __clz(sh.cnt[s])], 1u);
+  __syncthreads();
+  if (tid == 0) {
+    unsigned int total = 0;
+    int c = 32;
+    for (; c > 0; --c) {
+      if (total + s_class[c] > static_cast<unsigned int>(kHotPerWg)) break;
+      total += s_class[c];
+    }
+    s_min_class = c + 1;  // classes >= this fit
+  }
+  __syncthreads();
+  const unsigned int min_class = s_min_class;
   for (int s = tid; s < kSlots; s += kDThreads) {
-    if (sh.tag[s] != kTagFree && sh.cnt[s] >= kHotMin) {
+    if (sh.tag[s] != kTagFree && sh.cnt[s] >= kHotMin && 32u - __clz(sh.cnt[s]) >= min_class) {
       const unsigned int i = atomicAdd(&s_n, 1u);
-      if (i < kHotPerWg) hot.cand[int64_t(blockIdx.x) * kHotPerWg + i] = sh.tag[s];
+      if (i < static_cast<unsigned int>(kHotPerWg)) hot.cand[int64_t(blockIdx.x) * kHotPerWg + i] = sh.tag[s];
     }
   }
   __syncthreads();
   if (tid == 0)
-    hot.cand_n[blockIdx.x] = (s_n < kHotPerWg ? s_n : kHotPerWg) | (sh.cnt[kSideNull] >= kHotMin ? 0x80000000u : 0u);
+    hot.cand_n[blockIdx.x] = (s_n < static_cast<unsigned int>(kHotPerWg) ? s_n : kHotPerWg) | (sh.cnt[kSideNull] >= kHotMin ? 0x80000000u : 0u);
 }
 
 // Block 0 of k_clear_table_unless, when the local attempt was given up: candidates -> hot set.
+// A key is hot only if MANY row ranges report it (>= a quarter of those that gave up, at least 2):
+// sorted / clustered keys repeat inside one range and are reported by that range alone -- they
+// are not heavy hitters, and treating them as such cost 15 ms on sorted input.
+constexpr int kHotVoteSlots = 8192;  // LDS vote table (tags + counts = 64 KiB); inserts stop at 75 % load
 __device__ __forceinline__ void BuildHotSet(const HotMem& hot, int nwg, unsigned int* use_hot) {
-  __shared__ uint32_t s_set[kHotMapSlots];
-  __shared__ unsigned int s_count, s_null;
+  __shared__ uint32_t s_tag[kHotVoteSlots];
+  __shared__ unsigned int s_votes[kHotVoteSlots];
+  __shared__ unsigned int s_used, s_count, s_null_votes, s_reporting;
   const int tid = threadIdx.x;
-  for (int i = tid; i < kHotMapSlots; i += blockDim.x) s_set[i] = kTagFree;
-  if (tid == 0) { s_count = 0; s_null = 0; }
+  for (int i = tid; i < kHotVoteSlots; i += blockDim.x) { s_tag[i] = kTagFree; s_votes[i] = 0; }
+  if (tid == 0) { s_used = 0; s_count = 0; s_null_votes = 0; s_reporting = 0; }
   __syncthreads();
   for (int w = tid; w < nwg; w += blockDim.x) {
     const unsigned int cn = hot.cand_n[w];
-    if (cn >> 31) s_null = 1;
     const unsigned int n = cn & 0x7FFFFFFFu;
+    if (cn) atomicAdd(&s_reporting, 1u);
+    if (cn >> 31) atomicAdd(&s_null_votes, 1u);
     for (unsigned int i = 0; i < n && i < static_cast<unsigned int>(kHotPerWg); ++i) {
       const uint32_t tag = hot.cand[int64_t(w) * kHotPerWg + i];
       if (tag == kTagFree) continue;  // (the one key whose tag is the free marker stays cold)
-      uint32_t slot = tag & (kHotMapSlots - 1);
-      for (int probes = 0; probes < kHotMapSlots; ++probes) {
-        const uint32_t old = atomicCAS(&s_set[slot], kTagFree, tag);
+      uint32_t slot = tag & (kHotVoteSlots - 1);
+      for (int probes = 0; probes < 64; ++probes) {  // bounded: a crowded table just drops the candidate
+        uint32_t old = s_tag[slot];
         if (old == kTagFree) {
-          const unsigned int idx = atomicAdd(&s_count, 1u);
-          if (idx < static_cast<unsigned int>(kHotCap)) hot.tags[idx] = tag;
-          break;
+          if (s_used >= kHotVoteSlots * 3 / 4) break;
+          old = atomicCAS(&s_tag[slot], kTagFree, tag);
+          if (old == kTagFree) { atomicAdd(&s_used, 1u); old = tag; }
         }
-        if (old == tag) break;
-        slot = (slot + 1) & (kHotMapSlots - 1);
+        if (old == tag) { atomicAdd(&s_votes[slot], 1u); break; }
+        slot = (slot + 1) & (kHotVoteSlots - 1);
       }
+    }
+  }
+  __syncthreads();
+  const unsigned int quorum = s_reporting / 4 > 2 ? s_reporting / 4 : 2;
+  for (int i = tid; i < kHotVoteSlots; i += blockDim.x) {
+    if (s_tag[i] != kTagFree && s_votes[i] >= quorum) {
+      const unsigned int idx = atomicAdd(&s_count, 1u);
+      if (idx < static_cast<unsigned int>(kHotCap)) hot.tags[idx] = s_tag[i];
     }
   }
   __syncthreads();
   if (tid == 0) {
     const unsigned int n = s_count < static_cast<unsigned int>(kHotCap) ? s_count : kHotCap;
+    const unsigned int null_hot = s_null_votes >= quorum ? 1u : 0u;
     hot.count[0] = n;
-    hot.count[1] = s_null;
-    *use_hot = (n > 0 || s_null) ? 1u : 0u;
+    hot.count[1] = null_hot;
+    *use_hot = (n > 0 || null_hot) ? 1u : 0u;
   }
 }
 
@@ -2152,7 +2201,8 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
       nblocks_local = static_cast<int>(std::min<int64_t>(ctx->num_cus, (n + kDRows - 1) / kDRows));
       rows_per_block_local = (((n + nblocks_local - 1) / nblocks_local + kDRows - 1) / kDRows) * kDRows;
       const double mean = static_cast<double>(rows_per_block) / kP;
-      cap = (static_cast<int64_t>(mean * 1.25 + 8.0 * std::sqrt(mean) + 16.0) + 3) & ~int64_t(3);  // whole 64-byte sectors
+      // room for a key of up to ~0.25 % of the rows next to the uniform share (hotter keys are taken out before the scatter)
+      cap = (static_cast<int64_t>(mean * 2.0 + 8.0 * std::sqrt(mean) + 32.0) + 3) & ~int64_t(3);  // whole 64-byte sectors
       hist_n = int64_t(kP) * nblocks;
     } else if (path == 1) {
       nblocks = static_cast<int>(std::min<int64_t>(ctx->num_cus, (n + kPartRows - 1) / kPartRows));
@@ -2317,6 +2367,7 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
     const unsigned int overflow = status[0];
     if (overflow && fast) {  // capacity assumption failed: next (more general) path
       if (path == 3) path = 2;  // the partition attempt was part of path 3
+      if (overflow == kOverflowTable) path = 1;  // the two-pass variant has the same LDS tables: straight to the generic path
       continue;
     }
     if (overflow || G > group_capacity)
