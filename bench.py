@@ -257,8 +257,10 @@ def pmc_traffic(workload):
     total_kb = 0.0
     for line in open(path):
         parts = line.split()
-        if "avg" in parts and ("FETCH_SIZE" in parts or "WRITE_SIZE" in parts):
-            total_kb += float(parts[parts.index("avg") + 1])
+        if parts[:1] == ["PER_STEP_TOTAL"]:  # FETCH_SIZE and WRITE_SIZE, all kernels of one step
+            total_kb += float(parts[2])
+    if total_kb == 0.0:
+        return None, None
     return total_kb * 1024.0, os.path.relpath(path, ROOT)
 
 
