@@ -8,6 +8,7 @@
 //                   vectors (vector_selection_test.cc:296-321, 1038-1051; vector_sort_test.cc:423-464,
 //                   629-647; hash_aggregate_test.cc:251-292, 480-605; scalar_compare_test.cc:248-296;
 //                   scalar_arithmetic_test.cc:337-362) and its error codes.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -545,12 +546,93 @@ static int RunGpu() {
     CHECK_OK(me.status());
     if (me.ok()) CHECK(!me->scalar()->fields[0]->is_valid);
   }
+  {  // GroupBy's fused device path (one key column, one batch) returns the rows of the batch-wise Grouper path
+    const int64_t n = 400000;
+    std::vector<int64_t> vals(n);
+    std::vector<int32_t> keys(n);
+    std::vector<uint8_t> vvalid((n + 7) / 8 + 1, 0), kvalid((n + 7) / 8 + 1, 0);
+    uint64_t x = 12345;
+    int64_t vnulls = 0, knulls = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+      vals[i] = static_cast<int64_t>(x % 2001) - 1000;
+      keys[i] = static_cast<int32_t>((x >> 24) % 30000) - 15000;
+      if ((x >> 60) != 0) vvalid[i / 8] |= uint8_t(1u << (i % 8)); else ++vnulls;
+      if (((x >> 50) & 63) != 0) kvalid[i / 8] |= uint8_t(1u << (i % 8)); else ++knulls;
+    }
+    auto v = ArrayFromHost(pool, int64(), vals.data(), n, vvalid.data(), vnulls);
+    auto k = ArrayFromHost(pool, int32(), keys.data(), n, kvalid.data(), knulls);
+    CHECK(v.ok() && k.ok());
+    if (v.ok() && k.ok()) {
+      CountOptions co;
+      const std::vector<internal::Aggregate> aggs = {{"hash_sum", nullptr}, {"hash_count", &co}, {"hash_mean", nullptr}, {"hash_count", &co}};
+      const std::vector<Datum> args = {Datum(*v), Datum(*v), Datum(*v), Datum(*k)};
+      unsetenv("AMDARROW_GROUPBY_BATCHWISE");
+      auto fused = internal::GroupBy(args, {Datum(*k)}, aggs, &ctx);
+      setenv("AMDARROW_GROUPBY_BATCHWISE", "1", 1);
+      auto batch = internal::GroupBy(args, {Datum(*k)}, aggs, &ctx);
+      unsetenv("AMDARROW_GROUPBY_BATCHWISE");
+      CHECK_OK(fused.status());
+      CHECK_OK(batch.status());
+      if (fused.ok() && batch.ok()) {
+        CHECK(fused->length == batch->length && fused->length == 30001 && fused->field_names == batch->field_names);
+        CHECK(Same(Host<int64_t>(pool, *fused->columns[0]), Host<int64_t>(pool, *batch->columns[0])));
+        CHECK(Same(Host<int64_t>(pool, *fused->columns[1]), Host<int64_t>(pool, *batch->columns[1])));
+        CHECK(Same(Host<double>(pool, *fused->columns[2]), Host<double>(pool, *batch->columns[2])));
+        CHECK(Same(Host<int64_t>(pool, *fused->columns[3]), Host<int64_t>(pool, *batch->columns[3])));
+        CHECK(Same(Host<int32_t>(pool, *fused->columns[4]), Host<int32_t>(pool, *batch->columns[4])));
+        CHECK((fused->columns[4]->buffers[0] != nullptr) == (batch->columns[4]->buffers[0] != nullptr));
+        CHECK(fused->columns[0]->null_count == batch->columns[0]->null_count);
+      }
+    }
+  }
   CHECK(pool->bytes_allocated() >= 0 && pool->max_memory() > 0);  // the MemoryPool counters (memory_pool.h:38-105)
   printf("host_test gpu: %d checks, %d failures\n", g_checks, g_failures);
   return g_failures ? 1 : 0;
 }
 
+// host_test bench [rows]: the drop-in API timed end to end -- Filter + GroupBy through CallFunction /
+// internal::GroupBy on `rows` int64 values, int32 keys over 1 M groups, a 50 % mask.
+static int RunBench(int64_t n) {
+  auto pool_r = MemoryPool::Make(0);
+  if (!pool_r.ok()) { fprintf(stderr, "no device: %s\n", pool_r.status().ToString().c_str()); return 2; }
+  auto pool = *pool_r;
+  ExecContext ctx(pool);
+  std::vector<int64_t> vals(n);
+  std::vector<int32_t> keys(n);
+  std::vector<uint8_t> mask((n + 7) / 8 + 8, 0);
+  uint64_t x = 0x0ff1ce;
+  auto next = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+  for (int64_t i = 0; i < n; ++i) {
+    const uint64_t r = next();
+    vals[i] = static_cast<int64_t>(r % 201) - 100;
+    keys[i] = static_cast<int32_t>((r >> 20) % 1000000);
+    if ((r >> 50) & 1) mask[i / 8] |= uint8_t(1u << (i % 8));
+  }
+  auto v = ArrayFromHost(pool, int64(), vals.data(), n, nullptr, 0);
+  auto k = ArrayFromHost(pool, int32(), keys.data(), n, nullptr, 0);
+  auto m = ArrayFromHost(pool, boolean(), mask.data(), n, nullptr, 0);
+  if (!v.ok() || !k.ok() || !m.ok()) return 2;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  for (int rep = 0; rep < 4; ++rep) {
+    const double t0 = now();
+    auto fv = Filter(Datum(*v), Datum(*m), FilterOptions::Defaults(), &ctx);
+    auto fk = Filter(Datum(*k), Datum(*m), FilterOptions::Defaults(), &ctx);
+    if (!fv.ok() || !fk.ok()) { fprintf(stderr, "filter failed\n"); return 1; }
+    const double t1 = now();
+    CountOptions co;
+    auto r = internal::GroupBy({*fv, *fv}, {*fk}, {{"hash_sum", nullptr}, {"hash_count", &co}}, &ctx);
+    if (!r.ok()) { fprintf(stderr, "GroupBy failed: %s\n", r.status().ToString().c_str()); return 1; }
+    (void)amdarrow_ctx_synchronize(pool->ctx());
+    const double t2 = now();
+    printf("rep %d: Filter x2 %.3f ms, GroupBy{hash_sum,hash_count} %.3f ms, groups %lld\n", rep, (t1 - t0) * 1e3, (t2 - t1) * 1e3,
+           static_cast<long long>(r->length));
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 2 && !strcmp(argv[1], "bench")) return RunBench(argc >= 3 ? atoll(argv[2]) : 100000000);
   if (argc >= 2 && !strcmp(argv[1], "cpu")) return RunCpu();
   if (argc >= 2 && !strcmp(argv[1], "gpu")) return RunGpu();
   fprintf(stderr, "usage: host_test cpu|gpu\n");
