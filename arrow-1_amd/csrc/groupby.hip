@@ -588,7 +588,14 @@ struct FastArgs {
   ValueCol v; int has_values;
   const uint8_t* m_data; const uint8_t* m_valid; int64_t m_off;
   int64_t n; int64_t rows_per_block; int nblocks;
+  // Sub-problems (more than ~1.8 M groups): the top sub_bits hash bits select one of 2^sub_bits
+  // passes over the input, each with its own 512 partitions (the NEXT 9 bits) and table slice.
+  int sub_bits; uint32_t sub_id;
 };
+__device__ __forceinline__ uint32_t PartOf(uint32_t h, int sub_bits) { return (h << sub_bits) >> (32 - kPBits); }
+__device__ __forceinline__ bool InSub(uint32_t h, int sub_bits, uint32_t sub_id) {
+  return sub_bits == 0 || (h >> (32 - sub_bits)) == sub_id;
+}
 
 __device__ __forceinline__ bool FastSelected(const FastArgs& a, int64_t row) {
   if (!a.m_data) return true;
@@ -821,8 +828,8 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate(const uint4* re
 constexpr int kDThreads = kPartThreads;  // 1024
 constexpr int kDRows = kPartRows;         // 8192 rows per tile: 8 per thread
 
-__device__ __forceinline__ uint32_t FastPartition32(uint32_t x, bool is_null) {
-  return is_null ? 0u : (Fmix32(x) >> (32 - kPBits));
+__device__ __forceinline__ uint32_t FastPartition32(uint32_t x, bool is_null, int sub_bits) {
+  return is_null ? 0u : PartOf(Fmix32(x), sub_bits);  // the null key lives in partition 0 of sub-problem 0
 }
 
 struct TileRegs {
@@ -881,7 +888,9 @@ __global__ __launch_bounds__(kDThreads) void k_part_scatter_direct(FastArgs a, i
 #pragma unroll
     for (int j = 0; j < kIters; ++j) {
       if (t.sel[j]) {
-        rpart[j] = FastPartition32(t.x[j], t.flags[j] & kRecKeyNull);
+        const bool kn = (t.flags[j] & kRecKeyNull) != 0;
+        if (kn ? a.sub_id != 0 : !InSub(Fmix32(t.x[j]), a.sub_bits, a.sub_id)) { t.sel[j] = false; continue; }  // another pass takes it
+        rpart[j] = FastPartition32(t.x[j], kn, a.sub_bits);
         rrank[j] = atomicAdd(&s_cnt[buf][rpart[j]], 1u);
       }
     }
@@ -914,7 +923,7 @@ __global__ __launch_bounds__(kDThreads) void k_part_scatter_direct(FastArgs a, i
     const uint32_t total = s_off[kP - 1] + s_cnt[buf][kP - 1];
     for (uint32_t i = tid; i < total; i += kDThreads) {
       const uint4 r = s_rec[i];
-      const uint32_t p = FastPartition32(r.x, r.y & kRecKeyNull);
+      const uint32_t p = FastPartition32(r.x, r.y & kRecKeyNull, a.sub_bits);
       const uint32_t idx = s_cur[p] + (i - s_off[p]);
       if (idx < cap) regions[(int64_t(blockIdx.x) * kP + p) * cap + idx] = r;
       else over = true;
@@ -1016,11 +1025,12 @@ __device__ __forceinline__ void FastLoadTile(const FastArgs& a, const uint32_t* 
 // first consumer of the tile's registers, i.e. where the wave waits for its prefetched loads.
 __device__ __forceinline__ void FastRankTile(ScatterShared& sh, int buf, int lane, const uint32_t (&kx)[kFSteps],
                                              uint64_t mword, uint32_t (&rpart)[kFSteps], uint32_t (&rrank)[kFSteps],
-                                             bool (&sel)[kFSteps]) {
+                                             bool (&sel)[kFSteps], int sub_bits, uint32_t sub_id) {
 #pragma unroll
   for (int j = 0; j < kFSteps; ++j) {
-    sel[j] = (__shfl(mword, j, 64) >> lane) & 1;
-    rpart[j] = Fmix32(kx[j]) >> (32 - kPBits);
+    const uint32_t h = Fmix32(kx[j]);
+    sel[j] = ((__shfl(mword, j, 64) >> lane) & 1) && InSub(h, sub_bits, sub_id);
+    rpart[j] = PartOf(h, sub_bits);
     rrank[j] = 0;
     if (sel[j]) rrank[j] = atomicAdd(&sh.cnt[buf][rpart[j]], 1u);
   }
@@ -1045,7 +1055,7 @@ __device__ __forceinline__ void FastFinishTile(ScatterShared& sh, int buf, int64
                                                uint4* __restrict__ regions, int tid, int wave, int lane,
                                                const uint32_t (&kx)[kFSteps], const uint64_t (&kv)[kFSteps],
                                                uint64_t vword, const uint32_t (&rpart)[kFSteps],
-                                               const uint32_t (&rrank)[kFSteps], const bool (&sel)[kFSteps] PH_ARGS) {
+                                               const uint32_t (&rrank)[kFSteps], const bool (&sel)[kFSteps], int sub_bits PH_ARGS) {
   const int64_t wrow0 = tile0 + wave * (kFSteps * 64);
   using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
   // this workgroup's regions as one buffer: 32-bit offsets, cache policy per store (aux)
@@ -1117,7 +1127,7 @@ __device__ __forceinline__ void FastFinishTile(ScatterShared& sh, int buf, int64
     const uint32_t round = total - base < static_cast<uint32_t>(kFStage) ? total - base : static_cast<uint32_t>(kFStage);
     for (uint32_t i = tid; i < round; i += kFThreads) {
       const uint4 q = sh.rec[i];
-      const uint32_t p = Fmix32(q.x) >> (32 - kPBits);
+      const uint32_t p = PartOf(Fmix32(q.x), sub_bits);
       const uint32_t k = sh.carry_cnt[buf][p] + (base + i - sh.off[p]);  // position in (old carry + this tile's run)
       const uint32_t w = sh.wcnt[p];
       if (k < (w & 0x7FFFFFFFu)) {
@@ -1186,17 +1196,17 @@ __global__ __launch_bounds__(kFThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
   for (int64_t tile0 = lo; tile0 < hi; tile0 += 2 * kFRows) {
     const bool has_b = tile0 + kFRows < hi;
     words(tile0, mA, vA, &mw, &vw);
-    FastRankTile(sh, 0, lane, kxA, mw, rpart, rrank, sel);
+    FastRankTile(sh, 0, lane, kxA, mw, rpart, rrank, sel, a.sub_bits, a.sub_id);
     PH(0);
     if (has_b) FastLoadTile<MASK, VVALID>(a, keys, vals, tile0 + kFRows, hi, wave, lane, kxB, kvB, mB, vB);
-    FastFinishTile<VVALID>(sh, 0, tile0, cap, a.nblocks, regions, tid, wave, lane, kxA, kvA, vw, rpart, rrank, sel PH_PASS);
+    FastFinishTile<VVALID>(sh, 0, tile0, cap, a.nblocks, regions, tid, wave, lane, kxA, kvA, vw, rpart, rrank, sel, a.sub_bits PH_PASS);
     fin = 1;
     if (!has_b) break;
     words(tile0 + kFRows, mB, vB, &mw, &vw);
-    FastRankTile(sh, 1, lane, kxB, mw, rpart, rrank, sel);
+    FastRankTile(sh, 1, lane, kxB, mw, rpart, rrank, sel, a.sub_bits, a.sub_id);
     PH(0);
     if (tile0 + 2 * kFRows < hi) FastLoadTile<MASK, VVALID>(a, keys, vals, tile0 + 2 * kFRows, hi, wave, lane, kxA, kvA, mA, vA);
-    FastFinishTile<VVALID>(sh, 1, tile0 + kFRows, cap, a.nblocks, regions, tid, wave, lane, kxB, kvB, vw, rpart, rrank, sel PH_PASS);
+    FastFinishTile<VVALID>(sh, 1, tile0 + kFRows, cap, a.nblocks, regions, tid, wave, lane, kxB, kvB, vw, rpart, rrank, sel, a.sub_bits PH_PASS);
     fin = 0;
   }
 #ifdef SC_PHASES
@@ -1337,7 +1347,9 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
                                                                         int nblocks, int64_t cap, int k_bits,
                                                                         int acc_double, GroupTable t,
                                                                         unsigned long long* first_bitmap,
-                                                                        unsigned int* overflow, const unsigned int* run_if) {
+                                                                        unsigned int* overflow, const unsigned int* run_if,
+                                                                        int64_t slice0 /* first slot of this sub-problem's table slice */,
+                                                                        int64_t total_slots /* of all slices; 0 = not the first slice */) {
   __shared__ __attribute__((aligned(16))) unsigned int s_tag[kSlots + 4];
   __shared__ unsigned long long s_sum[kSlots + 2];
   __shared__ uint32_t s_first[kSlots + 2];
@@ -1402,7 +1414,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
   }
   __syncthreads();
   if (*abort_lds || __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // nothing reads the table
-  const int64_t g0 = int64_t(p) * kSlots;
+  const int64_t g0 = slice0 + int64_t(p) * kSlots;
   for (int s = tid; s < kSlots; s += kPartThreads) {
     const unsigned int tag = s_tag[s];
     // the shared numbering / emit kernels speak fmix64 of the packed key word
@@ -1432,8 +1444,8 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
       }
     }
   }
-  if (p == 0 && tid < 2) {
-    const int64_t T = int64_t(kP) * kSlots;
+  if (p == 0 && tid < 2 && total_slots > 0) {  // the two special slots behind the last slice stay empty on this path
+    const int64_t T = total_slots;
     t.hkeys[T + tid] = kEmpty; t.first[T + tid] = kNoRow; t.sums[T + tid] = 0; t.counts[T + tid] = 0;
   }
 }
@@ -2179,9 +2191,11 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
   unsigned long long* gx = nullptr;
   unsigned int* misc = nullptr;  // status words, see RankFirstRows; [64..] one flag per workgroup of the local path
   constexpr int kMaxFlags = 1024;
+  int sub_bits = 0;  // 2 after a partition's LDS table overflowed: four sub-problems, up to ~7 M groups
   for (;; --path) {
     const bool fast = path > 0;
-    const uint64_t T = fast ? uint64_t(kP) * kSlots
+    const int nsub = (fast && path == 2) ? 1 << sub_bits : 1;
+    const uint64_t T = fast ? uint64_t(nsub) * kP * kSlots
                             : NextPow2(2 * static_cast<uint64_t>(group_capacity < n ? group_capacity : n));
     Carver c;
     TableMem tm;
@@ -2200,7 +2214,7 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
       rows_per_block = (((n + nblocks - 1) / nblocks + tile - 1) / tile) * tile;
       nblocks_local = static_cast<int>(std::min<int64_t>(ctx->num_cus, (n + kDRows - 1) / kDRows));
       rows_per_block_local = (((n + nblocks_local - 1) / nblocks_local + kDRows - 1) / kDRows) * kDRows;
-      const double mean = static_cast<double>(rows_per_block) / kP;
+      const double mean = static_cast<double>(rows_per_block) / kP / nsub;
       // room for a key of up to ~0.25 % of the rows next to the uniform share (hotter keys are taken out before the scatter)
       cap = (static_cast<int64_t>(mean * 2.0 + 8.0 * std::sqrt(mean) + 32.0) + 3) & ~int64_t(3);  // whole 64-byte sectors
       hist_n = int64_t(kP) * nblocks;
@@ -2294,6 +2308,8 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
           run_if = abort_flag;
         }
         const unsigned int* use_hot = path == 3 ? misc + 5 : nullptr;
+        for (int sub = 0; sub < nsub; ++sub) {  // one pass per sub-problem (nsub == 1 unless a table overflowed before)
+        fa.sub_bits = nsub > 1 ? sub_bits : 0; fa.sub_id = static_cast<uint32_t>(sub);
         FastArgs fh = fa;  // the same scatter on the mask k_hot_aggregate wrote
         fh.m_data = hot.alt_mask; fh.m_valid = nullptr; fh.m_off = 0;
         if (headline_shape) {
@@ -2311,8 +2327,10 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
         }
         AA_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_part_aggregate_direct, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nblocks,
-                           cap, ks.total_bits, acc_double, t, r.bitmap, misc, run_if);
+                           cap, ks.total_bits, acc_double, t, r.bitmap, misc, run_if, int64_t(sub) * kP * kSlots,
+                           sub == 0 ? static_cast<int64_t>(T) : int64_t(0));
         AA_HIP(hipGetLastError());
+        }  // sub-problems
       } else {
         AA_HIP(hipMemsetAsync(hist + hist_n - 1, 0, 4, ctx->stream));
         hipLaunchKernelGGL(k_part_hist, dim3(nblocks), dim3(kPartThreads), 0, ctx->stream, fa, hist);
@@ -2367,7 +2385,13 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
     const unsigned int overflow = status[0];
     if (overflow && fast) {  // capacity assumption failed: next (more general) path
       if (path == 3) path = 2;  // the partition attempt was part of path 3
-      if (overflow == kOverflowTable) path = 1;  // the two-pass variant has the same LDS tables: straight to the generic path
+      if (overflow == kOverflowTable) {
+        // the two-pass variant has the same LDS tables.  More groups than 512 partitions hold: once
+        // more with four sub-problems (four passes over the input, 2048 partitions in effect),
+        // then the generic global-atomic table
+        if (sub_bits == 0) { sub_bits = 2; path = 3; }  // -> 2 after the loop's decrement
+        else path = 1;
+      }
       continue;
     }
     if (overflow || G > group_capacity)

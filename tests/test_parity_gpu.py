@@ -633,3 +633,17 @@ def test_filter_groupby_heavy_hitters(gpu, oracle, shape):
             assert x.shape == y.shape and np.allclose(x, y, rtol=1e-9), shape  # hot sums: other order
         else:
             assert np.array_equal(x, y), shape
+
+
+@pytest.mark.parametrize("n_groups", [3_000_000, 9_000_000])
+def test_filter_groupby_many_groups(gpu, oracle, n_groups):
+    """More groups than 512 partitions x 3584 LDS slots: the attempt stops early (kOverflowTable),
+    is repeated as four sub-problems (up to ~7 M groups) and, beyond that, lands on the generic
+    global-atomic table.  Every key distinct: the result is the input, in row order."""
+    rng = np.random.default_rng(71)
+    n = n_groups
+    v = R(rng, INT64, n, 0, 0)
+    k = Arr(INT32, rng.permutation(n).astype(np.int32))
+    m = Arr(BOOL, np.ones(n, bool))
+    for x, y in zip(oracle.filter_groupby_sum(v, k, m), gpu.filter_groupby_sum(v, k, m)):
+        assert np.array_equal(x, y)
