@@ -274,35 +274,57 @@ __global__ __launch_bounds__(kThreads) void k_take(TakeArgs a) {
   if (tid == 0) s_valid = 0;
   __syncthreads();
   unsigned long long my_valid = 0;
-  const int64_t nwaves_rows = (a.n + 63) & ~int64_t(63);
-  for (int64_t i = int64_t(blockIdx.x) * kThreads + tid; i < nwaves_rows; i += int64_t(gridDim.x) * kThreads) {
-    bool ok = i < a.n;
-    if (ok && a.i_valid) ok = GetBit(a.i_valid, a.i_off + i);
-    int64_t j = 0;
-    if (ok) {
-      const bool inb = IndexLoad<IdxT>::Load(a.i_data, a.i_off + i, a.v_len, &j);
-      if (!inb) {
-        ok = false;
+  // A wave takes 4 x 64 consecutive output rows per step.  The three dependent accesses of a row
+  // (index, the value's validity bit, the value) are issued for all four rows before any is used,
+  // with clamped addresses instead of branches: a gather is latency-bound and with one row per lane
+  // and step a random take ran at 28 G rows/s.
+  constexpr int kU = 4;
+  const int64_t wave_id = (int64_t(blockIdx.x) * kThreads + tid) >> 6;
+  const int64_t nwaves = (int64_t(gridDim.x) * kThreads) >> 6;
+  const bool have_values = a.v_len > 0;
+  for (int64_t base = wave_id * (64 * kU); base < a.n; base += nwaves * (64 * kU)) {
+    bool ok[kU];
+    int64_t j[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {  // indices (coalesced)
+      const int64_t i = base + 64 * u + lane;
+      const int64_t ic = i < a.n ? i : a.n - 1;
+      ok[u] = i < a.n;
+      if (a.i_valid) ok[u] = ok[u] && GetBit(a.i_valid, a.i_off + ic);
+      const bool inb = IndexLoad<IdxT>::Load(a.i_data, a.i_off + ic, a.v_len, &j[u]);
+      if (ok[u] && !inb) {
+        ok[u] = false;
         if (a.boundscheck) atomicMin(a.err_pos, static_cast<unsigned long long>(i));
       }
+      if (!ok[u]) j[u] = 0;  // a valid position for the unconditional gathers below
     }
-    // values' validity is consulted only when values.null_count != 0 (:306, :338)
-    if (ok && a.v_may_null) ok = GetBit(a.v_valid, a.v_off + j);
-    T v = 0;
-    if (ok) {
-      if (kBits) v = GetBit(reinterpret_cast<const uint8_t*>(a.v_data), a.v_off + j);
-      else v = reinterpret_cast<const T*>(a.v_data)[a.v_off + j];
+    bool vbit[kU];
+    T v[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {  // gathers, all in flight together
+      // values' validity is consulted only when values.null_count != 0 (:306, :338)
+      vbit[u] = (a.v_may_null && have_values) ? GetBit(a.v_valid, a.v_off + j[u]) : true;
+      if (!have_values) v[u] = 0;
+      else if (kBits) v[u] = GetBit(reinterpret_cast<const uint8_t*>(a.v_data), a.v_off + j[u]);
+      else v[u] = reinterpret_cast<const T*>(a.v_data)[a.v_off + j[u]];
     }
-    const uint64_t okmask = __ballot(ok);
-    if (kBits) {
-      const uint64_t vmask = __ballot(v != 0);
-      if (lane == 0) reinterpret_cast<uint64_t*>(a.out_values)[i >> 6] = vmask;
-    } else if (i < a.n) {
-      reinterpret_cast<T*>(a.out_values)[i] = v;  // null slots hold ValueCType{} (:318, :343)
-    }
-    if (lane == 0) {
-      reinterpret_cast<uint64_t*>(a.out_validity)[i >> 6] = okmask;
-      my_valid += __popcll(okmask);
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t i = base + 64 * u + lane;
+      if (base + 64 * u >= a.n) break;  // wave-uniform
+      const bool good = ok[u] && vbit[u];
+      const T val = good ? v[u] : T(0);  // null slots hold ValueCType{} (:318, :343)
+      const uint64_t okmask = __ballot(good);
+      if (kBits) {
+        const uint64_t vmask = __ballot(val != 0);
+        if (lane == 0) reinterpret_cast<uint64_t*>(a.out_values)[i >> 6] = vmask;
+      } else if (i < a.n) {
+        reinterpret_cast<T*>(a.out_values)[i] = val;
+      }
+      if (lane == 0) {
+        reinterpret_cast<uint64_t*>(a.out_validity)[i >> 6] = okmask;
+        my_valid += __popcll(okmask);
+      }
     }
   }
   if (lane == 0 && my_valid) atomicAdd(&s_valid, my_valid);
