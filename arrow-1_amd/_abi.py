@@ -59,6 +59,8 @@ SYMBOLS = {
     "amdarrow_take_indices": (C.c_int, [_P, _A, C.c_int, _P, _P, C.c_int64, C.POINTER(C.c_int), _O]),
     "amdarrow_take": (C.c_int, [_P, _A, _A, C.c_int, _P, _P, _O]),
     "amdarrow_sort_indices": (C.c_int, [_P, _A, C.c_int, C.c_int, _P]),
+    "amdarrow_sort_indices_multi": (C.c_int, [_P, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, _P]),
+    "amdarrow_concatenate": (C.c_int, [_P, _P, C.c_int, _P, _P, _O]),
     "amdarrow_compare": (C.c_int, [_P, C.c_int, _A, _P, _A, _P, _P, _P, _O]),
     "amdarrow_arith": (C.c_int, [_P, C.c_int, _A, _P, _A, _P, _P, _P, _O]),
     "amdarrow_boolean": (C.c_int, [_P, C.c_int, _A, C.c_int, _A, C.c_int, _P, _P, _O]),

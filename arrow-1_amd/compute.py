@@ -88,6 +88,34 @@ def sort_indices(ctx, chunks, order=ASCENDING):
     return DeviceArray(_abi.UINT64, out, None, total, 0, 0)
 
 
+def sort_indices_multi(ctx, keys, orders):
+    """CallFunction("sort_indices", {record_batch | table}, SortOptions{sort_keys}) --
+    vector_sort.cc:1632-1707.  keys: one list of chunks (DeviceArray) per sort key."""
+    keys = [[k] if isinstance(k, DeviceArray) else list(k) for k in keys]
+    flat = [c for k in keys for c in k]
+    total = sum(c.length for c in keys[0]) if keys else 0
+    dev = flat[0].values.device if flat else "cuda"
+    out = alloc_bytes(total * 8, dev)
+    arr = (CArray * max(len(flat), 1))(*[c.c() for c in flat])
+    nch = (C.c_int * max(len(keys), 1))(*[len(k) for k in keys])
+    ords = (C.c_int * max(len(keys), 1))(*[int(o) for o in orders])
+    check(ctx.lib, ctx.lib.amdarrow_sort_indices_multi(ctx.handle, arr, nch, ords, len(keys), _ptr(out)))
+    return DeviceArray(_abi.UINT64, out, None, total, 0, 0)
+
+
+def concatenate(ctx, chunks):
+    """arrow::Concatenate (array/concatenate.cc:171-201) of fixed-width / boolean arrays."""
+    total = sum(c.length for c in chunks)
+    t = chunks[0].type_id
+    dev = chunks[0].values.device
+    out_v = alloc_bytes((_values_bytes(t, total) + 7) // 8 * 8, dev)
+    out_b = alloc_bytes((total + 63) // 64 * 8, dev)
+    out = COut()
+    arr = (CArray * len(chunks))(*[c.c() for c in chunks])
+    check(ctx.lib, ctx.lib.amdarrow_concatenate(ctx.handle, arr, len(chunks), _ptr(out_v), _ptr(out_b), C.byref(out)))
+    return DeviceArray(t, out_v, out_b if out.has_validity else None, out.length, 0, out.null_count)
+
+
 def _binary(ctx, fn, op, lhs, rhs, out_type):
     arr = lhs if isinstance(lhs, DeviceArray) else rhs
     t, n = arr.type_id, arr.length

@@ -21,6 +21,8 @@ namespace amdarrow {
 
 constexpr int kTile = 4096;     // rows per tile = 64 bitmap words
 constexpr int kThreads = 256;   // 4 waves
+constexpr int kCThreads = 256;  // compaction workgroup
+constexpr int kCWaves = kCThreads / 64;
 
 struct FilterArgs {
   // filter
@@ -123,7 +125,7 @@ __device__ __forceinline__ void DepositFlags(const uint8_t* s_flags, uint64_t* s
                                              uint8_t* bm, int64_t bit_base) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t nlw = (count + 63) >> 6;
-  for (uint32_t lw = wave; lw < nlw; lw += kThreads / 64) {
+  for (uint32_t lw = wave; lw < nlw; lw += blockDim.x / 64) {
     const uint32_t i = lw * 64 + lane;
     const uint64_t b = __ballot(i < count && s_flags[i] != 0);
     if (lane == 0) s_packed[lw] = b;
@@ -133,7 +135,7 @@ __device__ __forceinline__ void DepositFlags(const uint8_t* s_flags, uint64_t* s
   const int64_t g0 = bit_base >> 6;
   const uint32_t ngw = (s + count + 63) >> 6;
   unsigned long long* words = reinterpret_cast<unsigned long long*>(bm);
-  for (uint32_t i = tid; i < ngw; i += kThreads) {
+  for (uint32_t i = tid; i < ngw; i += blockDim.x) {
     uint64_t w = (i < nlw) ? (s_packed[i] << s) : 0;
     if (s > 0 && i > 0) w |= s_packed[i - 1] >> (64 - s);
     const bool owned = (i > 0 || s == 0) && (uint64_t(i + 1) * 64 <= uint64_t(s) + count);
@@ -151,14 +153,14 @@ template <> struct UIntOf<8> { using T = uint64_t; };
 // W = value bytes (1,2,4,8); W == 0 selects bit-packed (boolean) values.
 // IOTA: the "value" of row r is r itself (GetTakeIndices).
 template <int W, bool IOTA>
-__global__ __launch_bounds__(kThreads) void k_filter_compact(FilterArgs a) {
+__global__ __launch_bounds__(kCThreads) void k_filter_compact(FilterArgs a) {
   using T = typename UIntOf<(W == 0 ? 1 : W)>::T;
   constexpr bool kBits = (W == 0);
   __shared__ uint64_t s_emit[64], s_sel[64], s_vvalid[64], s_bvals[64];
   __shared__ uint32_t s_base[64];
   __shared__ uint32_t s_count;
   __shared__ uint64_t s_packed[65];
-  __shared__ __attribute__((aligned(16))) T s_stage[kTile];  // values (or value-bit flags) by rank
+  __shared__ __attribute__((aligned(16))) T s_stage[kBits ? kTile : 1];  // value-bit flags by rank
   __shared__ uint8_t s_vflag[kTile];                          // validity flags by rank
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const T* values = reinterpret_cast<const T*>(a.v_data);
@@ -187,23 +189,23 @@ __global__ __launch_bounds__(kThreads) void k_filter_compact(FilterArgs a) {
     const bool fits = out_base + count <= a.out_capacity;  // never write past the caller's buffers
 
     // ---- gather selected values (loads only where the value is copied) ----
-    constexpr int kIters = kTile / kThreads;  // 16
+    constexpr int kIters = kTile / kCThreads;
     T vals[kIters];
     if (!IOTA && !kBits && count * 8 >= kTile) {
       // dense tile: every 64-byte sector holds a selected row anyway, so load all rows --
       // 16 independent loads in flight instead of 16 branches around one load each
 #pragma unroll
       for (int j = 0; j < kIters; ++j) {
-        const int64_t row = row0 + (j * 4 + wave) * 64 + lane;
+        const int64_t row = row0 + (j * kCWaves + wave) * 64 + lane;
         vals[j] = values[a.v_off + (row < a.length ? row : a.length - 1)];
       }
 #pragma unroll
       for (int j = 0; j < kIters; ++j)
-        if (!((s_sel[j * 4 + wave] >> lane) & 1)) vals[j] = 0;  // emitted-null slots carry 0
+        if (!((s_sel[j * kCWaves + wave] >> lane) & 1)) vals[j] = 0;  // emitted-null slots carry 0
     } else {
 #pragma unroll
       for (int j = 0; j < kIters; ++j) {
-        const int word = j * 4 + wave;
+        const int word = j * kCWaves + wave;
         const bool s = (s_sel[word] >> lane) & 1;
         const int64_t row = row0 + word * 64 + lane;
         T v = 0;
@@ -217,11 +219,15 @@ __global__ __launch_bounds__(kThreads) void k_filter_compact(FilterArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < kIters; ++j) {
-      const int word = j * 4 + wave;
+      const int word = j * kCWaves + wave;
       const uint64_t emit = s_emit[word];
       if ((emit >> lane) & 1) {
         const uint32_t rank = s_base[word] + RankBelowLane(emit);
-        s_stage[rank] = vals[j];  // emitted-null slots carry 0 (:743-746)
+        // emitted-null slots carry 0 (:743-746).  Fixed-width values go straight to their output
+        // slot: a wave's selected lanes hold consecutive ranks, so its stores cover one contiguous
+        // run, and without a value stage the workgroup needs 3 KB of LDS instead of 35.
+        if (!kBits) { if (fits) reinterpret_cast<T*>(a.out_values)[out_base + rank] = vals[j]; }
+        else s_stage[rank] = vals[j];
         if (a.has_validity) {
           // WriteNotNull / WriteMaybeNull / WriteNull (:646-657, :706-709)
           s_vflag[rank] = static_cast<uint8_t>(((s_sel[word] & s_vvalid[word]) >> lane) & 1);
@@ -230,10 +236,7 @@ __global__ __launch_bounds__(kThreads) void k_filter_compact(FilterArgs a) {
     }
     __syncthreads();
     if (fits) {
-      if (!kBits) {
-        T* out = reinterpret_cast<T*>(a.out_values) + out_base;
-        for (uint32_t i = tid; i < count; i += kThreads) out[i] = s_stage[i];
-      } else {
+      if (kBits) {
         DepositFlags(reinterpret_cast<const uint8_t*>(s_stage), s_packed, count,
                      reinterpret_cast<uint8_t*>(a.out_values), out_base);
         __syncthreads();
@@ -241,6 +244,38 @@ __global__ __launch_bounds__(kThreads) void k_filter_compact(FilterArgs a) {
       if (a.has_validity) DepositFlags(s_vflag, s_packed, count, a.out_validity, out_base);
     }
     __syncthreads();
+  }
+}
+
+// ---- Concatenate (array/concatenate.cc:70-92, 171-201) ---------------------------------------
+// A bitmap made of the bit ranges [off, off+length) of several sources laid end to end
+// (ConcatenateBitmaps); a source without a bitmap contributes set bits (Bitmap::AllSet, :67).
+struct BitPiece { const uint8_t* bits; int64_t off; int64_t length; int64_t out_start; };
+
+// One thread builds one output word: whole-word stores only, so the destination needs no
+// zero fill and no atomics however the pieces fall.  Bits past `total` in the last word are 0.
+__global__ __launch_bounds__(kThreads) void k_concat_bits(const BitPiece* pieces, int npieces, int64_t total, uint64_t* out) {
+  const int64_t nwords = (total + 63) >> 6;
+  for (int64_t w = int64_t(blockIdx.x) * kThreads + threadIdx.x; w < nwords; w += int64_t(gridDim.x) * kThreads) {
+    int64_t pos = w << 6;
+    const int64_t end = (pos + 64 < total) ? pos + 64 : total;
+    int lo = 0, hi = npieces - 1;
+    while (lo < hi) {  // the last piece that starts at or before pos
+      const int mid = (lo + hi + 1) >> 1;
+      if (pieces[mid].out_start <= pos) lo = mid; else hi = mid - 1;
+    }
+    uint64_t word = 0;
+    for (int c = lo; c < npieces && pos < end; ++c) {
+      const BitPiece p = pieces[c];
+      const int64_t in_piece = pos - p.out_start;
+      int64_t take = p.length - in_piece;
+      if (take <= 0) continue;  // an empty piece
+      if (take > end - pos) take = end - pos;
+      const uint64_t bits = LoadBitsOrOnes(p.bits, p.off + in_piece, static_cast<int>(take));
+      word |= bits << (pos & 63);
+      pos += take;
+    }
+    out[w] = word;
   }
 }
 
@@ -382,8 +417,8 @@ static int CheckFilter(const amdarrow_array* filter) {
 
 template <int W, bool IOTA>
 static int LaunchCompact(amdarrow_ctx* ctx, const FilterArgs& a) {
-  const int grid = GridFor(a.ntiles, 1, ctx->num_cus * 5);
-  hipLaunchKernelGGL((k_filter_compact<W, IOTA>), dim3(grid), dim3(kThreads), 0, ctx->stream, a);
+  const int grid = GridFor(a.ntiles, 1, ctx->num_cus * 8);
+  hipLaunchKernelGGL((k_filter_compact<W, IOTA>), dim3(grid), dim3(kCThreads), 0, ctx->stream, a);
   AA_HIP(hipGetLastError());
   return AMDARROW_OK;
 }
@@ -605,6 +640,70 @@ int amdarrow_take(amdarrow_ctx* ctx, const amdarrow_array* values, const amdarro
     return SetError(AMDARROW_INDEX_ERROR, "Index " + s + " out of bounds");
   }
   out->null_count = indices->length - static_cast<int64_t>(host[0]);  // :367
+  return AMDARROW_OK;
+}
+
+
+/* Concatenate, array/concatenate.cc:171-201 (fixed-width and boolean arrays). */
+int amdarrow_concatenate(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks, void* out_values,
+                         uint8_t* out_validity, amdarrow_out* out) {
+  if (nchunks < 1) return SetError(AMDARROW_INVALID, "Must pass at least one array");  // :428-430
+  const int type_id = chunks[0].type_id;
+  const int bw = BitWidth(type_id);
+  if (bw < 0) return SetError(AMDARROW_TYPE_ERROR, "concatenate: unsupported type");
+  int64_t total = 0, nulls = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    if (chunks[c].type_id != type_id) return SetError(AMDARROW_INVALID, "arrays to be concatenated must be identically typed");
+    total += chunks[c].length;
+    // :172-180: the null count adds up unless some input's is unknown
+    const int64_t nc = chunks[c].validity ? chunks[c].null_count : 0;
+    nulls = (nulls < 0 || nc < 0) ? -1 : nulls + nc;
+  }
+  out->length = total;
+  out->null_count = nulls;
+  out->has_validity = (nulls != 0 && out_validity != nullptr) ? 1 : 0;  // :190-192
+  if (total == 0) return AMDARROW_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  const bool bit_values = bw == 1;
+  const int ntables = (out->has_validity ? 1 : 0) + (bit_values ? 1 : 0);
+  if (ntables > 0) {
+    std::vector<BitPiece> host(static_cast<size_t>(ntables) * nchunks);
+    int64_t start = 0;
+    for (int c = 0; c < nchunks; ++c) {
+      int t = 0;
+      if (out->has_validity)
+        host[t++ * nchunks + c] = BitPiece{MayHaveNulls(&chunks[c]) ? chunks[c].validity : nullptr, chunks[c].offset,
+                                           chunks[c].length, start};
+      if (bit_values)
+        host[t * nchunks + c] = BitPiece{static_cast<const uint8_t*>(chunks[c].values), chunks[c].offset, chunks[c].length, start};
+      start += chunks[c].length;
+    }
+    void* base;
+    AA_TRY(Scratch(ctx, sizeof(BitPiece) * host.size(), &base));
+    AA_HIP(hipMemcpyAsync(base, host.data(), sizeof(BitPiece) * host.size(), hipMemcpyHostToDevice, ctx->stream));
+    AA_HIP(hipStreamSynchronize(ctx->stream));  // `host` is pageable
+    const BitPiece* d = static_cast<const BitPiece*>(base);
+    const int grid = GridFor((total + 63) / 64, kThreads, ctx->num_cus * 8);
+    int t = 0;
+    if (out->has_validity)
+      hipLaunchKernelGGL(k_concat_bits, dim3(grid), dim3(kThreads), 0, ctx->stream, d + (t++) * nchunks, nchunks, total,
+                         reinterpret_cast<uint64_t*>(out_validity));
+    if (bit_values)
+      hipLaunchKernelGGL(k_concat_bits, dim3(grid), dim3(kThreads), 0, ctx->stream, d + t * nchunks, nchunks, total,
+                         reinterpret_cast<uint64_t*>(out_values));
+    AA_HIP(hipGetLastError());
+  }
+  if (!bit_values) {  // ConcatenateBuffers (:199-203): byte ranges laid end to end
+    const int w = bw / 8;
+    char* dst = static_cast<char*>(out_values);
+    for (int c = 0; c < nchunks; ++c) {
+      if (chunks[c].length == 0) continue;
+      AA_HIP(hipMemcpyAsync(dst, static_cast<const char*>(chunks[c].values) + chunks[c].offset * w, chunks[c].length * w,
+                            hipMemcpyDeviceToDevice, ctx->stream));
+      dst += chunks[c].length * w;
+    }
+  }
+  AA_HIP(hipStreamSynchronize(ctx->stream));
   return AMDARROW_OK;
 }
 

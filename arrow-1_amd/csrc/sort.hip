@@ -81,6 +81,17 @@ __device__ __forceinline__ int FindChunk(const SortChunk* chunks, int nchunks, i
   return lo;
 }
 
+// Chunk holding logical row `row` (the last chunk that starts at or before it; an empty chunk
+// shares its start with its successor, so it is never the answer for a row that exists).
+__device__ __forceinline__ int FindChunkOfRow(const SortChunk* chunks, int nchunks, int64_t row) {
+  int lo = 0, hi = nchunks - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (chunks[mid].row_start <= row) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
 // class of a row: 0 sortable, 1 NaN, 2 null
 template <typename KeyT>
 __device__ __forceinline__ int Classify(const SortChunk& c, int type_id, int64_t r, KeyT key_mask, KeyT flip, KeyT* key) {
@@ -92,21 +103,33 @@ __device__ __forceinline__ int Classify(const SortChunk& c, int type_id, int64_t
 }
 
 // counts[class * ntiles + tile] for class 0..2
-template <typename KeyT>
+// PERM: the rows are visited in the order perm[0..n) (the result of sorting by the later sort
+// keys, RadixRecordBatchSorter vector_sort.cc:955-1045) instead of in logical order; tiles then
+// cut the positions, not the chunks, and every row looks its chunk up.
+template <typename KeyT, bool PERM>
 __global__ __launch_bounds__(kThreads) void k_sort_count(const SortChunk* chunks, int nchunks, int type_id, int64_t ntiles,
-                                                         uint32_t* counts) {
+                                                         const uint64_t* perm, int64_t n, uint32_t* counts) {
   __shared__ uint32_t s_c[3];
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     if (threadIdx.x < 3) s_c[threadIdx.x] = 0;
     __syncthreads();
-    const SortChunk c = chunks[FindChunk(chunks, nchunks, tile)];
-    const int64_t r0 = (tile - c.tile_start) * kCTile;
+    SortChunk c;
+    int64_t r0;
+    if (PERM) { r0 = tile * kCTile; c.length = n; }
+    else { c = chunks[FindChunk(chunks, nchunks, tile)]; r0 = (tile - c.tile_start) * kCTile; }
     uint32_t n1 = 0, n2 = 0, n0 = 0;
     for (int k = 0; k < kCTile / kThreads; ++k) {
       const int64_t r = r0 + k * kThreads + threadIdx.x;
       if (r < c.length) {
         KeyT key;
-        const int cls = Classify<KeyT>(c, type_id, r, ~KeyT(0), 0, &key);
+        int cls;
+        if (PERM) {
+          const int64_t row = static_cast<int64_t>(perm[r]);
+          const SortChunk rc = chunks[FindChunkOfRow(chunks, nchunks, row)];
+          cls = Classify<KeyT>(rc, type_id, row - rc.row_start, ~KeyT(0), 0, &key);
+        } else {
+          cls = Classify<KeyT>(c, type_id, r, ~KeyT(0), 0, &key);
+        }
         n0 += cls == 0; n1 += cls == 1; n2 += cls == 2;
       }
     }
@@ -122,25 +145,44 @@ __global__ __launch_bounds__(kThreads) void k_sort_count(const SortChunk* chunks
 
 // Stable 3-way partition.  offsets = exclusive scan of counts laid out [class][tile]: it is
 // directly the global output position (sortable rows first, then NaNs, then nulls).
-template <typename KeyT>
+template <typename KeyT, bool PERM>
 __global__ __launch_bounds__(kThreads) void k_sort_partition(const SortChunk* chunks, int nchunks, int type_id, int64_t ntiles,
+                                                             const uint64_t* perm, int64_t n,
                                                              const uint32_t* offsets, KeyT key_mask, KeyT flip, KeyT* keys,
                                                              uint32_t* idx, uint64_t* out_indices) {
   __shared__ uint32_t s_wave[3][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int kIters = kCTile / kThreads;  // 8; wave w owns rows [w*512, (w+1)*512) of the tile, in order
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const SortChunk c = chunks[FindChunk(chunks, nchunks, tile)];
-    const int64_t r0 = (tile - c.tile_start) * kCTile + wave * (kIters * 64);
+    SortChunk c;
+    int64_t r0;
+    if (PERM) { r0 = tile * kCTile + wave * (kIters * 64); c.length = n; c.row_start = 0; }
+    else { c = chunks[FindChunk(chunks, nchunks, tile)]; r0 = (tile - c.tile_start) * kCTile + wave * (kIters * 64); }
     KeyT key[kIters];
     int cls[kIters];
+    uint64_t rows[PERM ? kIters : 1];
     uint32_t tot[3] = {0, 0, 0};
+    if (PERM) {
+#pragma unroll
+      for (int j = 0; j < kIters; ++j) {  // the gathers below depend on these: issue them together
+        const int64_t r = r0 + j * 64 + lane;
+        rows[j] = perm[r < n ? r : n - 1];
+      }
+    }
 #pragma unroll
     for (int j = 0; j < kIters; ++j) {
       const int64_t r = r0 + j * 64 + lane;
       cls[j] = 3;
       key[j] = 0;
-      if (r < c.length) cls[j] = Classify<KeyT>(c, type_id, r, key_mask, flip, &key[j]);
+      if (PERM) {
+        if (r < n) {
+          const int64_t row = static_cast<int64_t>(rows[j]);
+          const SortChunk rc = chunks[FindChunkOfRow(chunks, nchunks, row)];
+          cls[j] = Classify<KeyT>(rc, type_id, row - rc.row_start, key_mask, flip, &key[j]);
+        }
+      } else if (r < c.length) {
+        cls[j] = Classify<KeyT>(c, type_id, r, key_mask, flip, &key[j]);
+      }
       tot[0] += __popcll(__ballot(cls[j] == 0));
       tot[1] += __popcll(__ballot(cls[j] == 1));
       tot[2] += __popcll(__ballot(cls[j] == 2));
@@ -158,7 +200,7 @@ __global__ __launch_bounds__(kThreads) void k_sort_partition(const SortChunk* ch
     for (int j = 0; j < kIters; ++j) {
       const int64_t r = r0 + j * 64 + lane;
       const uint64_t m0 = __ballot(cls[j] == 0), m1 = __ballot(cls[j] == 1), m2 = __ballot(cls[j] == 2);
-      const uint64_t gidx = static_cast<uint64_t>(c.row_start + r);
+      const uint64_t gidx = PERM ? rows[PERM ? j : 0] : static_cast<uint64_t>(c.row_start + r);
       if (cls[j] == 0) {
         const int64_t p = base[0] + RankBelowLane(m0);
         keys[p] = key[j];
@@ -525,7 +567,7 @@ int ScanU32InPlace(amdarrow_ctx* ctx, uint32_t* data, int64_t n, uint32_t* sums,
 
 template <typename KeyT>
 static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks, int type_id, int order, int64_t n,
-                    uint64_t* out, bool allow_onesweep = true) {
+                    uint64_t* out, const uint64_t* perm = nullptr, bool allow_onesweep = true) {
   constexpr int kPasses = sizeof(KeyT);
   const int key_bits = BitWidth(type_id);
   const KeyT key_mask = key_bits >= static_cast<int>(8 * sizeof(KeyT)) ? ~KeyT(0) : ((KeyT(1) << key_bits) - 1);
@@ -541,7 +583,7 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
     row += chunks[c].length;
     tiles += (chunks[c].length + kCTile - 1) / kCTile;
   }
-  const int64_t ntiles = tiles;
+  const int64_t ntiles = perm ? (n + kCTile - 1) / kCTile : tiles;
   const int64_t nblocks = (n + kRTile - 1) / kRTile;
   const int64_t hist_n = 256 * nblocks;
   const int64_t scan_nb = (std::max<int64_t>(hist_n, 3 * ntiles) + 2047) / 2048;
@@ -582,12 +624,20 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
 
   // 1. stable 3-way partition: sortable | NaN | null
   const int grid_t = GridFor(ntiles, 1, ctx->num_cus * 8);
-  hipLaunchKernelGGL((k_sort_count<KeyT>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, d_chunks, nchunks, type_id, ntiles,
-                     counts);
+  if (perm)
+    hipLaunchKernelGGL((k_sort_count<KeyT, true>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, d_chunks, nchunks, type_id,
+                       ntiles, perm, n, counts);
+  else
+    hipLaunchKernelGGL((k_sort_count<KeyT, false>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, d_chunks, nchunks, type_id,
+                       ntiles, perm, n, counts);
   AA_HIP(hipGetLastError());
   AA_TRY(ScanU32InPlace(ctx, counts, 3 * ntiles, sums, sumoff));  // counts -> offsets (rows < 2^32)
-  hipLaunchKernelGGL((k_sort_partition<KeyT>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, d_chunks, nchunks, type_id, ntiles,
-                     counts, key_mask, flip, keys_a, idx_a, out);
+  if (perm)
+    hipLaunchKernelGGL((k_sort_partition<KeyT, true>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, d_chunks, nchunks,
+                       type_id, ntiles, perm, n, counts, key_mask, flip, keys_a, idx_a, out);
+  else
+    hipLaunchKernelGGL((k_sort_partition<KeyT, false>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, d_chunks, nchunks,
+                       type_id, ntiles, perm, n, counts, key_mask, flip, keys_a, idx_a, out);
   AA_HIP(hipGetLastError());
   uint32_t n0_32 = 0;
   AA_TRY(ReadBack(ctx, counts + ntiles, 4, &n0_32));  // start of the NaN region = number of sortable rows
@@ -658,7 +708,7 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   if (onesweep) {
     unsigned int err = 0;
     AA_TRY(ReadBack(ctx, ctl + 15, 4, &err));
-    if (err) return SortImpl<KeyT>(ctx, chunks, nchunks, type_id, order, n, out, /*allow_onesweep=*/false);
+    if (err) return SortImpl<KeyT>(ctx, chunks, nchunks, type_id, order, n, out, perm, /*allow_onesweep=*/false);
   }
   return AMDARROW_OK;
 }
@@ -686,5 +736,52 @@ extern "C" int amdarrow_sort_indices(amdarrow_ctx* ctx, const amdarrow_array* ch
                     : SortImpl<uint64_t>(ctx, chunks, nchunks, type_id, order, n, out_indices);
   AA_TRY(rc);
   AA_HIP(hipStreamSynchronize(ctx->stream));
+  return AMDARROW_OK;
+}
+
+// Multi-key sort_indices (RadixRecordBatchSorter vector_sort.cc:955-1045 for batches,
+// MultipleKeyTableSorter :1381-1549 for tables -- the same order, MultipleKeyComparator
+// :1049-1180): one stable sort per key from the LAST key to the first.  Each stage visits the
+// rows in the order the previous stage left them, so rows that tie on the earlier keys keep the
+// order of the later ones; per key the classes are values (by that key's order), NaNs, nulls.
+// `chunks` lists key 0's chunks, then key 1's, ...; every key spans the same number of rows.
+extern "C" int amdarrow_sort_indices_multi(amdarrow_ctx* ctx, const amdarrow_array* chunks, const int* nchunks,
+                                           const int* orders, int nkeys, uint64_t* out_indices) {
+  if (nkeys < 1) return SetError(AMDARROW_INVALID, "Must specify one or more sort keys");  // vector_sort.cc:1634-1636
+  std::vector<const amdarrow_array*> first(nkeys);
+  int64_t n = -1;
+  const amdarrow_array* p = chunks;
+  for (int k = 0; k < nkeys; ++k) {
+    if (nchunks[k] < 1) return SetError(AMDARROW_INVALID, "sort_indices: a sort key without chunks");
+    first[k] = p;
+    int64_t len = 0;
+    for (int c = 0; c < nchunks[k]; ++c) {
+      if (p[c].type_id != p[0].type_id) return SetError(AMDARROW_TYPE_ERROR, "sort_indices: chunks differ in type");
+      len += p[c].length;
+    }
+    if (BitWidth(p[0].type_id) < 8) return SetError(AMDARROW_NOT_IMPLEMENTED, "sort_indices: numeric types only");
+    if (n >= 0 && len != n) return SetError(AMDARROW_INVALID, "sort_indices: sort keys differ in length");
+    n = len;
+    p += nchunks[k];
+  }
+  if (n >= (int64_t(1) << 32)) return SetError(AMDARROW_NOT_IMPLEMENTED, "sort_indices: 2^32 rows or more");
+  if (n == 0) return AMDARROW_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  // the stages ping-pong between `out_indices` and one temporary so that the last lands in out_indices
+  uint64_t* tmp = nullptr;
+  if (nkeys > 1) AA_HIP(hipMalloc(reinterpret_cast<void**>(&tmp), 8 * static_cast<size_t>(n)));
+  int rc = AMDARROW_OK;
+  const uint64_t* perm = nullptr;
+  for (int k = nkeys - 1; k >= 0 && rc == AMDARROW_OK; --k) {
+    uint64_t* dst = (k % 2 == 0) ? out_indices : tmp;
+    const int type_id = first[k][0].type_id;
+    rc = BitWidth(type_id) <= 32 ? SortImpl<uint32_t>(ctx, first[k], nchunks[k], type_id, orders[k], n, dst, perm)
+                                 : SortImpl<uint64_t>(ctx, first[k], nchunks[k], type_id, orders[k], n, dst, perm);
+    perm = dst;
+  }
+  const hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (tmp) (void)hipFree(tmp);
+  AA_TRY(rc);
+  AA_HIP(e);
   return AMDARROW_OK;
 }

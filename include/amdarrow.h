@@ -128,6 +128,13 @@ int amdarrow_filter(amdarrow_ctx* ctx, const amdarrow_array* values,
 int amdarrow_take_indices(amdarrow_ctx* ctx, const amdarrow_array* filter, int null_selection,
                           void* out_indices, uint8_t* out_validity, int64_t out_capacity,
                           int* out_index_width, amdarrow_out* out);
+/* Concatenate, array/concatenate.cc:171-201 -- what TakeCA/TakeCC (vector_selection.cc:1923-
+ * 1959) do to chunked values first.  out_values: sum(length) elements (bits for BOOL).
+ * out->null_count = sum of the chunks' counts, -1 if any is unknown (:172-180); the validity
+ * bitmap is written iff that is non-zero (:190) and out_validity is given.  Bitmaps are
+ * written in whole 8-byte words: size them to a multiple of 8 bytes. */
+int amdarrow_concatenate(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks,
+                         void* out_values, uint8_t* out_validity, amdarrow_out* out);
 /* PrimitiveTake, vector_selection.cc:493-530 (+CheckIndexBounds util/int_util.cc:534-561):
  * out[i] = values[indices[i]], null if index or value is null; validity always written;
  * AMDARROW_INDEX_ERROR "Index N out of bounds" when boundscheck != 0. */
@@ -141,6 +148,15 @@ int amdarrow_take(amdarrow_ctx* ctx, const amdarrow_array* values,
  * then nulls, ties by ascending index in both orders.  out_indices: sum(length) uint64. */
 int amdarrow_sort_indices(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks,
                           int order, uint64_t* out_indices);
+/* sort_indices over a record batch / table with several sort keys:
+ * RadixRecordBatchSorter vector_sort.cc:955-1045, MultipleKeyRecordBatchSorter :1184-1351,
+ * MultipleKeyTableSorter :1381-1549 (one order, defined by MultipleKeyComparator :1049-1180):
+ * lexicographic over the keys; within a key values by orders[k], then NaNs, then nulls; rows
+ * equal on every key by ascending index.  `chunks` holds key 0's nchunks[0] chunks, then
+ * key 1's, ...; all keys span the same number of rows.  out_indices: that many uint64. */
+int amdarrow_sort_indices_multi(amdarrow_ctx* ctx, const amdarrow_array* chunks,
+                                const int* nchunks, const int* orders, int nkeys,
+                                uint64_t* out_indices);
 
 /* ---- scalar_compare.cc / scalar_arithmetic.cc ---------------------------------------------- */
 /* Operand = array (lhs / rhs) or valid scalar (lhs_scalar / rhs_scalar: HOST pointer to one

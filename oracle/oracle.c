@@ -287,6 +287,120 @@ int orc_sort_indices(const orc_array* chunks, int nchunks, int order, uint64_t* 
   return ORC_OK;
 }
 
+/* ---- b5: multi-key sort_indices, vector_sort.cc:955-1549 ---------------------------- */
+/* One resolved sort key (ResolvedSortKey :1187-1205 / :1384-1420): its chunks, the logical
+ * row at which each starts (ChunkedArrayResolver :95-160) and its order. */
+typedef struct { const orc_array* chunks; int nchunks; int order; int64_t* starts; } mk_key;
+static const mk_key* g_mk_keys; static int g_mk_nkeys;
+static const orc_array* mk_resolve(const mk_key* k, int64_t row, int64_t* in_chunk) {
+  int lo = 0, hi = k->nchunks - 1;
+  while (lo < hi) { /* last chunk starting at or before row (empty chunks share a start with their successor) */
+    int mid = (lo + hi + 1) / 2;
+    if (k->starts[mid] <= row) lo = mid; else hi = mid - 1;
+  }
+  *in_chunk = row - k->starts[lo];
+  return &k->chunks[lo];
+}
+/* MultipleKeyComparator::CompareType / CompareTypeValue (:1105-1172): -1, 0, 1.  Null after
+ * everything, NaN after every number, both whatever the order; equal values (incl. -0.0 vs
+ * +0.0, NaN vs NaN, null vs null) compare 0 and the next key decides. */
+static int mk_compare_key(const mk_key* k, uint64_t l, uint64_t r) {
+  int64_t il, ir;
+  const orc_array* al = mk_resolve(k, (int64_t)l, &il);
+  const orc_array* ar = mk_resolve(k, (int64_t)r, &ir);
+  const int nl = !slot_valid(al, il), nr = !slot_valid(ar, ir);
+  if (nl && nr) return 0;
+  if (nl) return 1;
+  if (nr) return -1;
+  int c;
+  const int t = al->type_id;
+  if (is_float(t)) {
+    double x = t == ORC_FLOAT ? (double)((const float*)al->values)[al->offset + il] : ((const double*)al->values)[al->offset + il];
+    double y = t == ORC_FLOAT ? (double)((const float*)ar->values)[ar->offset + ir] : ((const double*)ar->values)[ar->offset + ir];
+    const int xn = isnan(x), yn = isnan(y);
+    if (xn && yn) return 0;
+    if (xn) return 1;
+    if (yn) return -1;
+    c = x == y ? 0 : (x > y ? 1 : -1);
+  } else {
+    /* sort_key is order preserving and maps equal values to equal keys */
+    const uint64_t x = sort_key(t, al->values, al->offset + il), y = sort_key(t, ar->values, ar->offset + ir);
+    c = x == y ? 0 : (x > y ? 1 : -1);
+  }
+  return k->order == ORC_DESCENDING ? -c : c;
+}
+static int mk_less(uint64_t l, uint64_t r) { /* MultipleKeyComparator::Compare :1062-1077 */
+  for (int k = 0; k < g_mk_nkeys; ++k) {
+    const int c = mk_compare_key(&g_mk_keys[k], l, r);
+    if (c != 0) return c < 0;
+  }
+  return 0;
+}
+/* std::stable_sort over the iota-initialised indices (:1640-1652, :1686-1704) */
+static void mk_merge_sort(uint64_t* a, uint64_t* tmp, int64_t n) {
+  if (n < 2) return;
+  const int64_t h = n / 2;
+  mk_merge_sort(a, tmp, h);
+  mk_merge_sort(a + h, tmp, n - h);
+  int64_t i = 0, j = h, o = 0;
+  while (i < h && j < n) tmp[o++] = mk_less(a[j], a[i]) ? a[j++] : a[i++]; /* right wins only if strictly less */
+  while (i < h) tmp[o++] = a[i++];
+  while (j < n) tmp[o++] = a[j++];
+  memcpy(a, tmp, 8 * (size_t)n);
+}
+int orc_sort_indices_multi(const orc_array* chunks, const int* nchunks, const int* orders, int nkeys, uint64_t* out) {
+  if (nkeys < 1) return fail(ORC_INVALID, "Must specify one or more sort keys"); /* :1634-1636 */
+  if (nkeys > 64) return fail(ORC_INVALID, "too many sort keys");
+  mk_key keys[64];
+  int64_t n = -1;
+  const orc_array* p = chunks;
+  for (int k = 0; k < nkeys; ++k) {
+    keys[k].chunks = p; keys[k].nchunks = nchunks[k]; keys[k].order = orders[k];
+    keys[k].starts = (int64_t*)malloc(8 * (size_t)(nchunks[k] + 1));
+    int64_t len = 0;
+    for (int c = 0; c < nchunks[k]; ++c) { keys[k].starts[c] = len; len += p[c].length; }
+    if (n >= 0 && len != n) { for (int q = 0; q <= k; ++q) free(keys[q].starts); return fail(ORC_INVALID, "sort keys differ in length"); }
+    n = len;
+    p += nchunks[k];
+  }
+  uint64_t* tmp = (uint64_t*)malloc(8 * (size_t)(n ? n : 1));
+  for (int64_t i = 0; i < n; ++i) out[i] = (uint64_t)i;
+  g_mk_keys = keys; g_mk_nkeys = nkeys;
+  mk_merge_sort(out, tmp, n);
+  free(tmp);
+  for (int k = 0; k < nkeys; ++k) free(keys[k].starts);
+  return ORC_OK;
+}
+
+/* ---- Concatenate, array/concatenate.cc:70-92, 171-201 -------------------------------- */
+int orc_concatenate(const orc_array* chunks, int nchunks, void* out_values, uint8_t* out_validity, orc_out* out) {
+  if (nchunks < 1) return fail(ORC_INVALID, "Must pass at least one array"); /* :428-430 */
+  const int t = chunks[0].type_id, bw = orc_bit_width(t);
+  int64_t total = 0, nulls = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    if (chunks[c].type_id != t) return fail(ORC_INVALID, "arrays to be concatenated must be identically typed"); /* :436-441 */
+    total += chunks[c].length;
+    const int64_t nc = arg_null_count(&chunks[c]); /* :172-180 */
+    nulls = (nulls < 0 || nc < 0) ? -1 : nulls + nc;
+  }
+  out->length = total; out->null_count = nulls; out->has_validity = nulls != 0; /* :190 */
+  int64_t pos = 0;
+  if (bw == 1) memset(out_values, 0, (size_t)((total + 7) / 8));
+  if (out->has_validity) memset(out_validity, 0, (size_t)((total + 7) / 8));
+  for (int c = 0; c < nchunks; ++c) {
+    const orc_array* a = &chunks[c];
+    for (int64_t i = 0; i < a->length; ++i) {
+      /* ConcatenateBitmaps :70-92: an absent bitmap contributes set bits */
+      if (out->has_validity && slot_valid(a, i)) set_bit(out_validity, pos + i);
+      if (bw == 1 && get_bit((const uint8_t*)a->values, a->offset + i)) set_bit((uint8_t*)out_values, pos + i);
+    }
+    if (bw != 1 && a->length > 0)
+      memcpy((char*)out_values + pos * (bw / 8), (const char*)a->values + a->offset * (bw / 8), (size_t)(a->length * (bw / 8)));
+    pos += a->length;
+  }
+  return ORC_OK;
+}
+
 /* ---- c1: GrouperImpl, hash_aggregate.cc:313-437 ------------------------------------- */
 struct orc_grouper {
   int nkeys; int types[8]; int widths[8]; /* value byte width per key column */

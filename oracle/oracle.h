@@ -98,6 +98,18 @@ int orc_take(const orc_array* values, const orc_array* indices, int boundscheck,
  * chunks[0..nchunks) are the chunks of one logical array; out has sum(length) entries. */
 int orc_sort_indices(const orc_array* chunks, int nchunks, int order, uint64_t* out);
 
+/* b5: sort_indices over a record batch / table with several sort keys -- RadixRecordBatchSorter
+ * vector_sort.cc:955-1045, MultipleKeyRecordBatchSorter :1184-1351, MultipleKeyTableSorter
+ * :1381-1549; the order is the one MultipleKeyComparator :1049-1180 defines.  chunks = key 0's
+ * nchunks[0] chunks, then key 1's, ...; orders[k] per key. */
+int orc_sort_indices_multi(const orc_array* chunks, const int* nchunks, const int* orders, int nkeys,
+                           uint64_t* out);
+
+/* Concatenate, array/concatenate.cc:171-201 (what TakeCA/TakeCC, vector_selection.cc:1923-1959,
+ * do to chunked values first).  out_validity is written iff the summed null count != 0. */
+int orc_concatenate(const orc_array* chunks, int nchunks, void* out_values, uint8_t* out_validity,
+                    orc_out* out);
+
 /* c1: Grouper::Consume, hash_aggregate.cc:358-408 -- dense ids in first-appearance
  * order.  Stateful across batches.  Keys: up to 8 fixed-width columns. */
 typedef struct orc_grouper orc_grouper;

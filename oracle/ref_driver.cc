@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "arrow/array.h"
+#include "arrow/array/concatenate.h"
 #include "arrow/array/data.h"
 #include "arrow/buffer.h"
 #include "arrow/chunked_array.h"
@@ -26,7 +27,9 @@
 #include "arrow/compute/registry.h"
 #include "arrow/compute/registry_internal.h"
 #include "arrow/datum.h"
+#include "arrow/record_batch.h"
 #include "arrow/scalar.h"
+#include "arrow/table.h"
 #include "arrow/type.h"
 #include "arrow/util/bit_util.h"
 #include "arrow/util/bitmap_ops.h"
@@ -196,6 +199,58 @@ int ref_sort_indices(const orc_array* chunks, int nchunks, int order, uint64_t* 
   if (!res.ok()) return Fail(res.status());
   const ArrayData& d = *res->array();
   std::memcpy(out, d.buffers[1]->data() + d.offset * 8, d.length * 8);
+  return 0;
+}
+
+// Multi-key sort_indices through the reference's meta function (vector_sort.cc:1632-1707):
+// a RecordBatch when every key is one chunk and !force_table (RadixRecordBatchSorter up to 8 keys,
+// MultipleKeyRecordBatchSorter above), else a Table (MultipleKeyTableSorter).
+static int SortMulti(const orc_array* chunks, const int* nchunks, const int* orders, int nkeys, bool force_table,
+                     uint64_t* out) {
+  std::vector<std::shared_ptr<Field>> fields;
+  std::vector<std::shared_ptr<ChunkedArray>> columns;
+  std::vector<SortKey> keys;
+  bool single = true;
+  const orc_array* p = chunks;
+  for (int k = 0; k < nkeys; ++k) {
+    ArrayVector arrs;
+    for (int c = 0; c < nchunks[k]; ++c) arrs.push_back(MakeArray(Wrap(&p[c])));
+    auto type = TypeOf(p[0].type_id);
+    const std::string name = "k" + std::to_string(k);
+    fields.push_back(field(name, type));
+    columns.push_back(std::make_shared<ChunkedArray>(arrs, type));
+    keys.emplace_back(name, orders[k] == ORC_DESCENDING ? SortOrder::Descending : SortOrder::Ascending);
+    single = single && nchunks[k] == 1;
+    p += nchunks[k];
+  }
+  SortOptions opts(keys);
+  Datum input;
+  if (single && !force_table) {
+    ArrayVector cols;
+    for (auto& c : columns) cols.push_back(c->chunk(0));
+    input = Datum(RecordBatch::Make(schema(fields), cols.empty() ? 0 : cols[0]->length(), cols));
+  } else {
+    input = Datum(Table::Make(schema(fields), columns));
+  }
+  auto res = CallFunction("sort_indices", {input}, &opts, Ctx());
+  if (!res.ok()) return Fail(res.status());
+  const ArrayData& d = *res->array();
+  std::memcpy(out, d.buffers[1]->data() + d.offset * 8, d.length * 8);
+  return 0;
+}
+int ref_sort_indices_multi(const orc_array* chunks, const int* nchunks, const int* orders, int nkeys, uint64_t* out) {
+  return SortMulti(chunks, nchunks, orders, nkeys, false, out);
+}
+int ref_sort_indices_multi_table(const orc_array* chunks, const int* nchunks, const int* orders, int nkeys, uint64_t* out) {
+  return SortMulti(chunks, nchunks, orders, nkeys, true, out);
+}
+
+int ref_concatenate(const orc_array* chunks, int nchunks, void* out_values, uint8_t* out_validity, orc_out* out) {
+  ArrayVector arrs;
+  for (int c = 0; c < nchunks; ++c) arrs.push_back(MakeArray(Wrap(&chunks[c])));
+  auto res = Concatenate(arrs, default_memory_pool());
+  if (!res.ok()) return Fail(res.status());
+  Export(*(*res)->data(), out_values, out_validity, out);
   return 0;
 }
 

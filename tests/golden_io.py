@@ -135,6 +135,37 @@ def iter_cases():
                 d[5::97] = np.nan
                 a = Arr(t, d, a.valid, off, n)
             yield ("aggregate", {}, [a])
+    # ---- multi-key sort_indices over batches and tables (vector_sort_test.cc:1108-1252
+    # random batches / tables: few distinct values so that ties reach the later keys, NaNs and nulls in
+    # every key) and Concatenate, which Take applies to chunked values (vector_selection.cc:1938) ----
+    key_types = [orc.INT8, orc.UINT16, orc.INT32, orc.UINT64, orc.INT64, FLOAT, DOUBLE, orc.UINT8, orc.INT16]
+
+    def key_column(t, m, null_prob, off):
+        a = R(rng, t, m, null_prob, off, lo=-2 if t not in (orc.UINT8, orc.UINT16, orc.UINT32, orc.UINT64) else 0, hi=2)
+        if t in (FLOAT, DOUBLE) and m:
+            d = a.data.copy()
+            d[rng.random(len(d)) < 0.1] = np.nan
+            d[rng.random(len(d)) < 0.1] = -0.0
+            a = Arr(t, d, a.valid, off, m)
+        return a
+    for nkeys in (2, 3, 9):
+        for null_prob in (0.0, 0.1, 0.5):
+            types = [key_types[(nkeys + 2 * k + int(null_prob * 10)) % len(key_types)] for k in range(nkeys)]
+            orders = [int(rng.integers(0, 2)) for _ in range(nkeys)]
+            cols = [key_column(t, 700, null_prob, k % 4) for k, t in enumerate(types)]
+            yield ("sort_indices_multi", dict(orders=orders, nchunks=[1] * nkeys), cols)
+            layouts = [[700], [300, 0, 400], [1, 699], [100] * 7]
+            flat, nch = [], []
+            for k, t in enumerate(types):
+                lay = layouts[(k + nkeys) % len(layouts)]
+                flat += [key_column(t, m, null_prob, (k + j) % 3) for j, m in enumerate(lay)]
+                nch.append(len(lay))
+            yield ("sort_indices_multi", dict(orders=orders, nchunks=nch), flat)
+    for t in [BOOL, orc.UINT8, orc.INT32, orc.DOUBLE]:
+        for probs in [(0.0, 0.0, 0.0), (0.0, 0.3, 0.0), (0.3, 1.0, 0.3)]:
+            chunks = [R(rng, t, m, probs[j % 3], off) for j, (m, off) in enumerate([(70, 0), (0, 2), (129, 5), (1, 63), (300, 64)])]
+            yield ("concatenate", {}, chunks)
+            yield ("concatenate", {}, chunks[2:3])
 
 
 def run_case(api, op, params, arrs):
@@ -152,6 +183,14 @@ def run_case(api, op, params, arrs):
             return res(api.take(arrs[0], arrs[1], params["boundscheck"]))
         if op == "sort_indices":
             return {"indices": api.sort_indices(arrs, params["order"])}
+        if op == "sort_indices_multi":
+            keys, i = [], 0
+            for m in params["nchunks"]:
+                keys.append(arrs[i:i + m])
+                i += m
+            return {"indices": api.sort_indices_multi(keys, params["orders"])}
+        if op == "concatenate":
+            return res(api.concatenate(arrs))
         if op == "grouper":
             ids, ng, uniq = api.group_ids([[a] for a in arrs])
             u = uniq[0]

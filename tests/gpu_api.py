@@ -58,6 +58,14 @@ class GpuApi:
             chunks = [chunks]
         return self._wrap(lambda: compute.sort_indices(self.ctx, [up(c) for c in chunks], order).values_numpy())
 
+    def sort_indices_multi(self, keys, orders):
+        keys = [[k] if isinstance(k, orc.Arr) else k for k in keys]
+        return self._wrap(lambda: compute.sort_indices_multi(self.ctx, [[up(c) for c in k] for k in keys],
+                                                             orders).values_numpy())
+
+    def concatenate(self, chunks):
+        return self._wrap(lambda: down(compute.concatenate(self.ctx, [up(c) for c in chunks])))
+
     def compare(self, op, lhs, rhs):
         f = lambda x: up(x) if isinstance(x, orc.Arr) else x  # noqa: E731
         return self._wrap(lambda: down(compute.compare(self.ctx, op, f(lhs), f(rhs))))

@@ -221,6 +221,28 @@ class Api:
         self._check(self._f("sort_indices")(arr, len(chunks), order, out.ctypes.data_as(C.c_void_p)))
         return out[:total]
 
+    def sort_indices_multi(self, keys, orders):
+        """keys: one Arr or list of chunk Arrs per sort key; orders: ASC/DESC per key."""
+        keys = [[k] if isinstance(k, Arr) else list(k) for k in keys]
+        flat = [c for k in keys for c in k]
+        arr = (CArr * max(len(flat), 1))(*[c.c() for c in flat])
+        nch = (C.c_int * max(len(keys), 1))(*[len(k) for k in keys])
+        ords = (C.c_int * max(len(keys), 1))(*[int(o) for o in orders])
+        total = sum(c.length for c in keys[0]) if keys else 0
+        out = np.zeros(total + 1, np.uint64)
+        self._check(self._f("sort_indices_multi")(arr, nch, ords, len(keys), out.ctypes.data_as(C.c_void_p)))
+        return out[:total]
+
+    def concatenate(self, chunks):
+        total = sum(c.length for c in chunks)
+        out_v = np.zeros(total * 8 + 16, np.uint8)
+        out_b = np.zeros(total // 8 + 16, np.uint8)
+        out = COut()
+        arr = (CArr * len(chunks))(*[c.c() for c in chunks])
+        self._check(self._f("concatenate")(arr, len(chunks), out_v.ctypes.data_as(C.c_void_p),
+                                           out_b.ctypes.data_as(C.c_void_p), C.byref(out)))
+        return self._result(chunks[0].type_id, out_v, out_b, out)
+
     def group_ids(self, key_batches):
         """key_batches: list of batches, each a list of key-column Arr.  Returns
         (ids per batch, num_groups, uniques per key column as (values, validity, null_count))."""

@@ -130,3 +130,44 @@ def test_scalar_aggregates_match_live_reference(oracle, reference):
             a = R(rng, t, n, p, off)
             x, y = reference.aggregate(a), oracle.aggregate(a)
             assert all(x[k] == y[k] or (x[k] != x[k] and y[k] != y[k]) for k in x), (t, n, p, x, y)
+
+
+def test_multi_key_sort_and_concatenate_match_live_reference(oracle, reference):
+    """SURVEY 8f.3 / a5 on a fresh seed.  The same keys go through all three reference sorters:
+    RadixRecordBatchSorter (batch, <= 8 keys), MultipleKeyRecordBatchSorter (batch, > 8 keys) and
+    MultipleKeyTableSorter (table) -- one order (MultipleKeyComparator, vector_sort.cc:1049-1180)."""
+    import ctypes as C
+    rng = np.random.default_rng(20260104)
+    R = orc.random_arr
+    types = [orc.INT8, orc.UINT8, orc.INT32, orc.UINT32, orc.INT64, orc.UINT64, orc.FLOAT, orc.DOUBLE, orc.INT16, orc.UINT16]
+
+    def col(t, n, p):
+        a = R(rng, t, n, p, int(rng.integers(0, 9)), lo=0, hi=3)
+        if t in (orc.FLOAT, orc.DOUBLE) and n:
+            d = a.data.copy()
+            d[rng.random(len(d)) < 0.15] = np.nan
+            d[rng.random(len(d)) < 0.15] = -0.0
+            a = orc.Arr(t, d, a.valid, a.offset, n)
+        return a
+    for n in (0, 1, 50, 1500):
+        for nkeys in (1, 2, 4, 10):
+            for p in (0.0, 0.2):
+                keys = [col(types[int(rng.integers(0, len(types)))], n, p) for _ in range(nkeys)]
+                orders = [int(rng.integers(0, 2)) for _ in range(nkeys)]
+                want = reference.sort_indices_multi(keys, orders)
+                assert np.array_equal(oracle.sort_indices_multi(keys, orders), want), (n, nkeys, p)
+                # the table sorter on the same single-chunk columns
+                flat = (orc.CArr * nkeys)(*[k.c() for k in keys])
+                nch = (C.c_int * nkeys)(*[1] * nkeys)
+                ords = (C.c_int * nkeys)(*orders)
+                out = np.zeros(n + 1, np.uint64)
+                assert reference.lib.ref_sort_indices_multi_table(flat, nch, ords, nkeys, out.ctypes.data_as(C.c_void_p)) == 0
+                assert np.array_equal(out[:n], want), ("table", n, nkeys, p)
+    for t in [orc.BOOL, orc.INT16, orc.FLOAT, orc.INT64]:
+        for nc in (None, -1):
+            chunks = [R(rng, t, m, p, off, null_count=nc, force_validity=(nc == -1))
+                      for m, p, off in [(5, 0, 0), (0, 0, 1), (200, .2, 3), (64, 0, 64), (77, 1.0, 9)]]
+            assert oracle.concatenate(chunks).same(reference.concatenate(chunks)), (t, nc)
+            assert oracle.concatenate(chunks[:2]).same(reference.concatenate(chunks[:2])), (t, nc)
+    with pytest.raises(orc.StatusError):
+        oracle.sort_indices_multi([], [])

@@ -647,3 +647,87 @@ def test_filter_groupby_many_groups(gpu, oracle, n_groups):
     m = Arr(BOOL, np.ones(n, bool))
     for x, y in zip(oracle.filter_groupby_sum(v, k, m), gpu.filter_groupby_sum(v, k, m)):
         assert np.array_equal(x, y)
+
+
+# ---- multi-key sort_indices, Concatenate ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("nkeys", [1, 2, 3, 9])
+def test_sort_indices_multi_key_random(gpu, oracle, nkeys):
+    """Batches (one chunk per key) and tables (each key chunked its own way) against the oracle:
+    few distinct values so ties reach the later keys; NaN, -0.0 and nulls in every key."""
+    rng = np.random.default_rng(70 + nkeys)
+    types = [INT8, orc.UINT8, INT32, orc.UINT32, INT64, orc.UINT64, FLOAT, DOUBLE, orc.INT16, UINT16]
+
+    def col(t, n, p, off):
+        a = R(rng, t, n, p, off, lo=0, hi=4)
+        if t in (FLOAT, DOUBLE) and n:
+            d = a.data.copy()
+            for val in (np.nan, -0.0, np.inf):
+                d[rng.random(len(d)) < 0.1] = val
+            a = Arr(t, d, a.valid, off, n)
+        return a
+    for n in (1, 300, 70_000):
+        for p in (0, .2, 1):
+            ts = [types[int(rng.integers(0, len(types)))] for _ in range(nkeys)]
+            orders = [int(rng.integers(0, 2)) for _ in range(nkeys)]
+            keys = [col(t, n, p, k % 5) for k, t in enumerate(ts)]
+            assert np.array_equal(gpu.sort_indices_multi(keys, orders), oracle.sort_indices_multi(keys, orders)), (n, p, ts)
+            lay = [[n], [n // 3, 0, n - n // 3], [1, n - 1] if n > 1 else [1], [n - n // 2, n // 2]]
+            tab = [[col(t, m, p, (k + j) % 3) for j, m in enumerate(lay[(k + 1) % 4])] for k, t in enumerate(ts)]
+            assert np.array_equal(gpu.sort_indices_multi(tab, orders), oracle.sort_indices_multi(tab, orders)), ("table", n, p)
+    # a first key with full-range values on top of a coarse second key
+    a = Arr(INT64, rng.integers(-2**62, 2**62, 50_000))
+    b = R(rng, INT32, 50_000, .1, 2, lo=0, hi=2)
+    for orders in ([ASC, DESC], [DESC, ASC]):
+        assert np.array_equal(gpu.sort_indices_multi([b, a], orders), oracle.sort_indices_multi([b, a], orders))
+
+
+@pytest.mark.gpu
+def test_sort_indices_multi_key_errors(gpu, oracle):
+    a, b = Arr(INT32, [1, 2, 3]), Arr(INT32, [1, 2])
+    for api in (oracle, gpu):
+        with pytest.raises(orc.StatusError) as ei:
+            api.sort_indices_multi([], [])
+        assert ei.value.code == orc.INVALID and ei.value.msg == "Must specify one or more sort keys"
+        with pytest.raises(orc.StatusError) as ei:
+            api.sort_indices_multi([a, b], [ASC, ASC])
+        assert ei.value.code == orc.INVALID
+    e = Arr(INT32, np.zeros(0, np.int32))
+    assert gpu.sort_indices_multi([e, e], [ASC, DESC]).tolist() == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", [BOOL, INT8, UINT16, INT32, FLOAT, INT64, DOUBLE])
+def test_concatenate_random(gpu, oracle, t):
+    rng = np.random.default_rng(80 + t)
+    for nc in (None, -1):
+        for sizes in ([(5, 0, 0), (0, 0, 1), (200, .2, 3), (64, 0, 64), (77, 1.0, 9)], [(100_000, .01, 7), (1, 0, 0), (33_333, 0, 5)],
+                      [(1, 0, 3)] * 70, [(0, 0, 0)], [(4096, 0, 0), (4096, 0, 0)]):
+            chunks = [R(rng, t, m, p, off, null_count=nc, force_validity=(nc == -1)) for m, p, off in sizes]
+            assert gpu.concatenate(chunks).same(oracle.concatenate(chunks)), (t, nc, sizes[:2])
+
+
+@pytest.mark.gpu
+def test_full_size_two_key_sort_is_lexicographic_stable_permutation(gpu, full):
+    """100 M rows, keys (int32 group key ascending, int64 value descending): sorted
+    lexicographically, ties in index order, and a permutation."""
+    import torch
+    from arrow1_amd import compute
+    idx = compute.sort_indices_multi(gpu.ctx, [full["keys_arr"], full["values"]], [ASC, DESC]).values[:N_FULL * 8].view(torch.int64)
+    k = full["keys"][idx]
+    assert bool((k[1:] >= k[:-1]).all())
+    same_k = k[1:] == k[:-1]
+    del k
+    valid = _bits(full["valid"], N_FULL)[idx]
+    v = full["vals"][idx]
+    # within a key: valid values descending, then nulls
+    assert bool((valid[:-1] | ~valid[1:])[same_k].all())
+    both = same_k & valid[1:] & valid[:-1]
+    assert bool((v[1:] <= v[:-1])[both].all())
+    tie = both & (v[1:] == v[:-1])
+    tie |= same_k & ~valid[1:] & ~valid[:-1]
+    assert bool((idx[1:] > idx[:-1])[tie].all())
+    del v, valid, both, tie, same_k
+    seen = torch.zeros(N_FULL, dtype=torch.bool, device="cuda")
+    seen[idx] = True
+    assert bool(seen.all())
