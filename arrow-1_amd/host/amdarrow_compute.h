@@ -69,7 +69,9 @@ class Result {
   T& ValueOrDie() { return value_; }
   const T& ValueOrDie() const { return value_; }
   T& operator*() { return value_; }
+  const T& operator*() const { return value_; }
   T* operator->() { return &value_; }
+  const T* operator->() const { return &value_; }
   T MoveValueUnsafe() { return std::move(value_); }
 
  private:
@@ -227,6 +229,80 @@ class ChunkedArray {
   int64_t length_ = 0, null_count_ = 0;
 };
 
+// arrow::Concatenate (array/concatenate.cc:428-449) for the path's fixed-width / boolean arrays
+class MemoryPool;
+Result<std::shared_ptr<ArrayData>> Concatenate(const std::vector<std::shared_ptr<ArrayData>>& arrays,
+                                               const std::shared_ptr<MemoryPool>& pool);
+
+// ---- Field / Schema / RecordBatch / Table (type.h:300-420, 1600-1700; record_batch.h:43-180;
+// table.h:44-200): the members the path's meta functions use.  Columns live in HBM. -----------------
+struct Field {
+  std::string name;
+  std::shared_ptr<DataType> type;
+};
+inline Field field(std::string name, std::shared_ptr<DataType> type) { return {std::move(name), std::move(type)}; }
+class Schema {
+ public:
+  explicit Schema(std::vector<Field> fields) : fields_(std::move(fields)) {}
+  int num_fields() const { return static_cast<int>(fields_.size()); }
+  const Field& field(int i) const { return fields_[i]; }
+  int GetFieldIndex(const std::string& name) const {  // -1 when absent (type.h:1648)
+    for (int i = 0; i < num_fields(); ++i) if (fields_[i].name == name) return i;
+    return -1;
+  }
+
+ private:
+  std::vector<Field> fields_;
+};
+inline std::shared_ptr<Schema> schema(std::vector<Field> fields) { return std::make_shared<Schema>(std::move(fields)); }
+class RecordBatch {
+ public:
+  static std::shared_ptr<RecordBatch> Make(std::shared_ptr<Schema> schema, int64_t num_rows,
+                                           std::vector<std::shared_ptr<ArrayData>> columns) {
+    return std::shared_ptr<RecordBatch>(new RecordBatch(std::move(schema), num_rows, std::move(columns)));
+  }
+  const std::shared_ptr<Schema>& schema() const { return schema_; }
+  int64_t num_rows() const { return num_rows_; }
+  int num_columns() const { return static_cast<int>(columns_.size()); }
+  const std::shared_ptr<ArrayData>& column(int i) const { return columns_[i]; }
+  std::shared_ptr<ArrayData> GetColumnByName(const std::string& name) const {  // record_batch.cc:164-167
+    const int i = schema_->GetFieldIndex(name);
+    return i < 0 ? nullptr : columns_[i];
+  }
+
+ private:
+  RecordBatch(std::shared_ptr<Schema> s, int64_t n, std::vector<std::shared_ptr<ArrayData>> c)
+      : schema_(std::move(s)), num_rows_(n), columns_(std::move(c)) {}
+  std::shared_ptr<Schema> schema_;
+  int64_t num_rows_;
+  std::vector<std::shared_ptr<ArrayData>> columns_;
+};
+class Table {
+ public:
+  // num_rows = -1: taken from the first column, 0 without columns (table.cc:58-70)
+  static std::shared_ptr<Table> Make(std::shared_ptr<Schema> schema, std::vector<std::shared_ptr<ChunkedArray>> columns,
+                                     int64_t num_rows = -1) {
+    if (num_rows < 0) num_rows = columns.empty() ? 0 : columns[0]->length();
+    return std::shared_ptr<Table>(new Table(std::move(schema), num_rows, std::move(columns)));
+  }
+  const std::shared_ptr<Schema>& schema() const { return schema_; }
+  int64_t num_rows() const { return num_rows_; }
+  int num_columns() const { return static_cast<int>(columns_.size()); }
+  const std::shared_ptr<ChunkedArray>& column(int i) const { return columns_[i]; }
+  const std::vector<std::shared_ptr<ChunkedArray>>& columns() const { return columns_; }
+  std::shared_ptr<ChunkedArray> GetColumnByName(const std::string& name) const {  // table.h:100-103
+    const int i = schema_->GetFieldIndex(name);
+    return i < 0 ? nullptr : columns_[i];
+  }
+
+ private:
+  Table(std::shared_ptr<Schema> s, int64_t n, std::vector<std::shared_ptr<ChunkedArray>> c)
+      : schema_(std::move(s)), num_rows_(n), columns_(std::move(c)) {}
+  std::shared_ptr<Schema> schema_;
+  int64_t num_rows_;
+  std::vector<std::shared_ptr<ChunkedArray>> columns_;
+};
+
 struct ValueDescr {
   enum Shape { ANY, ARRAY, SCALAR };
   std::shared_ptr<DataType> type;
@@ -243,6 +319,8 @@ class Datum {
   Datum(std::shared_ptr<ArrayData> a) : kind_(ARRAY), array_(std::move(a)) {}               // NOLINT
   Datum(std::shared_ptr<ChunkedArray> c) : kind_(CHUNKED_ARRAY), chunked_(std::move(c)) {}  // NOLINT
   Datum(std::shared_ptr<Scalar> s) : kind_(SCALAR), scalar_(std::move(s)) {}                // NOLINT
+  Datum(std::shared_ptr<RecordBatch> b) : kind_(RECORD_BATCH), batch_(std::move(b)) {}      // NOLINT
+  Datum(std::shared_ptr<Table> t) : kind_(TABLE), table_(std::move(t)) {}                   // NOLINT
   Kind kind() const { return kind_; }
   bool is_array() const { return kind_ == ARRAY; }
   bool is_scalar() const { return kind_ == SCALAR; }
@@ -250,6 +328,8 @@ class Datum {
   const std::shared_ptr<ArrayData>& array() const { return array_; }
   const std::shared_ptr<ChunkedArray>& chunked_array() const { return chunked_; }
   const std::shared_ptr<Scalar>& scalar() const { return scalar_; }
+  const std::shared_ptr<RecordBatch>& record_batch() const { return batch_; }
+  const std::shared_ptr<Table>& table() const { return table_; }
   std::shared_ptr<DataType> type() const;
   int64_t length() const;
   ValueDescr descr() const;
@@ -259,6 +339,8 @@ class Datum {
   std::shared_ptr<ArrayData> array_;
   std::shared_ptr<ChunkedArray> chunked_;
   std::shared_ptr<Scalar> scalar_;
+  std::shared_ptr<RecordBatch> batch_;
+  std::shared_ptr<Table> table_;
 };
 
 namespace compute {
@@ -556,6 +638,14 @@ class FunctionRegistry {
 FunctionRegistry* GetFunctionRegistry();
 
 namespace internal {
+// arrow::internal::RechunkArraysConsistently (array/util.cc:672-745): cut every group of chunks at
+// the union of all groups' chunk boundaries; empty chunks disappear.  Zero-copy slices.
+std::vector<std::vector<std::shared_ptr<ArrayData>>> RechunkArraysConsistently(
+    const std::vector<std::vector<std::shared_ptr<ArrayData>>>& groups);
+// GetTakeIndices (vector_selection.cc:92-237, api_vector.h:190): uint16 / uint32 positions of the
+// selected slots; nullable under EMIT_NULL.
+Result<std::shared_ptr<ArrayData>> GetTakeIndices(const ArrayData& filter, FilterOptions::NullSelectionBehavior null_selection,
+                                                  ExecContext* ctx);
 // The Register* hooks of the kernel files (registry_internal.h), HIP-backed.
 void RegisterVectorSelection(FunctionRegistry* registry);  // array_filter, filter, array_take, take
 void RegisterVectorSort(FunctionRegistry* registry);       // array_sort_indices, sort_indices
@@ -606,6 +696,7 @@ Result<Datum> CallFunction(const std::string& func_name, const std::vector<Datum
 Result<Datum> Filter(const Datum& values, const Datum& filter, const FilterOptions& options, ExecContext* ctx);
 Result<Datum> Take(const Datum& values, const Datum& indices, const TakeOptions& options, ExecContext* ctx);
 Result<Datum> SortIndices(const Datum& values, SortOrder order, ExecContext* ctx);
+Result<Datum> SortIndices(const Datum& values, const SortOptions& options, ExecContext* ctx);  // api_vector.cc:93-96
 Result<Datum> Compare(const Datum& left, const Datum& right, CompareOperator op, ExecContext* ctx);
 Result<Datum> Add(const Datum& left, const Datum& right, ArithmeticOptions options, ExecContext* ctx);
 Result<Datum> Subtract(const Datum& left, const Datum& right, ArithmeticOptions options, ExecContext* ctx);

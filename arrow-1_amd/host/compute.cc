@@ -7,6 +7,7 @@
 #include <cstring>
 #include <limits>
 #include <sstream>
+#include <vector>
 
 namespace amdarrow {
 
@@ -148,22 +149,31 @@ Result<std::shared_ptr<ArrayData>> ArrayFromHost(const std::shared_ptr<MemoryPoo
   }
   return ArrayData::Make(std::move(type), length, {nbuf, vbuf}, null_count);
 }
+// Bits [off, off+n) of a device bitmap -> host bits at offset 0.
+static Status CopyBitsToHost(const std::shared_ptr<MemoryPool>& pool, const uint8_t* dev, int64_t off, int64_t n, uint8_t* out) {
+  const int64_t first = off / 8, nbytes = (off % 8 + n + 7) / 8;
+  std::vector<uint8_t> raw(nbytes + 1, 0);
+  const int rc = amdarrow_memcpy_d2h(pool->ctx(), raw.data(), dev + first, nbytes);
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  const int shift = static_cast<int>(off % 8);
+  for (int64_t b = 0; b < (n + 7) / 8; ++b)
+    out[b] = static_cast<uint8_t>(shift == 0 ? raw[b] : ((raw[b] >> shift) | (raw[b + 1] << (8 - shift))));
+  return Status::OK();
+}
 Status CopyValuesToHost(const ArrayData& a, const std::shared_ptr<MemoryPool>& pool, void* out_values,
                         uint8_t* out_validity_bits) {
   const int bw = a.type->bit_width();
-  if (a.offset != 0) return Status::NotImplemented("CopyValuesToHost: sliced arrays");
-  const int64_t vbytes = bw == 1 ? (a.length + 7) / 8 : a.length * bw / 8;
-  if (vbytes && out_values) {
-    const int rc = amdarrow_memcpy_d2h(pool->ctx(), out_values, a.buffers[1]->data(), vbytes);
-    if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  if (a.length && out_values) {
+    if (bw == 1) {
+      AMD_RETURN_NOT_OK(CopyBitsToHost(pool, a.buffers[1]->data(), a.offset, a.length, static_cast<uint8_t*>(out_values)));
+    } else {
+      const int rc = amdarrow_memcpy_d2h(pool->ctx(), out_values, a.buffers[1]->data() + a.offset * bw / 8, a.length * bw / 8);
+      if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+    }
   }
   if (out_validity_bits && a.length) {
-    if (a.buffers[0]) {
-      const int rc = amdarrow_memcpy_d2h(pool->ctx(), out_validity_bits, a.buffers[0]->data(), (a.length + 7) / 8);
-      if (rc != AMDARROW_OK) return Status::FromAbi(rc);
-    } else {
-      memset(out_validity_bits, 0xFF, (a.length + 7) / 8);
-    }
+    if (a.buffers[0]) AMD_RETURN_NOT_OK(CopyBitsToHost(pool, a.buffers[0]->data(), a.offset, a.length, out_validity_bits));
+    else memset(out_validity_bits, 0xFF, (a.length + 7) / 8);
   }
   return Status::OK();
 }
@@ -192,14 +202,70 @@ int64_t Datum::length() const {
     case ARRAY: return array_->length;
     case CHUNKED_ARRAY: return chunked_->length();
     case SCALAR: return 1;
+    case RECORD_BATCH: return batch_->num_rows();  // datum.cc:108-124
+    case TABLE: return table_->num_rows();
     default: return -1;
   }
 }
+
+Result<std::shared_ptr<ArrayData>> Concatenate(const std::vector<std::shared_ptr<ArrayData>>& arrays,
+                                               const std::shared_ptr<MemoryPool>& pool) {
+  if (arrays.empty()) return Status::Invalid("Must pass at least one array");  // concatenate.cc:428-430
+  std::vector<amdarrow_array> abi;
+  int64_t total = 0, nulls = 0;
+  for (const auto& a : arrays) {
+    if (!a->type->Equals(*arrays[0]->type))  // :436-441
+      return Status::Invalid("arrays to be concatenated must be identically typed, but " + arrays[0]->type->ToString() +
+                             " and " + a->type->ToString() + " were encountered.");
+    abi.push_back(a->abi());
+    total += a->length;
+    const int64_t nc = a->buffers[0] ? a->null_count : 0;
+    nulls = (nulls < 0 || nc < 0) ? -1 : nulls + nc;
+  }
+  const int bw = arrays[0]->type->bit_width();
+  std::shared_ptr<Buffer> vbuf, nbuf;
+  if (bw == 1) { AMD_ASSIGN_OR_RAISE(vbuf, AllocateBitmap(total, pool)); }
+  else { AMD_ASSIGN_OR_RAISE(vbuf, AllocateBuffer(total * bw / 8, pool)); }
+  if (nulls != 0) { AMD_ASSIGN_OR_RAISE(nbuf, AllocateBitmap(total, pool)); }  // :190-192
+  amdarrow_out o;
+  const int rc = amdarrow_concatenate(pool->ctx(), abi.data(), static_cast<int>(abi.size()), vbuf->mutable_data(),
+                                      nbuf ? nbuf->mutable_data() : nullptr, &o);
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  return ArrayData::Make(arrays[0]->type, o.length, {nbuf, vbuf}, o.null_count);
+}
+
 ValueDescr Datum::descr() const {
   return kind_ == SCALAR ? ValueDescr::Scalar(type()) : ValueDescr::Array(type());
 }
 
 namespace compute {
+
+namespace internal {
+std::vector<std::vector<std::shared_ptr<ArrayData>>> RechunkArraysConsistently(
+    const std::vector<std::vector<std::shared_ptr<ArrayData>>>& groups) {
+  if (groups.size() <= 1) return groups;
+  int64_t total = 0;
+  for (const auto& a : groups.front()) total += a->length;
+  if (total == 0) return groups;
+  std::vector<std::vector<std::shared_ptr<ArrayData>>> out(groups.size());
+  std::vector<size_t> cur(groups.size(), 0);
+  std::vector<int64_t> off(groups.size(), 0);
+  for (int64_t start = 0; start < total;) {
+    int64_t len = std::numeric_limits<int64_t>::max();
+    for (size_t g = 0; g < groups.size(); ++g) {
+      while (off[g] == groups[g][cur[g]]->length) { ++cur[g]; off[g] = 0; }  // done and 0-length arrays
+      len = std::min(len, groups[g][cur[g]]->length - off[g]);
+    }
+    for (size_t g = 0; g < groups.size(); ++g) {
+      const auto& a = groups[g][cur[g]];
+      out[g].push_back(off[g] == 0 && len == a->length ? a : a->Slice(off[g], len));
+      off[g] += len;
+    }
+    start += len;
+  }
+  return out;
+}
+}  // namespace internal
 
 ExecContext::ExecContext(std::shared_ptr<MemoryPool> pool, FunctionRegistry* func_registry)
     : pool_(std::move(pool)), func_registry_(func_registry ? func_registry : GetFunctionRegistry()) {}
@@ -564,6 +630,9 @@ Result<Datum> Take(const Datum& values, const Datum& indices, const TakeOptions&
 Result<Datum> SortIndices(const Datum& values, SortOrder order, ExecContext* ctx) {
   SortOptions options({SortKey("not-used", order)});  // api_vector.cc:54-58
   return CallFunction("sort_indices", {values}, &options, ctx);
+}
+Result<Datum> SortIndices(const Datum& values, const SortOptions& options, ExecContext* ctx) {
+  return CallFunction("sort_indices", {values}, &options, ctx);  // api_vector.cc:93-96
 }
 Result<Datum> Compare(const Datum& left, const Datum& right, CompareOperator op, ExecContext* ctx) {
   static const char* names[] = {"equal", "not_equal", "greater", "greater_equal", "less", "less_equal"};  // api_scalar.cc:122-146

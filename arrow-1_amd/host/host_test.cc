@@ -311,6 +311,183 @@ static void TypedTests(const std::shared_ptr<MemoryPool>& pool, ExecContext* ctx
   }
 }
 
+// ---- batches and tables through the meta functions ---------------------------
+// Known answers of vector_selection_test.cc:660-689 (FilterRecordBatch), :737-796 (FilterTable),
+// :1460-1493 (TakeRecordBatch), :1536-1550 (TakeChunkedArray), :1596-1609 (TakeTable) and
+// vector_sort_test.cc:763-980 (batch / table sort_indices).  The reference's second column is utf8,
+// which is outside this path: a float64 column numbering the rows (10, 11, ...) stands in for it.
+static std::vector<uint64_t> HostU64(const std::shared_ptr<MemoryPool>& pool, const ArrayData& a) {
+  std::vector<uint64_t> out;
+  for (const auto& o : Host<uint64_t>(pool, a)) out.push_back(o.v);
+  return out;
+}
+static void TabularTests(const std::shared_ptr<MemoryPool>& pool, ExecContext* ctx) {
+  using I = int32_t;
+  using D = double;
+  auto schm = schema({field("a", int32()), field("b", float64())});
+  auto a = Dev<I>(pool, int32(), {N(I), V(I, 1), V(I, 2), V(I, 4)});
+  auto b = Dev<D>(pool, float64(), {V(D, 10), V(D, 11), V(D, 12), V(D, 13)});
+  auto batch = RecordBatch::Make(schm, 4, {a, b});
+  FilterOptions drop(FilterOptions::DROP), emit(FilterOptions::EMIT_NULL);
+  auto check_batch = [&](const Result<Datum>& r, const std::vector<Opt<I>>& wa, const std::vector<Opt<D>>& wb) {
+    CHECK_OK(r.status());
+    if (!r.ok()) return;
+    CHECK(r->kind() == Datum::RECORD_BATCH);
+    const auto& out = *r->record_batch();
+    CHECK(out.num_rows() == static_cast<int64_t>(wa.size()) && out.num_columns() == 2 && out.schema() == schm);
+    CHECK(Same(Host<I>(pool, *out.column(0)), wa));
+    CHECK(Same(Host<D>(pool, *out.column(1)), wb));
+  };
+  for (const auto* o : {&emit, &drop}) {
+    check_batch(Filter(Datum(batch), Datum(DevBool(pool, {0, 0, 0, 0})), *o, ctx), {}, {});
+    check_batch(Filter(Datum(batch), Datum(DevBool(pool, {1, 1, 1, 1})), *o, ctx), {N(I), V(I, 1), V(I, 2), V(I, 4)},
+                {V(D, 10), V(D, 11), V(D, 12), V(D, 13)});
+    check_batch(Filter(Datum(batch), Datum(DevBool(pool, {1, 0, 1, 0})), *o, ctx), {N(I), V(I, 2)}, {V(D, 10), V(D, 12)});
+  }
+  check_batch(Filter(Datum(batch), Datum(DevBool(pool, {0, 1, 1, -1})), drop, ctx), {V(I, 1), V(I, 2)}, {V(D, 11), V(D, 12)});
+  check_batch(Filter(Datum(batch), Datum(DevBool(pool, {0, 1, 1, -1})), emit, ctx), {V(I, 1), V(I, 2), N(I)}, {V(D, 11), V(D, 12), N(D)});
+  CHECK(Filter(Datum(batch), Datum(DevBool(pool, {0, 1, 1})), drop, ctx).status().IsInvalid());  // :1780-1782
+  CHECK(Filter(Datum(batch), Datum(a), drop, ctx).status().IsNotImplemented());                  // :1885-1887
+
+  // TakeRecordBatch with int8 and uint32 indices
+  for (int pass = 0; pass < 2; ++pass) {
+    auto idx = [&](const std::vector<int>& v) -> Datum {
+      if (pass == 0) { std::vector<Opt<int8_t>> o; for (int x : v) o.push_back(V(int8_t, x)); return Datum(Dev<int8_t>(pool, int8(), o)); }
+      std::vector<Opt<uint32_t>> o; for (int x : v) o.push_back(V(uint32_t, x)); return Datum(Dev<uint32_t>(pool, uint32(), o));
+    };
+    TakeOptions to;
+    check_batch(Take(Datum(batch), idx({}), to, ctx), {}, {});
+    check_batch(Take(Datum(batch), idx({3, 1, 3, 1, 3}), to, ctx), {V(I, 4), V(I, 1), V(I, 4), V(I, 1), V(I, 4)},
+                {V(D, 13), V(D, 11), V(D, 13), V(D, 11), V(D, 13)});
+    check_batch(Take(Datum(batch), idx({3, 1, 0}), to, ctx), {V(I, 4), V(I, 1), N(I)}, {V(D, 13), V(D, 11), V(D, 10)});
+    check_batch(Take(Datum(batch), idx({0, 2, 2, 2, 2, 2, 2}), to, ctx), {N(I), V(I, 2), V(I, 2), V(I, 2), V(I, 2), V(I, 2), V(I, 2)},
+                {V(D, 10), V(D, 12), V(D, 12), V(D, 12), V(D, 12), V(D, 12), V(D, 12)});
+  }
+
+  // TakeChunkedArray (:1536-1550)
+  using B = int8_t;
+  auto i8 = [&](const std::vector<int>& v) { std::vector<Opt<B>> o; for (int x : v) o.push_back(V(B, x)); return Dev<B>(pool, int8(), o); };
+  auto chunked = [&](std::vector<std::shared_ptr<ArrayData>> c, std::shared_ptr<DataType> t) { return std::make_shared<ChunkedArray>(std::move(c), t); };
+  auto flat = [&](const ChunkedArray& c) { std::vector<std::vector<int>> out; for (const auto& ch : c.chunks()) { std::vector<int> v; for (const auto& o : Host<B>(pool, *ch)) v.push_back(o.valid ? o.v : -99); out.push_back(v); } return out; };
+  {
+    TakeOptions to;
+    auto vals = chunked({i8({7}), i8({8, 9})}, int8());
+    auto r = Take(Datum(vals), Datum(i8({0, 1, 0, 2})), to, ctx);
+    CHECK_OK(r.status());
+    if (r.ok()) { CHECK(r->kind() == Datum::CHUNKED_ARRAY); CHECK((flat(*r->chunked_array()) == std::vector<std::vector<int>>{{7, 8, 7, 9}})); }
+    r = Take(Datum(vals), Datum(chunked({i8({0, 1, 0}), i8({}), i8({2})}, int8())), to, ctx);
+    CHECK_OK(r.status());
+    if (r.ok()) CHECK((flat(*r->chunked_array()) == std::vector<std::vector<int>>{{7, 8, 7}, {}, {9}}));
+    r = Take(Datum(vals), Datum(i8({2, 1})), to, ctx);
+    CHECK_OK(r.status());
+    if (r.ok()) CHECK((flat(*r->chunked_array()) == std::vector<std::vector<int>>{{9, 8}}));
+    CHECK(Take(Datum(vals), Datum(i8({0, 5})), to, ctx).status().IsIndexError());
+    CHECK(Take(Datum(vals), Datum(chunked({i8({0, 1, 0}), i8({5, 1})}, int8())), to, ctx).status().IsIndexError());
+    r = Take(Datum(chunked({i8({})}, int8())), Datum(i8({})), to, ctx);
+    CHECK_OK(r.status());
+    if (r.ok()) CHECK(r->chunked_array()->length() == 0);
+  }
+
+  // tables: columns chunked as {[null, 1], [2, 4]} (:1596-1609, :737-796)
+  auto tab_cols = [&]() {
+    return std::vector<std::shared_ptr<ChunkedArray>>{
+        chunked({Dev<I>(pool, int32(), {N(I), V(I, 1)}), Dev<I>(pool, int32(), {V(I, 2), V(I, 4)})}, int32()),
+        chunked({Dev<D>(pool, float64(), {V(D, 10), V(D, 11)}), Dev<D>(pool, float64(), {V(D, 12), V(D, 13)})}, float64())};
+  };
+  auto table = Table::Make(schm, tab_cols());
+  CHECK(table->num_rows() == 4);
+  auto check_table = [&](const Result<Datum>& r, const std::vector<std::vector<Opt<I>>>& wa, const std::vector<std::vector<Opt<D>>>& wb) {
+    CHECK_OK(r.status());
+    if (!r.ok()) return;
+    CHECK(r->kind() == Datum::TABLE);
+    const auto& out = *r->table();
+    int64_t rows = 0;
+    for (const auto& c : wa) rows += static_cast<int64_t>(c.size());
+    CHECK(out.num_rows() == rows && out.num_columns() == 2);
+    CHECK(out.column(0)->num_chunks() == static_cast<int>(wa.size()) && out.column(1)->num_chunks() == static_cast<int>(wb.size()));
+    if (out.column(0)->num_chunks() != static_cast<int>(wa.size())) return;
+    for (size_t c = 0; c < wa.size(); ++c) {
+      CHECK(Same(Host<I>(pool, *out.column(0)->chunk(static_cast<int>(c))), wa[c]));
+      CHECK(Same(Host<D>(pool, *out.column(1)->chunk(static_cast<int>(c))), wb[c]));
+    }
+  };
+  {
+    TakeOptions to;
+    check_table(Take(Datum(table), Datum(i8({})), to, ctx), {{}}, {{}});
+    check_table(Take(Datum(table), Datum(i8({3, 1, 0})), to, ctx), {{V(I, 4), V(I, 1), N(I)}}, {{V(D, 13), V(D, 11), V(D, 10)}});
+    check_table(Take(Datum(table), Datum(chunked({i8({0, 1}), i8({2, 3})}, int8())), to, ctx), {{N(I), V(I, 1)}, {V(I, 2), V(I, 4)}},
+                {{V(D, 10), V(D, 11)}, {V(D, 12), V(D, 13)}});
+    // FilterTable: filter as one array and chunked differently from the table; chunks that select nothing vanish
+    check_table(Filter(Datum(table), Datum(DevBool(pool, {0, 1, 1, -1})), drop, ctx), {{V(I, 1)}, {V(I, 2)}}, {{V(D, 11)}, {V(D, 12)}});
+    check_table(Filter(Datum(table), Datum(DevBool(pool, {0, 1, 1, -1})), emit, ctx), {{V(I, 1)}, {V(I, 2), N(I)}}, {{V(D, 11)}, {V(D, 12), N(D)}});
+    check_table(Filter(Datum(table), Datum(chunked({DevBool(pool, {0, 1, 1}), DevBool(pool, {-1})}, boolean())), emit, ctx),
+                {{V(I, 1)}, {V(I, 2)}, {N(I)}}, {{V(D, 11)}, {V(D, 12)}, {N(D)}});
+    check_table(Filter(Datum(table), Datum(DevBool(pool, {0, 0, 1, 1})), drop, ctx), {{V(I, 2), V(I, 4)}}, {{V(D, 12), V(D, 13)}});
+    check_table(Filter(Datum(table), Datum(DevBool(pool, {0, 0, 0, 0})), drop, ctx), {}, {});
+    CHECK(Filter(Datum(table), Datum(DevBool(pool, {0, 0, 0})), drop, ctx).status().IsInvalid());
+  }
+
+  // RechunkArraysConsistently (array_test.cc:2549-2580): {3,2,4} against {2,3,2,2} -> {2,1,2,2,2}
+  {
+    auto mk = [&](int n, int from) { std::vector<Opt<I>> o; for (int k = 0; k < n; ++k) o.push_back(V(I, from + k)); return Dev<I>(pool, int32(), o); };
+    auto out = internal::RechunkArraysConsistently({{mk(3, 1), mk(2, 4), mk(4, 6)}, {mk(2, 41), mk(3, 43), mk(2, 46), mk(2, 48)}});
+    CHECK(out.size() == 2 && out[0].size() == 5 && out[1].size() == 5);
+    const int want[] = {2, 1, 2, 2, 2};
+    for (size_t c = 0; c < 5 && out[0].size() == 5; ++c) CHECK(out[0][c]->length == want[c] && out[1][c]->length == want[c]);
+    if (out[0].size() == 5) CHECK(Same(Host<I>(pool, *out[0][1]), {V(I, 3)}) && Same(Host<I>(pool, *out[1][4]), {V(I, 48), V(I, 49)}));
+    auto empty = internal::RechunkArraysConsistently({{mk(0, 0), mk(0, 0)}, {}, {mk(0, 0)}});  // :2527-2547
+    CHECK(empty.size() == 3);
+  }
+
+  // Concatenate (concatenate_test.cc): validity only when some input has nulls
+  {
+    auto c = Concatenate({Dev<I>(pool, int32(), {V(I, 1), N(I)}), Dev<I>(pool, int32(), {}), Dev<I>(pool, int32(), {V(I, 3)})}, pool);
+    CHECK_OK(c.status());
+    if (c.ok()) { CHECK(Same(Host<I>(pool, **c), {V(I, 1), N(I), V(I, 3)})); CHECK((*c)->null_count == 1 && (*c)->buffers[0]); }
+    c = Concatenate({Dev<I>(pool, int32(), {V(I, 1)}), Dev<I>(pool, int32(), {V(I, 3)})}, pool);
+    CHECK_OK(c.status());
+    if (c.ok()) CHECK((*c)->null_count == 0 && !(*c)->buffers[0] && (*c)->length == 2);
+    auto cb = Concatenate({DevBool(pool, {1, 0, -1}), DevBool(pool, {1, 1, 1, 0, 1, 0, 0, 1, 1})}, pool);
+    CHECK_OK(cb.status());
+    if (cb.ok()) CHECK((HostBool(pool, **cb) == std::vector<int>{1, 0, -1, 1, 1, 1, 0, 1, 0, 0, 1, 1}));
+    CHECK(Concatenate({}, pool).status().IsInvalid());
+    CHECK(Concatenate({Dev<I>(pool, int32(), {V(I, 1)}), DevBool(pool, {1})}, pool).status().IsInvalid());
+  }
+
+  // sort_indices over batches and tables (vector_sort_test.cc:763-980)
+  {
+    using U8 = uint8_t; using U32 = uint32_t; using F = float;
+    const F nanf = std::numeric_limits<F>::quiet_NaN();
+    const D nan = std::numeric_limits<D>::quiet_NaN();
+    SortOptions ad({SortKey("a", SortOrder::Ascending), SortKey("b", SortOrder::Descending)});
+    auto s8 = schema({field("a", uint8()), field("b", uint32())});
+    auto sf = schema({field("a", float32()), field("b", float64())});
+    auto sorted = [&](const Datum& in, const SortOptions& o) { auto r = SortIndices(in, o, ctx); CHECK_OK(r.status()); return r.ok() ? HostU64(pool, *r->array()) : std::vector<uint64_t>{}; };
+    auto b1 = RecordBatch::Make(s8, 7, {Dev<U8>(pool, uint8(), {V(U8, 3), V(U8, 1), V(U8, 3), V(U8, 0), V(U8, 2), V(U8, 1), V(U8, 1)}),
+                                        Dev<U32>(pool, uint32(), {V(U32, 5), V(U32, 3), V(U32, 4), V(U32, 6), V(U32, 5), V(U32, 5), V(U32, 3)})});
+    CHECK((sorted(Datum(b1), ad) == std::vector<uint64_t>{3, 5, 1, 6, 4, 0, 2}));  // NoNull :763-781
+    auto b2 = RecordBatch::Make(s8, 6, {Dev<U8>(pool, uint8(), {N(U8), V(U8, 1), V(U8, 3), N(U8), V(U8, 2), V(U8, 1)}),
+                                        Dev<U32>(pool, uint32(), {V(U32, 5), V(U32, 3), N(U32), N(U32), V(U32, 5), V(U32, 5)})});
+    CHECK((sorted(Datum(b2), ad) == std::vector<uint64_t>{5, 1, 4, 2, 0, 3}));  // Null :783-800
+    auto t2 = Table::Make(s8, {chunked({Dev<U8>(pool, uint8(), {N(U8), V(U8, 1), V(U8, 3)}), Dev<U8>(pool, uint8(), {N(U8), V(U8, 2), V(U8, 1)})}, uint8()),
+                               chunked({Dev<U32>(pool, uint32(), {V(U32, 5), V(U32, 3), N(U32)}), Dev<U32>(pool, uint32(), {N(U32), V(U32, 5), V(U32, 5)})}, uint32())});
+    CHECK((sorted(Datum(t2), ad) == std::vector<uint64_t>{5, 1, 4, 2, 0, 3}));  // table, two chunks :904-914
+    auto b3 = RecordBatch::Make(sf, 8, {Dev<F>(pool, float32(), {V(F, 3), V(F, 1), V(F, 3), V(F, 0), V(F, nanf), V(F, nanf), V(F, nanf), V(F, 1)}),
+                                        Dev<D>(pool, float64(), {V(D, 5), V(D, nan), V(D, 4), V(D, 6), V(D, 5), V(D, nan), V(D, 5), V(D, 5)})});
+    CHECK((sorted(Datum(b3), ad) == std::vector<uint64_t>{3, 7, 1, 0, 2, 4, 6, 5}));  // NaN :802-821
+    auto t4 = Table::Make(sf, {chunked({Dev<F>(pool, float32(), {N(F), V(F, 1), V(F, 3), N(F)}), Dev<F>(pool, float32(), {V(F, nanf), V(F, nanf), V(F, nanf), V(F, 1)})}, float32()),
+                               chunked({Dev<D>(pool, float64(), {V(D, 5), V(D, 3), N(D), N(D)}), Dev<D>(pool, float64(), {N(D), V(D, nan), V(D, 5), V(D, 5)})}, float64())});
+    CHECK((sorted(Datum(t4), ad) == std::vector<uint64_t>{7, 1, 2, 6, 5, 4, 0, 3}));  // NaNAndNull, two chunks :967-980
+    // one key: delegates to the array / chunked-array sorters (:1638-1645, :1676-1683)
+    CHECK((sorted(Datum(b1), SortOptions({SortKey("b", SortOrder::Descending)})) == std::vector<uint64_t>{3, 0, 4, 5, 2, 1, 6}));
+    CHECK((sorted(Datum(t2), SortOptions({SortKey("a", SortOrder::Ascending)})) == std::vector<uint64_t>{1, 5, 4, 2, 0, 3}));
+    CHECK(SortIndices(Datum(b1), SortOptions(), ctx).status().IsInvalid());                                      // :1634-1636
+    CHECK(SortIndices(Datum(b1), SortOptions({SortKey("nope")}), ctx).status().IsInvalid());                     // :1639-1642
+    CHECK(SortIndices(Datum(t2), SortOptions({SortKey("a"), SortKey("zz")}), ctx).status().IsInvalid());
+    CHECK(SortIndices(Datum(t2), SortOptions({SortKey("a"), SortKey("zz")}), ctx).status().message() == "Nonexistent sort key column: zz");
+  }
+}
+
 static int RunGpu() {
   auto pool_r = MemoryPool::Make(0);
   if (!pool_r.ok()) { fprintf(stderr, "no device: %s\n", pool_r.status().ToString().c_str()); return 2; }
@@ -586,6 +763,7 @@ static int RunGpu() {
       }
     }
   }
+  TabularTests(pool, &ctx);
   CHECK(pool->bytes_allocated() >= 0 && pool->max_memory() > 0);  // the MemoryPool counters (memory_pool.h:38-105)
   printf("host_test gpu: %d checks, %d failures\n", g_checks, g_failures);
   return g_failures ? 1 : 0;

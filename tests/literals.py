@@ -11,7 +11,7 @@ from orc import Arr, BOOL, NUMERIC, INTS, FLOAT, DOUBLE, DROP, EMIT_NULL, ASC, D
 PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_literals.json")
 TYPE_GROUPS = {"numeric": NUMERIC, "integral": INTS, "real": [FLOAT, DOUBLE], "boolean": [BOOL],
                "int8": [orc.INT8], "uint8": [orc.UINT8], "float": [FLOAT], "double": [DOUBLE],
-               "int64": [orc.INT64], "int32": [orc.INT32]}
+               "int64": [orc.INT64], "int32": [orc.INT32], "uint32": [orc.UINT32]}
 CMP = {"equal": orc.EQ, "not_equal": orc.NE, "greater": orc.GT, "greater_equal": orc.GE, "less": orc.LT,
        "less_equal": orc.LE}
 BOOL_OPS = {"invert": orc.INVERT, "and": orc.AND, "and_not": orc.AND_NOT, "or": orc.OR, "xor": orc.XOR,
@@ -139,6 +139,12 @@ def run_all(api, skip_grouper_multi_batch=False):
             got = api.sort_indices(chunks, order)
             if got.tolist() != c[key]:
                 fails.append("%s %s: got %s" % (c["source"], key, got.tolist()))
+    for c in lit["sort_indices_multi"]:
+        ts = [TYPE_GROUPS[t][0] for t in c["types"]]
+        keys = [[arr(t, ch) for ch in col] for t, col in zip(ts, c["columns"])]
+        got = api.sort_indices_multi(keys, [ASC if o == "ascending" else DESC for o in c["orders"]])
+        if got.tolist() != c["indices"]:
+            fails.append("%s: got %s" % (c["source"], got.tolist()))
     for grp in lit["grouper"]:
         for t in TYPE_GROUPS[grp["types"]]:
             batches = [[arr(t, b["keys"])] for b in grp["batches"]]
