@@ -10,6 +10,7 @@ BOOL, UINT8, INT8, UINT16, INT16, UINT32, INT32, UINT64, INT64, FLOAT, DOUBLE = 
 DROP, EMIT_NULL = 0, 1
 ASCENDING, DESCENDING = 0, 1
 COUNT_NON_NULL, COUNT_NULL = 0, 1
+MINMAX_SKIP, MINMAX_EMIT_NULL = 0, 1
 EQ, NE, GT, GE, LT, LE = range(6)
 ADD, SUB, MUL, DIV, ADD_CHECKED, SUB_CHECKED, MUL_CHECKED, DIV_CHECKED = range(8)
 HASH_SUM, HASH_COUNT, HASH_MEAN = 0, 1, 2
@@ -74,6 +75,9 @@ SYMBOLS = {
     "amdarrow_grouper_num_groups": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "amdarrow_grouper_uniques": (C.c_int, [_P, C.c_int, _P, _P, _O]),
     "amdarrow_hash_aggregate": (C.c_int, [_P, C.c_int, _A, _P, C.c_int64, C.c_int, _P, _P, _O]),
+    "amdarrow_hash_minmax_init": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int64]),
+    "amdarrow_hash_minmax_accumulate": (C.c_int, [_P, _A, _P, _P, _P, _P, _P]),
+    "amdarrow_hash_minmax_finalize": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, _P, _O]),
     "amdarrow_hash_accumulate": (C.c_int, [_P, C.c_int, _A, _P, C.c_int, _P, _P]),
     "amdarrow_hash_finalize": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, _P, _P, _O]),
     "amdarrow_filter_groupby": (C.c_int, [_P, _A, _A, _A, C.c_int64, _P, _P, _P, _P, _P, C.POINTER(C.c_int64)]),

@@ -246,6 +246,49 @@ def hash_aggregate(ctx, func, values, ids, num_groups, count_mode=0):
     return DeviceArray(ot, out_v, out_b if out.has_validity else None, out.length, 0, out.null_count)
 
 
+class HashMinMax:
+    """hash_min_max's kernel state (GroupedMinMaxImpl, hash_aggregate.cc:627-768): resize / consume /
+    finalize over any number of batches."""
+
+    def __init__(self, ctx, value_type, device="cuda", null_handling=_abi.MINMAX_SKIP):
+        self.ctx, self.t, self.dev, self.mode = ctx, value_type, device, null_handling
+        self.num_groups, self.cap = 0, 0
+        self.mins = self.maxes = self.has_values = self.has_nulls = None
+
+    def _reserve(self, new_groups):  # MaybeReserve (:450-459) + the resize lambdas (:713-721)
+        if new_groups > self.cap:
+            cap = max(1024, 2 * new_groups)
+            w = _values_bytes(self.t, 1)
+            bufs = [alloc_bytes(cap * w, self.dev), alloc_bytes(cap * w, self.dev),
+                    alloc_bytes((cap + 63) // 64 * 8, self.dev, zero=True), alloc_bytes((cap + 63) // 64 * 8, self.dev, zero=True)]
+            for new, old in zip(bufs, (self.mins, self.maxes, self.has_values, self.has_nulls)):
+                if old is not None:
+                    new[:old.numel()] = old
+            self.mins, self.maxes, self.has_values, self.has_nulls = bufs
+            self.cap = cap
+        if new_groups > self.num_groups:
+            check(self.ctx.lib, self.ctx.lib.amdarrow_hash_minmax_init(self.ctx.handle, self.t, _ptr(self.mins), _ptr(self.maxes),
+                                                                       self.num_groups, new_groups - self.num_groups))
+            self.num_groups = new_groups
+
+    def consume(self, values, ids, num_groups):
+        self._reserve(num_groups)
+        cv = values.c()
+        check(self.ctx.lib, self.ctx.lib.amdarrow_hash_minmax_accumulate(self.ctx.handle, C.byref(cv), _ptr(ids), _ptr(self.mins),
+                                                                         _ptr(self.maxes), _ptr(self.has_values),
+                                                                         _ptr(self.has_nulls)))
+
+    def finalize(self):
+        """-> (mins, maxes): the two children of the reference's struct, one shared validity"""
+        n = self.num_groups
+        out_b = alloc_bytes((n + 63) // 64 * 8, self.dev, zero=True)
+        out = COut()
+        check(self.ctx.lib, self.ctx.lib.amdarrow_hash_minmax_finalize(self.ctx.handle, n, self.mode, _ptr(self.has_values),
+                                                                       _ptr(self.has_nulls), _ptr(out_b), C.byref(out)))
+        return (DeviceArray(self.t, self.mins, out_b, n, 0, out.null_count),
+                DeviceArray(self.t, self.maxes, out_b, n, 0, out.null_count))
+
+
 class Grouper:
     """internal::Grouper (api_aggregate.h:313-403): Consume(keys) -> uint32 ids in first-appearance order."""
 

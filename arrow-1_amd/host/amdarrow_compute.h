@@ -172,6 +172,9 @@ struct ArrayData {
   int64_t null_count = 0;
   int64_t offset = 0;
   std::vector<std::shared_ptr<Buffer>> buffers;  // [0] validity (may be null), [1] values
+  // StructArray children (array/data.h:232): only hash_min_max's {min, max} output has any
+  std::vector<std::shared_ptr<ArrayData>> child_data;
+  std::vector<std::string> child_names;
 
   static std::shared_ptr<ArrayData> Make(std::shared_ptr<DataType> type, int64_t length,
                                          std::vector<std::shared_ptr<Buffer>> buffers, int64_t null_count = kUnknownNullCount,
@@ -655,7 +658,7 @@ void RegisterScalarBoolean(FunctionRegistry* registry);    // invert, and, and_n
 void RegisterScalarValidity(FunctionRegistry* registry);   // is_valid, is_null, is_nan
 void RegisterScalarFillNull(FunctionRegistry* registry);   // fill_null
 void RegisterScalarAggregateBasic(FunctionRegistry* registry);  // count, sum, mean, min_max
-void RegisterHashAggregateBasic(FunctionRegistry* registry);  // hash_count, hash_sum, hash_mean
+void RegisterHashAggregateBasic(FunctionRegistry* registry);  // hash_count, hash_sum, hash_mean, hash_min_max
 
 // Grouper / GroupBy (api_aggregate.h:313-403)
 class Grouper {

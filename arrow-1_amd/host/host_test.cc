@@ -130,7 +130,7 @@ static int RunCpu() {
     FunctionRegistry* dev = GetFunctionRegistry();
     for (const char* n : {"filter", "array_filter", "take", "array_take", "sort_indices", "array_sort_indices", "equal", "not_equal",
                           "greater", "greater_equal", "less", "less_equal", "add", "subtract", "multiply", "divide", "add_checked",
-                          "subtract_checked", "multiply_checked", "divide_checked", "hash_sum", "hash_count", "hash_mean",
+                          "subtract_checked", "multiply_checked", "divide_checked", "hash_sum", "hash_count", "hash_mean", "hash_min_max",
                           "invert", "and", "and_not", "or", "xor", "and_kleene", "and_not_kleene", "or_kleene", "is_valid",
                           "is_null", "is_nan", "fill_null", "count", "sum", "mean", "min_max"})
       CHECK(dev->GetFunction(n).ok());
@@ -570,6 +570,31 @@ static int RunGpu() {
       CHECK(Same(Host<double>(pool, *r2->columns[0]), {V(double, 4.25), V(double, -0.125), N(double), V(double, 4.75)}));
       CHECK(Same(Host<int64_t>(pool, *r2->columns[1]), {V(int64_t, 1), V(int64_t, 2), V(int64_t, 3), N(int64_t)}));
     }
+    // GroupBy.MinMaxOnly (hash_aggregate_test.cc:516-553): struct{min, max}, null for a group without values;
+    // also over three batches, and with EMIT_NULL (a null in the group nulls it)
+    for (int pass = 0; pass < 3; ++pass) {
+      MinMaxOptions emit(MinMaxOptions::EMIT_NULL);
+      if (pass == 1) ctx.set_exec_chunksize(4);
+      auto mm = internal::GroupBy({Datum(argument)}, {Datum(key)}, {{"hash_min_max", pass == 2 ? &emit : nullptr}}, &ctx);
+      ctx.set_exec_chunksize(kDefaultExecChunksize);
+      CHECK_OK(mm.status());
+      if (!mm.ok()) continue;
+      CHECK(mm->length == 4 && mm->field_names == std::vector<std::string>({"hash_min_max", "key_0"}));
+      const ArrayData& st = *mm->columns[0];
+      CHECK(st.type->id() == Type::STRUCT && st.child_data.size() == 2 && st.child_names == std::vector<std::string>({"min", "max"}));
+      if (st.child_data.size() != 2) continue;
+      if (pass < 2) {
+        CHECK(Same(Host<double>(pool, *st.child_data[0]), {V(double, 1.0), V(double, -0.25), N(double), V(double, 0.75)}));
+        CHECK(Same(Host<double>(pool, *st.child_data[1]), {V(double, 3.25), V(double, 0.125), N(double), V(double, 4.0)}));
+      } else {  // group 1 holds a null argument
+        CHECK(Same(Host<double>(pool, *st.child_data[0]), {N(double), V(double, -0.25), N(double), V(double, 0.75)}));
+        CHECK(Same(Host<double>(pool, *st.child_data[1]), {N(double), V(double, 0.125), N(double), V(double, 4.0)}));
+      }
+      CHECK(st.child_data[0]->buffers[0] == st.child_data[1]->buffers[0]);  // one shared bitmap (:741-742)
+      CHECK(Same(Host<int64_t>(pool, *mm->columns[1]), {V(int64_t, 1), V(int64_t, 2), V(int64_t, 3), N(int64_t)}));
+    }
+    CHECK(internal::GroupBy({Datum(DevBool(pool, {1, 0}))}, {Datum(Dev<int64_t>(pool, int64(), {V(int64_t, 1), V(int64_t, 2)}))},
+                            {{"hash_min_max", nullptr}}, &ctx).status().IsNotImplemented());  // :674-676
     auto bad = internal::GroupBy({Datum(argument)}, {Datum(key)}, {{"hash_sum", nullptr}, {"hash_count", nullptr}}, &ctx);
     CHECK(bad.status().IsInvalid());  // aggregates.size() != arguments.size() (:811-815)
     CHECK(CallFunction("hash_sum", {Datum(argument), Datum(key), Datum(key)}, &ctx).status().IsNotImplemented());

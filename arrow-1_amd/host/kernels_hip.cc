@@ -628,6 +628,86 @@ HashAggregateKernel MakeHashKernel(int func) {  // MakeKernel :770-807
   return k;
 }
 
+// hash_min_max: GroupedMinMaxImpl (hash_aggregate.cc:627-768).  State = the reference's four builders
+// on the device; the output is the StructArray{min, max} whose children share one validity bitmap.
+struct GroupedMinMaxState : KernelState {
+  int null_handling = AMDARROW_MINMAX_SKIP;
+  std::shared_ptr<DataType> in_type;
+  std::shared_ptr<Buffer> mins, maxes, has_values, has_nulls;
+  int64_t num_groups = 0, capacity = 0;
+};
+Status ReserveMinMax(KernelContext* ctx, GroupedMinMaxState* st, int64_t new_groups) {  // MaybeReserve + resize lambdas :713-721
+  if (new_groups <= st->num_groups) return Status::OK();
+  const int w = st->in_type->bit_width() / 8;
+  if (new_groups > st->capacity) {
+    const int64_t cap = std::max<int64_t>(1024, 2 * new_groups);
+    AMD_ASSIGN_OR_RAISE(auto mn, ctx->Allocate(cap * w));
+    AMD_ASSIGN_OR_RAISE(auto mx, ctx->Allocate(cap * w));
+    AMD_ASSIGN_OR_RAISE(auto hv, ctx->AllocateBitmap(cap));
+    AMD_ASSIGN_OR_RAISE(auto hn, ctx->AllocateBitmap(cap));
+    if (st->num_groups > 0) {
+      int rc = amdarrow_memcpy_d2d(ctx->abi(), mn->mutable_data(), st->mins->data(), st->num_groups * w);
+      if (rc == AMDARROW_OK) rc = amdarrow_memcpy_d2d(ctx->abi(), mx->mutable_data(), st->maxes->data(), st->num_groups * w);
+      if (rc == AMDARROW_OK) rc = amdarrow_memcpy_d2d(ctx->abi(), hv->mutable_data(), st->has_values->data(), (st->num_groups + 7) / 8);
+      if (rc == AMDARROW_OK) rc = amdarrow_memcpy_d2d(ctx->abi(), hn->mutable_data(), st->has_nulls->data(), (st->num_groups + 7) / 8);
+      if (rc == AMDARROW_OK) rc = amdarrow_ctx_synchronize(ctx->abi());  // the old buffers are released below
+      if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+    }
+    st->mins = mn; st->maxes = mx; st->has_values = hv; st->has_nulls = hn; st->capacity = cap;
+  }
+  const int rc = amdarrow_hash_minmax_init(ctx->abi(), static_cast<int>(st->in_type->id()), st->mins->mutable_data(),
+                                           st->maxes->mutable_data(), st->num_groups, new_groups - st->num_groups);
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  st->num_groups = new_groups;
+  return Status::OK();
+}
+HashAggregateKernel MakeHashMinMaxKernel() {
+  HashAggregateKernel k;
+  k.signature.in_types = {InputType::Primitive(), InputType::Exact(Type::UINT32, ValueDescr::ARRAY),
+                          InputType::Exact(Type::UINT32, ValueDescr::SCALAR)};
+  k.signature.out_type = FixedOut(struct_());  // struct_({field("min", type), field("max", type)}) :750-752
+  k.init = [](KernelContext*, const std::shared_ptr<DataType>& in, const FunctionOptions* opts) -> Result<std::unique_ptr<KernelState>> {
+    if (in->bit_width() < 8 || in->id() == Type::HALF_FLOAT)
+      return Status::NotImplemented("Grouped MinMax data of type " + in->ToString());  // :674-684
+    auto st = std::unique_ptr<GroupedMinMaxState>(new GroupedMinMaxState());
+    st->in_type = in;
+    if (opts) st->null_handling = static_cast<const MinMaxOptions*>(opts)->null_handling == MinMaxOptions::EMIT_NULL
+                                      ? AMDARROW_MINMAX_EMIT_NULL : AMDARROW_MINMAX_SKIP;
+    return std::unique_ptr<KernelState>(std::move(st));
+  };
+  k.consume = [](KernelContext* ctx, KernelState* state, const ExecBatch& batch) -> Status {
+    auto* st = static_cast<GroupedMinMaxState*>(state);
+    uint32_t ng;
+    memcpy(&ng, &batch[2].scalar()->bits, 4);
+    AMD_RETURN_NOT_OK(ReserveMinMax(ctx, st, ng));
+    amdarrow_array v = batch[0].array()->abi();
+    const ArrayData& ids = *batch[1].array();
+    return Status::FromAbi(amdarrow_hash_minmax_accumulate(ctx->abi(), &v, reinterpret_cast<const uint32_t*>(ids.buffers[1]->data()) + ids.offset,
+                                                           st->mins->mutable_data(), st->maxes->mutable_data(),
+                                                           st->has_values->mutable_data(), st->has_nulls->mutable_data()));
+  };
+  k.merge = [](KernelContext*, KernelState&&, KernelState*) -> Status { return Status::NotImplemented("Merge hashed aggregations"); };
+  k.finalize = [](KernelContext* ctx, KernelState* state, Datum* out) -> Status {  // :729-748
+    auto* st = static_cast<GroupedMinMaxState*>(state);
+    auto result = ArrayData::Make(struct_(), st->num_groups, {nullptr, nullptr}, 0);
+    result->child_names = {"min", "max"};
+    std::shared_ptr<Buffer> nbuf;
+    amdarrow_out o;
+    o.length = 0; o.null_count = 0; o.has_validity = 1;
+    if (st->num_groups > 0) {
+      AMD_ASSIGN_OR_RAISE(nbuf, ctx->AllocateBitmap(st->num_groups));
+      const int rc = amdarrow_hash_minmax_finalize(ctx->abi(), st->num_groups, st->null_handling, st->has_values->data(),
+                                                   st->has_nulls->data(), nbuf->mutable_data(), &o);
+      if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+    }
+    result->child_data = {ArrayData::Make(st->in_type, st->num_groups, {nbuf, st->mins}, o.null_count),
+                          ArrayData::Make(st->in_type, st->num_groups, {nbuf, st->maxes}, o.null_count)};
+    *out = Datum(result);
+    return Status::OK();
+  };
+  return k;
+}
+
 template <typename Fn>
 void AddBinaryFunctions(FunctionRegistry* registry, const char* const* names, int n, bool compare, Fn make_exec) {
   for (int op = 0; op < n; ++op) {
@@ -839,6 +919,10 @@ void RegisterHashAggregateBasic(FunctionRegistry* registry) {
     (void)f->AddKernel(MakeHashKernel(d.func));
     (void)registry->AddFunction(std::move(f));
   }
+  static MinMaxOptions minmax_defaults = MinMaxOptions::Defaults();  // :1052-1057
+  auto f = std::make_shared<HashAggregateFunction>("hash_min_max", Arity::Ternary(), FunctionDoc{}, &minmax_defaults);
+  (void)f->AddKernel(MakeHashMinMaxKernel());
+  (void)registry->AddFunction(std::move(f));
 }
 
 // ---- Grouper (api_aggregate.h:313-340, hash_aggregate.cc:313-437) ---------------------------------------

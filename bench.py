@@ -46,6 +46,7 @@ WORKLOADS = {
     "take_random_i64": "Take int64 + validity by uint32 indices (uniform random, M = s*N of them)",
     "sort_u64": "sort_indices uint64 full range",
     "sort_f64": "sort_indices float64 U[0,1) + 0.1% NaN + 1% null",
+    "sort_2key": "sort_indices of a batch by (int32 key over --groups values ascending, int64 + validity descending)",
     "hash_agg_f64": "GroupBy sum/count over float64 (p_null .01), 1M int32 keys",
     "compare_i64": "greater(int64 array, int64 array)",
     "agg_f64": "count + sum + min_max of float64 + validity (one pass feeds the four scalar aggregates)",
@@ -95,6 +96,12 @@ def make_inputs(workload, n, dev, rank, sel):
         vals[torch.rand(n, device=dev, generator=gen) < 0.001] = float("nan")
         d["values"] = device.DeviceArray(_abi.DOUBLE, vals.view(torch.uint8), device_bitmap(n, 0.99, gen, dev), n, 0, -1)
         d["_keep"] = (vals,)
+    elif workload == "sort_2key":
+        vals = torch.randint(-2**62, 2**62, (n,), dtype=torch.int64, device=dev, generator=gen)
+        keys = torch.randint(0, NUM_GROUPS, (n,), dtype=torch.int32, device=dev, generator=gen)
+        d["values"] = device.DeviceArray(_abi.INT64, vals.view(torch.uint8), device_bitmap(n, 0.99, gen, dev), n, 0, -1)
+        d["keys"] = device.DeviceArray(_abi.INT32, keys.view(torch.uint8), None, n)
+        d["_keep"] = (vals, keys)
     elif workload == "hash_agg_f64":
         vals = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 1e3
         keys = torch.randint(0, NUM_GROUPS, (n,), dtype=torch.int32, device=dev, generator=gen)
@@ -122,6 +129,7 @@ def make_inputs(workload, n, dev, rank, sel):
 def bytes_per_row(workload, sel):
     return {"filter_groupby_sum_i64": 12.125, "filter_i64": 8.25 + 8.125 * sel, "take_i64": 20.25 * sel,
             "take_random_i64": 20.25 * sel, "sort_u64": 16.0, "sort_f64": 16.0, "hash_agg_f64": 12.125, "compare_i64": 16.25,
+            "sort_2key": 20.125,  # both key columns + validity in, uint64 indices out
             "mask_and_kleene": 0.75, "agg_f64": 8.125}[workload]  # 2 x (data + validity) bits in, data + validity bits out
 
 
@@ -159,6 +167,8 @@ def make_step(workload, ctx, inp, sel, world, rank):
             per = (chunks.length + NUM_CHUNKS - 1) // NUM_CHUNKS
             chunks = [chunks.slice(i * per, min(per, chunks.length - i * per)) for i in range(NUM_CHUNKS)]
         return lambda: compute.sort_indices(ctx, chunks)
+    if workload == "sort_2key":
+        return lambda: compute.sort_indices_multi(ctx, [inp["keys"], inp["values"]], [_abi.ASCENDING, _abi.DESCENDING])
     if workload == "compare_i64":
         return lambda: compute.compare(ctx, _abi.GT, inp["a"], inp["b"])
     if workload == "agg_f64":
@@ -177,7 +187,7 @@ def cpu_baseline(workload, sel):
     kind = "reference" if orc.have_ref() else "port"
     api = orc.Api("ref" if kind == "reference" else "orc")
     rng = np.random.default_rng(SEED)
-    n = {"sort_u64": 2_000_000, "sort_f64": 2_000_000}.get(workload, 8_000_000)
+    n = {"sort_u64": 2_000_000, "sort_f64": 2_000_000, "sort_2key": 2_000_000}.get(workload, 8_000_000)
 
     def nullable(type_id, data, p_null):
         return orc.Arr(type_id, data, rng.random(len(data)) >= p_null)
@@ -218,6 +228,11 @@ def cpu_baseline(workload, sel):
         vals = nullable(orc.DOUBLE, data, 0.01)
         call = lambda: api.sort_indices([vals])  # noqa: E731
         what = "sort_indices float64 (0.1% NaN, 1% null)"
+    elif workload == "sort_2key":
+        vals = nullable(orc.INT64, rng.integers(-2**62, 2**62, n), 0.01)
+        keys = orc.Arr(orc.INT32, rng.integers(0, NUM_GROUPS, n))
+        call = lambda: api.sort_indices_multi([keys, vals], [orc.ASC, orc.DESC])  # noqa: E731
+        what = "sort_indices(RecordBatch, {int32 asc, int64 desc}) -- RadixRecordBatchSorter"
     elif workload == "agg_f64":
         vals = nullable(orc.DOUBLE, rng.random(n) * 1e3, 0.01)
         call = lambda: api.aggregate(vals)  # noqa: E731
@@ -340,7 +355,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"filter_groupby_sum_i64": "int64", "filter_i64": "u64", "take_i64": "u64",
                                             "take_random_i64": "u64", "sort_u64": "u64", "sort_f64": "f64", "hash_agg_f64": "f64",
-                                            "compare_i64": "int64", "mask_and_kleene": "u64", "agg_f64": "f64"}[args.workload],
+                                            "compare_i64": "int64", "mask_and_kleene": "u64", "agg_f64": "f64", "sort_2key": "u64"}[args.workload],
             "data": "synthetic (device-generated, seed 0x0ff1ce + rank; HBM-resident before timing)",
             "config": {"workload": args.workload + ": " + WORKLOADS[args.workload], "rows_per_gpu": n,
                        "selectivity": sel, "groups": NUM_GROUPS, "sharding": "row-range, %d shard(s)" % world},

@@ -193,6 +193,28 @@ int amdarrow_hash_aggregate(amdarrow_ctx* ctx, int func, const amdarrow_array* v
                             const uint32_t* ids, int64_t num_groups, int count_mode,
                             void* out_values, uint8_t* out_validity, amdarrow_out* out);
 
+/* hash_min_max -- GroupedMinMaxImpl, hash_aggregate.cc:627-768, as the reference's init / resize /
+ * consume / finalize (kernel.h:681-721).  The caller owns the state of the reference's four
+ * builders (:704-707): mins / maxes (one element of the VALUE type per group) and the has_values /
+ * has_nulls bitmaps (zero-filled, sized in whole 8-byte words).
+ *   init        groups [first, first+count) get the anti-extremes (mins = max of the type / +inf,
+ *               maxes = min of the type / -inf, :629-642, :653-661) -- call when groups are added;
+ *   accumulate  one batch: a valid value updates mins[id], maxes[id] and has_values; a null marks
+ *               has_nulls (:652-672).  NaN never replaces an extreme (std::min / std::max);
+ *   finalize    validity of BOTH children: has_values, under AMDARROW_MINMAX_EMIT_NULL and not
+ *               has_nulls (:729-740); mins / maxes are the output buffers as they stand.
+ * Integers are bit-exact; float extremes are equal as values (the sign of a zero extreme follows
+ * row order in the reference and scheduling here).  BOOL / HALF_FLOAT: NotImplemented (:674-684). */
+enum { AMDARROW_MINMAX_SKIP = 0, AMDARROW_MINMAX_EMIT_NULL = 1 }; /* MinMaxOptions::Mode, api_aggregate.h:78-90 */
+int amdarrow_hash_minmax_init(amdarrow_ctx* ctx, int value_type_id, void* mins, void* maxes,
+                              int64_t first, int64_t count);
+int amdarrow_hash_minmax_accumulate(amdarrow_ctx* ctx, const amdarrow_array* values,
+                                    const uint32_t* ids, void* mins, void* maxes,
+                                    uint8_t* has_values, uint8_t* has_nulls);
+int amdarrow_hash_minmax_finalize(amdarrow_ctx* ctx, int64_t num_groups, int null_handling,
+                                  const uint8_t* has_values, const uint8_t* has_nulls,
+                                  uint8_t* out_validity, amdarrow_out* out);
+
 /* The same kernel split as the reference's HashAggregateKernel consume / finalize pair
  * (compute/kernel.h:681-721) for multi-batch GroupBy: accumulate adds one batch into caller-owned
  * device state -- sums (num_groups x 8 bytes) and counts (num_groups x int64), zeroed by the caller

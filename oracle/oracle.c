@@ -287,6 +287,50 @@ int orc_sort_indices(const orc_array* chunks, int nchunks, int order, uint64_t* 
   return ORC_OK;
 }
 
+/* ---- c4: GroupedMinMaxImpl, hash_aggregate.cc:627-768 -------------------------------- */
+#define MINMAX_CASE(ID, T, LO, HI)                                                          \
+  case ID: {                                                                                \
+    T* mn = (T*)out_mins; T* mx = (T*)out_maxes; const T* v = (const T*)values->values;     \
+    for (int64_t g = 0; g < num_groups; ++g) { mn[g] = HI; mx[g] = LO; } /* anti-extremes :653-661 */ \
+    for (int64_t i = 0; i < values->length; ++i) {                                          \
+      const uint32_t g = ids[i];                                                            \
+      if (!slot_valid(values, i)) { set_bit(has_nulls, g); continue; }                      \
+      const T x = v[values->offset + i];                                                    \
+      mx[g] = (mx[g] < x) ? x : mx[g]; /* std::max(a, b) = (a < b) ? b : a  (:667) */       \
+      mn[g] = (x < mn[g]) ? x : mn[g]; /* std::min(a, b) = (b < a) ? b : a  (:668) */       \
+      set_bit(has_values, g);                                                               \
+    }                                                                                       \
+  } break;
+int orc_hash_min_max(const orc_array* values, const uint32_t* ids, int64_t num_groups, int null_handling,
+                     void* out_mins, void* out_maxes, uint8_t* out_validity, orc_out* out) {
+  const size_t nb = (size_t)((num_groups + 7) / 8) + 1;
+  uint8_t* has_values = (uint8_t*)calloc(nb, 1);
+  uint8_t* has_nulls = (uint8_t*)calloc(nb, 1);
+  switch (values->type_id) {
+    MINMAX_CASE(ORC_UINT8, uint8_t, 0, UINT8_MAX)
+    MINMAX_CASE(ORC_INT8, int8_t, INT8_MIN, INT8_MAX)
+    MINMAX_CASE(ORC_UINT16, uint16_t, 0, UINT16_MAX)
+    MINMAX_CASE(ORC_INT16, int16_t, INT16_MIN, INT16_MAX)
+    MINMAX_CASE(ORC_UINT32, uint32_t, 0, UINT32_MAX)
+    MINMAX_CASE(ORC_INT32, int32_t, INT32_MIN, INT32_MAX)
+    MINMAX_CASE(ORC_UINT64, uint64_t, 0, UINT64_MAX)
+    MINMAX_CASE(ORC_INT64, int64_t, INT64_MIN, INT64_MAX)
+    MINMAX_CASE(ORC_FLOAT, float, -INFINITY, INFINITY)
+    MINMAX_CASE(ORC_DOUBLE, double, -INFINITY, INFINITY)
+    default:
+      free(has_values); free(has_nulls);
+      return fail(ORC_NOT_IMPLEMENTED, "Grouped MinMax data of this type"); /* :674-684 */
+  }
+  out->length = num_groups; out->null_count = 0; out->has_validity = 1;
+  memset(out_validity, 0, (size_t)((num_groups + 7) / 8));
+  for (int64_t g = 0; g < num_groups; ++g) { /* Finalize :729-740 */
+    const int ok = get_bit(has_values, g) && !(null_handling == 1 && get_bit(has_nulls, g));
+    if (ok) set_bit(out_validity, g); else ++out->null_count;
+  }
+  free(has_values); free(has_nulls);
+  return ORC_OK;
+}
+
 /* ---- b5: multi-key sort_indices, vector_sort.cc:955-1549 ---------------------------- */
 /* One resolved sort key (ResolvedSortKey :1187-1205 / :1384-1420): its chunks, the logical
  * row at which each starts (ChunkedArrayResolver :95-160) and its order. */

@@ -143,6 +143,12 @@ int orc_hash_aggregate(int func, const orc_array* values, const uint32_t* ids,
                        int64_t num_groups, int count_mode, void* out_values,
                        uint8_t* out_validity, orc_out* out);
 
+/* c4: hash_min_max -- GroupedMinMaxImpl, hash_aggregate.cc:627-768, one batch.  out_mins /
+ * out_maxes: num_groups elements of the value type (anti-extremes where a group saw no value,
+ * :629-642); out_validity: has_values, and under null_handling 1 (EMIT_NULL) also no null (:729-740). */
+int orc_hash_min_max(const orc_array* values, const uint32_t* ids, int64_t num_groups, int null_handling,
+                     void* out_mins, void* out_maxes, uint8_t* out_validity, orc_out* out);
+
 /* d1/d2: compare kernels, scalar_compare.cc:31-57,100-159; boolean output packed
  * LSB-first with trailing bits zero (bitmap_generate.h:62-108).  Operand i is an array
  * (lhs / rhs non-NULL) or a valid scalar (lhs_scalar / rhs_scalar -> one value of the

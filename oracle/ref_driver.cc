@@ -330,6 +330,40 @@ int ref_hash_aggregate(int func, const orc_array* values, const uint32_t* ids,
   return 0;
 }
 
+// hash_min_max through the reference's HashAggregateKernel (hash_aggregate.cc:627-768): the struct's
+// two children come back as out_mins / out_maxes, their shared bitmap as out_validity.
+int ref_hash_min_max(const orc_array* values, const uint32_t* ids, int64_t num_groups, int null_handling,
+                     void* out_mins, void* out_maxes, uint8_t* out_validity, orc_out* out) {
+  auto fres = Ctx()->func_registry()->GetFunction("hash_min_max");
+  if (!fres.ok()) return Fail(fres.status());
+  auto vals = Wrap(values);
+  auto kres = (*fres)->DispatchExact(
+      {ValueDescr::Array(vals->type), ValueDescr::Array(uint32()), ValueDescr::Scalar(uint32())});
+  if (!kres.ok()) return Fail(kres.status());
+  auto kernel = static_cast<const HashAggregateKernel*>(*kres);
+  MinMaxOptions opts(static_cast<MinMaxOptions::Mode>(null_handling));
+  KernelContext kctx(Ctx());
+  auto sres = kernel->init(&kctx, KernelInitArgs{kernel, {vals->type, uint32(), uint32()}, &opts});
+  if (!sres.ok()) return Fail(sres.status());
+  std::unique_ptr<KernelState> state = std::move(*sres);
+  kctx.SetState(state.get());
+  auto idbuf = std::make_shared<Buffer>(reinterpret_cast<const uint8_t*>(ids), values->length * 4);
+  auto id_arr = ArrayData::Make(uint32(), values->length, {nullptr, idbuf}, 0);
+  auto batch = ExecBatch::Make({Datum(vals), Datum(id_arr), Datum(static_cast<uint32_t>(num_groups))});
+  if (!batch.ok()) return Fail(batch.status());
+  Status st = kernel->consume(&kctx, *batch);
+  if (!st.ok()) return Fail(st);
+  Datum result;
+  st = kernel->finalize(&kctx, &result);
+  if (!st.ok()) return Fail(st);
+  const ArrayData& s = *result.array();
+  orc_out ignored;
+  Export(*s.child_data[0], out_mins, out_validity, out);
+  Export(*s.child_data[1], out_maxes, nullptr, &ignored);
+  out->null_count = num_groups - arrow::internal::CountSetBits(out_validity, 0, num_groups);
+  return 0;
+}
+
 static const char* kCmpNames[] = {"equal", "not_equal", "greater", "greater_equal", "less", "less_equal"};
 static const char* kArithNames[] = {"add", "subtract", "multiply", "divide",
                                     "add_checked", "subtract_checked", "multiply_checked", "divide_checked"};

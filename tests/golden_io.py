@@ -166,6 +166,18 @@ def iter_cases():
             chunks = [R(rng, t, m, probs[j % 3], off) for j, (m, off) in enumerate([(70, 0), (0, 2), (129, 5), (1, 63), (300, 64)])]
             yield ("concatenate", {}, chunks)
             yield ("concatenate", {}, chunks[2:3])
+    # ---- hash_min_max (hash_aggregate_test.cc:607-700 MinMaxOnly / MinMaxScalar: both null
+    # handlings, groups without values, NaN) ----
+    for t in NUMERIC:
+        for null_prob in [0.0, 0.25, 1.0]:
+            v = R(rng, t, 512, null_prob, 3)
+            if t in (FLOAT, DOUBLE):
+                d = v.data.copy()
+                d[rng.random(len(d)) < 0.1] = np.nan
+                v = Arr(t, d, v.valid, 3, 512)
+            ids = Arr(orc.UINT32, rng.integers(0, 95, 512))
+            for mode in (0, 1):
+                yield ("hash_min_max", dict(num_groups=100, null_handling=mode), [v, ids])
 
 
 def run_case(api, op, params, arrs):
@@ -199,6 +211,11 @@ def run_case(api, op, params, arrs):
         if op == "hash_aggregate":
             return res(api.hash_aggregate(params["func"], arrs[0], arrs[1].values(), params["num_groups"],
                                           params.get("count_mode", 0)))
+        if op == "hash_min_max":
+            mn, mx = api.hash_min_max(arrs[0], arrs[1].values(), params["num_groups"], params["null_handling"])
+            f = lambda r: r.values.view(np.uint8)  # noqa: E731
+            return {"mins": f(mn), "maxes": f(mx), "validity": mn.validity(),
+                    "meta": np.array([mn.length, mn.null_count], np.int64)}
         if op == "compare":
             rhs = arrs[1] if len(arrs) > 1 else params["rhs_scalar"]
             return res(api.compare(params["op"], arrs[0], rhs))
@@ -242,6 +259,10 @@ def same_output(got, want, float_tol=False):
         if a.shape != b.shape or not np.array_equal(a, b):
             if float_tol and k in ("values", "sums") and a.shape == b.shape and a.dtype == np.uint8 and a.size % 8 == 0:
                 if np.allclose(a.view(np.float64), b.view(np.float64), rtol=1e-12, atol=0, equal_nan=True):
+                    continue
+            if float_tol and k in ("mins", "maxes") and a.shape == b.shape and float_tol in ("f4", "f8"):
+                # grouped float extremes: equal as values (-0.0 == +0.0), see include/amdarrow.h
+                if np.array_equal(a.view(float_tol), b.view(float_tol), equal_nan=True):
                     continue
             if float_tol and k in ("sum", "minmax") and a.shape == b.shape and a.size % 8 == 0:
                 # scalar float sum: different (tree) order than the reference's pairwise blocks; inputs are

@@ -58,6 +58,28 @@ class GpuApi:
             chunks = [chunks]
         return self._wrap(lambda: compute.sort_indices(self.ctx, [up(c) for c in chunks], order).values_numpy())
 
+    def hash_min_max(self, values, ids, num_groups, null_handling=0, split=None):
+        """split: consume the batch as two batches cut at that row (state carried across batches)"""
+        import torch
+
+        def run():
+            st = compute.HashMinMax(self.ctx, values.type_id, "cuda", null_handling)
+            dids = torch.from_numpy(np.ascontiguousarray(ids, np.uint32).view(np.int32)).cuda()
+            if num_groups == 0 and values.length == 0:
+                st._reserve(0)
+            cuts = [0, values.length] if not split else [0, split, values.length]
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                part = orc.Arr(values.type_id, values.data, values.valid, values.offset + a, b - a,
+                               values.null_count if values.null_count in (0, -1) else -1)
+                # groups known so far: in a real GroupBy the grouper reports them batch by batch
+                known = num_groups if b == values.length else (int(ids[:b].max()) + 1 if b > 0 else 0)
+                st.consume(up(part), dids[a:b].contiguous(), known)
+            if st.num_groups < num_groups:
+                st._reserve(num_groups)
+            mn, mx = st.finalize()
+            return down(mn), down(mx)
+        return self._wrap(run)
+
     def sort_indices_multi(self, keys, orders):
         keys = [[k] if isinstance(k, orc.Arr) else k for k in keys]
         return self._wrap(lambda: compute.sort_indices_multi(self.ctx, [[up(c) for c in k] for k in keys],

@@ -221,6 +221,20 @@ class Api:
         self._check(self._f("sort_indices")(arr, len(chunks), order, out.ctypes.data_as(C.c_void_p)))
         return out[:total]
 
+    def hash_min_max(self, values, ids, num_groups, null_handling=0):
+        """-> (mins Result, maxes Result) sharing one validity"""
+        ids = np.ascontiguousarray(ids, np.uint32)
+        w = max(bit_width(values.type_id), 8) // 8
+        out_mn = np.zeros(num_groups * w + 16, np.uint8)
+        out_mx = np.zeros(num_groups * w + 16, np.uint8)
+        out_b = np.zeros(num_groups // 8 + 16, np.uint8)
+        out = COut()
+        cv = values.c()
+        self._check(self._f("hash_min_max")(C.byref(cv), ids.ctypes.data_as(C.c_void_p), C.c_int64(num_groups), null_handling,
+                                            out_mn.ctypes.data_as(C.c_void_p), out_mx.ctypes.data_as(C.c_void_p),
+                                            out_b.ctypes.data_as(C.c_void_p), C.byref(out)))
+        return self._result(values.type_id, out_mn, out_b, out), self._result(values.type_id, out_mx, out_b, out)
+
     def sort_indices_multi(self, keys, orders):
         """keys: one Arr or list of chunk Arrs per sort key; orders: ASC/DESC per key."""
         keys = [[k] if isinstance(k, Arr) else list(k) for k in keys]

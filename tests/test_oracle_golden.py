@@ -171,3 +171,23 @@ def test_multi_key_sort_and_concatenate_match_live_reference(oracle, reference):
             assert oracle.concatenate(chunks[:2]).same(reference.concatenate(chunks[:2])), (t, nc)
     with pytest.raises(orc.StatusError):
         oracle.sort_indices_multi([], [])
+
+
+def test_hash_min_max_matches_live_reference(oracle, reference):
+    """SURVEY 8f.2 (rest) on a fresh seed, both null handlings, NaN / -0.0 / empty groups: the
+    restatement is bit-identical (same sequential std::min / std::max as :667-668)."""
+    rng = np.random.default_rng(20260105)
+    R = orc.random_arr
+    for t in orc.NUMERIC:
+        for n, ng, p in [(0, 0, 0), (0, 5, 0), (1, 1, 0), (2000, 64, .2), (2000, 9, 1.0)]:
+            v = R(rng, t, n, p, 5)
+            if t in (orc.FLOAT, orc.DOUBLE) and n > 10:
+                d = v.data.copy()
+                d[rng.random(n + 5) < 0.1] = np.nan
+                d[rng.random(n + 5) < 0.1] = -0.0
+                d[rng.random(n + 5) < 0.1] = 0.0
+                v = orc.Arr(t, d, v.valid, 5, n)
+            ids = rng.integers(0, max(ng - 1, 1), n).astype(np.uint32)
+            for mode in (0, 1):
+                for a, b in zip(oracle.hash_min_max(v, ids, ng, mode), reference.hash_min_max(v, ids, ng, mode)):
+                    assert a.same(b), (t, n, ng, p, mode)

@@ -39,6 +39,8 @@ def test_committed_reference_outputs(gpu):
             msg = "error differs: %s vs %s" % (bytes(got.get("msg", b"")), bytes(want.get("msg", b"")))
         else:
             is_f64 = op in ("hash_aggregate", "filter_groupby_sum", "aggregate") and arrs[0].type_id in (FLOAT, DOUBLE)
+            if op == "hash_min_max" and arrs[0].type_id in (FLOAT, DOUBLE):
+                is_f64 = "f4" if arrs[0].type_id == FLOAT else "f8"  # float extremes: equal as values
             ok, msg = golden_io.same_output(got, want, float_tol=is_f64)
         if not ok:
             bad.append("case %d %s %s: %s" % (i, op, params, msg))
@@ -731,3 +733,36 @@ def test_full_size_two_key_sort_is_lexicographic_stable_permutation(gpu, full):
     seen = torch.zeros(N_FULL, dtype=torch.bool, device="cuda")
     seen[idx] = True
     assert bool(seen.all())
+
+
+# ---- hash_min_max ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", NUMERIC)
+def test_hash_min_max_random(gpu, oracle, t):
+    """Integers bit for bit incl. the anti-extremes of groups without values; floats equal as values
+    (NaN ignored, the sign of a zero extreme is order dependent).  One batch and the same rows as
+    two batches with the state carried over."""
+    rng = np.random.default_rng(90 + t)
+    for n, ng, p in [(1, 1, 0), (3000, 100, 0), (3000, 100, .25), (3000, 7, 1.0), (200_000, 50_000, .05), (200_000, 3, .5)]:
+        v = R(rng, t, n, p, 3)
+        if t in (FLOAT, DOUBLE) and n > 10:
+            d = v.data.copy()
+            d[rng.random(len(d)) < 0.1] = np.nan
+            d[rng.random(len(d)) < 0.05] = np.inf
+            v = Arr(t, d, v.valid, 3, n)
+        ids = rng.integers(0, max(ng - 2, 1), n).astype(np.uint32)  # the last groups stay empty
+        for mode in (0, 1):
+            want = oracle.hash_min_max(v, ids, ng, mode)
+            for split in (None, n // 3):
+                got = gpu.hash_min_max(v, ids, ng, mode, split=split)
+                for g, w in zip(got, want):
+                    assert np.array_equal(g.validity(), w.validity()) and g.null_count == w.null_count, (t, n, ng, p, mode, split)
+                    assert np.array_equal(g.values, w.values, equal_nan=t in (FLOAT, DOUBLE)), (t, n, ng, p, mode, split)
+
+
+@pytest.mark.gpu
+def test_hash_min_max_errors(gpu, oracle):
+    for api in (oracle, gpu):
+        with pytest.raises(orc.StatusError) as ei:
+            api.hash_min_max(Arr(BOOL, [True, False]), np.zeros(2, np.uint32), 1)
+        assert ei.value.code == orc.NOT_IMPLEMENTED
