@@ -11,6 +11,7 @@ DROP, EMIT_NULL = 0, 1
 ASCENDING, DESCENDING = 0, 1
 COUNT_NON_NULL, COUNT_NULL = 0, 1
 MINMAX_SKIP, MINMAX_EMIT_NULL = 0, 1
+DICT_ENCODE, DICT_MASK = 0, 1  # DictionaryEncodeOptions::NullEncodingBehavior, api_vector.h:67-82
 EQ, NE, GT, GE, LT, LE = range(6)
 ADD, SUB, MUL, DIV, ADD_CHECKED, SUB_CHECKED, MUL_CHECKED, DIV_CHECKED = range(8)
 HASH_SUM, HASH_COUNT, HASH_MEAN = 0, 1, 2
@@ -75,6 +76,7 @@ SYMBOLS = {
     "amdarrow_grouper_num_groups": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "amdarrow_grouper_uniques": (C.c_int, [_P, C.c_int, _P, _P, _O]),
     "amdarrow_hash_aggregate": (C.c_int, [_P, C.c_int, _A, _P, C.c_int64, C.c_int, _P, _P, _O]),
+    "amdarrow_dictionary_indices": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, _P, _P, _O]),
     "amdarrow_hash_minmax_init": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int64]),
     "amdarrow_hash_minmax_accumulate": (C.c_int, [_P, _A, _P, _P, _P, _P, _P]),
     "amdarrow_hash_minmax_finalize": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, _P, _O]),

@@ -333,6 +333,48 @@ class Grouper:
             pass
 
 
+def _group(ctx, arr):
+    g = Grouper(ctx, [arr.type_id])
+    try:
+        ids = g.consume([arr])
+        return ids, g.uniques(0), g.num_groups()
+    finally:
+        g.close()
+
+
+def unique(ctx, arr):
+    """CallFunction("unique") -- UniqueAction, vector_hash.cc:55-86: distinct values in order of first
+    appearance, a null (once) included."""
+    return _group(ctx, arr)[1]
+
+
+def value_counts(ctx, arr):
+    """CallFunction("value_counts") -- ValueCountsAction, vector_hash.cc:91-160: -> (values, counts int64),
+    the two children of the reference's struct."""
+    ids, uniq, ng = _group(ctx, arr)
+    counts = hash_aggregate(ctx, _abi.HASH_COUNT, ids, ids.values, ng, _abi.COUNT_NON_NULL)  # every row counts, null keys too
+    return uniq, counts
+
+
+def dictionary_encode(ctx, arr, null_encoding=_abi.DICT_MASK):
+    """CallFunction("dictionary_encode") -- DictEncodeAction, vector_hash.cc:165-225: -> (indices int32, dictionary)."""
+    ids, uniq, ng = _group(ctx, arr)
+    n = arr.length
+    if null_encoding == _abi.DICT_ENCODE:  # the null is a dictionary entry; the ids are the indices
+        return DeviceArray(_abi.INT32, ids.values, None, n, 0, 0), uniq
+    out_i = alloc_bytes(4 * n, ctx.device)
+    out_b = alloc_bytes((n + 63) // 64 * 8, ctx.device)
+    out = COut()
+    check(ctx.lib, ctx.lib.amdarrow_dictionary_indices(ctx.handle, _ptr(ids.values), n,
+                                                       _ptr(uniq.validity) if uniq.validity is not None else None, ng,
+                                                       _ptr(out_i), _ptr(out_b), C.byref(out)))
+    indices = DeviceArray(_abi.INT32, out_i, out_b if out.has_validity else None, n, 0, out.null_count)
+    if uniq.validity is not None:  # drop the null entry: Filter(uniques, is_valid(uniques))
+        kept = filter(ctx, uniq, is_valid(ctx, uniq))
+        uniq = DeviceArray(kept.type_id, kept.values, None, kept.length, 0, 0)  # a dictionary without nulls has no bitmap
+    return indices, uniq
+
+
 class GroupByResult:
     """StructArray{hash_sum, hash_count, key_0} of internal::GroupBy (hash_aggregate.cc:962-965),
     rows in first-appearance order, plus the first-row index of each group."""

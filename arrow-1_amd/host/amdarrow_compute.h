@@ -370,6 +370,10 @@ struct ArraySortOptions : public FunctionOptions {
   static ArraySortOptions Defaults() { return ArraySortOptions(); }
   SortOrder order;
 };
+struct PartitionNthOptions : public FunctionOptions {  // api_vector.h:80-88
+  explicit PartitionNthOptions(int64_t pivot) : pivot(pivot) {}
+  int64_t pivot;
+};
 struct SortKey {
   explicit SortKey(std::string name, SortOrder order = SortOrder::Ascending) : name(std::move(name)), order(order) {}
   std::string name;
@@ -651,7 +655,7 @@ Result<std::shared_ptr<ArrayData>> GetTakeIndices(const ArrayData& filter, Filte
                                                   ExecContext* ctx);
 // The Register* hooks of the kernel files (registry_internal.h), HIP-backed.
 void RegisterVectorSelection(FunctionRegistry* registry);  // array_filter, filter, array_take, take
-void RegisterVectorSort(FunctionRegistry* registry);       // array_sort_indices, sort_indices
+void RegisterVectorSort(FunctionRegistry* registry);       // array_sort_indices, sort_indices, partition_nth_indices
 void RegisterScalarComparison(FunctionRegistry* registry); // equal ... less_equal
 void RegisterScalarArithmetic(FunctionRegistry* registry); // add ... divide(_checked)
 void RegisterScalarBoolean(FunctionRegistry* registry);    // invert, and, and_not, or, xor, *_kleene
@@ -700,6 +704,7 @@ Result<Datum> Filter(const Datum& values, const Datum& filter, const FilterOptio
 Result<Datum> Take(const Datum& values, const Datum& indices, const TakeOptions& options, ExecContext* ctx);
 Result<Datum> SortIndices(const Datum& values, SortOrder order, ExecContext* ctx);
 Result<Datum> SortIndices(const Datum& values, const SortOptions& options, ExecContext* ctx);  // api_vector.cc:93-96
+Result<Datum> NthToIndices(const Datum& values, int64_t n, ExecContext* ctx);                  // api_vector.cc:43-48
 Result<Datum> Compare(const Datum& left, const Datum& right, CompareOperator op, ExecContext* ctx);
 Result<Datum> Add(const Datum& left, const Datum& right, ArithmeticOptions options, ExecContext* ctx);
 Result<Datum> Subtract(const Datum& left, const Datum& right, ArithmeticOptions options, ExecContext* ctx);

@@ -634,6 +634,10 @@ Result<Datum> SortIndices(const Datum& values, SortOrder order, ExecContext* ctx
 Result<Datum> SortIndices(const Datum& values, const SortOptions& options, ExecContext* ctx) {
   return CallFunction("sort_indices", {values}, &options, ctx);  // api_vector.cc:93-96
 }
+Result<Datum> NthToIndices(const Datum& values, int64_t n, ExecContext* ctx) {
+  PartitionNthOptions options(n);  // api_vector.cc:43-48
+  return CallFunction("partition_nth_indices", {values}, &options, ctx);
+}
 Result<Datum> Compare(const Datum& left, const Datum& right, CompareOperator op, ExecContext* ctx) {
   static const char* names[] = {"equal", "not_equal", "greater", "greater_equal", "less", "less_equal"};  // api_scalar.cc:122-146
   return CallFunction(names[op], {left, right}, nullptr, ctx);

@@ -8,6 +8,7 @@
 //                   vectors (vector_selection_test.cc:296-321, 1038-1051; vector_sort_test.cc:423-464,
 //                   629-647; hash_aggregate_test.cc:251-292, 480-605; scalar_compare_test.cc:248-296;
 //                   scalar_arithmetic_test.cc:337-362) and its error codes.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -128,7 +129,7 @@ static int RunCpu() {
   // ---- the default (device) registry carries the hot-path functions under the reference's names ----
   {
     FunctionRegistry* dev = GetFunctionRegistry();
-    for (const char* n : {"filter", "array_filter", "take", "array_take", "sort_indices", "array_sort_indices", "equal", "not_equal",
+    for (const char* n : {"filter", "array_filter", "take", "array_take", "sort_indices", "array_sort_indices", "partition_nth_indices", "equal", "not_equal",
                           "greater", "greater_equal", "less", "less_equal", "add", "subtract", "multiply", "divide", "add_checked",
                           "subtract_checked", "multiply_checked", "divide_checked", "hash_sum", "hash_count", "hash_mean", "hash_min_max",
                           "invert", "and", "and_not", "or", "xor", "and_kleene", "and_not_kleene", "or_kleene", "is_valid",
@@ -481,6 +482,34 @@ static void TabularTests(const std::shared_ptr<MemoryPool>& pool, ExecContext* c
     // one key: delegates to the array / chunked-array sorters (:1638-1645, :1676-1683)
     CHECK((sorted(Datum(b1), SortOptions({SortKey("b", SortOrder::Descending)})) == std::vector<uint64_t>{3, 0, 4, 5, 2, 1, 6}));
     CHECK((sorted(Datum(t2), SortOptions({SortKey("a", SortOrder::Ascending)})) == std::vector<uint64_t>{1, 5, 4, 2, 0, 3}));
+    // partition_nth_indices: the property the reference validates (vector_sort_test.cc:132-150, :198-260)
+    {
+      const std::vector<Opt<D>> vals = {N(D), V(D, 1), V(D, 3.3), N(D), V(D, 2), V(D, 5.3), V(D, nan), V(D, -7), V(D, 2)};
+      auto arr = Dev<D>(pool, float64(), vals);
+      for (int64_t n = 0; n <= static_cast<int64_t>(vals.size()); ++n) {
+        auto r = NthToIndices(Datum(arr), n, ctx);
+        CHECK_OK(r.status());
+        if (!r.ok()) continue;
+        CHECK(r->array()->null_count == 0);
+        const auto idx = HostU64(pool, *r->array());
+        std::vector<int> seen(vals.size(), 0);
+        for (uint64_t i : idx) if (i < vals.size()) ++seen[i];
+        CHECK(idx.size() == vals.size() && std::count(seen.begin(), seen.end(), 1) == static_cast<long>(vals.size()));
+        if (idx.size() != vals.size()) continue;
+        if (n == static_cast<int64_t>(vals.size())) { for (size_t i = 0; i < idx.size(); ++i) CHECK(idx[i] == i); continue; }
+        // NthComparator: nulls / NaNs compare as the largest
+        auto less_eq = [&](uint64_t l, uint64_t r) {
+          const bool ln = !vals[l].valid || vals[l].v != vals[l].v, rn = !vals[r].valid || vals[r].v != vals[r].v;
+          if (rn) return true;
+          if (ln) return false;
+          return vals[l].v <= vals[r].v;
+        };
+        for (int64_t i = 0; i < n; ++i) CHECK(less_eq(idx[i], idx[n]));
+        for (size_t i = n + 1; i < idx.size(); ++i) CHECK(less_eq(idx[n], idx[i]));
+      }
+      CHECK(NthToIndices(Datum(arr), 10, ctx).status().IsIndexError());
+      CHECK(CallFunction("partition_nth_indices", {Datum(arr)}, ctx).status().IsInvalid());  // no default options (:198-201)
+    }
     CHECK(SortIndices(Datum(b1), SortOptions(), ctx).status().IsInvalid());                                      // :1634-1636
     CHECK(SortIndices(Datum(b1), SortOptions({SortKey("nope")}), ctx).status().IsInvalid());                     // :1639-1642
     CHECK(SortIndices(Datum(t2), SortOptions({SortKey("a"), SortKey("zz")}), ctx).status().IsInvalid());

@@ -84,6 +84,32 @@ Status ExecArraySortIndices(KernelContext* ctx, const ExecBatch& batch, Datum* o
   return SortChunks(ctx, {batch[0].array()}, opts ? opts->order : SortOrder::Ascending, out);
 }
 
+// ---- partition_nth_indices (PartitionNthToIndices, vector_sort.cc:321-358) ---------------------------
+// The contract (and what the reference's tests validate, vector_sort_test.cc:132-150): a permutation
+// with the pivot-th smallest non-null, non-NaN value at `pivot`, nothing larger before it, nothing
+// smaller after it, NaNs and nulls at the end; std::nth_element leaves the order inside the two sides
+// unspecified.  The fully sorted order is one such answer, and on this device the radix sort IS the
+// selection algorithm of choice (a quickselect's data-dependent rounds each cost a pass over HBM), so
+// the kernel is sort_indices ascending.  pivot == length: the identity (:339-343).
+Status ExecPartitionNth(KernelContext* ctx, const ExecBatch& batch, Datum* out) {
+  const auto* opts = static_cast<const PartitionNthOptions*>(ctx->options());
+  if (!opts) return Status::Invalid("NthToIndices requires PartitionNthOptions");  // :328-330
+  const ArrayData& arr = *batch[0].array();
+  if (opts->pivot > arr.length) return Status::IndexError("NthToIndices index out of bound");  // :335-337
+  if (opts->pivot == arr.length) {
+    std::vector<uint64_t> iota(static_cast<size_t>(arr.length));
+    for (int64_t i = 0; i < arr.length; ++i) iota[i] = static_cast<uint64_t>(i);
+    AMD_ASSIGN_OR_RAISE(auto buf, ctx->Allocate(8 * arr.length));
+    if (arr.length) {
+      const int rc = amdarrow_memcpy_h2d(ctx->abi(), buf->mutable_data(), iota.data(), 8 * arr.length);
+      if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+    }
+    *out = Datum(ArrayData::Make(uint64(), arr.length, {nullptr, buf}, 0));
+    return Status::OK();
+  }
+  return SortChunks(ctx, {batch[0].array()}, SortOrder::Ascending, out);
+}
+
 // ---- compare / arithmetic (ScalarBinary applicators, codegen_internal.h:758-932) -------------------
 struct BinaryOperands {
   amdarrow_array l, r;
@@ -792,6 +818,19 @@ void RegisterVectorSort(FunctionRegistry* registry) {
   }
   (void)registry->AddFunction(std::move(f));
   (void)registry->AddFunction(std::make_shared<SortIndicesMetaFunction>());
+  // partition_nth_indices: no default options (:1758-1764; CallFunction without them is Invalid)
+  auto nth = std::make_shared<VectorFunction>("partition_nth_indices", Arity::Unary());
+  for (Type::type t : kNumeric) {
+    VectorKernel k;
+    k.signature.in_types = {InputType::Exact(t, ValueDescr::ARRAY)};
+    k.signature.out_type = FixedOut(uint64());
+    k.exec = ExecPartitionNth;
+    k.mem_allocation = MemAllocation::PREALLOCATE;
+    k.null_handling = NullHandling::OUTPUT_NOT_NULL;
+    k.can_execute_chunkwise = false;
+    (void)nth->AddKernel(std::move(k));
+  }
+  (void)registry->AddFunction(std::move(nth));
 }
 
 template <int... kOps>

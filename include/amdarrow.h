@@ -193,6 +193,17 @@ int amdarrow_hash_aggregate(amdarrow_ctx* ctx, int func, const amdarrow_array* v
                             const uint32_t* ids, int64_t num_groups, int count_mode,
                             void* out_values, uint8_t* out_validity, amdarrow_out* out);
 
+/* dictionary_encode's index column under DictionaryEncodeOptions::MASK (vector_hash.cc:165-225):
+ * `ids` = the Grouper's ids of the n rows, `uniques_validity` = the bitmap amdarrow_grouper_uniques
+ * wrote (NULL when no key is null), num_groups its length.  out_indices[i] = the row's position in
+ * the dictionary WITHOUT the null entry (ids past the null group move down by one), int32; rows of
+ * the null group get a null index (value 0).  out_validity: whole 8-byte words; out->has_validity
+ * iff some row is null.  unique / value_counts / ENCODE need no extra kernel: they are the
+ * uniques, the uniques + hash_count, and the ids themselves. */
+int amdarrow_dictionary_indices(amdarrow_ctx* ctx, const uint32_t* ids, int64_t n,
+                                const uint8_t* uniques_validity, int64_t num_groups,
+                                int32_t* out_indices, uint8_t* out_validity, amdarrow_out* out);
+
 /* hash_min_max -- GroupedMinMaxImpl, hash_aggregate.cc:627-768, as the reference's init / resize /
  * consume / finalize (kernel.h:681-721).  The caller owns the state of the reference's four
  * builders (:704-707): mins / maxes (one element of the VALUE type per group) and the has_values /

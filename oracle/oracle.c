@@ -287,6 +287,76 @@ int orc_sort_indices(const orc_array* chunks, int nchunks, int order, uint64_t* 
   return ORC_OK;
 }
 
+/* ---- 8f.4: vector_hash.cc -- unique / value_counts / dictionary_encode ----------------- */
+/* The memo table (util/hashing.h ScalarMemoTable / SmallScalarMemoTable): memo index = order of
+ * first appearance; entries match on equal bits; a null is its own entry.  The grouper above keeps
+ * exactly such a table over [null byte][value bytes] keys, so it serves as the memo table here. */
+static int memo_run(const orc_array* a, uint32_t** ids, orc_grouper** g) {
+  if (orc_bit_width(a->type_id) < 0) return fail(ORC_NOT_IMPLEMENTED, "hash kernels: type");
+  *g = orc_grouper_new(1, &a->type_id);
+  *ids = (uint32_t*)malloc(4 * (size_t)(a->length + 1));
+  return orc_grouper_consume(*g, a, *ids); /* RegularHashKernel::DoAppend :300-330, row by row */
+}
+static void memo_dictionary(const orc_grouper* g, void* out_values, uint8_t* out_validity, orc_out* out) {
+  int64_t nulls = 0;
+  orc_grouper_uniques(g, 0, out_values, out_validity, &nulls); /* GetDictionary :345-351 + DictionaryTraits */
+  out->length = orc_grouper_num_groups(g);
+  out->null_count = nulls;
+  out->has_validity = nulls > 0; /* the bitmap exists only when the table holds a null (dict_internal.h) */
+}
+int orc_unique(const orc_array* a, void* out_values, uint8_t* out_validity, orc_out* out) {
+  uint32_t* ids; orc_grouper* g;
+  int rc = memo_run(a, &ids, &g);
+  if (rc == ORC_OK) memo_dictionary(g, out_values, out_validity, out); /* UniqueFinalize :617-623 */
+  free(ids); orc_grouper_free(g);
+  return rc;
+}
+int orc_value_counts(const orc_array* a, void* out_values, uint8_t* out_validity, int64_t* out_counts, orc_out* out) {
+  uint32_t* ids; orc_grouper* g;
+  int rc = memo_run(a, &ids, &g);
+  if (rc == ORC_OK) {
+    memo_dictionary(g, out_values, out_validity, out);
+    memset(out_counts, 0, 8 * (size_t)out->length);
+    for (int64_t i = 0; i < a->length; ++i) ++out_counts[ids[i]]; /* ObserveFound / ObserveNullFound :117-146 */
+  }
+  free(ids); orc_grouper_free(g);
+  return rc;
+}
+int orc_dictionary_encode(const orc_array* a, int null_encoding, int32_t* out_indices, uint8_t* out_index_validity,
+                          orc_out* om, void* out_dict, uint8_t* out_dict_validity, orc_out* dm) {
+  om->length = a->length; om->null_count = 0; om->has_validity = 0;
+  if (null_encoding == 0) { /* ENCODE: nulls go through the memo table like values (ShouldEncodeNulls :210-212) */
+    uint32_t* ids; orc_grouper* g;
+    int rc = memo_run(a, &ids, &g);
+    if (rc == ORC_OK) {
+      memo_dictionary(g, out_dict, out_dict_validity, dm);
+      for (int64_t i = 0; i < a->length; ++i) out_indices[i] = (int32_t)ids[i];
+      memset(out_index_validity, 0xFF, (size_t)bytes_for_bits(a->length));
+    }
+    free(ids); orc_grouper_free(g);
+    return rc;
+  }
+  /* MASK: a null row appends a null index and never reaches the table (DoAppend with
+   * !ShouldEncodeNulls, :318-326; ObserveNullFound :187-194): the dictionary is the table of the
+   * valid rows alone. */
+  if (orc_bit_width(a->type_id) < 0) return fail(ORC_NOT_IMPLEMENTED, "hash kernels: type");
+  orc_grouper* g = orc_grouper_new(1, &a->type_id);
+  memset(out_index_validity, 0, (size_t)bytes_for_bits(a->length));
+  for (int64_t i = 0; i < a->length; ++i) {
+    if (!slot_valid(a, i)) { out_indices[i] = 0; ++om->null_count; continue; }
+    orc_array one = *a;
+    one.offset = a->offset + i; one.length = 1;
+    uint32_t id;
+    orc_grouper_consume(g, &one, &id);
+    out_indices[i] = (int32_t)id;
+    set_bit(out_index_validity, i);
+  }
+  om->has_validity = om->null_count > 0;
+  memo_dictionary(g, out_dict, out_dict_validity, dm);
+  orc_grouper_free(g);
+  return ORC_OK;
+}
+
 /* ---- c4: GroupedMinMaxImpl, hash_aggregate.cc:627-768 -------------------------------- */
 #define MINMAX_CASE(ID, T, LO, HI)                                                          \
   case ID: {                                                                                \

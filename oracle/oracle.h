@@ -149,6 +149,20 @@ int orc_hash_aggregate(int func, const orc_array* values, const uint32_t* ids,
 int orc_hash_min_max(const orc_array* values, const uint32_t* ids, int64_t num_groups, int null_handling,
                      void* out_mins, void* out_maxes, uint8_t* out_validity, orc_out* out);
 
+/* 8f.4: unique / value_counts / dictionary_encode -- compute/kernels/vector_hash.cc:55-225, 617-640
+ * over the memo table of util/hashing.h (ScalarMemoTable: a value matches an entry when its bit
+ * pattern hashes alike and CompareScalars agrees, :67-127 -- i.e. equal bits; a null is one more
+ * entry, GetOrInsertNull).  Distinct values keep the order of first appearance.
+ *   unique             the distinct values, the null (value bits 0) among them where it first occurred;
+ *   value_counts       the same values and the number of rows of each (nulls counted), int64;
+ *   dictionary_encode  int32 index of every row + the dictionary.  null_encoding 0 = ENCODE (the null is
+ *                      a dictionary entry), 1 = MASK (null rows get a null index of value 0 and the
+ *                      dictionary holds no null; api_vector.h:67-82). */
+int orc_unique(const orc_array* a, void* out_values, uint8_t* out_validity, orc_out* out);
+int orc_value_counts(const orc_array* a, void* out_values, uint8_t* out_validity, int64_t* out_counts, orc_out* out);
+int orc_dictionary_encode(const orc_array* a, int null_encoding, int32_t* out_indices, uint8_t* out_index_validity,
+                          orc_out* out_indices_meta, void* out_dict, uint8_t* out_dict_validity, orc_out* out_dict_meta);
+
 /* d1/d2: compare kernels, scalar_compare.cc:31-57,100-159; boolean output packed
  * LSB-first with trailing bits zero (bitmap_generate.h:62-108).  Operand i is an array
  * (lhs / rhs non-NULL) or a valid scalar (lhs_scalar / rhs_scalar -> one value of the

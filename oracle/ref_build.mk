@@ -65,6 +65,7 @@ SRCS := \
   $(A)/compute/kernels/scalar_validity.cc $(A)/compute/kernels/scalar_fill_null.cc \
   $(A)/compute/kernels/util_internal.cc \
   $(A)/compute/kernels/vector_selection.cc $(A)/compute/kernels/vector_sort.cc \
+  $(A)/compute/kernels/vector_hash.cc \
   $(A)/compute/kernels/scalar_cast_boolean.cc $(A)/compute/kernels/scalar_cast_internal.cc \
   $(A)/compute/kernels/scalar_cast_numeric.cc
 

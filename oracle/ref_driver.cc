@@ -58,6 +58,7 @@ FunctionRegistry* HotPathRegistry() {
     compute::internal::RegisterScalarFillNull(r.get());
     compute::internal::RegisterVectorSelection(r.get());
     compute::internal::RegisterVectorSort(r.get());
+    compute::internal::RegisterVectorHash(r.get());
     compute::internal::RegisterScalarAggregateBasic(r.get());
     compute::internal::RegisterHashAggregateBasic(r.get());
     return r;
@@ -361,6 +362,37 @@ int ref_hash_min_max(const orc_array* values, const uint32_t* ids, int64_t num_g
   Export(*s.child_data[0], out_mins, out_validity, out);
   Export(*s.child_data[1], out_maxes, nullptr, &ignored);
   out->null_count = num_groups - arrow::internal::CountSetBits(out_validity, 0, num_groups);
+  return 0;
+}
+
+// ---- unique / value_counts / dictionary_encode (vector_hash.cc) ----------------------
+int ref_unique(const orc_array* a, void* out_values, uint8_t* out_validity, orc_out* out) {
+  auto res = CallFunction("unique", {Datum(Wrap(a))}, nullptr, Ctx());
+  if (!res.ok()) return Fail(res.status());
+  Export(*res->array(), out_values, out_validity, out);
+  return 0;
+}
+int ref_value_counts(const orc_array* a, void* out_values, uint8_t* out_validity, int64_t* out_counts, orc_out* out) {
+  auto res = CallFunction("value_counts", {Datum(Wrap(a))}, nullptr, Ctx());
+  if (!res.ok()) return Fail(res.status());
+  const ArrayData& st = *res->array();
+  orc_out ignored;
+  Export(*st.child_data[0], out_values, out_validity, out);
+  Export(*st.child_data[1], out_counts, nullptr, &ignored);
+  return 0;
+}
+int ref_dictionary_encode(const orc_array* a, int null_encoding, int32_t* out_indices, uint8_t* out_index_validity,
+                          orc_out* om, void* out_dict, uint8_t* out_dict_validity, orc_out* dm) {
+  DictionaryEncodeOptions opts(null_encoding == 0 ? DictionaryEncodeOptions::ENCODE : DictionaryEncodeOptions::MASK);
+  auto res = CallFunction("dictionary_encode", {Datum(Wrap(a))}, &opts, Ctx());
+  if (!res.ok()) return Fail(res.status());
+  const ArrayData& d = *res->array();
+  auto indices = d.Copy();
+  indices->type = int32();
+  indices->dictionary = nullptr;
+  Export(*indices, out_indices, out_index_validity, om);
+  if (!om->has_validity) std::memset(out_index_validity, 0xFF, BitUtil::BytesForBits(d.length));
+  Export(*d.dictionary, out_dict, out_dict_validity, dm);
   return 0;
 }
 

@@ -178,6 +178,21 @@ def iter_cases():
             ids = Arr(orc.UINT32, rng.integers(0, 95, 512))
             for mode in (0, 1):
                 yield ("hash_min_max", dict(num_groups=100, null_handling=mode), [v, ids])
+    # ---- unique / value_counts / dictionary_encode (vector_hash_test.cc:60-140 CheckUnique /
+    # CheckValueCounts / CheckDictEncode; random arrays with few distinct values, NaN and both zeros) ----
+    for t in [BOOL] + NUMERIC:
+        for n, null_prob, off in [(0, 0.0, 0), (1, 1.0, 0), (400, 0.0, 3), (400, 0.2, 5), (400, 1.0, 0)]:
+            a = R(rng, t, n, null_prob, off, lo=-20 if t in (orc.INT8, orc.INT16, orc.INT32, orc.INT64, FLOAT, DOUBLE) else 0, hi=20)
+            if t in (FLOAT, DOUBLE) and n > 10:
+                d = a.data.copy()
+                d[::7] = np.nan
+                d[::11] = -0.0
+                d[::13] = 0.0
+                a = Arr(t, d, a.valid, off, n)
+            yield ("unique", {}, [a])
+            yield ("value_counts", {}, [a])
+            for ne in (0, 1):
+                yield ("dictionary_encode", dict(null_encoding=ne), [a])
 
 
 def run_case(api, op, params, arrs):
@@ -211,6 +226,27 @@ def run_case(api, op, params, arrs):
         if op == "hash_aggregate":
             return res(api.hash_aggregate(params["func"], arrs[0], arrs[1].values(), params["num_groups"],
                                           params.get("count_mode", 0)))
+        if op in ("unique", "value_counts", "dictionary_encode"):
+            def canon(r):  # the reference leaves the value under a null slot unspecified (the memo table's null entry)
+                d = res(r)
+                v = np.asarray(r.values).copy()
+                if r.has_validity:
+                    v[~r.validity()[:len(v)]] = 0
+                d["values"] = v.view(np.uint8) if v.dtype != bool else v
+                if not r.has_validity:
+                    d["validity"] = np.ones(r.length, bool)
+                return d
+            if op == "unique":
+                return canon(api.unique(arrs[0]))
+            if op == "value_counts":
+                u, c = api.value_counts(arrs[0])
+                d = canon(u)
+                d["counts"] = np.asarray(c, np.int64)
+                return d
+            i, dic = api.dictionary_encode(arrs[0], params["null_encoding"])
+            d = {"dict_" + k: v for k, v in canon(dic).items()}
+            d.update({"index_" + k: v for k, v in canon(i).items()})
+            return d
         if op == "hash_min_max":
             mn, mx = api.hash_min_max(arrs[0], arrs[1].values(), params["num_groups"], params["null_handling"])
             f = lambda r: r.values.view(np.uint8)  # noqa: E731

@@ -58,6 +58,25 @@ class GpuApi:
             chunks = [chunks]
         return self._wrap(lambda: compute.sort_indices(self.ctx, [up(c) for c in chunks], order).values_numpy())
 
+    # ---- SURVEY 8f.4 ----
+    def unique(self, a):
+        return self._wrap(lambda: down(compute.unique(self.ctx, up(a))))
+
+    def value_counts(self, a):
+        def run():
+            u, c = compute.value_counts(self.ctx, up(a))
+            return down(u), c.values_numpy()
+        return self._wrap(run)
+
+    def dictionary_encode(self, a, null_encoding=1):
+        def run():
+            i, d = compute.dictionary_encode(self.ctx, up(a), null_encoding)
+            r = down(i)
+            if i.validity is None:
+                r.validity_bits = np.packbits(np.ones(i.length, bool), bitorder="little")
+            return r, down(d)
+        return self._wrap(run)
+
     def hash_min_max(self, values, ids, num_groups, null_handling=0, split=None):
         """split: consume the batch as two batches cut at that row (state carried across batches)"""
         import torch

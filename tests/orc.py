@@ -119,6 +119,18 @@ class Result:
             return False
         return True
 
+    def same_valid(self, other):
+        """like same(), but value bytes are compared only where the slot is valid: for outputs whose
+        null slots the reference leaves unspecified (the memo table's null entry, vector_hash.cc)"""
+        if (self.length, self.null_count, self.has_validity) != (other.length, other.null_count, other.has_validity):
+            return False
+        v = self.validity() if self.has_validity else np.ones(self.length, bool)
+        w = other.validity() if other.has_validity else np.ones(other.length, bool)
+        if not np.array_equal(v, w):
+            return False
+        a, b = np.asarray(self.values)[:self.length][v], np.asarray(other.values)[:other.length][v]
+        return np.array_equal(a.view(np.uint8) if a.dtype != bool else a, b.view(np.uint8) if b.dtype != bool else b)
+
     def __repr__(self):
         return "Result(len=%d nulls=%d has_validity=%s values=%s validity=%s)" % (
             self.length, self.null_count, self.has_validity, self.values[:16], self.validity()[:16] if self.length else [])
@@ -220,6 +232,35 @@ class Api:
         out = np.zeros(total + 1, np.uint64)
         self._check(self._f("sort_indices")(arr, len(chunks), order, out.ctypes.data_as(C.c_void_p)))
         return out[:total]
+
+    # ---- unique / value_counts / dictionary_encode ----
+    def unique(self, a):
+        out_v = np.zeros(a.length * 8 + 16, np.uint8)
+        out_b = np.zeros(a.length // 8 + 16, np.uint8)
+        out, c = COut(), a.c()
+        self._check(self._f("unique")(C.byref(c), out_v.ctypes.data_as(C.c_void_p), out_b.ctypes.data_as(C.c_void_p), C.byref(out)))
+        return self._result(a.type_id, out_v, out_b, out)
+
+    def value_counts(self, a):
+        out_v = np.zeros(a.length * 8 + 16, np.uint8)
+        out_b = np.zeros(a.length // 8 + 16, np.uint8)
+        out_c = np.zeros(a.length + 2, np.int64)
+        out, c = COut(), a.c()
+        self._check(self._f("value_counts")(C.byref(c), out_v.ctypes.data_as(C.c_void_p), out_b.ctypes.data_as(C.c_void_p),
+                                            out_c.ctypes.data_as(C.c_void_p), C.byref(out)))
+        return self._result(a.type_id, out_v, out_b, out), out_c[:out.length].copy()
+
+    def dictionary_encode(self, a, null_encoding=1):
+        """-> (indices Result int32, dictionary Result); null_encoding 0 = ENCODE, 1 = MASK"""
+        out_i = np.zeros(a.length * 4 + 16, np.uint8)
+        out_ib = np.zeros(a.length // 8 + 16, np.uint8)
+        out_v = np.zeros(a.length * 8 + 16, np.uint8)
+        out_b = np.zeros(a.length // 8 + 16, np.uint8)
+        om, dm, c = COut(), COut(), a.c()
+        self._check(self._f("dictionary_encode")(C.byref(c), null_encoding, out_i.ctypes.data_as(C.c_void_p),
+                                                 out_ib.ctypes.data_as(C.c_void_p), C.byref(om), out_v.ctypes.data_as(C.c_void_p),
+                                                 out_b.ctypes.data_as(C.c_void_p), C.byref(dm)))
+        return self._result(INT32, out_i, out_ib, om), self._result(a.type_id, out_v, out_b, dm)
 
     def hash_min_max(self, values, ids, num_groups, null_handling=0):
         """-> (mins Result, maxes Result) sharing one validity"""

@@ -191,3 +191,24 @@ def test_hash_min_max_matches_live_reference(oracle, reference):
             for mode in (0, 1):
                 for a, b in zip(oracle.hash_min_max(v, ids, ng, mode), reference.hash_min_max(v, ids, ng, mode)):
                     assert a.same(b), (t, n, ng, p, mode)
+
+
+def test_vector_hash_functions_match_live_reference(oracle, reference):
+    """SURVEY 8f.4 on a fresh seed: unique / value_counts / dictionary_encode (both null encodings).
+    Values under a null slot are unspecified in the reference (the memo table's null entry is not
+    initialised for 16-bit and wider types), so they are compared where valid."""
+    rng = np.random.default_rng(20260106)
+    R = orc.random_arr
+    for t in [orc.BOOL] + orc.NUMERIC:
+        for n, p, off in [(0, 0, 0), (1, 0, 0), (1, 1.0, 0), (300, 0, 3), (300, .2, 5), (300, 1.0, 0), (5000, .05, 1)]:
+            a = R(rng, t, n, p, off, lo=0, hi=30)
+            if t in (orc.FLOAT, orc.DOUBLE) and n > 10:
+                d = a.data.copy()
+                d[::7], d[::11], d[::13] = np.nan, -0.0, 0.0
+                a = orc.Arr(t, d, a.valid, off, n)
+            assert oracle.unique(a).same_valid(reference.unique(a)), (t, n, p)
+            (u1, c1), (u2, c2) = oracle.value_counts(a), reference.value_counts(a)
+            assert u1.same_valid(u2) and np.array_equal(c1, c2), (t, n, p)
+            for ne in (0, 1):
+                (i1, d1), (i2, d2) = oracle.dictionary_encode(a, ne), reference.dictionary_encode(a, ne)
+                assert i1.same_valid(i2) and d1.same_valid(d2), (t, n, p, ne)

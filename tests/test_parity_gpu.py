@@ -766,3 +766,24 @@ def test_hash_min_max_errors(gpu, oracle):
         with pytest.raises(orc.StatusError) as ei:
             api.hash_min_max(Arr(BOOL, [True, False]), np.zeros(2, np.uint32), 1)
         assert ei.value.code == orc.NOT_IMPLEMENTED
+
+
+# ---- unique / value_counts / dictionary_encode on the group-by hash table ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", [BOOL] + NUMERIC)
+def test_unique_value_counts_dictionary_encode_random(gpu, oracle, t):
+    rng = np.random.default_rng(100 + t)
+    for n, p, off, hi in [(0, 0, 0, 5), (1, 0, 0, 5), (1, 1.0, 0, 5), (3000, 0, 3, 40), (3000, .2, 5, 40), (3000, 1.0, 0, 5),
+                          (300_000, .01, 1, 100_000)]:
+        a = R(rng, t, n, p, off, lo=0, hi=hi)
+        if t in (FLOAT, DOUBLE) and n > 10:
+            d = a.data.copy()
+            d[::7], d[::11], d[::13] = np.nan, -0.0, 0.0
+            a = Arr(t, d, a.valid, off, n)
+        assert gpu.unique(a).same_valid(oracle.unique(a)), (t, n, p)
+        (u1, c1), (u2, c2) = gpu.value_counts(a), oracle.value_counts(a)
+        assert u1.same_valid(u2) and np.array_equal(c1, c2), (t, n, p)
+        for ne in (0, 1):
+            (i1, d1), (i2, d2) = gpu.dictionary_encode(a, ne), oracle.dictionary_encode(a, ne)
+            assert i1.same_valid(i2), (t, n, p, ne, i1, i2)
+            assert d1.same_valid(d2), (t, n, p, ne, d1, d2)
