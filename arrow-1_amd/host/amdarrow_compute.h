@@ -95,7 +95,8 @@ class Result {
 // ---- types (arrow/type_fwd.h:277-313; only the primitive types on the path) -------------------------
 struct Type {
   enum type { NA = 0, BOOL = 1, UINT8, INT8, UINT16, INT16, UINT32, INT32, UINT64, INT64, HALF_FLOAT, FLOAT, DOUBLE,
-              STRUCT };  // STRUCT: only as the type of min_max's {min, max} result scalar
+              STRUCT,       // the {min, max} / {values, counts} results
+              DICTIONARY }; // dictionary_encode's result: int32 indices + ArrayData::dictionary
 };
 class DataType {
  public:
@@ -120,6 +121,7 @@ std::shared_ptr<DataType> int64();
 std::shared_ptr<DataType> float32();
 std::shared_ptr<DataType> float64();
 std::shared_ptr<DataType> struct_();  // field list carried by the StructScalar itself
+std::shared_ptr<DataType> dictionary_();  // dictionary(int32(), <type of ArrayData::dictionary>)
 std::shared_ptr<DataType> TypeFromId(Type::type id);
 bool is_integer(Type::type id);
 bool is_signed_integer(Type::type id);
@@ -175,6 +177,7 @@ struct ArrayData {
   // StructArray children (array/data.h:232): only hash_min_max's {min, max} output has any
   std::vector<std::shared_ptr<ArrayData>> child_data;
   std::vector<std::string> child_names;
+  std::shared_ptr<ArrayData> dictionary;  // DictionaryArray (array/data.h:240): buffers = the int32 indices
 
   static std::shared_ptr<ArrayData> Make(std::shared_ptr<DataType> type, int64_t length,
                                          std::vector<std::shared_ptr<Buffer>> buffers, int64_t null_count = kUnknownNullCount,
@@ -369,6 +372,12 @@ struct ArraySortOptions : public FunctionOptions {
   explicit ArraySortOptions(SortOrder order = SortOrder::Ascending) : order(order) {}
   static ArraySortOptions Defaults() { return ArraySortOptions(); }
   SortOrder order;
+};
+struct DictionaryEncodeOptions : public FunctionOptions {  // api_vector.h:67-82
+  enum NullEncodingBehavior { ENCODE, MASK };
+  explicit DictionaryEncodeOptions(NullEncodingBehavior n = MASK) : null_encoding_behavior(n) {}
+  static DictionaryEncodeOptions Defaults() { return DictionaryEncodeOptions(); }
+  NullEncodingBehavior null_encoding_behavior = MASK;
 };
 struct PartitionNthOptions : public FunctionOptions {  // api_vector.h:80-88
   explicit PartitionNthOptions(int64_t pivot) : pivot(pivot) {}
@@ -663,6 +672,7 @@ void RegisterScalarValidity(FunctionRegistry* registry);   // is_valid, is_null,
 void RegisterScalarFillNull(FunctionRegistry* registry);   // fill_null
 void RegisterScalarAggregateBasic(FunctionRegistry* registry);  // count, sum, mean, min_max
 void RegisterHashAggregateBasic(FunctionRegistry* registry);  // hash_count, hash_sum, hash_mean, hash_min_max
+void RegisterVectorHash(FunctionRegistry* registry);          // unique, value_counts, dictionary_encode
 
 // Grouper / GroupBy (api_aggregate.h:313-403)
 class Grouper {
@@ -705,6 +715,9 @@ Result<Datum> Take(const Datum& values, const Datum& indices, const TakeOptions&
 Result<Datum> SortIndices(const Datum& values, SortOrder order, ExecContext* ctx);
 Result<Datum> SortIndices(const Datum& values, const SortOptions& options, ExecContext* ctx);  // api_vector.cc:93-96
 Result<Datum> NthToIndices(const Datum& values, int64_t n, ExecContext* ctx);                  // api_vector.cc:43-48
+Result<Datum> Unique(const Datum& values, ExecContext* ctx);                                   // api_vector.cc:115-118
+Result<Datum> ValueCounts(const Datum& values, ExecContext* ctx);                              // api_vector.cc:130-133
+Result<Datum> DictionaryEncode(const Datum& values, const DictionaryEncodeOptions& options, ExecContext* ctx);  // :120-124
 Result<Datum> Compare(const Datum& left, const Datum& right, CompareOperator op, ExecContext* ctx);
 Result<Datum> Add(const Datum& left, const Datum& right, ArithmeticOptions options, ExecContext* ctx);
 Result<Datum> Subtract(const Datum& left, const Datum& right, ArithmeticOptions options, ExecContext* ctx);

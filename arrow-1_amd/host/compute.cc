@@ -37,17 +37,18 @@ int DataType::bit_width() const {
 }
 std::string DataType::ToString() const {
   static const char* names[] = {"null", "bool", "uint8", "int8", "uint16", "int16", "uint32", "int32", "uint64", "int64",
-                                "halffloat", "float", "double", "struct"};
+                                "halffloat", "float", "double", "struct", "dictionary"};
   return names[id_];
 }
 std::shared_ptr<DataType> TypeFromId(Type::type id) {
-  static std::shared_ptr<DataType> types[14];
+  static std::shared_ptr<DataType> types[15];
   static std::once_flag once;
-  std::call_once(once, [] { for (int i = 0; i < 14; ++i) types[i] = std::make_shared<DataType>(static_cast<Type::type>(i)); });
+  std::call_once(once, [] { for (int i = 0; i < 15; ++i) types[i] = std::make_shared<DataType>(static_cast<Type::type>(i)); });
   return types[id];
 }
 std::shared_ptr<DataType> boolean() { return TypeFromId(Type::BOOL); }
 std::shared_ptr<DataType> struct_() { return TypeFromId(Type::STRUCT); }
+std::shared_ptr<DataType> dictionary_() { return TypeFromId(Type::DICTIONARY); }
 std::shared_ptr<DataType> uint8() { return TypeFromId(Type::UINT8); }
 std::shared_ptr<DataType> int8() { return TypeFromId(Type::INT8); }
 std::shared_ptr<DataType> uint16() { return TypeFromId(Type::UINT16); }
@@ -605,6 +606,7 @@ FunctionRegistry* GetFunctionRegistry() {  // registry.cc:115-150, hot-path subs
     internal::RegisterVectorSelection(r.get());
     internal::RegisterVectorSort(r.get());
     internal::RegisterHashAggregateBasic(r.get());
+    internal::RegisterVectorHash(r.get());
     return r;
   }();
   return g_registry.get();
@@ -637,6 +639,11 @@ Result<Datum> SortIndices(const Datum& values, const SortOptions& options, ExecC
 Result<Datum> NthToIndices(const Datum& values, int64_t n, ExecContext* ctx) {
   PartitionNthOptions options(n);  // api_vector.cc:43-48
   return CallFunction("partition_nth_indices", {values}, &options, ctx);
+}
+Result<Datum> Unique(const Datum& values, ExecContext* ctx) { return CallFunction("unique", {values}, nullptr, ctx); }
+Result<Datum> ValueCounts(const Datum& values, ExecContext* ctx) { return CallFunction("value_counts", {values}, nullptr, ctx); }
+Result<Datum> DictionaryEncode(const Datum& values, const DictionaryEncodeOptions& options, ExecContext* ctx) {
+  return CallFunction("dictionary_encode", {values}, &options, ctx);
 }
 Result<Datum> Compare(const Datum& left, const Datum& right, CompareOperator op, ExecContext* ctx) {
   static const char* names[] = {"equal", "not_equal", "greater", "greater_equal", "less", "less_equal"};  // api_scalar.cc:122-146

@@ -129,7 +129,7 @@ static int RunCpu() {
   // ---- the default (device) registry carries the hot-path functions under the reference's names ----
   {
     FunctionRegistry* dev = GetFunctionRegistry();
-    for (const char* n : {"filter", "array_filter", "take", "array_take", "sort_indices", "array_sort_indices", "partition_nth_indices", "equal", "not_equal",
+    for (const char* n : {"filter", "array_filter", "take", "array_take", "sort_indices", "array_sort_indices", "partition_nth_indices", "unique", "value_counts", "dictionary_encode", "equal", "not_equal",
                           "greater", "greater_equal", "less", "less_equal", "add", "subtract", "multiply", "divide", "add_checked",
                           "subtract_checked", "multiply_checked", "divide_checked", "hash_sum", "hash_count", "hash_mean", "hash_min_max",
                           "invert", "and", "and_not", "or", "xor", "and_kleene", "and_not_kleene", "or_kleene", "is_valid",
@@ -453,6 +453,66 @@ static void TabularTests(const std::shared_ptr<MemoryPool>& pool, ExecContext* c
     if (cb.ok()) CHECK((HostBool(pool, **cb) == std::vector<int>{1, 0, -1, 1, 1, 1, 0, 1, 0, 0, 1, 1}));
     CHECK(Concatenate({}, pool).status().IsInvalid());
     CHECK(Concatenate({Dev<I>(pool, int32(), {V(I, 1)}), DevBool(pool, {1})}, pool).status().IsInvalid());
+  }
+
+  // unique / value_counts / dictionary_encode (vector_hash_test.cc:162-212)
+  {
+    auto vals = Dev<I>(pool, int32(), {V(I, 2), N(I), V(I, 2), V(I, 1), V(I, 2), V(I, 3), N(I)});
+    auto u = Unique(Datum(vals), ctx);
+    CHECK_OK(u.status());
+    if (u.ok()) CHECK(Same(Host<I>(pool, *u->array()), {V(I, 2), N(I), V(I, 1), V(I, 3)}));
+    auto vc = ValueCounts(Datum(vals), ctx);
+    CHECK_OK(vc.status());
+    if (vc.ok()) {
+      const ArrayData& st = *vc->array();
+      CHECK(st.type->id() == Type::STRUCT && st.child_names == std::vector<std::string>({"values", "counts"}) && st.length == 4);
+      CHECK(Same(Host<I>(pool, *st.child_data[0]), {V(I, 2), N(I), V(I, 1), V(I, 3)}));
+      CHECK(Same(Host<int64_t>(pool, *st.child_data[1]), {V(int64_t, 3), V(int64_t, 2), V(int64_t, 1), V(int64_t, 1)}));
+    }
+    auto six = Dev<I>(pool, int32(), {V(I, 2), N(I), V(I, 2), V(I, 1), V(I, 2), V(I, 3)});
+    auto de = DictionaryEncode(Datum(six), DictionaryEncodeOptions::Defaults(), ctx);
+    CHECK_OK(de.status());
+    if (de.ok()) {
+      const ArrayData& d = *de->array();
+      CHECK(d.type->id() == Type::DICTIONARY && d.dictionary && d.dictionary->type->id() == Type::INT32);
+      CHECK(Same(Host<I>(pool, *d.dictionary), {V(I, 2), V(I, 1), V(I, 3)}) && d.dictionary->buffers[0] == nullptr);
+      auto idx = ArrayData::Make(int32(), d.length, d.buffers, d.null_count, d.offset);
+      CHECK(Same(Host<I>(pool, *idx), {V(I, 0), N(I), V(I, 0), V(I, 1), V(I, 0), V(I, 2)}));
+    }
+    de = DictionaryEncode(Datum(six), DictionaryEncodeOptions(DictionaryEncodeOptions::ENCODE), ctx);  // api_vector.h:315
+    CHECK_OK(de.status());
+    if (de.ok()) {
+      const ArrayData& d = *de->array();
+      CHECK(Same(Host<I>(pool, *d.dictionary), {V(I, 2), N(I), V(I, 1), V(I, 3)}));
+      auto idx = ArrayData::Make(int32(), d.length, d.buffers, d.null_count, d.offset);
+      CHECK(Same(Host<I>(pool, *idx), {V(I, 0), V(I, 1), V(I, 0), V(I, 2), V(I, 0), V(I, 3)}));
+    }
+    // sliced input (:170-172, :197-200) and chunks sharing one memo table
+    auto seven = Dev<I>(pool, int32(), {V(I, 2), V(I, 1), N(I), V(I, 4), V(I, 3), V(I, 1), V(I, 42)});
+    de = DictionaryEncode(Datum(seven->Slice(1, 5)), DictionaryEncodeOptions::Defaults(), ctx);
+    CHECK_OK(de.status());
+    if (de.ok()) {
+      const ArrayData& d = *de->array();
+      CHECK(Same(Host<I>(pool, *d.dictionary), {V(I, 1), V(I, 4), V(I, 3)}));
+      CHECK(Same(Host<I>(pool, *ArrayData::Make(int32(), d.length, d.buffers, d.null_count, d.offset)), {V(I, 0), N(I), V(I, 1), V(I, 2), V(I, 0)}));
+    }
+    auto two = std::make_shared<ChunkedArray>(std::vector<std::shared_ptr<ArrayData>>{Dev<I>(pool, int32(), {V(I, 5), V(I, 7)}),
+                                                                                      Dev<I>(pool, int32(), {V(I, 7), N(I), V(I, 9), V(I, 5)})}, int32());
+    u = Unique(Datum(two), ctx);
+    CHECK_OK(u.status());
+    if (u.ok()) CHECK(Same(Host<I>(pool, *u->array()), {V(I, 5), V(I, 7), N(I), V(I, 9)}));
+    de = DictionaryEncode(Datum(two), DictionaryEncodeOptions::Defaults(), ctx);
+    CHECK_OK(de.status());
+    if (de.ok()) {
+      CHECK(de->kind() == Datum::CHUNKED_ARRAY && de->chunked_array()->num_chunks() == 2);
+      const ArrayData& c1 = *de->chunked_array()->chunk(1);
+      CHECK(Same(Host<I>(pool, *c1.dictionary), {V(I, 5), V(I, 7), V(I, 9)}));
+      CHECK(Same(Host<I>(pool, *ArrayData::Make(int32(), c1.length, c1.buffers, c1.null_count, c1.offset)), {V(I, 1), N(I), V(I, 2), V(I, 0)}));
+    }
+    auto zero = DictionaryEncode(Datum(std::make_shared<ChunkedArray>(std::vector<std::shared_ptr<ArrayData>>{}, int32())),
+                                 DictionaryEncodeOptions::Defaults(), ctx);  // ZeroChunks :203-212
+    CHECK_OK(zero.status());
+    if (zero.ok()) CHECK(zero->kind() == Datum::CHUNKED_ARRAY && zero->chunked_array()->num_chunks() == 0);
   }
 
   // sort_indices over batches and tables (vector_sort_test.cc:763-980)

@@ -1009,6 +1009,118 @@ Result<ExecBatch> Grouper::GetUniques() {
   return out;
 }
 
+// ---- unique / value_counts / dictionary_encode (vector_hash.cc:55-225, 617-760) ------------------------
+// The reference's three hash actions over one memo table; here over one Grouper (the same
+// first-appearance numbering, a null being one more entry), fed every chunk of the input in order.
+// They are registered as meta functions: the finalize hook that lets the reference's vector kernels
+// share state across chunks (kernel.h:611-631) is not part of this mirror's VectorKernel.
+namespace {
+struct Hashed {
+  std::vector<std::shared_ptr<ArrayData>> ids;  // per chunk
+  std::shared_ptr<ArrayData> uniques;
+  uint32_t num_groups = 0;
+};
+Result<Hashed> HashChunks(const Datum& input, ExecContext* ctx, std::vector<std::shared_ptr<ArrayData>>* chunks) {
+  if (input.is_array()) *chunks = {input.array()};
+  else if (input.kind() == Datum::CHUNKED_ARRAY) *chunks = input.chunked_array()->chunks();
+  else return Status::NotImplemented("hash kernels take arrays and chunked arrays");
+  auto type = input.type();
+  if (!type || type->bit_width() < 0 || type->id() == Type::HALF_FLOAT) return Status::NotImplemented("hash kernels: fixed-width types only");
+  AMD_ASSIGN_OR_RAISE(auto grouper, Grouper::Make({ValueDescr::Array(type)}, ctx));
+  Hashed h;
+  for (const auto& c : *chunks) {
+    AMD_ASSIGN_OR_RAISE(auto batch, ExecBatch::Make({Datum(c)}));
+    AMD_ASSIGN_OR_RAISE(Datum ids, grouper->Consume(batch));
+    h.ids.push_back(ids.array());
+  }
+  AMD_ASSIGN_OR_RAISE(auto uniques, grouper->GetUniques());
+  h.uniques = uniques.values[0].array();
+  h.num_groups = grouper->num_groups();
+  return h;
+}
+class UniqueFunction : public MetaFunction {
+ public:
+  UniqueFunction() : MetaFunction("unique", Arity::Unary()) {}
+  Result<Datum> ExecuteImpl(const std::vector<Datum>& args, const FunctionOptions*, ExecContext* ctx) const override {
+    std::vector<std::shared_ptr<ArrayData>> chunks;
+    AMD_ASSIGN_OR_RAISE(auto h, HashChunks(args[0], ctx, &chunks));
+    return Datum(h.uniques);  // UniqueFinalize :617-623
+  }
+};
+class ValueCountsFunction : public MetaFunction {
+ public:
+  ValueCountsFunction() : MetaFunction("value_counts", Arity::Unary()) {}
+  Result<Datum> ExecuteImpl(const std::vector<Datum>& args, const FunctionOptions*, ExecContext* ctx) const override {
+    std::vector<std::shared_ptr<ArrayData>> chunks;
+    AMD_ASSIGN_OR_RAISE(auto h, HashChunks(args[0], ctx, &chunks));
+    // ValueCountsAction :91-160: rows per memo index, nulls counted -- hash_count over the ids themselves
+    AMD_ASSIGN_OR_RAISE(auto counts, AllocateBuffer(8 * std::max<int64_t>(h.num_groups, 1), ctx->memory_pool()));
+    AMD_ASSIGN_OR_RAISE(auto scratch_sums, AllocateBuffer(8 * std::max<int64_t>(h.num_groups, 1), ctx->memory_pool()));
+    amdarrow_ctx* abi = ctx->memory_pool()->ctx();
+    int rc = amdarrow_memset(abi, counts->mutable_data(), 0, 8 * std::max<int64_t>(h.num_groups, 1));
+    if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+    for (const auto& ids : h.ids) {
+      amdarrow_array v = ids->abi();
+      rc = amdarrow_hash_accumulate(abi, AMDARROW_HASH_COUNT, &v, reinterpret_cast<const uint32_t*>(ids->buffers[1]->data()) + ids->offset,
+                                    AMDARROW_COUNT_NON_NULL, scratch_sums->mutable_data(), reinterpret_cast<int64_t*>(counts->mutable_data()));
+      if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+    }
+    rc = amdarrow_ctx_synchronize(abi);
+    if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+    auto out = ArrayData::Make(struct_(), h.num_groups, {nullptr, nullptr}, 0);  // BoxValueCounts :634-640
+    out->child_names = {"values", "counts"};
+    out->child_data = {h.uniques, ArrayData::Make(int64(), h.num_groups, {nullptr, counts}, 0)};
+    return Datum(out);
+  }
+};
+class DictionaryEncodeFunction : public MetaFunction {
+ public:
+  DictionaryEncodeFunction() : MetaFunction("dictionary_encode", Arity::Unary(), {}, &kDefaults) {}
+  Result<Datum> ExecuteImpl(const std::vector<Datum>& args, const FunctionOptions* options, ExecContext* ctx) const override {
+    const auto* opts = static_cast<const DictionaryEncodeOptions*>(options);
+    const bool mask = !opts || opts->null_encoding_behavior == DictionaryEncodeOptions::MASK;
+    std::vector<std::shared_ptr<ArrayData>> chunks;
+    AMD_ASSIGN_OR_RAISE(auto h, HashChunks(args[0], ctx, &chunks));
+    amdarrow_ctx* abi = ctx->memory_pool()->ctx();
+    std::shared_ptr<ArrayData> dict = h.uniques;
+    if (mask && dict->buffers[0]) {  // the dictionary holds no null: Filter(uniques, is_valid(uniques))
+      AMD_ASSIGN_OR_RAISE(Datum valid, CallFunction("is_valid", {Datum(dict)}, nullptr, ctx));
+      FilterOptions drop;
+      AMD_ASSIGN_OR_RAISE(Datum kept, CallFunction("array_filter", {Datum(dict), valid}, &drop, ctx));
+      dict = ArrayData::Make(dict->type, kept.array()->length, {nullptr, kept.array()->buffers[1]}, 0);
+    }
+    std::vector<std::shared_ptr<ArrayData>> out_chunks;
+    for (const auto& ids : h.ids) {
+      std::shared_ptr<ArrayData> indices;
+      if (!mask) {  // ENCODE: the ids are the indices (uint32 < 2^31 reads as int32)
+        indices = ArrayData::Make(dictionary_(), ids->length, {nullptr, ids->buffers[1]}, 0, ids->offset);
+      } else {
+        AMD_ASSIGN_OR_RAISE(auto ibuf, AllocateBuffer(4 * ids->length, ctx->memory_pool()));
+        AMD_ASSIGN_OR_RAISE(auto nbuf, AllocateBitmap(ids->length, ctx->memory_pool()));
+        amdarrow_out o;
+        const int rc = amdarrow_dictionary_indices(abi, reinterpret_cast<const uint32_t*>(ids->buffers[1]->data()) + ids->offset, ids->length,
+                                                   h.uniques->buffers[0] ? h.uniques->buffers[0]->data() : nullptr, h.num_groups,
+                                                   reinterpret_cast<int32_t*>(ibuf->mutable_data()), nbuf->mutable_data(), &o);
+        if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+        indices = ArrayData::Make(dictionary_(), ids->length, {o.has_validity ? nbuf : nullptr, ibuf}, o.null_count);
+      }
+      indices->dictionary = dict;  // DictEncodeFinalize :625-636: every chunk shares the final dictionary
+      out_chunks.push_back(std::move(indices));
+    }
+    if (args[0].is_array()) return Datum(out_chunks[0]);
+    return Datum(std::make_shared<ChunkedArray>(std::move(out_chunks), dictionary_()));
+  }
+  static DictionaryEncodeOptions kDefaults;
+};
+DictionaryEncodeOptions DictionaryEncodeFunction::kDefaults = DictionaryEncodeOptions::Defaults();
+}  // namespace
+
+void RegisterVectorHash(FunctionRegistry* registry) {
+  (void)registry->AddFunction(std::make_shared<UniqueFunction>());
+  (void)registry->AddFunction(std::make_shared<ValueCountsFunction>());
+  (void)registry->AddFunction(std::make_shared<DictionaryEncodeFunction>());
+}
+
 // ---- GroupBy (hash_aggregate.cc:890-966) -----------------------------------------------------------------
 namespace {
 // The fused device path (amdarrow_filter_groupby without a mask: partitioned LDS tables, 1 pass per

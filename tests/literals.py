@@ -145,6 +145,24 @@ def run_all(api, skip_grouper_multi_batch=False):
         got = api.sort_indices_multi(keys, [ASC if o == "ascending" else DESC for o in c["orders"]])
         if got.tolist() != c["indices"]:
             fails.append("%s: got %s" % (c["source"], got.tolist()))
+    for grp in lit["vector_hash"]:
+        for t in TYPE_GROUPS[grp["types"]]:
+            for c in grp["cases"]:
+                a = arr(t, c["values"])
+                if "slice" in c:
+                    a = Arr(t, a.data, a.valid, c["slice"][0], c["slice"][1])
+                if grp["fn"] == "unique":
+                    u = api.unique(a)
+                    check(grp["source"], logical(u.values, u.validity() if u.has_validity else np.ones(u.length, bool)), expect(t, c["unique"]))
+                elif grp["fn"] == "value_counts":
+                    u, n = api.value_counts(a)
+                    check(grp["source"], logical(u.values, u.validity() if u.has_validity else np.ones(u.length, bool)), expect(t, c["unique"]))
+                    check(grp["source"] + " counts", list(n.tolist()), c["counts"])
+                else:
+                    i, dic = api.dictionary_encode(a, 1)
+                    check(grp["source"] + " dictionary", logical(dic.values, np.ones(dic.length, bool)), expect(t, c["dictionary"]))
+                    check(grp["source"] + " indices", logical(i.values, i.validity() if i.has_validity else np.ones(i.length, bool)),
+                          expect(orc.INT32, c["indices"]))
     for grp in lit["grouper"]:
         for t in TYPE_GROUPS[grp["types"]]:
             batches = [[arr(t, b["keys"])] for b in grp["batches"]]
