@@ -43,6 +43,7 @@ struct amdarrow_ctx {
   void* pinned_dev = nullptr;  // the same memory as the device sees it (kernels may store status words there)
   hipEvent_t status_event = nullptr;  // marks the kernel that stored them
   int num_cus = 256;
+  int lds_rank_ordered = -1;  // sort.hip LdsAtomicsLaneOrdered(): -1 not probed yet, 0 no, 1 yes
   int64_t bytes_allocated = 0;
   int64_t max_memory = 0;
   std::unordered_map<void*, int64_t> allocs;

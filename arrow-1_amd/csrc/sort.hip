@@ -406,7 +406,13 @@ __global__ __launch_bounds__(kThreads) void k_digit_bases(const unsigned int* gh
 constexpr int kOThreads = 256;            // one-sweep block
 constexpr int kOWaves = kOThreads / 64;
 
-template <typename KeyT, bool LAST>
+// ARANK: a key's rank among the keys of its wave with the same digit is what the LDS atomic that
+// counts it returns -- the hardware serves the lanes of one ds_add_rtn in ascending lane order and a
+// wave's LDS operations in program order, so the returned counts follow (step, lane) order, which
+// is the stable order.  That ordering is not an architectural promise: LdsAtomicsLaneOrdered()
+// checks it on the device once per context, and the ballot-based match-any ranking (!ARANK, ~10x
+// the instructions) stays as the variant for a device that fails the check.
+template <typename KeyT, bool LAST, bool ARANK>
 __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_in, const uint32_t* idx_in, int64_t n, int shift,
                                                               const uint32_t* dbase /* [256] of this pass */,
                                                               uint32_t* lookback /* [nblocks][256], zeroed */,
@@ -438,10 +444,14 @@ __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_i
       idx[j] = idx_in[base + li];
     }
   }
+  uint32_t rk[ARANK ? kIters : 1];
 #pragma unroll
   for (int j = 0; j < kIters; ++j) {
     const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
-    if (li < count) atomicAdd(&s_whist[wave][(key[j] >> shift) & 255], 1u);
+    if (li < count) {
+      const uint32_t r = atomicAdd(&s_whist[wave][(key[j] >> shift) & 255], 1u);
+      if (ARANK) rk[ARANK ? j : 0] = r;
+    }
   }
   __syncthreads();
   uint32_t tot = 0;
@@ -477,6 +487,14 @@ __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_i
     const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
     const bool live = li < count;
     const uint32_t d = (key[j] >> shift) & 255;
+    if (ARANK) {
+      if (live) {
+        const uint32_t lpos = s_whist[wave][d] + rk[ARANK ? j : 0];
+        s_keys[lpos] = key[j];
+        s_idx[lpos] = idx[j];
+      }
+      continue;
+    }
     // match-any on the 8 digit bits among live lanes
     uint64_t m = __ballot(live);
 #pragma unroll
@@ -551,6 +569,180 @@ __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_i
   }
 }
 
+// ---- windowed LDS sort: the tail of the hybrid sort ---------------------------------------------------
+// After one-sweep passes over the TOP digits only, the keys are ordered by those digits and every
+// run of equal top digits ("segment") still has to be ordered by the remaining ones.  For spread-out
+// keys the segments are short, so the rest of the sort never has to touch HBM again: a workgroup
+// takes the segments that START inside its tile of kWTile positions (at most kWSpan keys: the tile
+// plus the tail of its last segment), sorts them in LDS by every digit that varies among them --
+// LSD passes with the same match-any ranking as the global passes, stable -- and writes the row
+// indices out.  Whole segments only, hence independent of the neighbours.  A segment longer than
+// kWSpan - kWTile is reported through `error`; the host then redoes the sort with LSD passes only.
+constexpr int kWThreads = 256;  // 512 / 1024 threads per window measured within 8 %: the kernel is bound by LDS traffic
+constexpr int kWWaves = kWThreads / 64;
+constexpr int kWTile = 2048;
+constexpr int kWSpan = 4096;
+struct WindowDigits { int n; int shift[8]; };
+
+template <typename KeyT, bool ARANK>
+__global__ __launch_bounds__(kWThreads) void k_window_sort(const KeyT* keys, const uint32_t* idx_in, int64_t n, KeyT top_mask,
+                                                          WindowDigits digits, unsigned int* error, uint64_t* out64) {
+  constexpr int kIters = kWSpan / kWThreads;  // 16; wave w owns local positions [w*1024, (w+1)*1024), in order
+  __shared__ KeyT s_keys[kWSpan];
+  __shared__ uint32_t s_idx[kWSpan];
+  __shared__ uint32_t s_whist[kWWaves][256];
+  __shared__ uint32_t s_scan[4];
+  __shared__ uint32_t s_lo, s_hi;
+  __shared__ KeyT s_or, s_and;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t p0 = int64_t(blockIdx.x) * kWTile;
+  const int64_t left = n - p0;
+  const uint32_t cand = left >= kWSpan ? kWSpan : static_cast<uint32_t>(left);  // candidate keys [p0, p0 + cand)
+  if (tid == 0) { s_lo = kWSpan; s_hi = kWSpan; s_or = 0; s_and = ~KeyT(0); }
+
+  KeyT key[kIters];
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+    key[j] = li < cand ? keys[p0 + li] : KeyT(0);
+    s_keys[li] = key[j];
+  }
+  const KeyT before = p0 > 0 ? keys[p0 - 1] : KeyT(0);
+  __syncthreads();
+  // segment heads: lo = first head inside the tile, hi = first head at or after the tile's end
+  uint32_t lo = kWSpan, hi = kWSpan;
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+    if (li < cand) {
+      const KeyT prev = li > 0 ? s_keys[li - 1] : before;
+      const bool head = (p0 + li == 0) || ((prev ^ key[j]) & top_mask) != 0;
+      if (head && li < kWTile && li < lo) lo = li;
+      if (head && li >= kWTile && li < hi) hi = li;
+    }
+  }
+  if (lo < kWSpan) atomicMin(&s_lo, lo);
+  if (hi < kWSpan) atomicMin(&s_hi, hi);
+  __syncthreads();
+  lo = s_lo;
+  hi = s_hi;
+  if (lo == kWSpan) return;  // no segment starts here: an earlier tile owns these keys
+  if (hi == kWSpan) {
+    if (p0 + cand < n) {  // the last segment runs past the window
+      if (tid == 0) __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    hi = cand;  // the input ends inside the window
+  }
+  const uint32_t count = hi - lo;
+  // bring the window to local positions [0, count): keys from LDS, their row indices from memory
+  uint32_t idx[kIters];
+  KeyT k_or = 0, k_and = ~KeyT(0);
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+    const bool live = li < count;
+    key[j] = live ? s_keys[lo + li] : KeyT(0);
+    idx[j] = live ? idx_in[p0 + lo + li] : 0u;
+    if (live) { k_or |= key[j]; k_and &= key[j]; }
+  }
+  // bits that differ somewhere in the window: a digit without any is already in order
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    k_or |= __shfl_xor(k_or, o);
+    k_and &= __shfl_xor(k_and, o);
+  }
+  if (lane == 0) {
+    if (sizeof(KeyT) == 8) {
+      atomicOr(reinterpret_cast<unsigned long long*>(&s_or), static_cast<unsigned long long>(k_or));
+      atomicAnd(reinterpret_cast<unsigned long long*>(&s_and), static_cast<unsigned long long>(k_and));
+    } else {
+      atomicOr(reinterpret_cast<unsigned int*>(&s_or), static_cast<unsigned int>(k_or));
+      atomicAnd(reinterpret_cast<unsigned int*>(&s_and), static_cast<unsigned int>(k_and));
+    }
+  }
+  __syncthreads();
+  const KeyT varying = s_or ^ s_and;
+
+  for (int p = 0; p < digits.n; ++p) {
+    const int shift = digits.shift[p];
+    if (((varying >> shift) & 255) == 0) continue;
+    for (int i = tid; i < kWWaves * 256; i += kWThreads) (&s_whist[0][0])[i] = 0;
+    __syncthreads();
+    uint32_t rk[ARANK ? kIters : 1];
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+      if (li < count) {
+        const uint32_t r = atomicAdd(&s_whist[wave][(key[j] >> shift) & 255], 1u);
+        if (ARANK) rk[ARANK ? j : 0] = r;  // rank among this wave's keys of the digit, in (step, lane) order
+      }
+    }
+    __syncthreads();
+    {  // thread d < 256: exclusive scan over digits, then per-wave bases of digit d
+      uint32_t c[kWWaves], tot = 0;
+      uint32_t incl = 0;
+      if (tid < 256) {
+#pragma unroll
+        for (int w = 0; w < kWWaves; ++w) { c[w] = s_whist[w][tid]; tot += c[w]; }
+        incl = WaveInclusiveScan(tot);
+        if (lane == 63) s_scan[wave] = incl;
+      }
+      __syncthreads();
+      if (tid < 256) {
+        uint32_t run = incl - tot;
+        for (int w = 0; w < wave; ++w) run += s_scan[w];
+#pragma unroll
+        for (int w = 0; w < kWWaves; ++w) { s_whist[w][tid] = run; run += c[w]; }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+      if (wave * (kIters * 64) + j * 64 >= count) continue;  // no live key in this step (wave-uniform)
+      const bool live = li < count;
+      const uint32_t d = (key[j] >> shift) & 255;
+      if (ARANK) {
+        if (live) {
+          const uint32_t lpos = s_whist[wave][d] + rk[ARANK ? j : 0];
+          s_keys[lpos] = key[j];
+          s_idx[lpos] = idx[j];
+        }
+        continue;
+      }
+      uint64_t m = __ballot(live);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const uint64_t bb = __ballot((d >> b) & 1);
+        m &= ((d >> b) & 1) ? bb : ~bb;
+      }
+      if (live) {
+        const uint32_t rank = RankBelowLane(m);
+        const uint32_t old = s_whist[wave][d];
+        __builtin_amdgcn_wave_barrier();
+        if (rank == 0) s_whist[wave][d] = old + __popcll(m);
+        const uint32_t lpos = old + rank;
+        s_keys[lpos] = key[j];
+        s_idx[lpos] = idx[j];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+      if (li < count) { key[j] = s_keys[li]; idx[j] = s_idx[li]; }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+    if (li < count) out64[p0 + lo + li] = idx[j];
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void k_widen_indices(const uint32_t* idx, int64_t n, uint64_t* out) {
   for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < n; i += int64_t(gridDim.x) * kThreads) out[i] = idx[i];
 }
@@ -565,10 +757,70 @@ int ScanU32InPlace(amdarrow_ctx* ctx, uint32_t* data, int64_t n, uint32_t* sums,
   return AMDARROW_OK;
 }
 
+// One workgroup ranks pseudo-random digits (uniform over 256 values, over 4 values, all equal) both
+// ways and counts the keys whose atomic rank differs from the match-any rank.
+__global__ __launch_bounds__(256) void k_probe_lds_rank(unsigned int* mismatches) {
+  __shared__ uint32_t s_cnt[4][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned int bad = 0;
+  for (int round = 0; round < 24; ++round) {
+    for (int i = tid; i < 4 * 256; i += 256) (&s_cnt[0][0])[i] = 0;
+    __syncthreads();
+    uint32_t d[8], rk[8], seen[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      uint32_t x = (round * 8 + j) * 256 + tid;
+      x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+      d[j] = round % 3 == 0 ? (x & 255) : round % 3 == 1 ? (x & 3) : 7u;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rk[j] = atomicAdd(&s_cnt[wave][d[j]], 1u);
+    __syncthreads();
+    for (int i = tid; i < 4 * 256; i += 256) (&s_cnt[0][0])[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      uint64_t m = ~uint64_t(0);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const uint64_t bb = __ballot((d[j] >> b) & 1);
+        m &= ((d[j] >> b) & 1) ? bb : ~bb;
+      }
+      const uint32_t rank = RankBelowLane(m);
+      const uint32_t old = s_cnt[wave][d[j]];
+      __builtin_amdgcn_wave_barrier();
+      if (rank == 0) s_cnt[wave][d[j]] = old + __popcll(m);
+      __builtin_amdgcn_wave_barrier();
+      seen[j] = old + rank;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bad += rk[j] != seen[j];
+    __syncthreads();
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+
+// Does an LDS atomic hand out its return values in lane order on this device (see k_radix_onesweep)?
+// Checked once per context; any mismatch -- or a failed launch -- selects the ballot ranking.
+static bool LdsAtomicsLaneOrdered(amdarrow_ctx* ctx) {
+  if (ctx->lds_rank_ordered < 0) {
+    ctx->lds_rank_ordered = 0;
+    void* base;
+    if (!getenv("AMDARROW_SORT_BALLOT_RANK") && Scratch(ctx, 256, &base) == AMDARROW_OK &&
+        hipMemsetAsync(base, 0, 4, ctx->stream) == hipSuccess) {
+      hipLaunchKernelGGL(k_probe_lds_rank, dim3(1), dim3(256), 0, ctx->stream, static_cast<unsigned int*>(base));
+      unsigned int bad = 1;
+      if (hipGetLastError() == hipSuccess && ReadBack(ctx, base, 4, &bad) == AMDARROW_OK && bad == 0) ctx->lds_rank_ordered = 1;
+    }
+  }
+  return ctx->lds_rank_ordered == 1;
+}
+
 template <typename KeyT>
 static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks, int type_id, int order, int64_t n,
-                    uint64_t* out, const uint64_t* perm = nullptr, bool allow_onesweep = true) {
+                    uint64_t* out, const uint64_t* perm = nullptr, bool allow_onesweep = true, bool allow_hybrid = true) {
   constexpr int kPasses = sizeof(KeyT);
+  const bool arank = LdsAtomicsLaneOrdered(ctx);  // before the arena is carved: the probe borrows it
   const int key_bits = BitWidth(type_id);
   const KeyT key_mask = key_bits >= static_cast<int>(8 * sizeof(KeyT)) ? ~KeyT(0) : ((KeyT(1) << key_bits) - 1);
   const KeyT flip = order == AMDARROW_DESCENDING ? key_mask : 0;  // Descending = complemented key
@@ -600,7 +852,7 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   const size_t o_sums = cv.Take(4 * scan_nb);
   const size_t o_sumoff = cv.Take(8 * (scan_nb + 1));
   const size_t o_dbase = cv.Take(4 * 256 * kPasses);
-  const size_t o_ctl = cv.Take(256);  // [15] error word of the one-sweep passes
+  const size_t o_ctl = cv.Take(256);  // [14] error word of the window sort, [15] of the one-sweep passes
   const size_t o_lookback = cv.Take(4 * static_cast<size_t>(hist_n) * kPasses);
   void* base;
   AA_TRY(Scratch(ctx, cv.off, &base));
@@ -668,6 +920,34 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   const int64_t nb0 = (n0 + kRTile - 1) / kRTile;
   const int64_t hn0 = 256 * nb0;
   const bool onesweep = allow_onesweep && n0 < (int64_t(1) << 30) && !getenv("AMDARROW_SORT_THREE_KERNEL");
+  // Hybrid: one-sweep passes over the top `top` active digits only, the rest in LDS (k_window_sort).
+  // Worth it when it saves at least two passes over HBM, and possible when the runs of equal top
+  // digits are short.  Their length is estimated from the digit histograms as if the digits were
+  // independent (n0 x the largest share of each top digit); the window kernel checks the real
+  // lengths and reports a run that does not fit, in which case the sort is redone without it.
+  int top = 0;
+  const char* min_env = getenv("AMDARROW_SORT_HYBRID_MIN");  // testing knob: smallest input that takes the hybrid path
+  const int64_t hybrid_min = min_env ? atoll(min_env) : (int64_t(1) << 21);
+  if (onesweep && allow_hybrid && n0 >= hybrid_min && !getenv("AMDARROW_SORT_NO_HYBRID")) {
+    for (int m = 2; m <= 4 && top == 0; ++m) {
+      if (static_cast<int>(active.size()) < m + 2) break;
+      double expected = static_cast<double>(n0);
+      for (int q = 0; q < m; ++q) {
+        const int p = active[active.size() - 1 - q];
+        unsigned int mx = 0;
+        for (int d = 0; d < 256; ++d) mx = std::max(mx, h[p * 256 + d]);
+        expected *= static_cast<double>(mx) / static_cast<double>(n0);
+      }
+      if (expected <= 0.8 * (kWSpan - kWTile)) top = m;
+    }
+  }
+  WindowDigits wd{};
+  KeyT top_mask = 0;
+  if (top) {
+    for (int p : active) wd.shift[wd.n++] = 8 * p;
+    for (int q = 0; q < top; ++q) top_mask |= KeyT(255) << (8 * active[active.size() - 1 - q]);
+    active.erase(active.begin(), active.end() - top);  // the global passes: the top digits, lowest first
+  }
   if (onesweep) {
     hipLaunchKernelGGL(k_digit_bases, dim3(kPasses), dim3(kThreads), 0, ctx->stream, ghist, dbase);
     AA_HIP(hipGetLastError());
@@ -676,16 +956,14 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   }
   for (size_t a = 0; a < active.size(); ++a) {
     const int shift = 8 * active[a];
-    const bool last = a + 1 == active.size();
+    const bool last = a + 1 == active.size() && !top;
     if (onesweep) {
       uint32_t* lb = lookback + static_cast<size_t>(hn0) * a;
       const uint32_t* db = dbase + 256 * active[a];
-      if (last)
-        hipLaunchKernelGGL((k_radix_onesweep<KeyT, true>), dim3(static_cast<unsigned>(nb0)), dim3(kOThreads), 0, ctx->stream,
-                           keys_a, idx_a, n0, shift, db, lb, ctl + 15, keys_b, idx_b, out);
-      else
-        hipLaunchKernelGGL((k_radix_onesweep<KeyT, false>), dim3(static_cast<unsigned>(nb0)), dim3(kOThreads), 0, ctx->stream,
-                           keys_a, idx_a, n0, shift, db, lb, ctl + 15, keys_b, idx_b, out);
+      auto* pass = last ? (arank ? k_radix_onesweep<KeyT, true, true> : k_radix_onesweep<KeyT, true, false>)
+                        : (arank ? k_radix_onesweep<KeyT, false, true> : k_radix_onesweep<KeyT, false, false>);
+      hipLaunchKernelGGL(pass, dim3(static_cast<unsigned>(nb0)), dim3(kOThreads), 0, ctx->stream, keys_a, idx_a, n0, shift, db, lb,
+                         ctl + 15, keys_b, idx_b, out);
       AA_HIP(hipGetLastError());
       std::swap(keys_a, keys_b);
       std::swap(idx_a, idx_b);
@@ -705,10 +983,17 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
     std::swap(keys_a, keys_b);
     std::swap(idx_a, idx_b);
   }
+  if (top) {
+    auto* window = arank ? k_window_sort<KeyT, true> : k_window_sort<KeyT, false>;
+    hipLaunchKernelGGL(window, dim3(static_cast<unsigned>((n0 + kWTile - 1) / kWTile)), dim3(kWThreads), 0, ctx->stream, keys_a, idx_a,
+                       n0, top_mask, wd, ctl + 14, out);
+    AA_HIP(hipGetLastError());
+  }
   if (onesweep) {
-    unsigned int err = 0;
-    AA_TRY(ReadBack(ctx, ctl + 15, 4, &err));
-    if (err) return SortImpl<KeyT>(ctx, chunks, nchunks, type_id, order, n, out, perm, /*allow_onesweep=*/false);
+    unsigned int err[2] = {0, 0};  // [0] a run of equal top digits too long for the window, [1] a one-sweep pass gave up
+    AA_TRY(ReadBack(ctx, ctl + 14, 8, err));
+    if (err[1]) return SortImpl<KeyT>(ctx, chunks, nchunks, type_id, order, n, out, perm, /*allow_onesweep=*/false, false);
+    if (err[0]) return SortImpl<KeyT>(ctx, chunks, nchunks, type_id, order, n, out, perm, /*allow_onesweep=*/true, /*allow_hybrid=*/false);
   }
   return AMDARROW_OK;
 }

@@ -787,3 +787,41 @@ def test_unique_value_counts_dictionary_encode_random(gpu, oracle, t):
             (i1, d1), (i2, d2) = gpu.dictionary_encode(a, ne), oracle.dictionary_encode(a, ne)
             assert i1.same_valid(i2), (t, n, p, ne, i1, i2)
             assert d1.same_valid(d2), (t, n, p, ne, d1, d2)
+
+
+# ---- hybrid sort: global passes over the top digits, the rest in LDS windows ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", NUMERIC)
+def test_sort_hybrid_windows_match_oracle(gpu, oracle, t, monkeypatch):
+    """The hybrid path forced onto small inputs (AMDARROW_SORT_HYBRID_MIN) so that every shape is
+    checked against the oracle: spread-out keys (hybrid taken), clustered keys whose runs overflow
+    the window (detected, redone with LSD passes), ties, NaN / null tails, descending, chunked."""
+    monkeypatch.setenv("AMDARROW_SORT_HYBRID_MIN", "1")
+    rng = np.random.default_rng(200 + t)
+    info = None if t in (FLOAT, DOUBLE) else np.iinfo(orc.NP_OF[t])
+    for n in (5000, 70_000, 300_000):
+        for shape in ("full", "ties", "clustered", "nulls"):
+            if info is not None:
+                if shape == "clustered":  # few distinct top digits, many distinct low ones: long runs of equal top digits
+                    d = (rng.integers(0, 3, n) * (int(info.max) // 4) + rng.integers(0, 200, n)).astype(orc.NP_OF[t])
+                elif shape == "ties":
+                    d = rng.integers(info.min, info.max, n // 50 + 1, endpoint=True, dtype=orc.NP_OF[t])[rng.integers(0, n // 50 + 1, n)]
+                else:
+                    d = rng.integers(info.min, info.max, n, endpoint=True, dtype=orc.NP_OF[t])
+            else:
+                d = (rng.standard_normal(n) * 10.0 ** rng.integers(-30, 30, n)).astype(orc.NP_OF[t])
+                if shape == "clustered":
+                    d = (rng.random(n) + 1.0).astype(orc.NP_OF[t])
+                elif shape == "ties":
+                    d = d[rng.integers(0, n // 50 + 1, n)]
+                d[rng.random(n) < 0.01] = np.nan
+                d[rng.random(n) < 0.01] = -0.0
+            a = Arr(t, d, (rng.random(n) > 0.05) if shape == "nulls" else None)
+            for order in (ASC, DESC):
+                assert np.array_equal(gpu.sort_indices(a, order), oracle.sort_indices(a, order)), (t, n, shape, order)
+        chunks = [R(rng, t, m, .05, k) for k, m in enumerate([n // 2, 0, n // 3, 7])]
+        assert np.array_equal(gpu.sort_indices(chunks, ASC), oracle.sort_indices(chunks, ASC))
+    if t in (INT64, DOUBLE):  # two keys: the second stage visits the rows through the first stage's permutation
+        k1 = Arr(INT32, rng.integers(-2**31, 2**31, 60_000))
+        k2 = Arr(t, rng.integers(0, 5, 60_000).astype(orc.NP_OF[t]))
+        assert np.array_equal(gpu.sort_indices_multi([k2, k1], [ASC, DESC]), oracle.sort_indices_multi([k2, k1], [ASC, DESC]))
