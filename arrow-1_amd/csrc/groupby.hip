@@ -2184,6 +2184,21 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
   const bool fast_ok = ks.total_bits <= 32 && n >= (int64_t(1) << 18) && n < (int64_t(1) << 30);
   int path = fast_ok ? 3 : 0;  // 3 = local pre-aggregation with the partition path queued behind it
   if (const char* env = getenv("AMDARROW_GROUPBY_PATH")) path = std::min(path, atoi(env));
+  // Path 3 first tries to pre-aggregate every row range in LDS and looks for heavy hitters; with many
+  // evenly spread groups both give up (~60 us of kernels and launches for nothing).  A call of the
+  // same shape as the last one that went that way starts at the partition path directly; if its
+  // capacity assumption then fails (the data changed character) the call starts over at path 3, and
+  // every 16th hinted call takes path 3 anyway so that a change for the better is noticed too.
+  amdarrow_ctx::GroupByHint shape;
+  shape.n = n; shape.key_type = keys->type_id; shape.value_type = values ? values->type_id : 0;
+  shape.has_mask = mask != nullptr; shape.has_value_validity = values && values->validity != nullptr;
+  auto& hint = ctx->gb_hint;
+  bool hinted = false;
+  if (path == 3 && hint.n == shape.n && hint.key_type == shape.key_type && hint.value_type == shape.value_type &&
+      hint.has_mask == shape.has_mask && hint.has_value_validity == shape.has_value_validity &&
+      !getenv("AMDARROW_GROUPBY_PATH") && !getenv("AMDARROW_GROUPBY_NO_HINT")) {
+    if (++hint.uses % 16 != 0) { path = 2; hinted = true; }
+  }
   const bool headline_shape = ks.total_bits == 32 && k_load_bits == 32 && !keys->validity && values &&
                               BitWidth(values->type_id) == 64 && !m_valid;
   GroupTable t{};
@@ -2383,6 +2398,12 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
 #endif
     memcpy(&G, status + 6, 8);
     const unsigned int overflow = status[0];
+    if (overflow && fast && hinted) {  // the hint was wrong for this input: forget it, start over with the full path 3
+      hinted = false;
+      hint.n = -1;
+      path = 4;  // -> 3 after the loop's decrement
+      continue;
+    }
     if (overflow && fast) {  // capacity assumption failed: next (more general) path
       if (path == 3) path = 2;  // the partition attempt was part of path 3
       if (overflow == kOverflowTable) {
@@ -2397,6 +2418,11 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
     if (overflow || G > group_capacity)
       return SetError(AMDARROW_CAPACITY_ERROR,
                       "group-by: more than group_capacity = " + std::to_string(group_capacity) + " groups");
+    if (path == 3 && !hinted) {
+      // status[1]: the local pre-aggregation gave up; status[5]: heavy hitters were taken out
+      if (status[1] != 0 && status[5] == 0 && sub_bits == 0) { shape.uses = hint.n == shape.n ? hint.uses : 0; hint = shape; }
+      else hint.n = -1;
+    }
     *out_num_groups = G;
     break;
   }

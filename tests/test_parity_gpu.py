@@ -825,3 +825,25 @@ def test_sort_hybrid_windows_match_oracle(gpu, oracle, t, monkeypatch):
         k1 = Arr(INT32, rng.integers(-2**31, 2**31, 60_000))
         k2 = Arr(t, rng.integers(0, 5, 60_000).astype(orc.NP_OF[t]))
         assert np.array_equal(gpu.sort_indices_multi([k2, k1], [ASC, DESC]), oracle.sort_indices_multi([k2, k1], [ASC, DESC]))
+
+
+@pytest.mark.gpu
+def test_filter_groupby_path_hint_follows_the_data(gpu, oracle):
+    """Calls of one shape in a row: many spread-out groups (the hint is learnt and the next calls start
+    at the partition path), then the same shape with a heavy hitter (the hinted path overflows its
+    regions and the call starts over), then few groups (local path), then spread-out again.  Every
+    call returns the reference's rows; 20 calls in a row cross the periodic re-probe."""
+    rng = np.random.default_rng(77)
+    n = 2_000_000
+
+    def data(kind):
+        base = rng.integers(0, 300_000, n)
+        if kind == "hot":
+            base[rng.random(n) < 0.4] = 11
+        elif kind == "few":
+            base = rng.integers(0, 500, n)
+        return R(rng, INT64, n, 0.0, 0), Arr(INT32, base), R(rng, BOOL, n, 0.0, 0)
+    for kind in ["spread", "spread", "spread", "hot", "hot", "few", "spread", "few", "spread"] + ["spread"] * 20:
+        v, k, m = data(kind)
+        for x, y in zip(oracle.filter_groupby_sum(v, k, m), gpu.filter_groupby_sum(v, k, m)):
+            assert np.array_equal(x, y), kind
