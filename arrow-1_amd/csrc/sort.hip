@@ -578,10 +578,13 @@ __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_i
 // LSD passes with the same match-any ranking as the global passes, stable -- and writes the row
 // indices out.  Whole segments only, hence independent of the neighbours.  A segment longer than
 // kWSpan - kWTile is reported through `error`; the host then redoes the sort with LSD passes only.
-constexpr int kWThreads = 256;  // 512 / 1024 threads per window measured within 8 %: the kernel is bound by LDS traffic
+constexpr int kWThreads = 256;  // 512 / 1024 threads per window measure 8 % slower
 constexpr int kWWaves = kWThreads / 64;
 constexpr int kWTile = 2048;
 constexpr int kWSpan = 4096;
+constexpr int kWBucketBits = 12;
+constexpr int kWBuckets = 1 << kWBucketBits;  // buckets of the window's one-pass sort
+constexpr int kWMaxBucket = 24;             // more keys than this in one bucket: LSD passes instead
 struct WindowDigits { int n; int shift[8]; };
 
 template <typename KeyT, bool ARANK>
@@ -589,25 +592,34 @@ __global__ __launch_bounds__(kWThreads) void k_window_sort(const KeyT* keys, con
                                                           WindowDigits digits, unsigned int* error, uint64_t* out64) {
   constexpr int kIters = kWSpan / kWThreads;  // 16; wave w owns local positions [w*1024, (w+1)*1024), in order
   __shared__ KeyT s_keys[kWSpan];
-  __shared__ uint32_t s_idx[kWSpan];
+  __shared__ uint32_t s_idx[kWSpan];  // LSD passes: the row indices; bucket pass: 16-bit bucket counters + 16-bit positions
   __shared__ uint32_t s_whist[kWWaves][256];
-  __shared__ uint32_t s_scan[4];
-  __shared__ uint32_t s_lo, s_hi;
-  __shared__ KeyT s_or, s_and;
+  __shared__ uint32_t s_scan[16];
+  __shared__ uint32_t s_lo, s_hi, s_big;
+  __shared__ KeyT s_or, s_and, s_min, s_max;
+  uint32_t* s_cnt2 = s_idx;                                             // kWBuckets / 2 words: two 16-bit counters each
+  uint16_t* s_pos = reinterpret_cast<uint16_t*>(s_idx + kWBuckets / 2);  // kWSpan window positions, in sorted order
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t p0 = int64_t(blockIdx.x) * kWTile;
   const int64_t left = n - p0;
   const uint32_t cand = left >= kWSpan ? kWSpan : static_cast<uint32_t>(left);  // candidate keys [p0, p0 + cand)
-  if (tid == 0) { s_lo = kWSpan; s_hi = kWSpan; s_or = 0; s_and = ~KeyT(0); }
+  if (tid == 0) { s_lo = kWSpan; s_hi = kWSpan; s_or = 0; s_and = ~KeyT(0); s_min = ~KeyT(0); s_max = 0; s_big = 0; }
 
   KeyT key[kIters];
+  uint32_t idx[kIters];
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {  // keys and row indices of every candidate in one round of loads
+    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+    key[j] = li < cand ? keys[p0 + li] : KeyT(0);
+    idx[j] = li < cand ? idx_in[p0 + li] : 0u;
+  }
+  const KeyT before = p0 > 0 ? keys[p0 - 1] : KeyT(0);
 #pragma unroll
   for (int j = 0; j < kIters; ++j) {
     const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
-    key[j] = li < cand ? keys[p0 + li] : KeyT(0);
     s_keys[li] = key[j];
+    s_idx[li] = idx[j];
   }
-  const KeyT before = p0 > 0 ? keys[p0 - 1] : KeyT(0);
   __syncthreads();
   // segment heads: lo = first head inside the tile, hi = first head at or after the tile's end
   uint32_t lo = kWSpan, hi = kWSpan;
@@ -635,34 +647,134 @@ __global__ __launch_bounds__(kWThreads) void k_window_sort(const KeyT* keys, con
     hi = cand;  // the input ends inside the window
   }
   const uint32_t count = hi - lo;
-  // bring the window to local positions [0, count): keys from LDS, their row indices from memory
-  uint32_t idx[kIters];
-  KeyT k_or = 0, k_and = ~KeyT(0);
+  // bring the window to local positions [0, count)
+  KeyT k_or = 0, k_and = ~KeyT(0), k_min = ~KeyT(0), k_max = 0;
 #pragma unroll
   for (int j = 0; j < kIters; ++j) {
     const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
     const bool live = li < count;
     key[j] = live ? s_keys[lo + li] : KeyT(0);
-    idx[j] = live ? idx_in[p0 + lo + li] : 0u;
-    if (live) { k_or |= key[j]; k_and &= key[j]; }
+    idx[j] = live ? s_idx[lo + li] : 0u;
+    if (live) {
+      k_or |= key[j]; k_and &= key[j];
+      k_min = key[j] < k_min ? key[j] : k_min;
+      k_max = key[j] > k_max ? key[j] : k_max;
+    }
   }
   // bits that differ somewhere in the window: a digit without any is already in order
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     k_or |= __shfl_xor(k_or, o);
     k_and &= __shfl_xor(k_and, o);
+    const KeyT a = __shfl_xor(k_min, o), b = __shfl_xor(k_max, o);
+    k_min = a < k_min ? a : k_min;
+    k_max = b > k_max ? b : k_max;
   }
   if (lane == 0) {
     if (sizeof(KeyT) == 8) {
       atomicOr(reinterpret_cast<unsigned long long*>(&s_or), static_cast<unsigned long long>(k_or));
       atomicAnd(reinterpret_cast<unsigned long long*>(&s_and), static_cast<unsigned long long>(k_and));
+      atomicMin(reinterpret_cast<unsigned long long*>(&s_min), static_cast<unsigned long long>(k_min));
+      atomicMax(reinterpret_cast<unsigned long long*>(&s_max), static_cast<unsigned long long>(k_max));
     } else {
       atomicOr(reinterpret_cast<unsigned int*>(&s_or), static_cast<unsigned int>(k_or));
       atomicAnd(reinterpret_cast<unsigned int*>(&s_and), static_cast<unsigned int>(k_and));
+      atomicMin(reinterpret_cast<unsigned int*>(&s_min), static_cast<unsigned int>(k_min));
+      atomicMax(reinterpret_cast<unsigned int*>(&s_max), static_cast<unsigned int>(k_max));
     }
   }
   __syncthreads();
   const KeyT varying = s_or ^ s_and;
+
+  // ---- bucket pass: ONE counting pass instead of one LSD pass per varying digit ----------------------
+  // bucket = (key - min) >> shift with shift such that the window's key range spans <= kWBuckets
+  // buckets: monotone in the key, so after the keys are grouped by bucket only the few keys that
+  // share a bucket are out of order, and every thread finishes its own stretch of the window with an
+  // insertion sort on (key, window position) -- the position makes the result stable whatever order
+  // the counting atomics handed out inside a bucket.  Spread-out keys put < 1 key in a bucket on
+  // average.  A crowded bucket (keys clustered inside the window) sends the window to the LSD passes.
+  {
+    const KeyT kmin = s_min, range = s_max - kmin;
+    const int bits = range == 0 ? 0 : (sizeof(KeyT) == 8 ? 64 - __clzll(static_cast<long long>(range)) : 32 - __clz(static_cast<int>(range)));
+    const int bshift = bits > kWBucketBits ? bits - kWBucketBits : 0;
+    for (int i = tid; i < kWBuckets / 2; i += kWThreads) s_cnt2[i] = 0;
+    __syncthreads();
+    uint32_t brank[kIters], bucket[kIters];
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+      bucket[j] = 0; brank[j] = 0;
+      if (li < count) {
+        bucket[j] = static_cast<uint32_t>((key[j] - kmin) >> bshift);
+        const int half = (bucket[j] & 1) * 16;
+        brank[j] = (atomicAdd(&s_cnt2[bucket[j] >> 1], 1u << half) >> half) & 0xFFFFu;
+      }
+    }
+    __syncthreads();
+    // exclusive scan of the bucket counts: thread t owns buckets [t * per, (t + 1) * per)
+    constexpr int kPer = kWBuckets / kWThreads;  // 16
+    uint32_t cnt[kPer], start = 0, biggest = 0;
+#pragma unroll
+    for (int q = 0; q < kPer / 2; ++q) {
+      const uint32_t w2 = s_cnt2[tid * (kPer / 2) + q];
+      cnt[2 * q] = w2 & 0xFFFFu; cnt[2 * q + 1] = w2 >> 16;
+      start += cnt[2 * q] + cnt[2 * q + 1];
+      biggest = cnt[2 * q] > biggest ? cnt[2 * q] : biggest;
+      biggest = cnt[2 * q + 1] > biggest ? cnt[2 * q + 1] : biggest;
+    }
+    const uint32_t mine = start;  // keys in this thread's buckets
+    const uint32_t incl = WaveInclusiveScan(mine);
+    if (lane == 63) s_scan[wave] = incl;
+    if (biggest > kWMaxBucket) s_big = 1;
+    __syncthreads();
+    if (s_big == 0) {
+      uint32_t run = incl - mine;
+      for (int w = 0; w < wave; ++w) run += s_scan[w];
+      const uint32_t first = run;  // this thread's stretch of the sorted window: [first, first + mine)
+#pragma unroll
+      for (int q = 0; q < kPer / 2; ++q) {
+        const uint32_t a = run; run += cnt[2 * q];
+        const uint32_t b = run; run += cnt[2 * q + 1];
+        s_cnt2[tid * (kPer / 2) + q] = a | (b << 16);  // bucket starts (< 4096) replace the counts
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < kIters; ++j) {
+        const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+        if (li < count) {
+          const uint32_t at = ((s_cnt2[bucket[j] >> 1] >> ((bucket[j] & 1) * 16)) & 0xFFFFu) + brank[j];
+          s_keys[at] = key[j];
+          s_pos[at] = static_cast<uint16_t>(li);
+        }
+      }
+      __syncthreads();
+      for (uint32_t i = first + 1; i < first + mine; ++i) {  // insertion sort of a nearly sorted stretch
+        const KeyT k = s_keys[i];
+        const uint16_t ps = s_pos[i];
+        uint32_t at = i;
+        while (at > first) {
+          const KeyT pk = s_keys[at - 1];
+          const uint16_t pp = s_pos[at - 1];
+          if (pk < k || (pk == k && pp < ps)) break;
+          s_keys[at] = pk; s_pos[at] = pp;
+          --at;
+        }
+        if (at != i) { s_keys[at] = k; s_pos[at] = ps; }
+      }
+      __syncthreads();
+      // the keys are done with: their space carries the row indices from window order to sorted order
+      uint32_t* s_rows = reinterpret_cast<uint32_t*>(s_keys);
+#pragma unroll
+      for (int j = 0; j < kIters; ++j) {
+        const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+        if (li < count) s_rows[li] = idx[j];
+      }
+      __syncthreads();
+      for (uint32_t i = tid; i < count; i += kWThreads) out64[p0 + lo + i] = s_rows[s_pos[i]];
+      return;
+    }
+    __syncthreads();  // crowded: the LSD passes below reuse s_idx
+  }
 
   for (int p = 0; p < digits.n; ++p) {
     const int shift = digits.shift[p];
