@@ -22,6 +22,7 @@
 #include "common.h"
 
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 namespace amdarrow {
@@ -869,6 +870,38 @@ int ScanU32InPlace(amdarrow_ctx* ctx, uint32_t* data, int64_t n, uint32_t* sums,
   return AMDARROW_OK;
 }
 
+// Do 4096 keys sampled at a fixed stride contain the same key twice?  A value that shows up twice in
+// such a sample holds on the order of n / 4096 rows or more -- a run of equal keys no window can take.
+// The digit histograms cannot see that (a thousand distinct heavy values fill every digit evenly),
+// so the hybrid path asks this one workgroup first.  LDS hash set, linear probing.
+constexpr int kSampleKeys = 4096;
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_sample_has_duplicates(const KeyT* keys, int64_t n, unsigned int* out) {
+  constexpr int kSlots = 2 * kSampleKeys;
+  __shared__ KeyT s_set[kSlots];
+  __shared__ unsigned int s_dup;
+  using Word = typename std::conditional<sizeof(KeyT) == 8, unsigned long long, unsigned int>::type;
+  const KeyT kEmpty = ~KeyT(0);
+  for (int i = threadIdx.x; i < kSlots; i += 256) s_set[i] = kEmpty;
+  if (threadIdx.x == 0) s_dup = 0;
+  __syncthreads();
+  const int64_t stride = n / kSampleKeys;
+  for (int i = threadIdx.x; i < kSampleKeys; i += 256) {
+    KeyT k = keys[int64_t(i) * stride];
+    if (k == kEmpty) continue;  // the one value the set cannot hold; it does not decide anything
+    uint64_t h = static_cast<uint64_t>(k) * 0x9E3779B97F4A7C15ull;
+    uint32_t slot = static_cast<uint32_t>(h >> 40) & (kSlots - 1);
+    for (;;) {
+      const KeyT seen = static_cast<KeyT>(atomicCAS(reinterpret_cast<Word*>(&s_set[slot]), static_cast<Word>(kEmpty), static_cast<Word>(k)));
+      if (seen == kEmpty) break;
+      if (seen == k) { s_dup = 1; break; }
+      slot = (slot + 1) & (kSlots - 1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *out = s_dup;
+}
+
 // One workgroup ranks pseudo-random digits (uniform over 256 values, over 4 values, all equal) both
 // ways and counts the keys whose atomic rank differs from the match-any rank.
 __global__ __launch_bounds__(256) void k_probe_lds_rank(unsigned int* mismatches) {
@@ -964,7 +997,7 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   const size_t o_sums = cv.Take(4 * scan_nb);
   const size_t o_sumoff = cv.Take(8 * (scan_nb + 1));
   const size_t o_dbase = cv.Take(4 * 256 * kPasses);
-  const size_t o_ctl = cv.Take(256);  // [14] error word of the window sort, [15] of the one-sweep passes
+  const size_t o_ctl = cv.Take(256);  // [13] duplicate-sample flag, [14] error word of the window sort, [15] of the one-sweep passes
   const size_t o_lookback = cv.Take(4 * static_cast<size_t>(hist_n) * kPasses);
   void* base;
   AA_TRY(Scratch(ctx, cv.off, &base));
@@ -1040,7 +1073,16 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   int top = 0;
   const char* min_env = getenv("AMDARROW_SORT_HYBRID_MIN");  // testing knob: smallest input that takes the hybrid path
   const int64_t hybrid_min = min_env ? atoll(min_env) : (int64_t(1) << 21);
-  if (onesweep && allow_hybrid && n0 >= hybrid_min && !getenv("AMDARROW_SORT_NO_HYBRID")) {
+  bool heavy_values = false;
+  if (onesweep && allow_hybrid && n0 >= hybrid_min && n0 >= kSampleKeys && static_cast<int>(active.size()) >= 4 &&
+      !min_env /* the testing knob forces the attempt */ && !getenv("AMDARROW_SORT_NO_HYBRID")) {
+    hipLaunchKernelGGL((k_sample_has_duplicates<KeyT>), dim3(1), dim3(256), 0, ctx->stream, keys_a, n0, ctl + 13);
+    AA_HIP(hipGetLastError());
+    unsigned int dup = 0;
+    AA_TRY(ReadBack(ctx, ctl + 13, 4, &dup));
+    heavy_values = dup != 0;
+  }
+  if (onesweep && allow_hybrid && !heavy_values && n0 >= hybrid_min && !getenv("AMDARROW_SORT_NO_HYBRID")) {
     for (int m = 2; m <= 4 && top == 0; ++m) {
       if (static_cast<int>(active.size()) < m + 2) break;
       double expected = static_cast<double>(n0);

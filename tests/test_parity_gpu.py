@@ -847,3 +847,33 @@ def test_filter_groupby_path_hint_follows_the_data(gpu, oracle):
         v, k, m = data(kind)
         for x, y in zip(oracle.filter_groupby_sum(v, k, m), gpu.filter_groupby_sum(v, k, m)):
             assert np.array_equal(x, y), kind
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["uniform", "thousand-heavy-values", "one-heavy-value", "sorted", "narrow-range"])
+def test_sort_large_inputs_by_shape(gpu, shape):
+    """4 M uint64 rows (large enough for the hybrid path by default) in shapes that take it, refuse it
+    (duplicates in the sample) or overflow its windows: the result is a stable sort every time."""
+    import torch
+    from arrow1_amd import compute, device
+    n = 4_000_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    v = torch.randint(-2**63, 2**63 - 1, (n,), dtype=torch.int64, device="cuda", generator=g)
+    if shape == "thousand-heavy-values":
+        v = v[:1000][torch.randint(0, 1000, (n,), device="cuda", generator=g)]
+    elif shape == "one-heavy-value":
+        v[torch.rand(n, device="cuda", generator=g) < 0.02] = 12345
+    elif shape == "sorted":
+        v = torch.sort(v ^ (-2**63)).values ^ (-2**63)
+    elif shape == "narrow-range":
+        v = torch.randint(0, 2**36, (n,), dtype=torch.int64, device="cuda", generator=g)
+    arr = device.DeviceArray(orc.UINT64, v.contiguous().view(torch.uint8), None, n)
+    idx = compute.sort_indices(gpu.ctx, arr).values[:n * 8].view(torch.int64)
+    sv = v[idx] ^ (-2**63)
+    assert bool((sv[1:] >= sv[:-1]).all()), shape
+    ties = sv[1:] == sv[:-1]
+    assert bool((idx[1:][ties] > idx[:-1][ties]).all()), shape
+    seen = torch.zeros(n, dtype=torch.bool, device="cuda")
+    seen[idx] = True
+    assert bool(seen.all()), shape
