@@ -1273,15 +1273,17 @@ __device__ __forceinline__ int ProbeInsert(unsigned int* s_tag, unsigned int* s_
   return -1;
 }
 
-constexpr int kAggUnroll = 4;                  // records per lane and step
-constexpr int kAggStep = 64 * kAggUnroll;      // records per wave and step
+constexpr int kAggUnroll = 4;                  // records per lane and step (local path)
+constexpr int kPaUnroll = 4;                   // records per lane and step (partition aggregate; 5: +5 %, 6 spills: +10 %)
+constexpr int kAggStep = 64 * kPaUnroll;       // records per wave and step of the partition aggregate
 
 // Issue the (unconditional, clamped) streaming loads of one step: records [i0, i0 + kAggStep) of `seg`.
-__device__ __forceinline__ void AggLoad(uint4 (&rec)[kAggUnroll], const uint4* seg, uint32_t i0, uint32_t cnt, int lane) {
+template <int N>
+__device__ __forceinline__ void AggLoad(uint4 (&rec)[N], const uint4* seg, uint32_t i0, uint32_t cnt, int lane) {
   using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
   const uint32_t last = cnt ? cnt - 1 : 0;
 #pragma unroll
-  for (int u = 0; u < kAggUnroll; ++u) {
+  for (int u = 0; u < N; ++u) {
     const uint32_t i = i0 + lane + 64 * u;
     const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(&seg[i < cnt ? i : last]));
     rec[u] = make_uint4(v.x, v.y, v.z, v.w);
@@ -1289,21 +1291,22 @@ __device__ __forceinline__ void AggLoad(uint4 (&rec)[kAggUnroll], const uint4* s
 }
 
 // Fold one step into the LDS table.  Returns false when the table overflowed.
-__device__ __forceinline__ bool AggFold(const uint4 (&rec)[kAggUnroll], const bool (&live)[kAggUnroll], int acc_double,
+template <int N>
+__device__ __forceinline__ bool AggFold(const uint4 (&rec)[N], const bool (&live)[N], int acc_double,
                                         unsigned int* s_tag, unsigned long long* s_sum, uint32_t* s_first,
                                         unsigned int* s_cnt, unsigned int* s_groups, unsigned int limit = kSlotLimit) {
   bool ok = true;
-  uint32_t h[kAggUnroll];
-  int slot[kAggUnroll];
-  uint4 home1[kAggUnroll], home2[kAggUnroll];
+  uint32_t h[N];
+  int slot[N];
+  uint4 home1[N], home2[N];
 #pragma unroll
-  for (int u = 0; u < kAggUnroll; ++u) {
+  for (int u = 0; u < N; ++u) {
     h[u] = Fmix32(rec[u].x);
     home1[u] = *reinterpret_cast<const uint4*>(&s_tag[(h[u] & (kBuckets - 1)) * kBucket]);
     home2[u] = *reinterpret_cast<const uint4*>(&s_tag[((h[u] >> kBucketBits) & (kBuckets - 1)) * kBucket]);
   }
 #pragma unroll
-  for (int u = 0; u < kAggUnroll; ++u) {
+  for (int u = 0; u < N; ++u) {
     if (!live[u]) { slot[u] = -2; continue; }
     if (rec[u].y & kRecKeyNull) slot[u] = kSideNull;
     else if (h[u] == kTagFree) slot[u] = kSideFree;
@@ -1316,7 +1319,7 @@ __device__ __forceinline__ bool AggFold(const uint4 (&rec)[kAggUnroll], const bo
     }
   }
 #pragma unroll
-  for (int u = 0; u < kAggUnroll; ++u) {
+  for (int u = 0; u < N; ++u) {
     if (slot[u] == -2) continue;
     if (slot[u] < 0) { ok = false; continue; }
     const uint4 r = rec[u];
@@ -1331,12 +1334,13 @@ __device__ __forceinline__ bool AggFold(const uint4 (&rec)[kAggUnroll], const bo
   return ok;
 }
 
-__device__ __forceinline__ bool AggFoldStep(const uint4 (&rec)[kAggUnroll], uint32_t i0, uint32_t cnt, int lane,
+template <int N>
+__device__ __forceinline__ bool AggFoldStep(const uint4 (&rec)[N], uint32_t i0, uint32_t cnt, int lane,
                                             int acc_double, unsigned int* s_tag, unsigned long long* s_sum,
                                             uint32_t* s_first, unsigned int* s_cnt, unsigned int* s_groups) {
-  bool live[kAggUnroll];
+  bool live[N];
 #pragma unroll
-  for (int u = 0; u < kAggUnroll; ++u) live[u] = i0 + lane + 64 * u < cnt;
+  for (int u = 0; u < N; ++u) live[u] = i0 + lane + 64 * u < cnt;
   return AggFold(rec, live, acc_double, s_tag, s_sum, s_first, s_cnt, s_groups);
 }
 
@@ -1388,7 +1392,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
     const uint4* seg = regions + (int64_t(wave + kWaves * jb) * kP + p) * cap;  // segment k: seg + k * seg_stride
     int k = 0;
     uint32_t i0 = 0, cnt = __shfl(my_cnt, 0);
-    uint4 ra[kAggUnroll], rb[kAggUnroll];
+    uint4 ra[kPaUnroll], rb[kPaUnroll];
     AggLoad(ra, seg, i0, cnt, lane);
     for (;;) {
       // step after (k, i0): the rest of the segment, else the next segment (a step of an empty
