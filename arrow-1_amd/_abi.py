@@ -76,6 +76,9 @@ SYMBOLS = {
     "amdarrow_grouper_num_groups": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "amdarrow_grouper_uniques": (C.c_int, [_P, C.c_int, _P, _P, _O]),
     "amdarrow_hash_aggregate": (C.c_int, [_P, C.c_int, _A, _P, C.c_int64, C.c_int, _P, _P, _O]),
+    "amdarrow_dense_merge_scatter": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, _P, _P]),
+    "amdarrow_dense_merge_order": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int64,
+                                             _P, _P, _P, _P, _P]),
     "amdarrow_dictionary_indices": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, _P, _P, _O]),
     "amdarrow_hash_minmax_init": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int64]),
     "amdarrow_hash_minmax_accumulate": (C.c_int, [_P, _A, _P, _P, _P, _P, _P]),

@@ -125,6 +125,52 @@ def merge_dense(part, st, rank, group=None):
     return Partial(keys, key_valid, sums, counts if not is_f else counts.to(torch.int64)), n_present
 
 
+# ---- dense protocol on the device: the HIP kernels of csrc/dist_merge.hip around the two all-reduces ----
+class DenseDeviceState:
+    """Accumulators and outputs of the device merge, allocated once per plan: acc[2][R + 2]
+    (sums | counts; column R = the null key, acc[0][R + 1] = keys outside the range), owner[R + 1],
+    and the merged table (capacity rows) with its group count in a device word."""
+
+    def __init__(self, kmin, R, is_float, key_torch, capacity, device):
+        self.kmin, self.R, self.is_float, self.capacity = kmin, R, is_float, capacity
+        self.acc = torch.zeros(2, R + 2, dtype=torch.float64 if is_float else torch.int64, device=device)
+        self.owner = torch.zeros(R + 1, dtype=torch.int64, device=device)
+        rows = min(R + 1, capacity * 64)
+        self.rows = rows
+        self.out_keys = torch.zeros(rows, dtype=key_torch, device=device)
+        self.out_valid = torch.zeros(rows, dtype=torch.uint8, device=device)
+        self.out_sums = torch.zeros(rows, dtype=torch.float64 if is_float else torch.int64, device=device)
+        self.out_counts = torch.zeros(rows, dtype=torch.int64, device=device)
+        self.n_present = torch.zeros(1, dtype=torch.int64, device=device)
+
+    @property
+    def bad(self):
+        return self.acc[0, self.R + 1:self.R + 2]
+
+
+def merge_dense_device(ctx, key_type, r_keys, r_key_validity, r_sums, r_counts, num_groups, st, rank, world,
+                       all_reduce=None):
+    """One rank's merge step on the device.  r_*: the fused kernel's output buffers (keys, validity
+    BITMAP, 8-byte sums, int64 counts; uint8 tensors).  all_reduce(tensor, op): defaults to
+    torch.distributed (RCCL); the single-GPU test passes a stand-in that combines simulated ranks.
+    -> (Partial over the preallocated outputs, n_present device tensor).  No host sync."""
+    from ._abi import check
+    lib, h = ctx.lib, ctx.handle
+    check(lib, lib.amdarrow_dense_merge_scatter(h, r_keys.data_ptr(), key_type, r_key_validity.data_ptr(), 1, r_sums.data_ptr(),
+                                                r_counts.data_ptr(), num_groups, st.kmin, st.R, rank, int(st.is_float),
+                                                st.acc.data_ptr(), st.owner.data_ptr()))
+    if all_reduce is None:
+        tdist.all_reduce(st.acc, op=tdist.ReduceOp.SUM)     # sums, counts and the out-of-range count in one message
+        tdist.all_reduce(st.owner, op=tdist.ReduceOp.MIN)   # who saw the key first, and where in its order
+    else:
+        all_reduce(st.acc, "sum")
+        all_reduce(st.owner, "min")
+    check(lib, lib.amdarrow_dense_merge_order(h, st.acc.data_ptr(), st.owner.data_ptr(), st.kmin, st.R, world, st.capacity, key_type,
+                                              int(st.is_float), st.rows, st.out_keys.data_ptr(), st.out_valid.data_ptr(),
+                                              st.out_sums.data_ptr(), st.out_counts.data_ptr(), st.n_present.data_ptr()))
+    return Partial(st.out_keys, st.out_valid.view(torch.bool), st.out_sums, st.out_counts), st.n_present
+
+
 # ---- GPU binding -------------------------------------------------------------------------------
 def _pack_bits(bits):
     """bool tensor -> Arrow LSB-first bitmap (uint8 tensor, padded)"""
@@ -185,6 +231,7 @@ class GroupByMerger:
         self._merge_bufs = None
         self._dense = None          # [DenseState, DenseState] once planned; False = use the gather protocol
         self._side = torch.cuda.Stream(device=ctx.device) if world > 1 else None
+        self._side_ctx = None
         self._slot = 0
         self._bufs = None
         self._pending = [None, None]
@@ -222,8 +269,8 @@ class GroupByMerger:
         if self.key_torch in (torch.int8, torch.uint8, torch.int16, torch.int32, torch.int64) and 0 < R <= DENSE_LIMIT:
             # head-room: later batches may see keys a little outside the first batch's range
             pad = max(1024, R // 8)
-            dt = torch.float64 if self.is_float else torch.int64
-            self._dense = [DenseState(lo - pad, R + 2 * pad, dt, part.keys.device) for _ in range(2)]
+            self._dense = [DenseDeviceState(lo - pad, R + 2 * pad, self.is_float, self.key_torch, self.cap, part.keys.device)
+                           for _ in range(2)]
         else:
             self._dense = False
 
@@ -240,18 +287,22 @@ class GroupByMerger:
         if self._pending[slot] is not None:   # the buffers of step i-2 are about to be overwritten
             self._pending[slot].wait()
         r = compute.filter_groupby(self.ctx, values, keys, mask, buffers=self._bufs[slot])
-        part = self._partial_of(r)
         if self._dense is None:
-            self._plan(part)
+            self._plan(self._partial_of(r))
         if self._dense is False:
-            merged = merge_partials(part, self._local_merge, self.world)
+            merged = merge_partials(self._partial_of(r), self._local_merge, self.world)
             return merged
+        if self._side_ctx is None:  # the merge kernels run on the side stream: a context of their own, bound to it
+            from .device import Context
+            with torch.cuda.stream(self._side):
+                self._side_ctx = Context(self.ctx.device.index)
         main = torch.cuda.current_stream(self.ctx.device)
         done_local = torch.cuda.Event()
         done_local.record(main)
         with torch.cuda.stream(self._side):
             self._side.wait_event(done_local)
-            mpart, n_present = merge_dense(part, self._dense[slot], self.rank)
+            mpart, n_present = merge_dense_device(self._side_ctx, self.key_type, r.keys, r.key_validity, r.sums, r.counts, r.num_groups,
+                                                  self._dense[slot], self.rank, self.world)
             ev = torch.cuda.Event()
             ev.record(self._side)
         res = MergedResult(mpart, n_present, ev, self._dense[slot].bad)

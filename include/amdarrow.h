@@ -193,6 +193,30 @@ int amdarrow_hash_aggregate(amdarrow_ctx* ctx, int func, const amdarrow_array* v
                             const uint32_t* ids, int64_t num_groups, int count_mode,
                             void* out_values, uint8_t* out_validity, amdarrow_out* out);
 
+/* The device half of the multi-GPU group-by merge (protocol in arrow-1_amd/dist.py): the
+ * reference has no counterpart -- its GroupBy is single-process (hash_aggregate.cc:890-966); the
+ * merged table is what that GroupBy returns on the concatenated shards, first-appearance order
+ * (:391-401) included.  Dense protocol for integer keys of a small global range [kmin, kmin + R):
+ *   scatter  this rank's partial table (keys / validity bytes / 8-byte sums / int64 counts, in local
+ *            first-appearance order) into acc[2][R + 2] (sums | counts; column R = the null key,
+ *            acc[0][R + 1] = keys outside the range) and owner[R + 1] = rank << 32 | local id
+ *            (INT64_MAX where absent).  The caller then all-reduces acc with SUM and owner with MIN;
+ *   order    reads the reduced arrays back out in global order (rank-major, local id minor) into
+ *            out_* (capacity rows) and stores the group count to a DEVICE word: no host round trip.
+ * counts_as_double: acc holds float64 (sums of a float column; counts ride along as exact doubles).
+ * Both calls are stream-ordered. */
+int amdarrow_dense_merge_scatter(amdarrow_ctx* ctx, const void* keys, int key_type,
+                                 const uint8_t* key_valid /* NULL = all valid */,
+                                 int valid_is_bitmap /* 1: LSB-first bits, 0: one byte per group */,
+                                 const void* sums,
+                                 const int64_t* counts, int64_t num_groups, int64_t kmin, int64_t R,
+                                 int rank, int counts_as_double, void* acc, void* owner);
+int amdarrow_dense_merge_order(amdarrow_ctx* ctx, const void* acc, const void* owner, int64_t kmin,
+                               int64_t R, int world, int64_t capacity, int key_type,
+                               int counts_as_double, int64_t out_capacity, void* out_keys,
+                               uint8_t* out_key_valid_bytes, void* out_sums, int64_t* out_counts,
+                               int64_t* out_num_groups_dev);
+
 /* dictionary_encode's index column under DictionaryEncodeOptions::MASK (vector_hash.cc:165-225):
  * `ids` = the Grouper's ids of the n rows, `uniques_validity` = the bitmap amdarrow_grouper_uniques
  * wrote (NULL when no key is null), num_groups its length.  out_indices[i] = the row's position in

@@ -424,7 +424,70 @@ def test_sharded_groupby_merge_on_gpu(gpu, oracle):
     assert G == len(es) and int(st.bad.item()) == 0
     assert np.array_equal(dpart.sums[:G].cpu().numpy(), es) and np.array_equal(dpart.counts[:G].cpu().numpy(), ec)
     assert np.array_equal(dpart.keys[:G].cpu().numpy(), ek.astype(np.int64))
+    # the device kernels of the same protocol (csrc/dist_merge.hip) on the 1-rank group
+    dst = adist.DenseDeviceState(lo - 5, hi - lo + 11, False, torch.int32, 1 << 17, torch.device("cuda"))
+    dp, npres = adist.merge_dense_device(gpu.ctx, INT32, r.keys, r.key_validity, r.sums, r.counts, r.num_groups, dst, 0, 1)
+    G = int(npres.item())
+    assert G == len(es) and int(dst.bad.item()) == 0
+    assert np.array_equal(dp.sums[:G].cpu().numpy(), es) and np.array_equal(dp.counts[:G].cpu().numpy(), ec)
+    assert np.array_equal(dp.keys[:G].cpu().numpy(), ek)
     tdist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("vt,key_nulls,kt", [(INT64, 0.0, INT32), (INT64, 0.05, INT32), (DOUBLE, 0.02, INT64), (INT64, 0.0, INT16)])
+def test_dense_merge_kernels_three_simulated_ranks(gpu, oracle, vt, key_nulls, kt):
+    """csrc/dist_merge.hip with three row-range shards run one after the other on this GPU; the
+    all-reduces are emulated by adding / taking the minimum of the three ranks' arrays.  The merged
+    table must be the reference's GroupBy over the unsharded rows, first-appearance order included;
+    keys outside the planned range are counted, not merged."""
+    import torch
+    from arrow1_amd import _abi, compute, device, dist as adist
+    rng = np.random.default_rng(31)
+    n = 900_000
+    hi = 30_000 if kt != INT16 else 20_000
+    v, k, m = R(rng, vt, n, .01, 0), R(rng, kt, n, key_nulls, 0, lo=-hi, hi=hi), R(rng, BOOL, n, 0.0, 0)
+    es, ec, ek, ekv = oracle.filter_groupby_sum(v, k, m)
+    cuts = [0, 300_032, 600_064, n]
+    world, cap = 3, 1 << 17
+    is_f = vt == DOUBLE
+    kt_torch = {INT16: torch.int16, INT32: torch.int32, INT64: torch.int64}[kt]
+    results = []
+    for lo_, hi_ in zip(cuts[:-1], cuts[1:]):
+        sl = lambda a: Arr(a.type_id, a.data[lo_:hi_], None if a.valid is None else a.valid[lo_:hi_])  # noqa: E731
+        up = lambda a: device.DeviceArray.from_numpy(a.type_id, a.data, a.valid, 0, len(a.data), None)  # noqa: E731
+        results.append(compute.filter_groupby(gpu.ctx, up(sl(v)), up(sl(k)), up(sl(m)), buffers=compute.GroupByBuffers("cuda", cap, kt)))
+    for kmin, R_ in [(-hi - 7, 2 * hi + 20), (-hi + 1000, 2 * hi - 3000)]:  # the second plan leaves keys outside
+        states = [adist.DenseDeviceState(kmin, R_, is_f, kt_torch, cap, torch.device("cuda")) for _ in range(world)]
+        # phase 1 on every "rank": scatter; then emulate the all-reduces; then phase 2 on rank 0's state
+        for rank, (r, st) in enumerate(zip(results, states)):
+            _abi.check(gpu.ctx.lib, gpu.ctx.lib.amdarrow_dense_merge_scatter(
+                gpu.ctx.handle, r.keys.data_ptr(), kt, r.key_validity.data_ptr(), 1, r.sums.data_ptr(), r.counts.data_ptr(),
+                r.num_groups, kmin, R_, rank, int(is_f), st.acc.data_ptr(), st.owner.data_ptr()))
+        acc = sum(st.acc for st in states)
+        owner = torch.stack([st.owner for st in states]).min(0).values
+
+        def fake_all_reduce(t, op):
+            t.copy_(acc if op == "sum" else owner)
+        dp, npres = adist.merge_dense_device(gpu.ctx, kt, results[0].keys, results[0].key_validity, results[0].sums, results[0].counts,
+                                             results[0].num_groups, states[0], 0, world, all_reduce=fake_all_reduce)
+        G = int(npres.item())
+        keys = dp.keys[:G].cpu().numpy()
+        valid = dp.key_valid[:G].cpu().numpy()
+        inside = ~ekv | ((ek >= kmin) & (ek < kmin + R_))
+        assert G == int(inside.sum())
+        assert np.array_equal(valid, ekv[inside])
+        assert np.array_equal(keys[valid], ek[inside][ekv[inside]])
+        got_s = dp.sums[:G].cpu().numpy()
+        if is_f:
+            assert np.allclose(got_s, es[inside], rtol=F64_RTOL)
+        else:
+            assert np.array_equal(got_s, es[inside])
+        assert np.array_equal(dp.counts[:G].cpu().numpy(), ec[inside])
+        if kmin == -hi - 7:
+            assert float(states[0].bad.item()) == 0
+        else:
+            assert float(states[0].bad.item()) > 0
 
 
 @pytest.mark.parametrize("path", ["3", "2", "1", "0"])
