@@ -21,13 +21,20 @@ constexpr int kDmTile = 4096;
 int LaunchScanU32(amdarrow_ctx* ctx, const uint32_t* counts, int64_t n, int64_t* offsets);  // selection.hip
 
 // acc: [2][R + 2] 8-byte words (row 0 sums, row 1 counts; column R = the null key, column R + 1 of
-// row 0 = number of keys outside the planned range); owner: [R + 1].
+// row 0 = number of keys outside the planned range); owner: [R + 2], the last word carries
+// -(local group count) through the MIN all-reduce: afterwards it is -(the largest local table), the
+// stride of the slot array.
 __global__ __launch_bounds__(kDmThreads) void k_dense_clear(unsigned long long* acc, unsigned long long* owner, int64_t R) {
   for (int64_t i = int64_t(blockIdx.x) * kDmThreads + threadIdx.x; i < R + 2; i += int64_t(gridDim.x) * kDmThreads) {
     acc[i] = 0;
     acc[R + 2 + i] = 0;
     if (i <= R) owner[i] = kNoOwner;
+    if (i == R + 1) owner[i] = 0;
   }
+}
+__device__ __forceinline__ int64_t SlotStride(const unsigned long long* owner, int64_t R, int64_t capacity) {
+  const int64_t g = -static_cast<int64_t>(owner[R + 1]);
+  return g < 1 ? 1 : (g > capacity ? capacity : g);
 }
 
 __device__ __forceinline__ int64_t LoadKey(const void* keys, int key_type, int64_t g) {
@@ -48,6 +55,7 @@ __global__ __launch_bounds__(kDmThreads) void k_dense_scatter(const void* keys, 
                                                               int64_t num_groups, int64_t kmin, int64_t R, int rank, int counts_as_double,
                                                               unsigned long long* acc, unsigned long long* owner) {
   unsigned long long outside = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) owner[R + 1] = static_cast<unsigned long long>(-num_groups);
   for (int64_t g = int64_t(blockIdx.x) * kDmThreads + threadIdx.x; g < num_groups; g += int64_t(gridDim.x) * kDmThreads) {
     int64_t col = R;  // the null key
     if (!key_valid || (valid_is_bitmap ? GetBit(key_valid, g) : key_valid[g] != 0)) {
@@ -68,19 +76,28 @@ __global__ __launch_bounds__(kDmThreads) void k_dense_scatter(const void* keys, 
 }
 
 // After the all-reduces: every present key drops (column + 1) into the slot its owner word names.
+__global__ __launch_bounds__(kDmThreads) void k_dense_clear_slots(const unsigned long long* owner, int64_t R, int64_t capacity,
+                                                                  int world, uint32_t* slots) {
+  const int64_t nslots = world * SlotStride(owner, R, capacity);
+  for (int64_t i = int64_t(blockIdx.x) * kDmThreads + threadIdx.x; i < nslots; i += int64_t(gridDim.x) * kDmThreads) slots[i] = 0;
+}
 __global__ __launch_bounds__(kDmThreads) void k_dense_slots(const unsigned long long* owner, int64_t R, int64_t capacity, int world,
                                                             uint32_t* slots) {
+  const int64_t stride = SlotStride(owner, R, capacity);
   for (int64_t i = int64_t(blockIdx.x) * kDmThreads + threadIdx.x; i <= R; i += int64_t(gridDim.x) * kDmThreads) {
     const unsigned long long o = owner[i];
     if (o == kNoOwner) continue;
     const int64_t r = static_cast<int64_t>(o >> 32), g = static_cast<int64_t>(o & 0xFFFFFFFFull);
-    if (r < world && g < capacity) slots[r * capacity + g] = static_cast<uint32_t>(i + 1);
+    if (r < world && g < stride) slots[r * stride + g] = static_cast<uint32_t>(i + 1);
   }
 }
 
-__global__ __launch_bounds__(kDmThreads) void k_dense_tile_counts(const uint32_t* slots, int64_t nslots, uint32_t* counts) {
+// counts[tile] for every tile of the host's upper bound; tiles past the live slots count 0
+__global__ __launch_bounds__(kDmThreads) void k_dense_tile_counts(const uint32_t* slots, const unsigned long long* owner, int64_t R,
+                                                                  int64_t capacity, int world, int64_t ntiles, uint32_t* counts) {
   __shared__ uint32_t s_c;
-  for (int64_t tile = blockIdx.x; tile * kDmTile < nslots; tile += gridDim.x) {
+  const int64_t nslots = world * SlotStride(owner, R, capacity);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     if (threadIdx.x == 0) s_c = 0;
     __syncthreads();
     uint32_t c = 0;
@@ -97,15 +114,17 @@ __global__ __launch_bounds__(kDmThreads) void k_dense_tile_counts(const uint32_t
 }
 
 // Emit the merged table in slot order = global first-appearance order.
-__global__ __launch_bounds__(kDmThreads) void k_dense_emit(const uint32_t* slots, int64_t nslots, const int64_t* offsets, int64_t ntiles,
+__global__ __launch_bounds__(kDmThreads) void k_dense_emit(const uint32_t* slots, const unsigned long long* owner, int64_t capacity,
+                                                           int world, const int64_t* offsets, int64_t ntiles,
                                                            const unsigned long long* acc, int64_t R, int64_t kmin, int key_type,
                                                            int counts_as_double, int64_t out_capacity, void* out_keys,
                                                            uint8_t* out_key_valid /* bytes */, unsigned long long* out_sums,
                                                            long long* out_counts, long long* out_num_groups) {
   __shared__ uint32_t s_wave[kDmThreads / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t nslots = world * SlotStride(owner, R, capacity);
   if (blockIdx.x == 0 && threadIdx.x == 0) *out_num_groups = offsets[ntiles];
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int64_t tile = blockIdx.x; tile < ntiles && tile * kDmTile < nslots; tile += gridDim.x) {
     int64_t base = offsets[tile];
     for (int k = 0; k < kDmTile / kDmThreads; ++k) {  // 16 rounds of 256 slots, in order
       const int64_t i = tile * kDmTile + k * kDmThreads + threadIdx.x;
@@ -179,15 +198,16 @@ int amdarrow_dense_merge_order(amdarrow_ctx* ctx, const void* acc, const void* o
   auto* slots = reinterpret_cast<uint32_t*>(b + o_slots);
   auto* counts = reinterpret_cast<uint32_t*>(b + o_counts);
   auto* offsets = reinterpret_cast<int64_t*>(b + o_offsets);
-  AA_HIP(hipMemsetAsync(slots, 0, 4 * static_cast<size_t>(nslots), ctx->stream));
-  hipLaunchKernelGGL(k_dense_slots, dim3(GridFor(R + 1, kDmThreads, ctx->num_cus * 8)), dim3(kDmThreads), 0, ctx->stream,
-                     static_cast<const unsigned long long*>(owner), R, capacity, world, slots);
-  hipLaunchKernelGGL(k_dense_tile_counts, dim3(GridFor(ntiles, 1, ctx->num_cus * 8)), dim3(kDmThreads), 0, ctx->stream, slots, nslots,
-                     counts);
+  const auto* own = static_cast<const unsigned long long*>(owner);
+  hipLaunchKernelGGL(k_dense_clear_slots, dim3(ctx->num_cus * 8), dim3(kDmThreads), 0, ctx->stream, own, R, capacity, world, slots);
+  hipLaunchKernelGGL(k_dense_slots, dim3(GridFor(R + 1, kDmThreads, ctx->num_cus * 8)), dim3(kDmThreads), 0, ctx->stream, own, R,
+                     capacity, world, slots);
+  hipLaunchKernelGGL(k_dense_tile_counts, dim3(GridFor(ntiles, 1, ctx->num_cus * 8)), dim3(kDmThreads), 0, ctx->stream, slots, own, R,
+                     capacity, world, ntiles, counts);
   AA_HIP(hipGetLastError());
   AA_TRY(LaunchScanU32(ctx, counts, ntiles, offsets));
-  hipLaunchKernelGGL(k_dense_emit, dim3(GridFor(ntiles, 1, ctx->num_cus * 8)), dim3(kDmThreads), 0, ctx->stream, slots, nslots, offsets,
-                     ntiles, static_cast<const unsigned long long*>(acc), R, kmin, key_type, counts_as_double, out_capacity, out_keys,
+  hipLaunchKernelGGL(k_dense_emit, dim3(GridFor(ntiles, 1, ctx->num_cus * 8)), dim3(kDmThreads), 0, ctx->stream, slots, own, capacity,
+                     world, offsets, ntiles, static_cast<const unsigned long long*>(acc), R, kmin, key_type, counts_as_double, out_capacity, out_keys,
                      out_key_valid_bytes, static_cast<unsigned long long*>(out_sums), reinterpret_cast<long long*>(out_counts),
                      reinterpret_cast<long long*>(out_num_groups_dev));
   AA_HIP(hipGetLastError());

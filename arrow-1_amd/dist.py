@@ -134,8 +134,8 @@ class DenseDeviceState:
     def __init__(self, kmin, R, is_float, key_torch, capacity, device):
         self.kmin, self.R, self.is_float, self.capacity = kmin, R, is_float, capacity
         self.acc = torch.zeros(2, R + 2, dtype=torch.float64 if is_float else torch.int64, device=device)
-        self.owner = torch.zeros(R + 1, dtype=torch.int64, device=device)
-        rows = min(R + 1, capacity * 64)
+        self.owner = torch.zeros(R + 2, dtype=torch.int64, device=device)  # [R + 1]: -(largest local table) after the MIN
+        rows = R + 1
         self.rows = rows
         self.out_keys = torch.zeros(rows, dtype=key_torch, device=device)
         self.out_valid = torch.zeros(rows, dtype=torch.uint8, device=device)

@@ -199,8 +199,9 @@ int amdarrow_hash_aggregate(amdarrow_ctx* ctx, int func, const amdarrow_array* v
  * (:391-401) included.  Dense protocol for integer keys of a small global range [kmin, kmin + R):
  *   scatter  this rank's partial table (keys / validity bytes / 8-byte sums / int64 counts, in local
  *            first-appearance order) into acc[2][R + 2] (sums | counts; column R = the null key,
- *            acc[0][R + 1] = keys outside the range) and owner[R + 1] = rank << 32 | local id
- *            (INT64_MAX where absent).  The caller then all-reduces acc with SUM and owner with MIN;
+ *            acc[0][R + 1] = keys outside the range) and owner[R + 2]: owner[col] = rank << 32 | local id
+ *            (INT64_MAX where absent), owner[R + 1] = -(local group count), which the MIN turns into
+ *            the stride of the slot array.  The caller then all-reduces acc with SUM and owner with MIN;
  *   order    reads the reduced arrays back out in global order (rank-major, local id minor) into
  *            out_* (capacity rows) and stores the group count to a DEVICE word: no host round trip.
  * counts_as_double: acc holds float64 (sums of a float column; counts ride along as exact doubles).
