@@ -27,6 +27,11 @@ class CArray(C.Structure):
                 ("offset", C.c_int64), ("type_id", C.c_int32), ("null_count", C.c_int64)]
 
 
+class CBinaryArray(C.Structure):
+    _fields_ = [("offsets", C.c_void_p), ("data", C.c_void_p), ("validity", C.c_void_p), ("length", C.c_int64),
+                ("offset", C.c_int64), ("null_count", C.c_int64)]
+
+
 class COut(C.Structure):
     _fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("has_validity", C.c_int32)]
 
@@ -61,6 +66,8 @@ SYMBOLS = {
     "amdarrow_take_indices": (C.c_int, [_P, _A, C.c_int, _P, _P, C.c_int64, C.POINTER(C.c_int), _O]),
     "amdarrow_take": (C.c_int, [_P, _A, _A, C.c_int, _P, _P, _O]),
     "amdarrow_sort_indices": (C.c_int, [_P, _A, C.c_int, C.c_int, _P]),
+    "amdarrow_binary_take_offsets": (C.c_int, [_P, C.POINTER(CBinaryArray), _A, C.c_int, _P, _P, C.POINTER(C.c_int64), _O]),
+    "amdarrow_binary_take_data": (C.c_int, [_P, C.POINTER(CBinaryArray), _A, _P, _P]),
     "amdarrow_sort_indices_multi": (C.c_int, [_P, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, _P]),
     "amdarrow_concatenate": (C.c_int, [_P, _P, C.c_int, _P, _P, _O]),
     "amdarrow_compare": (C.c_int, [_P, C.c_int, _A, _P, _A, _P, _P, _P, _O]),

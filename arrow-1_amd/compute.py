@@ -76,6 +76,35 @@ def take(ctx, values, indices, boundscheck=True):
     return DeviceArray(values.type_id, out_v, out_b, out.length, 0, out.null_count)
 
 
+def binary_take(ctx, values, indices, boundscheck=True):
+    """CallFunction("take") on a BinaryArray / StringArray -- VarBinaryImpl, vector_selection.cc:1493-1573."""
+    from .device import DeviceBinaryArray
+    n = indices.length
+    dev = values.offsets.device
+    out_o = alloc_bytes(4 * (n + 1), dev)
+    out_b = alloc_bytes((n + 63) // 64 * 8, dev)
+    out, nbytes = COut(), C.c_int64(0)
+    cv, ci = values.c(), indices.c()
+    check(ctx.lib, ctx.lib.amdarrow_binary_take_offsets(ctx.handle, C.byref(cv), C.byref(ci), int(boundscheck), _ptr(out_o), _ptr(out_b),
+                                                        C.byref(nbytes), C.byref(out)))
+    out_d = alloc_bytes(nbytes.value, dev)
+    check(ctx.lib, ctx.lib.amdarrow_binary_take_data(ctx.handle, C.byref(cv), C.byref(ci), _ptr(out_o), _ptr(out_d)))
+    return DeviceBinaryArray(out_o, out_d, out_b, out.length, 0, out.null_count)
+
+
+def binary_filter(ctx, values, mask, null_selection=DROP):
+    """CallFunction("filter") on a BinaryArray / StringArray -- BinaryFilter, vector_selection.cc:840-1124: the Take of
+    GetTakeIndices(mask), with BinaryFilter's conventions for the validity buffer and the null count (:1090-1112)."""
+    from .device import DeviceBinaryArray
+    idx = take_indices(ctx, mask, null_selection)
+    r = binary_take(ctx, values, idx, boundscheck=False)
+    vnc = values.null_count if values.validity is not None else 0
+    fnc = mask.null_count if mask.validity is not None else 0
+    keep_validity = vnc != 0 or fnc != 0
+    null_count = 0 if (vnc == 0 and (null_selection == DROP or fnc == 0)) else -1
+    return DeviceBinaryArray(r.offsets, r.data, r.validity if keep_validity else None, r.length, 0, null_count)
+
+
 def sort_indices(ctx, chunks, order=ASCENDING):
     """CallFunction("sort_indices", {array | chunked_array}, SortOptions) -- vector_sort.cc:1565-1630."""
     if isinstance(chunks, DeviceArray):

@@ -471,6 +471,101 @@ static int RunCompaction(amdarrow_ctx* ctx, FilterArgs a, int width_bytes /*0 = 
 
 }  // namespace amdarrow
 
+namespace amdarrow {
+
+// ---- Take of variable-width binary values (32-bit offsets) -------------------------------------------
+// VarBinaryImpl over Selection::VisitTake (vector_selection.cc:1203-1320, 1493-1573): out[i] =
+// values[indices[i]], null -- and zero bytes long -- if the index or the value is null; the output
+// always carries a validity bitmap (FinishCommon :1250-1255).  Two passes: the lengths (with the
+// bounds check and the validity words) scanned into the output offsets, then the bytes.
+struct BinaryTakeArgs {
+  const int32_t* v_offsets; const uint8_t* v_data; const uint8_t* v_valid; int64_t v_off; int64_t v_len; int v_may_null;
+  const void* i_data; const uint8_t* i_valid; int64_t i_off; int64_t n;
+  int boundscheck;
+  uint32_t* out_lengths;     // n + 1 words: lengths here, offsets after the scan
+  uint8_t* out_validity;
+  unsigned long long* valid_count;  // slotted counters, counter 0
+  unsigned long long* err_pos;
+};
+
+template <typename IdxT>
+__global__ __launch_bounds__(kThreads) void k_binary_take_lengths(BinaryTakeArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  unsigned long long my_valid = 0;
+  const int64_t wave_id = (int64_t(blockIdx.x) * kThreads + tid) >> 6;
+  const int64_t nwaves = (int64_t(gridDim.x) * kThreads) >> 6;
+  for (int64_t base = wave_id * 64; base < a.n; base += nwaves * 64) {
+    const int64_t i = base + lane;
+    const int64_t ic = i < a.n ? i : a.n - 1;
+    bool ok = i < a.n;
+    if (a.i_valid) ok = ok && GetBit(a.i_valid, a.i_off + ic);
+    int64_t j;
+    const bool inb = IndexLoad<IdxT>::Load(a.i_data, a.i_off + ic, a.v_len, &j);
+    if (ok && !inb) {
+      ok = false;
+      if (a.boundscheck) atomicMin(a.err_pos, static_cast<unsigned long long>(i));
+    }
+    if (!ok) j = 0;
+    uint32_t len = 0;
+    if (a.v_len > 0) {
+      const bool vbit = a.v_may_null ? GetBit(a.v_valid, a.v_off + j) : true;
+      const int32_t o0 = a.v_offsets[a.v_off + j], o1 = a.v_offsets[a.v_off + j + 1];
+      ok = ok && vbit;
+      len = ok ? static_cast<uint32_t>(o1 - o0) : 0u;
+    } else {
+      ok = false;
+    }
+    const uint64_t okmask = __ballot(ok);
+    if (i < a.n) a.out_lengths[i] = len;
+    if (lane == 0) {
+      reinterpret_cast<uint64_t*>(a.out_validity)[i >> 6] = okmask;
+      my_valid += __popcll(okmask);
+    }
+  }
+  if (lane == 0 && my_valid) atomicAdd(CounterSlot(a.valid_count), my_valid);
+}
+
+// out_offsets[n] = total, or the overflow flag when it does not fit an int32 offset
+// ("Take operation overflowed binary array capacity", :1540-1544; kOffsetLimit = INT32_MAX - 1).
+__global__ void k_binary_close_offsets(uint32_t* offsets, int64_t n, const int64_t* total, unsigned long long* err_pos) {
+  const int64_t t = *total;
+  offsets[n] = static_cast<uint32_t>(t);
+  if (t > 2147483646) err_pos[1] = 1;
+}
+
+// A wave copies the bytes of 64 consecutive output rows, one row at a time with all its lanes.
+template <typename IdxT>
+__global__ __launch_bounds__(kThreads) void k_binary_take_data(BinaryTakeArgs a, const uint32_t* out_offsets, uint8_t* out_data) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int64_t wave_id = (int64_t(blockIdx.x) * kThreads + tid) >> 6;
+  const int64_t nwaves = (int64_t(gridDim.x) * kThreads) >> 6;
+  for (int64_t base = wave_id * 64; base < a.n; base += nwaves * 64) {
+    const int64_t i = base + lane;
+    uint32_t dst = 0, len = 0;
+    int64_t src = 0;
+    if (i < a.n) {
+      dst = out_offsets[i];
+      len = out_offsets[i + 1] - dst;
+      if (len) {  // a row with bytes has a valid, in-range index and a valid value
+        int64_t j;
+        IndexLoad<IdxT>::Load(a.i_data, a.i_off + i, a.v_len, &j);
+        src = a.v_offsets[a.v_off + j];
+      }
+    }
+    uint64_t todo = __ballot(len != 0);
+    while (todo) {
+      const int r = __ffsll(static_cast<long long>(todo)) - 1;
+      todo &= todo - 1;
+      const uint32_t rlen = __shfl(len, r), rdst = __shfl(dst, r);
+      const int64_t rsrc = __shfl(src, r);
+      for (uint32_t b = lane; b < rlen; b += 64) out_data[rdst + b] = a.v_data[rsrc + b];
+    }
+  }
+}
+
+
+}  // namespace amdarrow
+
 using namespace amdarrow;
 
 extern "C" {
@@ -703,6 +798,114 @@ int amdarrow_concatenate(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nc
       dst += chunks[c].length * w;
     }
   }
+  AA_HIP(hipStreamSynchronize(ctx->stream));
+  return AMDARROW_OK;
+}
+
+
+/* Take of BinaryArray / StringArray values (32-bit offsets): VarBinaryImpl, vector_selection.cc:1493-1573.
+ * Pass 1 -- offsets, validity, null count, bounds check; *out_data_bytes = bytes pass 2 will write. */
+int amdarrow_binary_take_offsets(amdarrow_ctx* ctx, const amdarrow_binary_array* values, const amdarrow_array* indices, int boundscheck,
+                                 int32_t* out_offsets, uint8_t* out_validity, int64_t* out_data_bytes, amdarrow_out* out) {
+  const int iw = BitWidth(indices->type_id) / 8;
+  const bool sgn = indices->type_id == AMDARROW_INT8 || indices->type_id == AMDARROW_INT16 || indices->type_id == AMDARROW_INT32 ||
+                   indices->type_id == AMDARROW_INT64;
+  if (iw < 1 || indices->type_id == AMDARROW_FLOAT || indices->type_id == AMDARROW_DOUBLE || indices->type_id == AMDARROW_BOOL)
+    return SetError(AMDARROW_TYPE_ERROR, "take: indices must be integers");
+  out->length = indices->length;
+  out->null_count = 0;
+  out->has_validity = 1;
+  *out_data_bytes = 0;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  const int64_t n = indices->length;
+  if (n == 0) {
+    AA_HIP(hipMemsetAsync(out_offsets, 0, 4, ctx->stream));
+    AA_HIP(hipStreamSynchronize(ctx->stream));
+    return AMDARROW_OK;
+  }
+  const int64_t nb = (n + 2047) / 2048;
+  Carver c;
+  const size_t o_cnt = c.Take(kCounterBytes);
+  const size_t o_err = c.Take(256);
+  const size_t o_sums = c.Take(4 * static_cast<size_t>(nb));
+  const size_t o_sumoff = c.Take(8 * static_cast<size_t>(nb + 1));
+  void* base;
+  AA_TRY(Scratch(ctx, c.off, &base));
+  char* b = static_cast<char*>(base);
+  auto* counters = reinterpret_cast<unsigned long long*>(b + o_cnt);
+  auto* err = reinterpret_cast<unsigned long long*>(b + o_err);
+  auto* sums = reinterpret_cast<uint32_t*>(b + o_sums);
+  auto* sumoff = reinterpret_cast<int64_t*>(b + o_sumoff);
+  AA_TRY(ClearCounters(ctx, counters));
+  const unsigned long long init[2] = {~0ull, 0ull};
+  AA_HIP(hipMemcpyAsync(err, init, 16, hipMemcpyHostToDevice, ctx->stream));
+  BinaryTakeArgs a{};
+  a.v_offsets = values->offsets; a.v_data = values->data; a.v_valid = values->validity; a.v_off = values->offset;
+  a.v_len = values->length; a.v_may_null = values->validity && values->null_count != 0;
+  a.i_data = indices->values; a.i_valid = MayHaveNulls(indices) ? indices->validity : nullptr; a.i_off = indices->offset; a.n = n;
+  a.boundscheck = boundscheck;
+  a.out_lengths = reinterpret_cast<uint32_t*>(out_offsets); a.out_validity = out_validity; a.valid_count = counters; a.err_pos = err;
+  const int grid = GridFor(n, kThreads, ctx->num_cus * 8);
+#define AA_BIN(K, ...)                                                                                               \
+  do {                                                                                                               \
+    if (iw == 1) { if (sgn) hipLaunchKernelGGL((K<int8_t>), dim3(grid), dim3(kThreads), 0, ctx->stream, __VA_ARGS__);  \
+                   else hipLaunchKernelGGL((K<uint8_t>), dim3(grid), dim3(kThreads), 0, ctx->stream, __VA_ARGS__); }   \
+    else if (iw == 2) { if (sgn) hipLaunchKernelGGL((K<int16_t>), dim3(grid), dim3(kThreads), 0, ctx->stream, __VA_ARGS__); \
+                        else hipLaunchKernelGGL((K<uint16_t>), dim3(grid), dim3(kThreads), 0, ctx->stream, __VA_ARGS__); } \
+    else if (iw == 4) { if (sgn) hipLaunchKernelGGL((K<int32_t>), dim3(grid), dim3(kThreads), 0, ctx->stream, __VA_ARGS__); \
+                        else hipLaunchKernelGGL((K<uint32_t>), dim3(grid), dim3(kThreads), 0, ctx->stream, __VA_ARGS__); } \
+    else { if (sgn) hipLaunchKernelGGL((K<int64_t>), dim3(grid), dim3(kThreads), 0, ctx->stream, __VA_ARGS__);       \
+           else hipLaunchKernelGGL((K<uint64_t>), dim3(grid), dim3(kThreads), 0, ctx->stream, __VA_ARGS__); }        \
+  } while (0)
+  AA_BIN(k_binary_take_lengths, a);
+  AA_HIP(hipGetLastError());
+  AA_TRY(ScanU32InPlace(ctx, a.out_lengths, n, sums, sumoff));
+  hipLaunchKernelGGL(k_binary_close_offsets, dim3(1), dim3(1), 0, ctx->stream, a.out_lengths, n, sumoff + nb, err);
+  AA_HIP(hipGetLastError());
+  unsigned long long host_valid = 0, host_err[2] = {0, 0};
+  int64_t total = 0;
+  AA_TRY(ReadCounters(ctx, counters, 1, &host_valid));
+  AA_TRY(ReadBack(ctx, err, 16, host_err));
+  AA_TRY(ReadBack(ctx, sumoff + nb, 8, &total));
+  if (boundscheck && host_err[0] != ~0ull) {
+    unsigned char raw[8] = {0};
+    AA_HIP(hipMemcpyAsync(raw, static_cast<const char*>(indices->values) + (indices->offset + host_err[0]) * iw, iw, hipMemcpyDeviceToHost,
+                          ctx->stream));
+    AA_HIP(hipStreamSynchronize(ctx->stream));
+    std::string s;
+    if (sgn) {
+      long long v = iw == 1 ? *reinterpret_cast<int8_t*>(raw) : iw == 2 ? *reinterpret_cast<int16_t*>(raw)
+                  : iw == 4 ? *reinterpret_cast<int32_t*>(raw) : *reinterpret_cast<int64_t*>(raw);
+      s = std::to_string(v);
+    } else {
+      unsigned long long v = iw == 1 ? *reinterpret_cast<uint8_t*>(raw) : iw == 2 ? *reinterpret_cast<uint16_t*>(raw)
+                           : iw == 4 ? *reinterpret_cast<uint32_t*>(raw) : *reinterpret_cast<uint64_t*>(raw);
+      s = std::to_string(v);
+    }
+    return SetError(AMDARROW_INDEX_ERROR, "Index " + s + " out of bounds");
+  }
+  if (host_err[1]) return SetError(AMDARROW_INVALID, "Take operation overflowed binary array capacity");
+  *out_data_bytes = total;
+  out->null_count = n - static_cast<int64_t>(host_valid);
+  return AMDARROW_OK;
+}
+
+/* Pass 2 -- the bytes, into out_data (>= the size pass 1 reported). */
+int amdarrow_binary_take_data(amdarrow_ctx* ctx, const amdarrow_binary_array* values, const amdarrow_array* indices,
+                              const int32_t* out_offsets, uint8_t* out_data) {
+  const int iw = BitWidth(indices->type_id) / 8;
+  const bool sgn = indices->type_id == AMDARROW_INT8 || indices->type_id == AMDARROW_INT16 || indices->type_id == AMDARROW_INT32 ||
+                   indices->type_id == AMDARROW_INT64;
+  const int64_t n = indices->length;
+  if (n == 0) return AMDARROW_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  BinaryTakeArgs a{};
+  a.v_offsets = values->offsets; a.v_data = values->data; a.v_off = values->offset; a.v_len = values->length;
+  a.i_data = indices->values; a.i_off = indices->offset; a.n = n;
+  const int grid = GridFor(n, kThreads, ctx->num_cus * 8);
+  AA_BIN(k_binary_take_data, a, reinterpret_cast<const uint32_t*>(out_offsets), out_data);
+#undef AA_BIN
+  AA_HIP(hipGetLastError());
   AA_HIP(hipStreamSynchronize(ctx->stream));
   return AMDARROW_OK;
 }

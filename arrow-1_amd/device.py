@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from . import _abi
-from ._abi import BOOL, CArray, check, load_library
+from ._abi import BOOL, CArray, CBinaryArray, check, load_library
 
 NP_OF = {_abi.UINT8: np.uint8, _abi.INT8: np.int8, _abi.UINT16: np.uint16, _abi.INT16: np.int16,
          _abi.UINT32: np.uint32, _abi.INT32: np.int32, _abi.UINT64: np.uint64, _abi.INT64: np.int64,
@@ -52,6 +52,54 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+class DeviceBinaryArray:
+    """A BinaryArray / StringArray (32-bit offsets) in HBM: offsets int32[offset + length + 1], data bytes,
+    optional validity bitmap -- buffers validity | offsets | data of array/array_binary.h."""
+
+    def __init__(self, offsets, data, validity, length, offset=0, null_count=0):
+        self.offsets, self.data, self.validity = offsets, data, validity
+        self.length, self.offset = int(length), int(offset)
+        self.null_count = 0 if validity is None else int(null_count)
+
+    @staticmethod
+    def from_items(items, offset=0, length=None, null_count=None, device="cuda"):
+        """items: list of bytes / None (None = null slot)"""
+        lens = [0 if x is None else len(x) for x in items]
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        raw = np.frombuffer(b"".join(x or b"" for x in items) + b"\0" * 8, np.uint8)
+        o = alloc_bytes(off.nbytes, device, zero=True)
+        o[:off.nbytes] = torch.from_numpy(off.view(np.uint8).copy())
+        d = alloc_bytes(len(raw), device, zero=True)
+        d[:len(raw)] = torch.from_numpy(raw.copy())
+        valid = np.array([x is not None for x in items], bool)
+        n = len(items) - offset if length is None else length
+        v = None
+        if not valid.all():
+            bits = np.packbits(valid, bitorder="little")
+            v = alloc_bytes(len(bits), device, zero=True)
+            v[:len(bits)] = torch.from_numpy(bits.copy())
+        nc = int((~valid[offset:offset + n]).sum()) if null_count is None else null_count
+        return DeviceBinaryArray(o, d, v, n, offset, nc)
+
+    def c(self):
+        s = CBinaryArray()
+        s.offsets, s.data = self.offsets.data_ptr(), self.data.data_ptr()
+        s.validity = None if self.validity is None else self.validity.data_ptr()
+        s.length, s.offset, s.null_count = self.length, self.offset, self.null_count
+        return s
+
+    def to_items(self):
+        off = self.offsets[:(self.offset + self.length + 1) * 4].cpu().numpy().view(np.int32)[self.offset:]
+        end = int(off[-1]) if self.length else 0
+        data = self.data[:end].cpu().numpy() if end else np.zeros(0, np.uint8)
+        if self.validity is None:
+            valid = np.ones(self.length, bool)
+        else:
+            valid = np.unpackbits(self.validity[:(self.offset + self.length + 7) // 8].cpu().numpy(),
+                                  bitorder="little")[self.offset:self.offset + self.length].astype(bool)
+        return [bytes(data[off[i]:off[i + 1]]) if valid[i] else None for i in range(self.length)]
 
 
 class DeviceArray:

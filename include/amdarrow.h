@@ -128,6 +128,31 @@ int amdarrow_filter(amdarrow_ctx* ctx, const amdarrow_array* values,
 int amdarrow_take_indices(amdarrow_ctx* ctx, const amdarrow_array* filter, int null_selection,
                           void* out_indices, uint8_t* out_validity, int64_t out_capacity,
                           int* out_index_width, amdarrow_out* out);
+/* BinaryArray / StringArray with 32-bit offsets (array/array_binary.h; buffers validity | offsets | data). */
+typedef struct amdarrow_binary_array {
+  const int32_t* offsets;   /* (offset + length + 1) entries */
+  const uint8_t* data;
+  const uint8_t* validity;  /* LSB bitmap or NULL */
+  int64_t length;
+  int64_t offset;
+  int64_t null_count;       /* -1 = unknown */
+} amdarrow_binary_array;
+/* Take of variable-width values -- VarBinaryImpl over Selection::VisitTake, vector_selection.cc:
+ * 1203-1320, 1493-1573: out[i] = values[indices[i]]; null and zero bytes long if the index or the
+ * value is null; validity always written; IndexError as amdarrow_take; "Take operation overflowed binary
+ * array capacity" (Invalid) past INT32_MAX - 1 bytes.  Two calls, because the byte count is a result:
+ *   offsets  out_offsets[indices.length + 1], out_validity, out->null_count, *out_data_bytes;
+ *   data     the bytes into out_data (>= *out_data_bytes), with the offsets of the first call.
+ * Filter of such values is this Take over amdarrow_take_indices(filter) (the identity the reference's
+ * ValidateFilter checks, vector_selection_test.cc:74-100); BinaryFilter's validity / null_count
+ * conventions (:1085-1124) are applied by the host kernel. */
+int amdarrow_binary_take_offsets(amdarrow_ctx* ctx, const amdarrow_binary_array* values,
+                                 const amdarrow_array* indices, int boundscheck, int32_t* out_offsets,
+                                 uint8_t* out_validity, int64_t* out_data_bytes, amdarrow_out* out);
+int amdarrow_binary_take_data(amdarrow_ctx* ctx, const amdarrow_binary_array* values,
+                              const amdarrow_array* indices, const int32_t* out_offsets,
+                              uint8_t* out_data);
+
 /* Concatenate, array/concatenate.cc:171-201 -- what TakeCA/TakeCC (vector_selection.cc:1923-
  * 1959) do to chunked values first.  out_values: sum(length) elements (bits for BOOL).
  * out->null_count = sum of the chunks' counts, -1 if any is unknown (:172-180); the validity

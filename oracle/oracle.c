@@ -222,6 +222,83 @@ int orc_take(const orc_array* values, const orc_array* idx, int boundscheck, voi
   return ORC_OK;
 }
 
+/* ---- 8f.4: variable-width Take / Filter, vector_selection.cc:840-1124, 1203-1320, 1493-1573 ---- */
+static inline int bin_valid(const orc_binary* v, int64_t i) { return v->validity ? get_bit(v->validity, v->offset + i) : 1; }
+static void bin_append(const orc_binary* v, int64_t i, int32_t* out_offsets, uint8_t* out_data, int64_t pos, int32_t* fill) {
+  const int32_t o0 = v->offsets[v->offset + i], o1 = v->offsets[v->offset + i + 1];
+  out_offsets[pos] = *fill;
+  memcpy(out_data + *fill, v->data + o0, (size_t)(o1 - o0)); /* data_builder.UnsafeAppend :1550 */
+  *fill += o1 - o0;
+}
+int orc_binary_take(const orc_binary* values, const orc_array* indices, int boundscheck, int32_t* out_offsets,
+                    uint8_t* out_data, uint8_t* out_validity, orc_out* out) {
+  const int64_t n = indices->length;
+  if (boundscheck) { /* CheckIndexBounds first (TakeExec :2080-2090; int_util.cc:534-561) */
+    for (int64_t i = 0; i < n; ++i) {
+      if (!slot_valid(indices, i)) continue;
+      int neg; int64_t v = load_index(indices, i, &neg);
+      const int oob = indices->type_id == ORC_UINT64 ? ((uint64_t)v >= (uint64_t)values->length) : (neg || v >= values->length);
+      if (oob) {
+        char msg[96];
+        if (indices->type_id == ORC_UINT64) snprintf(msg, sizeof msg, "Index %llu out of bounds", (unsigned long long)v);
+        else snprintf(msg, sizeof msg, "Index %lld out of bounds", (long long)v);
+        return fail(ORC_INDEX_ERROR, msg);
+      }
+    }
+  }
+  memset(out_validity, 0, (size_t)bytes_for_bits(n));
+  out->length = n; out->null_count = 0; out->has_validity = 1; /* FinishCommon :1250-1255 */
+  int32_t fill = 0;
+  const int values_have_nulls = values->validity && values->null_count != 0; /* MayHaveNulls :1265 */
+  for (int64_t i = 0; i < n; ++i) {
+    int neg = 0;
+    int ok = slot_valid(indices, i);
+    int64_t u = 0;
+    if (ok) {
+      u = load_index(indices, i, &neg);
+      if (indices->type_id == ORC_UINT64 ? ((uint64_t)u >= (uint64_t)values->length) : (neg || u >= values->length)) ok = 0;
+    }
+    if (ok && values_have_nulls && !bin_valid(values, u)) ok = 0;
+    if (ok) {
+      if ((int64_t)fill + (values->offsets[values->offset + u + 1] - values->offsets[values->offset + u]) > 2147483646LL)
+        return fail(ORC_INVALID, "Take operation overflowed binary array capacity"); /* :1540-1544 */
+      bin_append(values, u, out_offsets, out_data, i, &fill);
+      set_bit(out_validity, i);
+    } else {
+      out_offsets[i] = fill; /* visit_null :1556-1559 */
+      ++out->null_count;
+    }
+  }
+  out_offsets[n] = fill;
+  return ORC_OK;
+}
+int orc_binary_filter(const orc_binary* values, const orc_array* filter, int null_selection, int32_t* out_offsets,
+                      uint8_t* out_data, uint8_t* out_validity, orc_out* out) {
+  if (filter->length != values->length) return fail(ORC_INVALID, "Array arguments must all be the same length");
+  const int64_t vnc = values->validity ? values->null_count : 0, fnc = arg_null_count(filter);
+  const int with_validity = vnc != 0 || fnc != 0; /* :1099-1112 */
+  int64_t pos = 0;
+  int32_t fill = 0;
+  memset(out_validity, 0, (size_t)bytes_for_bits(values->length));
+  for (int64_t i = 0; i < values->length; ++i) {
+    const int fvalid = slot_valid(filter, i), fset = fvalid && bool_at(filter, i);
+    if (fset) {
+      if (bin_valid(values, i)) { bin_append(values, i, out_offsets, out_data, pos, &fill); set_bit(out_validity, pos); }
+      else out_offsets[pos] = fill;
+      ++pos;
+    } else if (!fvalid && null_selection == ORC_EMIT_NULL) {
+      out_offsets[pos] = fill;
+      ++pos;
+    }
+  }
+  out_offsets[pos] = fill;
+  out->length = pos;
+  out->has_validity = with_validity;
+  out->null_count = (vnc == 0 && (null_selection == ORC_DROP || fnc == 0)) ? 0 : -1; /* :1090-1096 */
+  if (!with_validity) for (int64_t i = 0; i < pos; ++i) set_bit(out_validity, i);
+  return ORC_OK;
+}
+
 /* ---- b: sort_indices, vector_sort.cc:224-575, 657-832 ------------------------------ */
 typedef struct { uint64_t key; uint64_t idx; } sort_rec;
 static int cmp_rec(const void* a, const void* b) {

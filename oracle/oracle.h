@@ -94,6 +94,20 @@ int orc_take_indices(const orc_array* filter, int null_selection, void* out_indi
 int orc_take(const orc_array* values, const orc_array* indices, int boundscheck,
              void* out_values, uint8_t* out_validity, orc_out* out);
 
+/* 8f.4: variable-width (binary / utf8, 32-bit offsets) Take and Filter.
+ * Take: VarBinaryImpl over Selection::VisitTake, vector_selection.cc:1203-1320, 1493-1573 -- validity always
+ * present, a null row is zero bytes long.  Filter: BinaryFilter[NonNull]Impl :840-1124 -- validity present iff
+ * values.null_count != 0 || filter.null_count != 0 (stored counts), out->null_count 0 or -1 as :1090-1096.
+ * out_data must hold the selected bytes (never more than the input's). */
+typedef struct orc_binary {
+  const int32_t* offsets; const uint8_t* data; const uint8_t* validity;
+  int64_t length; int64_t offset; int64_t null_count;
+} orc_binary;
+int orc_binary_take(const orc_binary* values, const orc_array* indices, int boundscheck, int32_t* out_offsets,
+                    uint8_t* out_data, uint8_t* out_validity, orc_out* out);
+int orc_binary_filter(const orc_binary* values, const orc_array* filter, int null_selection, int32_t* out_offsets,
+                      uint8_t* out_data, uint8_t* out_validity, orc_out* out);
+
 /* b1-b3: array_sort_indices / ChunkedArraySorter, vector_sort.cc:373-575, 657-832.
  * chunks[0..nchunks) are the chunks of one logical array; out has sum(length) entries. */
 int orc_sort_indices(const orc_array* chunks, int nchunks, int order, uint64_t* out);

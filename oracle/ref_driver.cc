@@ -396,6 +396,44 @@ int ref_dictionary_encode(const orc_array* a, int null_encoding, int32_t* out_in
   return 0;
 }
 
+// ---- variable-width (binary) Take / Filter through the reference's "take" / "filter" ----
+static std::shared_ptr<ArrayData> WrapBinary(const orc_binary* a) {
+  const int64_t n = a->offset + a->length;
+  std::shared_ptr<Buffer> validity;
+  if (a->validity) validity = std::make_shared<Buffer>(a->validity, BitUtil::BytesForBits(n));
+  auto offsets = std::make_shared<Buffer>(reinterpret_cast<const uint8_t*>(a->offsets), (n + 1) * 4);
+  auto data = std::make_shared<Buffer>(a->data, n ? a->offsets[n] : 0);
+  return ArrayData::Make(binary(), a->length, {validity, offsets, data}, a->validity ? a->null_count : 0, a->offset);
+}
+static void ExportBinary(const ArrayData& d, int32_t* out_offsets, uint8_t* out_data, uint8_t* out_validity, orc_out* out) {
+  out->length = d.length;
+  out->null_count = d.null_count.load();
+  out->has_validity = d.buffers[0] != nullptr;
+  std::memset(out_validity, 0, BitUtil::BytesForBits(d.length));
+  if (d.buffers[0] && d.length > 0) arrow::internal::CopyBitmap(d.buffers[0]->data(), d.offset, d.length, out_validity, 0);
+  else for (int64_t i = 0; i < d.length; ++i) BitUtil::SetBit(out_validity, i);
+  const int32_t* off = d.GetValues<int32_t>(1);
+  const int32_t base = d.length || d.buffers[1] ? off[0] : 0;
+  for (int64_t i = 0; i <= d.length; ++i) out_offsets[i] = off[i] - base;
+  if (d.length > 0 && d.buffers[2]) std::memcpy(out_data, d.buffers[2]->data() + base, off[d.length] - base);
+}
+int ref_binary_take(const orc_binary* values, const orc_array* indices, int boundscheck, int32_t* out_offsets,
+                    uint8_t* out_data, uint8_t* out_validity, orc_out* out) {
+  TakeOptions opts(boundscheck != 0);
+  auto res = CallFunction("take", {Datum(WrapBinary(values)), Datum(Wrap(indices))}, &opts, Ctx());
+  if (!res.ok()) return Fail(res.status());
+  ExportBinary(*res->array(), out_offsets, out_data, out_validity, out);
+  return 0;
+}
+int ref_binary_filter(const orc_binary* values, const orc_array* filter, int null_selection, int32_t* out_offsets,
+                      uint8_t* out_data, uint8_t* out_validity, orc_out* out) {
+  FilterOptions opts(static_cast<FilterOptions::NullSelectionBehavior>(null_selection));
+  auto res = CallFunction("filter", {Datum(WrapBinary(values)), Datum(Wrap(filter))}, &opts, Ctx());
+  if (!res.ok()) return Fail(res.status());
+  ExportBinary(*res->array(), out_offsets, out_data, out_validity, out);
+  return 0;
+}
+
 static const char* kCmpNames[] = {"equal", "not_equal", "greater", "greater_equal", "less", "less_equal"};
 static const char* kArithNames[] = {"add", "subtract", "multiply", "divide",
                                     "add_checked", "subtract_checked", "multiply_checked", "divide_checked"};

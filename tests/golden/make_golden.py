@@ -29,6 +29,11 @@ def main():
     for op, params, arrs in golden_io.iter_cases():
         entry = {"op": op, "params": params, "inputs": [], "outputs": {}}
         for a in arrs:
+            if isinstance(a, orc.BinArr):
+                entry["inputs"].append({"type": "binary", "offset": a.offset, "length": a.length, "null_count": a.null_count,
+                                        "offsets": put(a.offsets), "data": put(a.data),
+                                        "valid": None if a.valid is None else put(a.valid)})
+                continue
             entry["inputs"].append({"type": a.type_id, "offset": a.offset, "length": a.length,
                                     "null_count": a.null_count, "data": put(a.data),
                                     "valid": None if a.valid is None else put(a.valid)})

@@ -178,6 +178,26 @@ def iter_cases():
             ids = Arr(orc.UINT32, rng.integers(0, 95, 512))
             for mode in (0, 1):
                 yield ("hash_min_max", dict(num_groups=100, null_handling=mode), [v, ids])
+    # ---- variable-width Take / Filter (vector_selection_test.cc:445-520 TestFilterKernelWithString,
+    # :1180-1230 TestTakeKernelWithString: random strings, nulls on either side, slices) ----
+    def rand_bin(m, p_null, off):
+        items = []
+        for _ in range(m + off):
+            if rng.random() < p_null:
+                items.append(None)
+            else:
+                items.append(bytes(rng.integers(97, 123, int(rng.integers(0, 13))).astype(np.uint8)))
+        return orc.BinArr(items, off, m, pad=int(rng.integers(0, 4)))
+    for m, pv, off in [(0, 0.0, 0), (1, 0.0, 0), (300, 0.0, 2), (300, 0.2, 3), (300, 1.0, 0)]:
+        v = rand_bin(m, pv, off)
+        for pf in (0.0, 0.15):
+            f = R(rng, BOOL, m, pf, 5)
+            for ns in (DROP, EMIT_NULL):
+                yield ("binary_filter", dict(null_selection=ns), [v, f])
+        if m:
+            for it in (orc.INT8, orc.UINT32, orc.INT64):
+                i = R(rng, it, 200, 0.1, 2, lo=0, hi=min(m - 1, 100))
+                yield ("binary_take", dict(boundscheck=True), [v, i])
     # ---- unique / value_counts / dictionary_encode (vector_hash_test.cc:60-140 CheckUnique /
     # CheckValueCounts / CheckDictEncode; random arrays with few distinct values, NaN and both zeros) ----
     for t in [BOOL] + NUMERIC:
@@ -226,6 +246,11 @@ def run_case(api, op, params, arrs):
         if op == "hash_aggregate":
             return res(api.hash_aggregate(params["func"], arrs[0], arrs[1].values(), params["num_groups"],
                                           params.get("count_mode", 0)))
+        if op in ("binary_take", "binary_filter"):
+            r = api.binary_take(arrs[0], arrs[1], params["boundscheck"]) if op == "binary_take" else \
+                api.binary_filter(arrs[0], arrs[1], params["null_selection"])
+            return {"offsets": r.offsets.astype(np.int32), "data": r.data, "validity": r.validity(),
+                    "meta": np.array([r.length, r.null_count, int(r.has_validity)], np.int64)}
         if op in ("unique", "value_counts", "dictionary_encode"):
             def canon(r):  # the reference leaves the value under a null slot unspecified (the memo table's null entry)
                 d = res(r)
@@ -326,7 +351,14 @@ def load_golden():
 
     out = []
     for c in man["cases"]:
-        arrs = [Arr(i["type"], get(i["data"]), None if i["valid"] is None else get(i["valid"]), i["offset"],
-                    i["length"], i["null_count"]) for i in c["inputs"]]
+        def arr_of(i):
+            if i["type"] == "binary":
+                off, data = get(i["offsets"]), get(i["data"])
+                valid = np.ones(len(off) - 1, bool) if i["valid"] is None else get(i["valid"])
+                items = [bytes(data[off[k]:off[k + 1]]) if valid[k] else None for k in range(len(off) - 1)]
+                return orc.BinArr(items, i["offset"], i["length"], i["null_count"], pad=int(off[0]))
+            return Arr(i["type"], get(i["data"]), None if i["valid"] is None else get(i["valid"]), i["offset"],
+                       i["length"], i["null_count"])
+        arrs = [arr_of(i) for i in c["inputs"]]
         out.append((c["op"], c["params"], arrs, {k: get(v) for k, v in c["outputs"].items()}))
     return out

@@ -58,6 +58,25 @@ class GpuApi:
             chunks = [chunks]
         return self._wrap(lambda: compute.sort_indices(self.ctx, [up(c) for c in chunks], order).values_numpy())
 
+    # ---- variable-width Take / Filter ----
+    @staticmethod
+    def _up_bin(b):
+        return device.DeviceBinaryArray.from_items(b.items, b.offset, b.length, b.null_count if b.vbits is not None else 0)
+
+    @staticmethod
+    def _down_bin(d):
+        n = d.length
+        off = d.offsets[:(n + 1) * 4].cpu().numpy().view(np.int32).copy()
+        data = d.data[:int(off[-1]) if n else 0].cpu().numpy().copy()
+        bits = d.validity[:(n + 7) // 8].cpu().numpy().copy() if d.validity is not None else np.packbits(np.ones(n, bool), bitorder="little")
+        return orc.BinResult(off, data, np.concatenate([bits, np.zeros(8, np.uint8)]), _Out(n, d.null_count, d.validity is not None))
+
+    def binary_take(self, values, indices, boundscheck=True):
+        return self._wrap(lambda: self._down_bin(compute.binary_take(self.ctx, self._up_bin(values), up(indices), boundscheck)))
+
+    def binary_filter(self, values, filt, null_sel=orc.DROP):
+        return self._wrap(lambda: self._down_bin(compute.binary_filter(self.ctx, self._up_bin(values), up(filt), null_sel)))
+
     # ---- SURVEY 8f.4 ----
     def unique(self, a):
         return self._wrap(lambda: down(compute.unique(self.ctx, up(a))))

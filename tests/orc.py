@@ -45,6 +45,11 @@ class CArr(C.Structure):
                 ("offset", C.c_int64), ("type_id", C.c_int32), ("null_count", C.c_int64)]
 
 
+class CBin(C.Structure):
+    _fields_ = [("offsets", C.c_void_p), ("data", C.c_void_p), ("validity", C.c_void_p), ("length", C.c_int64),
+                ("offset", C.c_int64), ("null_count", C.c_int64)]
+
+
 class COut(C.Structure):
     _fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("has_validity", C.c_int32)]
 
@@ -100,6 +105,55 @@ def agg_to_dict(type_id, valid_count, s, mn, mx):
             return int(np.array([bits], np.uint64).view(np.int64)[0])
         return int(bits)
     return {"valid_count": int(valid_count), "sum": conv(s), "min": conv(mn), "max": conv(mx)}
+
+
+class BinArr:
+    """A BinaryArray (32-bit offsets) for the test APIs: items = list of bytes / None."""
+
+    def __init__(self, items, offset=0, length=None, null_count=None, pad=0):
+        items = [None] * 0 + list(items)
+        self.items = items
+        lens = [0 if x is None else len(x) for x in items]
+        self.offsets = np.concatenate([[pad], pad + np.cumsum(lens)]).astype(np.int32)
+        self.data = np.frombuffer(b"\0" * pad + b"".join(x or b"" for x in items) + b"\0" * 8, np.uint8).copy()
+        valid = np.array([x is not None for x in items], bool)
+        self.valid = None if valid.all() else valid
+        self.vbits = None if self.valid is None else np.concatenate([pack(valid), np.zeros(8, np.uint8)])
+        self.offset = offset
+        self.length = len(items) - offset if length is None else length
+        nc = int((~valid[offset:offset + self.length]).sum())
+        self.null_count = nc if null_count is None else null_count
+
+    def c(self):
+        s = CBin()
+        s.offsets = self.offsets.ctypes.data_as(C.c_void_p)
+        s.data = self.data.ctypes.data_as(C.c_void_p)
+        s.validity = None if self.vbits is None else self.vbits.ctypes.data_as(C.c_void_p)
+        s.length, s.offset, s.null_count = self.length, self.offset, self.null_count if self.vbits is not None else 0
+        return s
+
+    def logical(self):
+        return self.items[self.offset:self.offset + self.length]
+
+
+class BinResult:
+    def __init__(self, offsets, data, validity_bits, out):
+        self.length, self.null_count, self.has_validity = out.length, out.null_count, bool(out.has_validity)
+        self.offsets = offsets[:self.length + 1].copy()
+        self.data = data[:int(self.offsets[-1]) if self.length else 0].copy()
+        self.validity_bits = validity_bits[:(self.length + 7) // 8].copy()
+
+    def validity(self):
+        return unpack(self.validity_bits, self.length)
+
+    def logical(self):
+        v = self.validity()
+        return [bytes(self.data[self.offsets[i]:self.offsets[i + 1]]) if v[i] else None for i in range(self.length)]
+
+    def same(self, other):
+        return ((self.length, self.null_count, self.has_validity) == (other.length, other.null_count, other.has_validity) and
+                np.array_equal(self.offsets, other.offsets) and np.array_equal(self.data, other.data) and
+                np.array_equal(self.validity(), other.validity()))
 
 
 class Result:
@@ -232,6 +286,23 @@ class Api:
         out = np.zeros(total + 1, np.uint64)
         self._check(self._f("sort_indices")(arr, len(chunks), order, out.ctypes.data_as(C.c_void_p)))
         return out[:total]
+
+    # ---- variable-width Take / Filter ----
+    def _bin_call(self, fn, values, sel, flag, n_out_max):
+        total = int(values.offsets[-1]) + 16
+        out_o = np.zeros(n_out_max + 2, np.int32)
+        out_d = np.zeros(max(total * max(1, (n_out_max + values.length) // max(values.length, 1)), 16) + 16, np.uint8)
+        out_b = np.zeros(n_out_max // 8 + 16, np.uint8)
+        out, cv, cs = COut(), values.c(), sel.c()
+        self._check(self._f(fn)(C.byref(cv), C.byref(cs), flag, out_o.ctypes.data_as(C.c_void_p), out_d.ctypes.data_as(C.c_void_p),
+                                out_b.ctypes.data_as(C.c_void_p), C.byref(out)))
+        return BinResult(out_o, out_d, out_b, out)
+
+    def binary_take(self, values, indices, boundscheck=True):
+        return self._bin_call("binary_take", values, indices, int(boundscheck), indices.length)
+
+    def binary_filter(self, values, filt, null_sel=DROP):
+        return self._bin_call("binary_filter", values, filt, null_sel, filt.length)
 
     # ---- unique / value_counts / dictionary_encode ----
     def unique(self, a):

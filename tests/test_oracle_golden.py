@@ -212,3 +212,31 @@ def test_vector_hash_functions_match_live_reference(oracle, reference):
             for ne in (0, 1):
                 (i1, d1), (i2, d2) = oracle.dictionary_encode(a, ne), reference.dictionary_encode(a, ne)
                 assert i1.same_valid(i2) and d1.same_valid(d2), (t, n, p, ne)
+
+
+def _rand_bin(rng, n, p_null, off=0, maxlen=12):
+    items = []
+    for _ in range(n + off):
+        items.append(None if rng.random() < p_null else bytes(rng.integers(97, 123, int(rng.integers(0, maxlen + 1))).astype(np.uint8)))
+    return orc.BinArr(items, off, n, pad=int(rng.integers(0, 5)))
+
+
+def test_binary_take_and_filter_match_live_reference(oracle, reference):
+    """SURVEY 8f.4 on a fresh seed: Take / Filter of BinaryArrays (32-bit offsets) incl. slices, null values,
+    null indices / filter slots under both null selections, every index width, and the IndexError text."""
+    rng = np.random.default_rng(20260107)
+    for n in (0, 1, 7, 200, 3000):
+        for pv in (0, .2, 1.0):
+            v = _rand_bin(rng, n, pv, off=int(rng.integers(0, 4)))
+            for pf in (0, .15):
+                f = orc.random_arr(rng, orc.BOOL, n, pf, int(rng.integers(0, 9)))
+                for ns in (orc.DROP, orc.EMIT_NULL):
+                    assert oracle.binary_filter(v, f, ns).same(reference.binary_filter(v, f, ns)), (n, pv, pf, ns)
+            if n:
+                for it in orc.INTS:
+                    i = orc.random_arr(rng, it, int(rng.integers(0, 300)), .1, 2, lo=0, hi=min(n - 1, 100))
+                    assert oracle.binary_take(v, i).same(reference.binary_take(v, i)), (n, pv, it)
+    for api in (oracle, reference):
+        with pytest.raises(orc.StatusError) as ei:
+            api.binary_take(orc.BinArr([b"a", b"bb"]), orc.Arr(orc.INT32, [0, 2]))
+        assert ei.value.code == orc.INDEX_ERROR and ei.value.msg == "Index 2 out of bounds"

@@ -940,3 +940,40 @@ def test_sort_large_inputs_by_shape(gpu, shape):
     seen = torch.zeros(n, dtype=torch.bool, device="cuda")
     seen[idx] = True
     assert bool(seen.all()), shape
+
+
+# ---- variable-width (binary / utf8) Take and Filter ----
+def _rand_bin(rng, n, p_null, off=0, maxlen=12):
+    items = []
+    for _ in range(n + off):
+        items.append(None if rng.random() < p_null else bytes(rng.integers(97, 123, int(rng.integers(0, maxlen + 1))).astype(np.uint8)))
+    return orc.BinArr(items, off, n)
+
+
+@pytest.mark.gpu
+def test_binary_take_and_filter_random(gpu, oracle):
+    rng = np.random.default_rng(300)
+    for n, maxlen in [(0, 5), (1, 5), (7, 5), (200, 12), (5000, 40), (60_000, 3), (3000, 300)]:
+        for pv in (0, .2, 1.0):
+            v = _rand_bin(rng, n, pv, off=int(rng.integers(0, 4)), maxlen=maxlen)
+            for pf in (0, .15):
+                f = R(rng, BOOL, n, pf, int(rng.integers(0, 9)))
+                for ns in (DROP, EMIT_NULL):
+                    assert gpu.binary_filter(v, f, ns).same(oracle.binary_filter(v, f, ns)), (n, pv, pf, ns)
+            if n:
+                for it in INTS:
+                    i = R(rng, it, int(rng.integers(0, 700)), .1, 2, lo=0, hi=min(n - 1, 100))
+                    assert gpu.binary_take(v, i).same(oracle.binary_take(v, i)), (n, pv, it)
+    for api in (oracle, gpu):
+        with pytest.raises(orc.StatusError) as ei:
+            api.binary_take(orc.BinArr([b"a", b"bb"]), Arr(INT32, [0, 2]))
+        assert ei.value.code == orc.INDEX_ERROR and ei.value.msg == "Index 2 out of bounds"
+    # reference literals: TestFilterKernelWithString (vector_selection_test.cc:445-452), TestTakeKernelWithString (:1183-1190)
+    s = orc.BinArr([b"a", b"b", b"c"])
+    assert gpu.binary_filter(s, Arr(BOOL, [False, True, False])).logical() == [b"b"]
+    assert gpu.binary_filter(orc.BinArr([None, b"b", b"c"]), Arr(BOOL, [False, True, False])).logical() == [b"b"]
+    assert gpu.binary_filter(s, Arr(BOOL, [False, True, True], [False, True, True])).logical() == [b"b", b"c"]
+    assert gpu.binary_filter(s, Arr(BOOL, [False, True, True], [False, True, True]), EMIT_NULL).logical() == [None, b"b", b"c"]
+    assert gpu.binary_take(s, Arr(INT8, [0, 1, 0], [True, False, True])).logical() == [b"a", None, b"a"]
+    assert gpu.binary_take(orc.BinArr([None, b"b", b"c"]), Arr(INT8, [0, 1, 0], [True, False, True])).logical() == [None, None, None]
+    assert gpu.binary_take(s, Arr(INT8, [2, 1])).logical() == [b"c", b"b"]
