@@ -96,7 +96,8 @@ class Result {
 struct Type {
   enum type { NA = 0, BOOL = 1, UINT8, INT8, UINT16, INT16, UINT32, INT32, UINT64, INT64, HALF_FLOAT, FLOAT, DOUBLE,
               STRUCT,       // the {min, max} / {values, counts} results
-              DICTIONARY }; // dictionary_encode's result: int32 indices + ArrayData::dictionary
+              DICTIONARY,   // dictionary_encode's result: int32 indices + ArrayData::dictionary
+              BINARY, STRING }; // 32-bit offsets; buffers = validity | offsets | data (Filter / Take only)
 };
 class DataType {
  public:
@@ -122,6 +123,9 @@ std::shared_ptr<DataType> float32();
 std::shared_ptr<DataType> float64();
 std::shared_ptr<DataType> struct_();  // field list carried by the StructScalar itself
 std::shared_ptr<DataType> dictionary_();  // dictionary(int32(), <type of ArrayData::dictionary>)
+std::shared_ptr<DataType> binary();
+std::shared_ptr<DataType> utf8();
+inline bool is_binary_like(Type::type id) { return id == Type::BINARY || id == Type::STRING; }  // type_traits.h
 std::shared_ptr<DataType> TypeFromId(Type::type id);
 bool is_integer(Type::type id);
 bool is_signed_integer(Type::type id);
@@ -186,12 +190,18 @@ struct ArrayData {
   bool MayHaveNulls() const { return null_count != 0 && buffers[0] != nullptr; }
   // The C-ABI view (= PrimitiveArg, kernels/util_internal.h:35-47)
   amdarrow_array abi() const;
+  amdarrow_binary_array binary_abi() const;  // BINARY / STRING: buffers[1] offsets, buffers[2] data
 };
 
 // Host -> device construction helpers (what a caller with host Arrow arrays does first).
 Result<std::shared_ptr<ArrayData>> ArrayFromHost(const std::shared_ptr<MemoryPool>& pool, std::shared_ptr<DataType> type,
                                                  const void* values, int64_t length, const uint8_t* validity_bits = nullptr,
                                                  int64_t null_count = kUnknownNullCount);
+// A StringArray / BinaryArray from host strings; `valid[i] == false` makes slot i null (its bytes are ignored).
+Result<std::shared_ptr<ArrayData>> BinaryFromHost(const std::shared_ptr<MemoryPool>& pool, std::shared_ptr<DataType> type,
+                                                  const std::vector<std::string>& items, const std::vector<bool>& valid = {});
+// ... and back: (value, is_valid) per slot.
+Result<std::vector<std::pair<std::string, bool>>> BinaryToHost(const ArrayData& a, const std::shared_ptr<MemoryPool>& pool);
 // Device -> host copies for inspection.
 Status CopyValuesToHost(const ArrayData& a, const std::shared_ptr<MemoryPool>& pool, void* out_values,
                         uint8_t* out_validity_bits);

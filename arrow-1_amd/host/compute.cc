@@ -37,18 +37,20 @@ int DataType::bit_width() const {
 }
 std::string DataType::ToString() const {
   static const char* names[] = {"null", "bool", "uint8", "int8", "uint16", "int16", "uint32", "int32", "uint64", "int64",
-                                "halffloat", "float", "double", "struct", "dictionary"};
+                                "halffloat", "float", "double", "struct", "dictionary", "binary", "string"};
   return names[id_];
 }
 std::shared_ptr<DataType> TypeFromId(Type::type id) {
-  static std::shared_ptr<DataType> types[15];
+  static std::shared_ptr<DataType> types[17];
   static std::once_flag once;
-  std::call_once(once, [] { for (int i = 0; i < 15; ++i) types[i] = std::make_shared<DataType>(static_cast<Type::type>(i)); });
+  std::call_once(once, [] { for (int i = 0; i < 17; ++i) types[i] = std::make_shared<DataType>(static_cast<Type::type>(i)); });
   return types[id];
 }
 std::shared_ptr<DataType> boolean() { return TypeFromId(Type::BOOL); }
 std::shared_ptr<DataType> struct_() { return TypeFromId(Type::STRUCT); }
 std::shared_ptr<DataType> dictionary_() { return TypeFromId(Type::DICTIONARY); }
+std::shared_ptr<DataType> binary() { return TypeFromId(Type::BINARY); }
+std::shared_ptr<DataType> utf8() { return TypeFromId(Type::STRING); }
 std::shared_ptr<DataType> uint8() { return TypeFromId(Type::UINT8); }
 std::shared_ptr<DataType> int8() { return TypeFromId(Type::INT8); }
 std::shared_ptr<DataType> uint16() { return TypeFromId(Type::UINT16); }
@@ -129,6 +131,63 @@ amdarrow_array ArrayData::abi() const {
   a.type_id = static_cast<int32_t>(type->id());
   a.null_count = null_count;
   return a;
+}
+static Status CopyBitsToHost(const std::shared_ptr<MemoryPool>& pool, const uint8_t* dev, int64_t off, int64_t n, uint8_t* out);
+amdarrow_binary_array ArrayData::binary_abi() const {
+  amdarrow_binary_array a;
+  a.offsets = buffers.size() > 1 && buffers[1] ? reinterpret_cast<const int32_t*>(buffers[1]->data()) : nullptr;
+  a.data = buffers.size() > 2 && buffers[2] ? buffers[2]->data() : nullptr;
+  a.validity = buffers[0] ? buffers[0]->data() : nullptr;
+  a.length = length;
+  a.offset = offset;
+  a.null_count = null_count;
+  return a;
+}
+Result<std::shared_ptr<ArrayData>> BinaryFromHost(const std::shared_ptr<MemoryPool>& pool, std::shared_ptr<DataType> type,
+                                                  const std::vector<std::string>& items, const std::vector<bool>& valid) {
+  const int64_t n = static_cast<int64_t>(items.size());
+  std::vector<int32_t> offsets(n + 1, 0);
+  std::string bytes;
+  std::vector<uint8_t> bits((n + 7) / 8 + 1, 0);
+  int64_t nulls = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const bool ok = valid.empty() || valid[i];
+    if (ok) { bytes += items[i]; bits[i / 8] |= uint8_t(1u << (i % 8)); } else { ++nulls; }
+    offsets[i + 1] = static_cast<int32_t>(bytes.size());
+  }
+  AMD_ASSIGN_OR_RAISE(auto obuf, AllocateBuffer(4 * (n + 1), pool));
+  AMD_ASSIGN_OR_RAISE(auto dbuf, AllocateBuffer(static_cast<int64_t>(bytes.size()), pool));
+  int rc = amdarrow_memcpy_h2d(pool->ctx(), obuf->mutable_data(), offsets.data(), 4 * (n + 1));
+  if (rc == AMDARROW_OK && !bytes.empty()) rc = amdarrow_memcpy_h2d(pool->ctx(), dbuf->mutable_data(), bytes.data(), static_cast<int64_t>(bytes.size()));
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  std::shared_ptr<Buffer> nbuf;
+  if (nulls > 0) {
+    AMD_ASSIGN_OR_RAISE(nbuf, AllocateBuffer((n + 7) / 8, pool));
+    rc = amdarrow_memcpy_h2d(pool->ctx(), nbuf->mutable_data(), bits.data(), (n + 7) / 8);
+    if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  }
+  auto d = ArrayData::Make(std::move(type), n, {nbuf, obuf}, nulls);
+  d->buffers.push_back(dbuf);
+  return d;
+}
+Result<std::vector<std::pair<std::string, bool>>> BinaryToHost(const ArrayData& a, const std::shared_ptr<MemoryPool>& pool) {
+  std::vector<std::pair<std::string, bool>> out;
+  if (a.length == 0) return out;
+  std::vector<int32_t> offsets(a.length + 1);
+  int rc = amdarrow_memcpy_d2h(pool->ctx(), offsets.data(), a.buffers[1]->data() + 4 * a.offset, 4 * (a.length + 1));
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  std::string bytes(static_cast<size_t>(offsets[a.length] - offsets[0]), '\0');
+  if (!bytes.empty()) {
+    rc = amdarrow_memcpy_d2h(pool->ctx(), &bytes[0], a.buffers[2]->data() + offsets[0], static_cast<int64_t>(bytes.size()));
+    if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  }
+  std::vector<uint8_t> bits((a.length + 7) / 8 + 1, 0xFF);
+  if (a.buffers[0]) AMD_RETURN_NOT_OK(CopyBitsToHost(pool, a.buffers[0]->data(), a.offset, a.length, bits.data()));
+  for (int64_t i = 0; i < a.length; ++i) {
+    const bool ok = (bits[i / 8] >> (i % 8)) & 1;
+    out.emplace_back(ok ? bytes.substr(offsets[i] - offsets[0], offsets[i + 1] - offsets[i]) : std::string(), ok);
+  }
+  return out;
 }
 Result<std::shared_ptr<ArrayData>> ArrayFromHost(const std::shared_ptr<MemoryPool>& pool, std::shared_ptr<DataType> type,
                                                  const void* values, int64_t length, const uint8_t* validity_bits,

@@ -141,7 +141,7 @@ static int RunCpu() {
     auto direct = CallFunction("hash_sum", {Datum(arr), Datum(arr), Datum(arr)}, &dctx);
     CHECK(direct.status().IsNotImplemented() && direct.status().message() == "Direct execution of HASH_AGGREGATE functions");
     CHECK((*dev->GetFunction("filter"))->kind() == Function::META);
-    CHECK((*dev->GetFunction("array_take"))->num_kernels() == 1);
+    CHECK((*dev->GetFunction("array_take"))->num_kernels() == 3);  // primitive, binary, utf8
     CHECK((*dev->GetFunction("array_sort_indices"))->num_kernels() == 10);
     // a product call without a device pool must raise, not compute on the CPU
     auto nofallback = CallFunction("add", {Datum(arr), Datum(arr)}, &dctx);
@@ -363,6 +363,49 @@ static void TabularTests(const std::shared_ptr<MemoryPool>& pool, ExecContext* c
     check_batch(Take(Datum(batch), idx({3, 1, 0}), to, ctx), {V(I, 4), V(I, 1), N(I)}, {V(D, 13), V(D, 11), V(D, 10)});
     check_batch(Take(Datum(batch), idx({0, 2, 2, 2, 2, 2, 2}), to, ctx), {N(I), V(I, 2), V(I, 2), V(I, 2), V(I, 2), V(I, 2), V(I, 2)},
                 {V(D, 10), V(D, 12), V(D, 12), V(D, 12), V(D, 12), V(D, 12), V(D, 12)});
+  }
+
+  // the same vectors with the reference's own utf8 column "b" (vector_selection_test.cc:660-689, 1460-1493)
+  {
+    using SV = std::vector<std::pair<std::string, bool>>;
+    auto sschm = schema({field("a", int32()), field("b", utf8())});
+    auto sb = BinaryFromHost(pool, utf8(), {"yo", "", "hello", "eh"});
+    CHECK_OK(sb.status());
+    if (sb.ok()) {
+      auto sbatch = RecordBatch::Make(sschm, 4, {a, *sb});
+      auto strs = [&](const Result<Datum>& r) -> SV {
+        CHECK_OK(r.status());
+        if (!r.ok()) return {};
+        auto h = BinaryToHost(*r->record_batch()->column(1), pool);
+        CHECK_OK(h.status());
+        return h.ok() ? *h : SV{};
+      };
+      CHECK((strs(Filter(Datum(sbatch), Datum(DevBool(pool, {1, 0, 1, 0})), drop, ctx)) == SV{{"yo", true}, {"hello", true}}));
+      CHECK((strs(Filter(Datum(sbatch), Datum(DevBool(pool, {0, 1, 1, -1})), drop, ctx)) == SV{{"", true}, {"hello", true}}));
+      CHECK((strs(Filter(Datum(sbatch), Datum(DevBool(pool, {0, 1, 1, -1})), emit, ctx)) == SV{{"", true}, {"hello", true}, {"", false}}));
+      CHECK((strs(Filter(Datum(sbatch), Datum(DevBool(pool, {0, 0, 0, 0})), drop, ctx)) == SV{}));
+      TakeOptions to;
+      auto idx = Dev<int8_t>(pool, int8(), {V(int8_t, 3), V(int8_t, 1), V(int8_t, 0)});
+      auto taken = Take(Datum(sbatch), Datum(idx), to, ctx);
+      CHECK((strs(taken) == SV{{"eh", true}, {"", true}, {"yo", true}}));
+      if (taken.ok()) CHECK(Same(Host<I>(pool, *taken->record_batch()->column(0)), {V(I, 4), V(I, 1), N(I)}));
+      // arrays: TestFilterKernelWithString :445-452, TestTakeKernelWithString :1183-1190, null values and null indices
+      auto abc = BinaryFromHost(pool, utf8(), {"a", "b", "c"}), nbc = BinaryFromHost(pool, utf8(), {"", "b", "c"}, {false, true, true});
+      CHECK_OK(abc.status());
+      CHECK_OK(nbc.status());
+      if (abc.ok() && nbc.ok()) {
+        auto one = [&](const Result<Datum>& r) -> SV { CHECK_OK(r.status()); if (!r.ok()) return {}; auto h = BinaryToHost(*r->array(), pool); return h.ok() ? *h : SV{}; };
+        CHECK((one(Filter(Datum(*abc), Datum(DevBool(pool, {0, 1, 0})), drop, ctx)) == SV{{"b", true}}));
+        CHECK((one(Filter(Datum(*nbc), Datum(DevBool(pool, {1, 1, 0})), drop, ctx)) == SV{{"", false}, {"b", true}}));
+        auto i8n = Dev<int8_t>(pool, int8(), {V(int8_t, 0), N(int8_t), V(int8_t, 0)});
+        CHECK((one(Take(Datum(*abc), Datum(i8n), to, ctx)) == SV{{"a", true}, {"", false}, {"a", true}}));
+        CHECK((one(Take(Datum(*nbc), Datum(i8n), to, ctx)) == SV{{"", false}, {"", false}, {"", false}}));
+        auto bad = Dev<int8_t>(pool, int8(), {V(int8_t, 0), V(int8_t, 5)});
+        CHECK(Take(Datum(*abc), Datum(bad), to, ctx).status().IsIndexError());
+        auto f = Filter(Datum(*abc), Datum(DevBool(pool, {0, 1, 1})), drop, ctx);
+        if (f.ok()) CHECK(f->array()->buffers[0] == nullptr && f->array()->null_count == 0);  // BinaryFilterNonNullImpl: no bitmap
+      }
+    }
   }
 
   // TakeChunkedArray (:1536-1550)
