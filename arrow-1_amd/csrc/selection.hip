@@ -533,7 +533,8 @@ __global__ void k_binary_close_offsets(uint32_t* offsets, int64_t n, const int64
   if (t > 2147483646) err_pos[1] = 1;
 }
 
-// A wave copies the bytes of 64 consecutive output rows, one row at a time with all its lanes.
+// A wave copies the bytes of 64 consecutive output rows: short rows lane by lane, long rows one at a
+// time with all its lanes.
 template <typename IdxT>
 __global__ __launch_bounds__(kThreads) void k_binary_take_data(BinaryTakeArgs a, const uint32_t* out_offsets, uint8_t* out_data) {
   const int tid = threadIdx.x, lane = tid & 63;
@@ -552,7 +553,21 @@ __global__ __launch_bounds__(kThreads) void k_binary_take_data(BinaryTakeArgs a,
         src = a.v_offsets[a.v_off + j];
       }
     }
-    uint64_t todo = __ballot(len != 0);
+    // short rows (the usual string): every lane moves its own row, eight bytes in flight per step
+    constexpr uint32_t kShort = 48;
+    const uint32_t mine = len <= kShort ? len : 0;
+    uint32_t longest = mine;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(longest, o); longest = other > longest ? other : longest; }
+    for (uint32_t b0 = 0; b0 < longest; b0 += 8) {
+      uint8_t byte[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) byte[k] = (b0 + k < mine) ? a.v_data[src + b0 + k] : uint8_t(0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) if (b0 + k < mine) out_data[dst + b0 + k] = byte[k];
+    }
+    // long rows: one at a time with all lanes of the wave
+    uint64_t todo = __ballot(len > kShort);
     while (todo) {
       const int r = __ffsll(static_cast<long long>(todo)) - 1;
       todo &= todo - 1;

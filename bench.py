@@ -46,6 +46,7 @@ WORKLOADS = {
     "take_random_i64": "Take int64 + validity by uint32 indices (uniform random, M = s*N of them)",
     "sort_u64": "sort_indices uint64 full range",
     "sort_f64": "sort_indices float64 U[0,1) + 0.1% NaN + 1% null",
+    "filter_utf8": "Filter of a utf8 column (lengths U[0,16], mean 8 bytes; 32-bit offsets), Bernoulli(s) mask, DROP",
     "sort_2key": "sort_indices of a batch by (int32 key over --groups values ascending, int64 + validity descending)",
     "hash_agg_f64": "GroupBy sum/count over float64 (p_null .01), 1M int32 keys",
     "compare_i64": "greater(int64 array, int64 array)",
@@ -96,6 +97,16 @@ def make_inputs(workload, n, dev, rank, sel):
         vals[torch.rand(n, device=dev, generator=gen) < 0.001] = float("nan")
         d["values"] = device.DeviceArray(_abi.DOUBLE, vals.view(torch.uint8), device_bitmap(n, 0.99, gen, dev), n, 0, -1)
         d["_keep"] = (vals,)
+    elif workload == "filter_utf8":
+        lens = torch.randint(0, 17, (n,), dtype=torch.int32, device=dev, generator=gen)
+        off = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        torch.cumsum(lens, 0, dtype=torch.int32, out=off[1:])
+        total = int(off[-1].item())
+        data = torch.randint(97, 123, (total + 8,), dtype=torch.uint8, device=dev, generator=gen)
+        d["values"] = device.DeviceBinaryArray(off.view(torch.uint8), data, None, n)
+        d["mask"] = device.DeviceArray(_abi.BOOL, device_bitmap(n, sel, gen, dev), None, n)
+        d["_keep"] = (off, data)
+        d["_mean_len"] = total / n
     elif workload == "sort_2key":
         vals = torch.randint(-2**62, 2**62, (n,), dtype=torch.int64, device=dev, generator=gen)
         keys = torch.randint(0, NUM_GROUPS, (n,), dtype=torch.int32, device=dev, generator=gen)
@@ -130,6 +141,7 @@ def bytes_per_row(workload, sel):
     return {"filter_groupby_sum_i64": 12.125, "filter_i64": 8.25 + 8.125 * sel, "take_i64": 20.25 * sel,
             "take_random_i64": 20.25 * sel, "sort_u64": 16.0, "sort_f64": 16.0, "hash_agg_f64": 12.125, "compare_i64": 16.25,
             "sort_2key": 20.125,  # both key columns + validity in, uint64 indices out
+            "filter_utf8": 4 + 8 + 0.125 + sel * (4 + 8),  # offsets + bytes (mean 8) + mask in, offsets + bytes out
             "mask_and_kleene": 0.75, "agg_f64": 8.125}[workload]  # 2 x (data + validity) bits in, data + validity bits out
 
 
@@ -167,6 +179,8 @@ def make_step(workload, ctx, inp, sel, world, rank):
             per = (chunks.length + NUM_CHUNKS - 1) // NUM_CHUNKS
             chunks = [chunks.slice(i * per, min(per, chunks.length - i * per)) for i in range(NUM_CHUNKS)]
         return lambda: compute.sort_indices(ctx, chunks)
+    if workload == "filter_utf8":
+        return lambda: compute.binary_filter(ctx, inp["values"], inp["mask"])
     if workload == "sort_2key":
         return lambda: compute.sort_indices_multi(ctx, [inp["keys"], inp["values"]], [_abi.ASCENDING, _abi.DESCENDING])
     if workload == "compare_i64":
@@ -228,6 +242,16 @@ def cpu_baseline(workload, sel):
         vals = nullable(orc.DOUBLE, data, 0.01)
         call = lambda: api.sort_indices([vals])  # noqa: E731
         what = "sort_indices float64 (0.1% NaN, 1% null)"
+    elif workload == "filter_utf8":
+        n = 4_000_000
+        lens = rng.integers(0, 17, n)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        v = orc.BinArr.__new__(orc.BinArr)
+        v.items, v.offsets, v.data = None, off, rng.integers(97, 123, int(off[-1]) + 8).astype(np.uint8)
+        v.valid, v.vbits, v.offset, v.length, v.null_count = None, None, 0, n, 0
+        mask = orc.Arr(orc.BOOL, rng.random(n) < sel)
+        call = lambda: api.binary_filter(v, mask)  # noqa: E731
+        what = "filter utf8 (mean 8 bytes), mask %.0f%%" % (sel * 100)
     elif workload == "sort_2key":
         vals = nullable(orc.INT64, rng.integers(-2**62, 2**62, n), 0.01)
         keys = orc.Arr(orc.INT32, rng.integers(0, NUM_GROUPS, n))
@@ -355,7 +379,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"filter_groupby_sum_i64": "int64", "filter_i64": "u64", "take_i64": "u64",
                                             "take_random_i64": "u64", "sort_u64": "u64", "sort_f64": "f64", "hash_agg_f64": "f64",
-                                            "compare_i64": "int64", "mask_and_kleene": "u64", "agg_f64": "f64", "sort_2key": "u64"}[args.workload],
+                                            "compare_i64": "int64", "mask_and_kleene": "u64", "agg_f64": "f64", "sort_2key": "u64", "filter_utf8": "u8"}[args.workload],
             "data": "synthetic (device-generated, seed 0x0ff1ce + rank; HBM-resident before timing)",
             "config": {"workload": args.workload + ": " + WORKLOADS[args.workload], "rows_per_gpu": n,
                        "selectivity": sel, "groups": NUM_GROUPS, "sharding": "row-range, %d shard(s)" % world},
