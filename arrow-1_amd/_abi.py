@@ -66,6 +66,8 @@ SYMBOLS = {
     "amdarrow_take_indices": (C.c_int, [_P, _A, C.c_int, _P, _P, C.c_int64, C.POINTER(C.c_int), _O]),
     "amdarrow_take": (C.c_int, [_P, _A, _A, C.c_int, _P, _P, _O]),
     "amdarrow_sort_indices": (C.c_int, [_P, _A, C.c_int, C.c_int, _P]),
+    "amdarrow_binary_concatenate_size": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "amdarrow_binary_concatenate": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _O]),
     "amdarrow_binary_take_offsets": (C.c_int, [_P, C.POINTER(CBinaryArray), _A, C.c_int, _P, _P, C.POINTER(C.c_int64), _O]),
     "amdarrow_binary_take_data": (C.c_int, [_P, C.POINTER(CBinaryArray), _A, _P, _P]),
     "amdarrow_sort_indices_multi": (C.c_int, [_P, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, _P]),

@@ -92,6 +92,22 @@ def binary_take(ctx, values, indices, boundscheck=True):
     return DeviceBinaryArray(out_o, out_d, out_b, out.length, 0, out.null_count)
 
 
+def binary_concatenate(ctx, chunks):
+    """arrow::Concatenate of BinaryArrays / StringArrays (array/concatenate.cc:100-160, 203-214)."""
+    from ._abi import CBinaryArray
+    from .device import DeviceBinaryArray
+    arr = (CBinaryArray * len(chunks))(*[c.c() for c in chunks])
+    rows, nbytes = C.c_int64(0), C.c_int64(0)
+    check(ctx.lib, ctx.lib.amdarrow_binary_concatenate_size(ctx.handle, arr, len(chunks), C.byref(rows), C.byref(nbytes)))
+    dev = chunks[0].offsets.device
+    out_o = alloc_bytes(4 * (rows.value + 1), dev)
+    out_d = alloc_bytes(nbytes.value, dev)
+    out_b = alloc_bytes((rows.value + 63) // 64 * 8, dev)
+    out = COut()
+    check(ctx.lib, ctx.lib.amdarrow_binary_concatenate(ctx.handle, arr, len(chunks), _ptr(out_o), _ptr(out_d), _ptr(out_b), C.byref(out)))
+    return DeviceBinaryArray(out_o, out_d, out_b if out.has_validity else None, out.length, 0, out.null_count)
+
+
 def binary_filter(ctx, values, mask, null_selection=DROP):
     """CallFunction("filter") on a BinaryArray / StringArray -- BinaryFilter, vector_selection.cc:840-1124: the Take of
     GetTakeIndices(mask), with BinaryFilter's conventions for the validity buffer and the null count (:1090-1112)."""

@@ -279,6 +279,23 @@ __global__ __launch_bounds__(kThreads) void k_concat_bits(const BitPiece* pieces
   }
 }
 
+// Offsets of concatenated variable-width arrays (ConcatenateOffsets, array/concatenate.cc:100-160): piece c's
+// offsets are rebased so that its first value starts where piece c - 1's bytes end.
+struct OffsetPiece { const int32_t* offsets; int64_t off; int64_t length; int64_t out_start; int64_t rebase; /* out = in + rebase */ };
+__global__ __launch_bounds__(kThreads) void k_concat_offsets(const OffsetPiece* pieces, int npieces, int64_t total, int64_t total_bytes,
+                                                            int32_t* out) {
+  for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i <= total; i += int64_t(gridDim.x) * kThreads) {
+    if (i == total) { out[i] = static_cast<int32_t>(total_bytes); continue; }
+    int lo = 0, hi = npieces - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (pieces[mid].out_start <= i) lo = mid; else hi = mid - 1;
+    }
+    const OffsetPiece p = pieces[lo];
+    out[i] = static_cast<int32_t>(p.offsets[p.off + (i - p.out_start)] + p.rebase);
+  }
+}
+
 // ---- Take ---------------------------------------------------------------------------------
 struct TakeArgs {
   const void* v_data; const uint8_t* v_valid; int64_t v_off; int64_t v_len; int v_may_null;
@@ -920,6 +937,72 @@ int amdarrow_binary_take_data(amdarrow_ctx* ctx, const amdarrow_binary_array* va
   const int grid = GridFor(n, kThreads, ctx->num_cus * 8);
   AA_BIN(k_binary_take_data, a, reinterpret_cast<const uint32_t*>(out_offsets), out_data);
 #undef AA_BIN
+  AA_HIP(hipGetLastError());
+  AA_HIP(hipStreamSynchronize(ctx->stream));
+  return AMDARROW_OK;
+}
+
+
+/* Concatenate of BinaryArrays / StringArrays (32-bit offsets): ConcatenateImpl::Visit(BinaryType), array/concatenate.cc:
+ * 203-214 -- offsets rebased piece by piece, only the referenced byte range of every piece copied. */
+int amdarrow_binary_concatenate_size(amdarrow_ctx* ctx, const amdarrow_binary_array* chunks, int nchunks, int64_t* out_rows,
+                                     int64_t* out_data_bytes) {
+  if (nchunks < 1) return SetError(AMDARROW_INVALID, "Must pass at least one array");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  int64_t rows = 0, bytes = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    rows += chunks[c].length;
+    if (chunks[c].length == 0) continue;
+    int32_t first = 0, last = 0;
+    AA_TRY(ReadBack(ctx, chunks[c].offsets + chunks[c].offset, 4, &first));
+    AA_TRY(ReadBack(ctx, chunks[c].offsets + chunks[c].offset + chunks[c].length, 4, &last));
+    bytes += last - first;
+  }
+  if (bytes > 2147483647LL) return SetError(AMDARROW_INVALID, "offset overflow while concatenating arrays");  // :138-141
+  *out_rows = rows;
+  *out_data_bytes = bytes;
+  return AMDARROW_OK;
+}
+
+int amdarrow_binary_concatenate(amdarrow_ctx* ctx, const amdarrow_binary_array* chunks, int nchunks, int32_t* out_offsets,
+                                uint8_t* out_data, uint8_t* out_validity, amdarrow_out* out) {
+  if (nchunks < 1) return SetError(AMDARROW_INVALID, "Must pass at least one array");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::vector<OffsetPiece> op(nchunks);
+  std::vector<BitPiece> bp(nchunks);
+  int64_t rows = 0, bytes = 0, nulls = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    const amdarrow_binary_array& a = chunks[c];
+    int32_t first = 0, last = 0;
+    if (a.length > 0) {
+      AA_TRY(ReadBack(ctx, a.offsets + a.offset, 4, &first));
+      AA_TRY(ReadBack(ctx, a.offsets + a.offset + a.length, 4, &last));
+      AA_HIP(hipMemcpyAsync(out_data + bytes, a.data + first, static_cast<size_t>(last - first), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    op[c] = OffsetPiece{a.offsets, a.offset, a.length, rows, bytes - first};
+    bp[c] = BitPiece{(a.validity && a.null_count != 0) ? a.validity : nullptr, a.offset, a.length, rows};
+    const int64_t nc = a.validity ? a.null_count : 0;
+    nulls = (nulls < 0 || nc < 0) ? -1 : nulls + nc;
+    rows += a.length;
+    bytes += last - first;
+  }
+  out->length = rows;
+  out->null_count = nulls;
+  out->has_validity = (nulls != 0 && out_validity != nullptr) ? 1 : 0;
+  void* base;
+  Carver cv;
+  const size_t o_op = cv.Take(sizeof(OffsetPiece) * nchunks);
+  const size_t o_bp = cv.Take(sizeof(BitPiece) * nchunks);
+  AA_TRY(Scratch(ctx, cv.off, &base));
+  char* b = static_cast<char*>(base);
+  AA_HIP(hipMemcpyAsync(b + o_op, op.data(), sizeof(OffsetPiece) * nchunks, hipMemcpyHostToDevice, ctx->stream));
+  AA_HIP(hipMemcpyAsync(b + o_bp, bp.data(), sizeof(BitPiece) * nchunks, hipMemcpyHostToDevice, ctx->stream));
+  AA_HIP(hipStreamSynchronize(ctx->stream));  // pageable host tables
+  hipLaunchKernelGGL(k_concat_offsets, dim3(GridFor(rows + 1, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream,
+                     reinterpret_cast<const OffsetPiece*>(b + o_op), nchunks, rows, bytes, out_offsets);
+  if (out->has_validity && rows > 0)
+    hipLaunchKernelGGL(k_concat_bits, dim3(GridFor((rows + 63) / 64, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream,
+                       reinterpret_cast<const BitPiece*>(b + o_bp), nchunks, rows, reinterpret_cast<uint64_t*>(out_validity));
   AA_HIP(hipGetLastError());
   AA_HIP(hipStreamSynchronize(ctx->stream));
   return AMDARROW_OK;

@@ -282,6 +282,24 @@ Result<std::shared_ptr<ArrayData>> Concatenate(const std::vector<std::shared_ptr
     const int64_t nc = a->buffers[0] ? a->null_count : 0;
     nulls = (nulls < 0 || nc < 0) ? -1 : nulls + nc;
   }
+  if (is_binary_like(arrays[0]->type->id())) {  // ConcatenateImpl::Visit(BinaryType) :203-214
+    std::vector<amdarrow_binary_array> babi;
+    for (const auto& a : arrays) babi.push_back(a->binary_abi());
+    int64_t rows = 0, nbytes = 0;
+    int rc = amdarrow_binary_concatenate_size(pool->ctx(), babi.data(), static_cast<int>(babi.size()), &rows, &nbytes);
+    if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+    AMD_ASSIGN_OR_RAISE(auto obuf, AllocateBuffer(4 * (rows + 1), pool));
+    AMD_ASSIGN_OR_RAISE(auto dbuf, AllocateBuffer(nbytes, pool));
+    std::shared_ptr<Buffer> vb;
+    if (nulls != 0) { AMD_ASSIGN_OR_RAISE(vb, AllocateBitmap(rows, pool)); }
+    amdarrow_out bo;
+    rc = amdarrow_binary_concatenate(pool->ctx(), babi.data(), static_cast<int>(babi.size()), reinterpret_cast<int32_t*>(obuf->mutable_data()),
+                                     dbuf->mutable_data(), vb ? vb->mutable_data() : nullptr, &bo);
+    if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+    auto d = ArrayData::Make(arrays[0]->type, bo.length, {vb, obuf}, bo.null_count);
+    d->buffers.push_back(dbuf);
+    return d;
+  }
   const int bw = arrays[0]->type->bit_width();
   std::shared_ptr<Buffer> vbuf, nbuf;
   if (bw == 1) { AMD_ASSIGN_OR_RAISE(vbuf, AllocateBitmap(total, pool)); }

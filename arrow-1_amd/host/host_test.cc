@@ -402,6 +402,15 @@ static void TabularTests(const std::shared_ptr<MemoryPool>& pool, ExecContext* c
         CHECK((one(Take(Datum(*nbc), Datum(i8n), to, ctx)) == SV{{"", false}, {"", false}, {"", false}}));
         auto bad = Dev<int8_t>(pool, int8(), {V(int8_t, 0), V(int8_t, 5)});
         CHECK(Take(Datum(*abc), Datum(bad), to, ctx).status().IsIndexError());
+        // chunked utf8 values are concatenated first (TakeCA :1923-1943)
+        auto chunked_s = std::make_shared<ChunkedArray>(std::vector<std::shared_ptr<ArrayData>>{*abc, *nbc}, utf8());
+        auto i6 = Dev<int8_t>(pool, int8(), {V(int8_t, 5), V(int8_t, 0), V(int8_t, 3), V(int8_t, 4)});
+        auto tc = Take(Datum(chunked_s), Datum(i6), to, ctx);
+        CHECK_OK(tc.status());
+        if (tc.ok()) {
+          auto h = BinaryToHost(*tc->chunked_array()->chunk(0), pool);
+          CHECK(h.ok() && (*h == SV{{"c", true}, {"a", true}, {"", false}, {"b", true}}));
+        }
         auto f = Filter(Datum(*abc), Datum(DevBool(pool, {0, 1, 1})), drop, ctx);
         if (f.ok()) CHECK(f->array()->buffers[0] == nullptr && f->array()->null_count == 0);  // BinaryFilterNonNullImpl: no bitmap
       }

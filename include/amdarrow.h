@@ -153,6 +153,16 @@ int amdarrow_binary_take_data(amdarrow_ctx* ctx, const amdarrow_binary_array* va
                               const amdarrow_array* indices, const int32_t* out_offsets,
                               uint8_t* out_data);
 
+/* Concatenate of BinaryArrays / StringArrays -- ConcatenateImpl::Visit(BinaryType) + ConcatenateOffsets,
+ * array/concatenate.cc:100-160, 203-214: `size` reports the rows and data bytes (only the byte range every
+ * chunk references is copied), then the call proper fills out_offsets[rows + 1], out_data and (iff the summed
+ * null count != 0) out_validity in whole 8-byte words. */
+int amdarrow_binary_concatenate_size(amdarrow_ctx* ctx, const amdarrow_binary_array* chunks, int nchunks,
+                                     int64_t* out_rows, int64_t* out_data_bytes);
+int amdarrow_binary_concatenate(amdarrow_ctx* ctx, const amdarrow_binary_array* chunks, int nchunks,
+                                int32_t* out_offsets, uint8_t* out_data, uint8_t* out_validity,
+                                amdarrow_out* out);
+
 /* Concatenate, array/concatenate.cc:171-201 -- what TakeCA/TakeCC (vector_selection.cc:1923-
  * 1959) do to chunked values first.  out_values: sum(length) elements (bits for BOOL).
  * out->null_count = sum of the chunks' counts, -1 if any is unknown (:172-180); the validity

@@ -230,6 +230,37 @@ static void bin_append(const orc_binary* v, int64_t i, int32_t* out_offsets, uin
   memcpy(out_data + *fill, v->data + o0, (size_t)(o1 - o0)); /* data_builder.UnsafeAppend :1550 */
   *fill += o1 - o0;
 }
+int orc_binary_concatenate(const orc_binary* chunks, int nchunks, int32_t* out_offsets, uint8_t* out_data,
+                           uint8_t* out_validity, orc_out* out) {
+  if (nchunks < 1) return fail(ORC_INVALID, "Must pass at least one array");
+  int64_t rows = 0, nulls = 0, bytes = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    rows += chunks[c].length;
+    const int64_t nc = chunks[c].validity ? chunks[c].null_count : 0; /* :172-180 */
+    nulls = (nulls < 0 || nc < 0) ? -1 : nulls + nc;
+  }
+  out->length = rows; out->null_count = nulls; out->has_validity = nulls != 0; /* :190 */
+  memset(out_validity, 0, (size_t)bytes_for_bits(rows));
+  int64_t pos = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    const orc_binary* a = &chunks[c];
+    const int32_t first = a->length ? a->offsets[a->offset] : 0;
+    for (int64_t i = 0; i < a->length; ++i) {
+      out_offsets[pos + i] = (int32_t)(a->offsets[a->offset + i] - first + bytes); /* PutOffsets :143-160 */
+      if (out->has_validity && bin_valid(a, i)) set_bit(out_validity, pos + i);
+    }
+    if (a->length) {
+      const int32_t last = a->offsets[a->offset + a->length];
+      if (bytes + (last - first) > 2147483647LL) return fail(ORC_INVALID, "offset overflow while concatenating arrays");
+      memcpy(out_data + bytes, a->data + first, (size_t)(last - first)); /* value_ranges :209-212 */
+      bytes += last - first;
+    }
+    pos += a->length;
+  }
+  out_offsets[rows] = (int32_t)bytes;
+  if (!out->has_validity) for (int64_t i = 0; i < rows; ++i) set_bit(out_validity, i);
+  return ORC_OK;
+}
 int orc_binary_take(const orc_binary* values, const orc_array* indices, int boundscheck, int32_t* out_offsets,
                     uint8_t* out_data, uint8_t* out_validity, orc_out* out) {
   const int64_t n = indices->length;

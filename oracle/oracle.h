@@ -103,6 +103,9 @@ typedef struct orc_binary {
   const int32_t* offsets; const uint8_t* data; const uint8_t* validity;
   int64_t length; int64_t offset; int64_t null_count;
 } orc_binary;
+/* Concatenate of binary arrays: ConcatenateOffsets + the referenced byte ranges, array/concatenate.cc:100-160, 203-214 */
+int orc_binary_concatenate(const orc_binary* chunks, int nchunks, int32_t* out_offsets, uint8_t* out_data,
+                           uint8_t* out_validity, orc_out* out);
 int orc_binary_take(const orc_binary* values, const orc_array* indices, int boundscheck, int32_t* out_offsets,
                     uint8_t* out_data, uint8_t* out_validity, orc_out* out);
 int orc_binary_filter(const orc_binary* values, const orc_array* filter, int null_selection, int32_t* out_offsets,

@@ -417,6 +417,15 @@ static void ExportBinary(const ArrayData& d, int32_t* out_offsets, uint8_t* out_
   for (int64_t i = 0; i <= d.length; ++i) out_offsets[i] = off[i] - base;
   if (d.length > 0 && d.buffers[2]) std::memcpy(out_data, d.buffers[2]->data() + base, off[d.length] - base);
 }
+int ref_binary_concatenate(const orc_binary* chunks, int nchunks, int32_t* out_offsets, uint8_t* out_data,
+                           uint8_t* out_validity, orc_out* out) {
+  ArrayVector arrs;
+  for (int c = 0; c < nchunks; ++c) arrs.push_back(MakeArray(WrapBinary(&chunks[c])));
+  auto res = Concatenate(arrs, default_memory_pool());
+  if (!res.ok()) return Fail(res.status());
+  ExportBinary(*(*res)->data(), out_offsets, out_data, out_validity, out);
+  return 0;
+}
 int ref_binary_take(const orc_binary* values, const orc_array* indices, int boundscheck, int32_t* out_offsets,
                     uint8_t* out_data, uint8_t* out_validity, orc_out* out) {
   TakeOptions opts(boundscheck != 0);

@@ -71,6 +71,9 @@ class GpuApi:
         bits = d.validity[:(n + 7) // 8].cpu().numpy().copy() if d.validity is not None else np.packbits(np.ones(n, bool), bitorder="little")
         return orc.BinResult(off, data, np.concatenate([bits, np.zeros(8, np.uint8)]), _Out(n, d.null_count, d.validity is not None))
 
+    def binary_concatenate(self, chunks):
+        return self._wrap(lambda: self._down_bin(compute.binary_concatenate(self.ctx, [self._up_bin(c) for c in chunks])))
+
     def binary_take(self, values, indices, boundscheck=True):
         return self._wrap(lambda: self._down_bin(compute.binary_take(self.ctx, self._up_bin(values), up(indices), boundscheck)))
 

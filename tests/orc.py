@@ -298,6 +298,16 @@ class Api:
                                 out_b.ctypes.data_as(C.c_void_p), C.byref(out)))
         return BinResult(out_o, out_d, out_b, out)
 
+    def binary_concatenate(self, chunks):
+        rows = sum(c.length for c in chunks)
+        total = sum(int(c.offsets[-1]) for c in chunks) + 16
+        out_o, out_d, out_b = np.zeros(rows + 2, np.int32), np.zeros(total, np.uint8), np.zeros(rows // 8 + 16, np.uint8)
+        out = COut()
+        arr = (CBin * len(chunks))(*[c.c() for c in chunks])
+        self._check(self._f("binary_concatenate")(arr, len(chunks), out_o.ctypes.data_as(C.c_void_p), out_d.ctypes.data_as(C.c_void_p),
+                                                  out_b.ctypes.data_as(C.c_void_p), C.byref(out)))
+        return BinResult(out_o, out_d, out_b, out)
+
     def binary_take(self, values, indices, boundscheck=True):
         return self._bin_call("binary_take", values, indices, int(boundscheck), indices.length)
 

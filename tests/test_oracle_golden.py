@@ -240,3 +240,10 @@ def test_binary_take_and_filter_match_live_reference(oracle, reference):
         with pytest.raises(orc.StatusError) as ei:
             api.binary_take(orc.BinArr([b"a", b"bb"]), orc.Arr(orc.INT32, [0, 2]))
         assert ei.value.code == orc.INDEX_ERROR and ei.value.msg == "Index 2 out of bounds"
+
+
+def test_binary_concatenate_matches_live_reference(oracle, reference):
+    rng = np.random.default_rng(20260108)
+    for sizes in ([(5, 0, 0), (0, 0, 1), (200, .2, 3), (64, 0, 2), (77, 1.0, 1)], [(3, 0, 0)], [(0, 0, 0)], [(10, .5, 2), (10, 0, 0)]):
+        chunks = [_rand_bin(rng, n, p, off) for n, p, off in sizes]
+        assert oracle.binary_concatenate(chunks).same(reference.binary_concatenate(chunks)), sizes

@@ -977,3 +977,12 @@ def test_binary_take_and_filter_random(gpu, oracle):
     assert gpu.binary_take(s, Arr(INT8, [0, 1, 0], [True, False, True])).logical() == [b"a", None, b"a"]
     assert gpu.binary_take(orc.BinArr([None, b"b", b"c"]), Arr(INT8, [0, 1, 0], [True, False, True])).logical() == [None, None, None]
     assert gpu.binary_take(s, Arr(INT8, [2, 1])).logical() == [b"c", b"b"]
+
+
+@pytest.mark.gpu
+def test_binary_concatenate_random(gpu, oracle):
+    rng = np.random.default_rng(301)
+    for sizes in ([(5, 0, 0), (0, 0, 1), (200, .2, 3), (64, 0, 2), (77, 1.0, 1)], [(3, 0, 0)], [(0, 0, 0)], [(10, .5, 2), (10, 0, 0)],
+                  [(1, 0, 0)] * 40, [(40_000, .01, 5), (1, 0, 0), (33_333, 0, 7)]):
+        chunks = [_rand_bin(rng, n, p, off) for n, p, off in sizes]
+        assert gpu.binary_concatenate(chunks).same(oracle.binary_concatenate(chunks)), sizes[:2]
