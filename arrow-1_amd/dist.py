@@ -171,6 +171,139 @@ def merge_dense_device(ctx, key_type, r_keys, r_key_validity, r_sums, r_counts, 
     return Partial(st.out_keys, st.out_valid.view(torch.bool), st.out_sums, st.out_counts), st.n_present
 
 
+# ---- sharded sort_indices: a sample sort over the row-range shards ------------------
+# sort_indices does not shard with one all-reduce: the rows have to move.  Every rank sorts its own row
+# range (stable, NaNs and nulls last: the single-GPU kernel), the ranks agree on world - 1 splitters from
+# evenly spaced samples of their sorted keys, every rank cuts its sorted run at the splitters and sends
+# piece j to rank j (all-to-all; NaN and null rows go to the last rank), and rank j sorts what it
+# received -- the runs arrive in source-rank order, each in local index order among equal keys, so the
+# stable local sort yields the global order of vector_sort.cc:373-575 including its tie-breaking by
+# index.  Rank j ends up with the global row indices of the j-th key range; the concatenation over the
+# ranks is sort_indices of the whole column (a ChunkedArray with `world` chunks).
+# `ops` binds the two array operations to the HIP kernels (SortOps below) or, in the CPU / gloo test, to
+# the oracle: argsort(values, valid, order) -> int64 permutation.
+_UNSIGNED_MASK = {"uint8": 0xFF, "uint16": 0xFFFF, "uint32": 0xFFFFFFFF}
+
+
+def _ordered(t, kind, descending):
+    """A few gathered keys -> a tensor whose `<` is the sort order (float64, or int64 with the order kept)."""
+    if kind in ("float32", "float64"):
+        v = t.to(torch.float64)
+        return -v if descending else v
+    if kind == "uint64":
+        v = t.view(torch.int64) ^ (-2 ** 63)  # order-preserving map of the unsigned range onto int64
+    elif kind in _UNSIGNED_MASK:
+        v = t.view({"uint8": torch.int8, "uint16": torch.int16, "uint32": torch.int32}[kind]).to(torch.int64) & _UNSIGNED_MASK[kind]
+    else:
+        v = t.to(torch.int64)
+    return ~v if descending else v  # ~x reverses the order of two's complement integers without overflow
+
+
+def _exchange(send, send_counts, recv_counts, group=None):
+    """Variable all-to-all of rows of `send` (first dimension), pieces laid out in destination order."""
+    world = len(send_counts)
+    out = torch.empty((int(sum(recv_counts)),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+    if tdist.get_backend(group) == "nccl":
+        tdist.all_to_all_single(out, send.contiguous(), [int(c) for c in recv_counts], [int(c) for c in send_counts], group=group)
+        return out
+    # gloo has no all-to-all: gather every rank's padded send buffer and cut out what is addressed here
+    rank = tdist.get_rank(group)
+    dev = send.device
+    cap = torch.tensor([send.shape[0]], dtype=torch.int64, device=dev)
+    caps = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    tdist.all_gather(caps, cap, group=group)
+    m = int(max(int(c.item()) for c in caps))
+    padded = torch.zeros((max(m, 1),) + tuple(send.shape[1:]), dtype=send.dtype, device=dev)
+    padded[:send.shape[0]] = send
+    bufs = [torch.zeros_like(padded) for _ in range(world)]
+    tdist.all_gather(bufs, padded, group=group)
+    sc = torch.tensor([int(c) for c in send_counts], dtype=torch.int64, device=dev)
+    all_sc = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(world)]
+    tdist.all_gather(all_sc, sc, group=group)
+    pos = 0
+    for src in range(world):
+        counts = [int(x) for x in all_sc[src].tolist()]
+        start = sum(counts[:rank])
+        out[pos:pos + counts[rank]] = bufs[src][start:start + counts[rank]]
+        pos += counts[rank]
+    return out
+
+
+def sharded_sort_indices(ops, values, valid, row0, kind, descending, rank, world, group=None, samples=64):
+    """values: this rank's rows (1-D tensor; uint64 as an int64 view), valid: bool tensor or None, row0: global
+    index of its first row, kind: numpy-style dtype name.  -> int64 tensor: global row indices of this
+    rank's key range, in sorted order."""
+    dev = values.device
+    n = values.shape[0]
+    is_float = kind in ("float32", "float64")
+    perm = ops.argsort(values, valid, descending)
+    sv = values[perm]
+    svalid = valid[perm] if valid is not None else torch.ones(n, dtype=torch.bool, device=dev)
+    n_null = int((~svalid).sum().item())
+    n_nan = int(torch.isnan(sv[:n - n_null]).sum().item()) if is_float and n > n_null else 0
+    n0 = n - n_null - n_nan  # [0, n0) sortable keys in order, then the NaNs, then the nulls
+    # --- splitters from evenly spaced samples of every rank's sorted keys
+    take = torch.linspace(0, max(n0 - 1, 0), samples, device=dev).to(torch.int64) if n0 > 0 else torch.zeros(0, dtype=torch.int64, device=dev)
+    mine = _ordered(sv[take], kind, descending) if n0 > 0 else torch.zeros(0, dtype=torch.float64 if is_float else torch.int64, device=dev)
+    padded = torch.zeros(samples, dtype=mine.dtype, device=dev)
+    padded[:mine.shape[0]] = mine
+    have = torch.tensor([mine.shape[0]], dtype=torch.int64, device=dev)
+    all_s = [torch.zeros_like(padded) for _ in range(world)]
+    all_h = [torch.zeros_like(have) for _ in range(world)]
+    tdist.all_gather(all_s, padded, group=group)
+    tdist.all_gather(all_h, have, group=group)
+    pool = torch.cat([all_s[r][:int(all_h[r].item())] for r in range(world)])
+    pool = torch.sort(pool).values
+    if pool.shape[0] > 0:
+        at = (torch.arange(1, world, device=dev) * pool.shape[0]) // world
+        splitters = pool[at.clamp(max=pool.shape[0] - 1)]
+    else:
+        splitters = torch.zeros(world - 1, dtype=padded.dtype, device=dev)
+    # --- cut the sorted run: piece j = keys k with splitter[j-1] < k <= splitter[j] (upper bounds by bisection,
+    # on the device, a handful of gathered keys per step: no pass over the data, no dtype restrictions)
+    lo = torch.zeros(world - 1, dtype=torch.int64, device=dev)
+    hi = torch.full((world - 1,), n0, dtype=torch.int64, device=dev)
+    for _ in range(max(1, int(n0).bit_length())):
+        mid = (lo + hi) // 2
+        probe = _ordered(sv[mid.clamp(max=max(n0 - 1, 0))], kind, descending) if n0 > 0 else splitters
+        go_right = (probe <= splitters) & (mid < hi)
+        lo = torch.where(go_right, mid + 1, lo)
+        hi = torch.where(go_right, hi, mid)
+    bounds = [0] + [int(x) for x in lo.tolist()] + [n0]
+    send_counts = [bounds[j + 1] - bounds[j] for j in range(world)]
+    send_counts[-1] += n_nan + n_null  # NaNs and nulls sort after every key: they all belong to the last rank
+    counts_t = torch.tensor(send_counts, dtype=torch.int64, device=dev)
+    all_c = [torch.zeros_like(counts_t) for _ in range(world)]
+    tdist.all_gather(all_c, counts_t, group=group)
+    recv_counts = [int(all_c[src][rank].item()) for src in range(world)]
+    # --- move keys, validity and global row numbers
+    gidx = perm.to(torch.int64) + row0
+    rv = _exchange(sv, send_counts, recv_counts, group)
+    rvalid = _exchange(svalid.to(torch.uint8), send_counts, recv_counts, group).to(torch.bool)
+    ridx = _exchange(gidx, send_counts, recv_counts, group)
+    # --- the received runs are in source-rank order: one more stable sort finishes this rank's range
+    perm2 = ops.argsort(rv, None if bool(rvalid.all()) else rvalid, descending)
+    return ridx[perm2]
+
+
+class SortOps:
+    """sharded_sort_indices' array operation on the HIP kernels."""
+
+    def __init__(self, ctx, type_id):
+        self.ctx, self.type_id = ctx, type_id
+
+    def argsort(self, values, valid, descending):
+        from . import _abi, compute
+        from .device import DeviceArray
+        n = values.shape[0]
+        if n == 0:
+            return torch.zeros(0, dtype=torch.int64, device=values.device)
+        vbuf = None if valid is None else _pack_bits(valid)
+        arr = DeviceArray(self.type_id, values.contiguous().view(torch.uint8), vbuf, n, 0, -1)
+        r = compute.sort_indices(self.ctx, arr, _abi.DESCENDING if descending else _abi.ASCENDING)
+        return r.values[:n * 8].view(torch.int64)
+
+
 # ---- GPU binding -------------------------------------------------------------------------------
 def _pack_bits(bits):
     """bool tensor -> Arrow LSB-first bitmap (uint8 tensor, padded)"""

@@ -173,6 +173,16 @@ def make_step(workload, ctx, inp, sel, world, rank):
         idx = device.DeviceArray(_abi.UINT32, ridx.view(torch.uint8), None, m)
         inp["_keep_idx"] = ridx
         return lambda: compute.take(ctx, inp["values"], idx)
+    if workload in ("sort_u64", "sort_f64") and world > 1:
+        # one global sort of world x rows: the sample sort of dist.sharded_sort_indices (one all-to-all)
+        from arrow1_amd import dist as adist
+        vals = inp["_keep"][0]
+        valid = None
+        if inp["values"].validity is not None:
+            valid = adist._unpack_bits(inp["values"].validity, inp["values"].length)
+        ops = adist.SortOps(ctx, inp["values"].type_id)
+        kind = "uint64" if workload == "sort_u64" else "float64"
+        return lambda: adist.sharded_sort_indices(ops, vals, valid, rank * inp["values"].length, kind, False, rank, world)
     if workload in ("sort_u64", "sort_f64"):
         chunks = inp["values"]
         if NUM_CHUNKS > 1:  # the same rows as NUM_CHUNKS equal slices: a ChunkedArray (vector_sort.cc:657-832)

@@ -79,3 +79,83 @@ def test_sharded_groupby_matches_single_process(null_keys):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+# ---- sharded sort_indices (sample sort) over gloo, the oracle standing in for the local sort kernel ----
+def _sort_worker(rank, world, port, n, case, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    import orc
+    from __graft_entry__ import load_package
+    load_package()
+    from arrow1_amd import dist as adist
+    o = orc.Api("orc")
+    kind, type_id, descending, null_p = case[:4]
+    rng = np.random.default_rng(0x0ff1ce)
+    if kind == "float64":
+        data = rng.standard_normal(n) * 10.0 ** rng.integers(-3, 4, n)
+        data[rng.random(n) < 0.02] = np.nan
+        data[rng.random(n) < 0.02] = -0.0
+        data[::97] = data[0]
+    elif kind == "uint64":
+        data = rng.integers(0, 2 ** 64, n, dtype=np.uint64)
+        data[::50] = data[1]
+    else:
+        data = rng.integers(-1000, 1000, n)  # many ties
+    valid = rng.random(n) >= null_p if null_p else None
+    per = ((n // world + 63) // 64) * 64
+    lo, hi = rank * per, (min(n, (rank + 1) * per) if rank < world - 1 else n)
+    if case[4] == "empty-rank" and rank == 1:
+        hi = lo  # a rank without rows
+
+    class OracleOps:
+        def argsort(self, values, v, desc):
+            arr = values.numpy()
+            if kind == "uint64":
+                arr = arr.view(np.uint64)
+            a = orc.Arr(type_id, arr, None if v is None else v.numpy())
+            return torch.from_numpy(o.sort_indices([a], orc.DESC if desc else orc.ASC).astype(np.int64))
+
+    local = data[lo:hi]
+    t = torch.from_numpy(local.view(np.int64) if kind == "uint64" else local.copy())
+    tv = None if valid is None else torch.from_numpy(valid[lo:hi].copy())
+    out = adist.sharded_sort_indices(OracleOps(), t, tv, lo, kind, descending, rank, world)
+    if case[4] == "empty-rank":
+        # rows [lo1, hi1) of the skipped rank do not take part: compare against the sort of the rest
+        keep = np.ones(n, bool)
+        keep[per:min(n, 2 * per)] = False
+    else:
+        keep = np.ones(n, bool)
+    q.put((rank, out.numpy(), None))
+    if rank == 0:
+        rows = np.nonzero(keep)[0]
+        full = orc.Arr(type_id, data[rows], None if valid is None else valid[rows])
+        want = rows[o.sort_indices([full], orc.DESC if descending else orc.ASC).astype(np.int64)]
+        q.put((-1, want, None))
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", [("int64", 9, False, 0.0, ""), ("int64", 9, True, 0.1, ""), ("float64", 12, False, 0.05, ""),
+                                  ("float64", 12, True, 0.0, ""), ("uint64", 8, False, 0.0, ""), ("int64", 9, False, 0.0, "empty-rank")])
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_sort_indices_matches_single_process(case, world):
+    import orc  # noqa: F401  (type ids in the case tuples are orc's)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() * 7 + hash(case) % 97 + world) % 2000
+    procs = [ctx.Process(target=_sort_worker, args=(r, world, port, 6000, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world + 1):
+        r, arr, _ = q.get(timeout=60)
+        got[r] = arr
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    merged = np.concatenate([got[r] for r in range(world)])
+    assert np.array_equal(merged, got[-1]), case

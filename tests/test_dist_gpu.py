@@ -70,3 +70,61 @@ def test_two_ranks_one_gpu_dense_merge():
         p.join(300)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _sort_worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as tdist
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import orc
+    from __graft_entry__ import load_package
+    load_package()
+    from arrow1_amd import _abi, device, dist as adist
+    ctx = device.Context(0)
+    rng = np.random.default_rng(0x0ff1ce)
+    ok = True
+    for kind, tid, desc, null_p in [("float64", _abi.DOUBLE, False, 0.03), ("int64", _abi.INT64, True, 0.0), ("uint64", _abi.UINT64, False, 0.0)]:
+        if kind == "float64":
+            data = rng.standard_normal(n) * 10.0 ** rng.integers(-3, 4, n)
+            data[rng.random(n) < 0.01] = np.nan
+        elif kind == "uint64":
+            data = rng.integers(0, 2 ** 64, n, dtype=np.uint64)
+        else:
+            data = rng.integers(-5000, 5000, n)
+        valid = rng.random(n) >= null_p if null_p else None
+        per = ((n // world + 63) // 64) * 64
+        lo, hi = rank * per, (min(n, (rank + 1) * per) if rank < world - 1 else n)
+        local = data[lo:hi]
+        t = torch.from_numpy(local.view(np.int64) if kind == "uint64" else local.copy()).cuda()
+        tv = None if valid is None else torch.from_numpy(valid[lo:hi].copy()).cuda()
+        out = adist.sharded_sort_indices(adist.SortOps(ctx, tid), t, tv, lo, kind, desc, rank, world).cpu().numpy()
+        gathered = [None] * world
+        tdist.all_gather_object(gathered, out)
+        if rank == 0:
+            o = orc.Api("orc")
+            want = o.sort_indices([orc.Arr({"float64": orc.DOUBLE, "int64": orc.INT64, "uint64": orc.UINT64}[kind], data, valid)],
+                                  orc.DESC if desc else orc.ASC).astype(np.int64)
+            ok &= bool(np.array_equal(np.concatenate(gathered), want))
+    if rank == 0:
+        q.put(bool(ok))
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_sharded_sort():
+    """The sample sort of dist.sharded_sort_indices with the HIP sort as the local operation, two ranks on the
+    one device (collectives over gloo): the concatenated result is sort_indices of the whole column."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30650 + os.getpid() % 300
+    procs = [ctx.Process(target=_sort_worker, args=(r, 2, port, 300_000, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
