@@ -180,8 +180,8 @@ def merge_dense_device(ctx, key_type, r_keys, r_key_validity, r_sums, r_counts, 
 # stable local sort yields the global order of vector_sort.cc:373-575 including its tie-breaking by
 # index.  Rank j ends up with the global row indices of the j-th key range; the concatenation over the
 # ranks is sort_indices of the whole column (a ChunkedArray with `world` chunks).
-# `ops` binds the two array operations to the HIP kernels (SortOps below) or, in the CPU / gloo test, to
-# the oracle: argsort(values, valid, order) -> int64 permutation.
+# `ops` binds the array operation to the HIP kernels (SortOps below) or, in the CPU / gloo test, to a
+# CPU stand-in the test supplies: argsort(values, valid, descending) -> int64 permutation.
 _UNSIGNED_MASK = {"uint8": 0xFF, "uint16": 0xFFFF, "uint32": 0xFFFFFFFF}
 
 
