@@ -150,7 +150,11 @@ template <typename KeyT, bool PERM>
 __global__ __launch_bounds__(kThreads) void k_sort_partition(const SortChunk* chunks, int nchunks, int type_id, int64_t ntiles,
                                                              const uint64_t* perm, int64_t n,
                                                              const uint32_t* offsets, KeyT key_mask, KeyT flip, KeyT* keys,
-                                                             uint32_t* idx, uint64_t* out_indices) {
+                                                             uint32_t* idx, uint64_t* out_indices, unsigned int* ghist) {
+  // the digit histograms of all passes ride along (the keys are in registers anyway): hist[pass * 256 + digit]
+  constexpr int kPasses = sizeof(KeyT);
+  __shared__ unsigned int s_h[kPasses * 256];
+  for (int i = threadIdx.x; i < kPasses * 256; i += kThreads) s_h[i] = 0;
   __shared__ uint32_t s_wave[3][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int kIters = kCTile / kThreads;  // 8; wave w owns rows [w*512, (w+1)*512) of the tile, in order
@@ -206,6 +210,8 @@ __global__ __launch_bounds__(kThreads) void k_sort_partition(const SortChunk* ch
         const int64_t p = base[0] + RankBelowLane(m0);
         keys[p] = key[j];
         idx[p] = static_cast<uint32_t>(gidx);
+#pragma unroll
+        for (int q = 0; q < kPasses; ++q) atomicAdd(&s_h[q * 256 + ((key[j] >> (8 * q)) & 255)], 1u);
       } else if (cls[j] == 1) {
         out_indices[base[1] + RankBelowLane(m1)] = gidx;
       } else if (cls[j] == 2) {
@@ -215,23 +221,8 @@ __global__ __launch_bounds__(kThreads) void k_sort_partition(const SortChunk* ch
     }
     __syncthreads();
   }
-}
-
-// All passes' digit histograms in one read of the keys: hist[pass * 256 + digit].
-template <typename KeyT>
-__global__ __launch_bounds__(kThreads) void k_radix_global_hist(const KeyT* keys, int64_t n, unsigned int* hist) {
-  constexpr int kPasses = sizeof(KeyT);
-  __shared__ unsigned int s_h[kPasses * 256];
-  for (int i = threadIdx.x; i < kPasses * 256; i += kThreads) s_h[i] = 0;
-  __syncthreads();
-  for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < n; i += int64_t(gridDim.x) * kThreads) {
-    const KeyT k = keys[i];
-#pragma unroll
-    for (int p = 0; p < kPasses; ++p) atomicAdd(&s_h[p * 256 + ((k >> (8 * p)) & 255)], 1u);
-  }
-  __syncthreads();
   for (int i = threadIdx.x; i < kPasses * 256; i += kThreads)
-    if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
+    if (s_h[i]) atomicAdd(&ghist[i], s_h[i]);
 }
 
 // block_hist[digit * nblocks + block]
@@ -1019,7 +1010,8 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   AA_HIP(hipMemcpyAsync(d_chunks, hc.data(), sizeof(SortChunk) * nchunks, hipMemcpyHostToDevice, ctx->stream));
   AA_HIP(hipStreamSynchronize(ctx->stream));  // hc is pageable host memory
 
-  // 1. stable 3-way partition: sortable | NaN | null
+  // 1. stable 3-way partition: sortable | NaN | null (+ the digit histograms of the sortable keys)
+  AA_HIP(hipMemsetAsync(ghist, 0, 4 * 256 * kPasses, ctx->stream));
   const int grid_t = GridFor(ntiles, 1, ctx->num_cus * 8);
   if (perm)
     hipLaunchKernelGGL((k_sort_count<KeyT, true>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, d_chunks, nchunks, type_id,
@@ -1031,21 +1023,17 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   AA_TRY(ScanU32InPlace(ctx, counts, 3 * ntiles, sums, sumoff));  // counts -> offsets (rows < 2^32)
   if (perm)
     hipLaunchKernelGGL((k_sort_partition<KeyT, true>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, d_chunks, nchunks,
-                       type_id, ntiles, perm, n, counts, key_mask, flip, keys_a, idx_a, out);
+                       type_id, ntiles, perm, n, counts, key_mask, flip, keys_a, idx_a, out, ghist);
   else
     hipLaunchKernelGGL((k_sort_partition<KeyT, false>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, d_chunks, nchunks,
-                       type_id, ntiles, perm, n, counts, key_mask, flip, keys_a, idx_a, out);
+                       type_id, ntiles, perm, n, counts, key_mask, flip, keys_a, idx_a, out, ghist);
   AA_HIP(hipGetLastError());
   uint32_t n0_32 = 0;
   AA_TRY(ReadBack(ctx, counts + ntiles, 4, &n0_32));  // start of the NaN region = number of sortable rows
   const int64_t n0 = n0_32;
   if (n0 == 0) return AMDARROW_OK;
 
-  // 2. histograms of every digit; skip digits on which all keys agree
-  AA_HIP(hipMemsetAsync(ghist, 0, 4 * 256 * kPasses, ctx->stream));
-  hipLaunchKernelGGL((k_radix_global_hist<KeyT>), dim3(GridFor(n0, kThreads * 16, ctx->num_cus * 4)), dim3(kThreads), 0,
-                     ctx->stream, keys_a, n0, ghist);
-  AA_HIP(hipGetLastError());
+  // 2. histograms of every digit (built by the partition kernel); skip digits on which all keys agree
   std::vector<unsigned int> h(256 * kPasses);
   for (int p = 0; p < kPasses; p += 4)  // ReadBack moves at most 4 KiB
     AA_TRY(ReadBack(ctx, ghist + 256 * p, 4 * 256 * (kPasses - p < 4 ? kPasses - p : 4), h.data() + 256 * p));
