@@ -481,16 +481,41 @@ def filter_groupby(ctx, values, keys, mask=None, group_capacity=None, buffers=No
                          keys.type_id)
 
 
+_BOOL_OPS = {"invert": _abi.INVERT, "and": _abi.AND, "and_not": _abi.AND_NOT, "or": _abi.OR, "xor": _abi.XOR,
+             "and_kleene": _abi.AND_KLEENE, "and_not_kleene": _abi.AND_NOT_KLEENE, "or_kleene": _abi.OR_KLEENE}
+
+
 def call_function(ctx, name, args, options=None):
     """CallFunction(name, args, options, ctx) for the functions on the path (same names as the
     reference registry; unknown name -> KeyError like registry.cc:62-64)."""
     options = options or {}
+    from .device import DeviceBinaryArray
     if name in ("filter", "array_filter"):
+        if isinstance(args[0], DeviceBinaryArray):
+            return binary_filter(ctx, args[0], args[1], options.get("null_selection_behavior", DROP))
         return filter(ctx, args[0], args[1], options.get("null_selection_behavior", DROP))
     if name in ("take", "array_take"):
+        if isinstance(args[0], DeviceBinaryArray):
+            return binary_take(ctx, args[0], args[1], options.get("boundscheck", True))
         return take(ctx, args[0], args[1], options.get("boundscheck", True))
     if name in ("sort_indices", "array_sort_indices"):
+        if "sort_keys" in options:  # a batch / table: args[0] = {column name: chunks}, sort_keys = [(name, order), ...]
+            keys = options["sort_keys"]
+            return sort_indices_multi(ctx, [args[0][k] for k, _ in keys], [o for _, o in keys])
         return sort_indices(ctx, args[0], options.get("order", ASCENDING))
+    simple = {"unique": unique, "value_counts": value_counts, "is_valid": is_valid, "is_nan": is_nan}
+    if name in simple:
+        return simple[name](ctx, args[0])
+    if name == "is_null":
+        return is_valid(ctx, args[0], is_null=True)
+    if name == "dictionary_encode":
+        return dictionary_encode(ctx, args[0], options.get("null_encoding_behavior", _abi.DICT_MASK))
+    if name == "fill_null":
+        return fill_null(ctx, args[0], args[1])
+    if name in _BOOL_OPS:
+        return boolean(ctx, _BOOL_OPS[name], args[0], args[1] if len(args) > 1 else None)
+    if name in ("count", "sum", "mean", "min_max"):
+        return aggregate(ctx, args[0])
     if name in _CMP:
         return compare(ctx, _CMP[name], args[0], args[1])
     if name in _ARITH:

@@ -986,3 +986,28 @@ def test_binary_concatenate_random(gpu, oracle):
                   [(1, 0, 0)] * 40, [(40_000, .01, 5), (1, 0, 0), (33_333, 0, 7)]):
         chunks = [_rand_bin(rng, n, p, off) for n, p, off in sizes]
         assert gpu.binary_concatenate(chunks).same(oracle.binary_concatenate(chunks)), sizes[:2]
+
+
+@pytest.mark.gpu
+def test_call_function_names_of_the_widened_rows(gpu, oracle):
+    """compute.call_function resolves the reference's function names for the rows added after the hot path."""
+    from arrow1_amd import _abi, compute
+    from gpu_api import up
+    rng = np.random.default_rng(400)
+    a = R(rng, INT32, 5000, .1, 2, lo=0, hi=50)
+    ctx = gpu.ctx
+    assert compute.call_function(ctx, "unique", [up(a)]).length == oracle.unique(a).length
+    u, c = compute.call_function(ctx, "value_counts", [up(a)])
+    assert np.array_equal(c.values_numpy(), oracle.value_counts(a)[1])
+    i, d = compute.call_function(ctx, "dictionary_encode", [up(a)])
+    assert d.length == oracle.dictionary_encode(a)[1].length and i.null_count == oracle.dictionary_encode(a)[0].null_count
+    b = R(rng, INT32, 5000, 0, 0, lo=0, hi=3)
+    got = compute.call_function(ctx, "sort_indices", [{"x": [up(b)], "y": [up(a)]}], {"sort_keys": [("x", ASC), ("y", DESC)]})
+    assert np.array_equal(got.values_numpy(), oracle.sort_indices_multi([b, a], [ASC, DESC]))
+    s = orc.BinArr([b"x", None, b"yz"])
+    assert gpu._down_bin(compute.call_function(ctx, "take", [gpu._up_bin(s), up(Arr(INT8, [2, 0]))])).logical() == [b"yz", b"x"]
+    m = R(rng, BOOL, 5000, .1, 1)
+    assert compute.call_function(ctx, "is_null", [up(a)]).length == 5000
+    assert compute.call_function(ctx, "and_kleene", [up(m), up(m)]).length == 5000
+    with pytest.raises(_abi.AmdArrowError):
+        compute.call_function(ctx, "no_such_function", [up(a)])
