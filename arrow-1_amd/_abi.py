@@ -94,6 +94,8 @@ SYMBOLS = {
     "amdarrow_hash_minmax_finalize": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, _P, _O]),
     "amdarrow_hash_accumulate": (C.c_int, [_P, C.c_int, _A, _P, C.c_int, _P, _P]),
     "amdarrow_hash_finalize": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, _P, _P, _O]),
+    "amdarrow_filter_groupby_multi": (C.c_int, [_P, _A, _P, C.c_int, _A, C.c_int64, _P, _P, _P, _P, C.POINTER(C.c_int64), _P,
+                                                C.POINTER(C.c_int64)]),
     "amdarrow_filter_groupby": (C.c_int, [_P, _A, _A, _A, C.c_int64, _P, _P, _P, _P, _P, C.POINTER(C.c_int64)]),
 }
 

@@ -481,6 +481,34 @@ def filter_groupby(ctx, values, keys, mask=None, group_capacity=None, buffers=No
                          keys.type_id)
 
 
+def filter_groupby_multi(ctx, values, keys, mask=None, group_capacity=None):
+    """The fused Filter -> GroupBy{hash_sum, hash_count} over several key columns (packed into one key word on the
+    device).  -> (num_groups, sums DeviceArray, counts DeviceArray, [key DeviceArray per column], first_rows tensor).
+    Raises AmdArrowError NotImplemented / CapacityError for shapes the packed path does not take."""
+    n = keys[0].length
+    cap = group_capacity if group_capacity is not None else n
+    dev = keys[0].values.device
+    sums, counts = alloc_bytes(cap * 8, dev), alloc_bytes(cap * 8, dev)
+    first_rows = alloc_bytes(cap * 4, dev)
+    kbufs = [alloc_bytes(((cap * bit_width(k.type_id) + 63) // 64) * 8, dev) for k in keys]
+    vbufs = [alloc_bytes((cap + 63) // 64 * 8, dev) for _ in keys]
+    karr = (CArray * len(keys))(*[k.c() for k in keys])
+    kp = (C.c_void_p * len(keys))(*[b.data_ptr() for b in kbufs])
+    vp = (C.c_void_p * len(keys))(*[b.data_ptr() for b in vbufs])
+    nulls = (C.c_int64 * len(keys))()
+    ng = C.c_int64(0)
+    cv = values.c() if values is not None else None
+    cm = mask.c() if mask is not None else None
+    check(ctx.lib, ctx.lib.amdarrow_filter_groupby_multi(ctx.handle, C.byref(cv) if cv is not None else None, karr, len(keys),
+                                                         C.byref(cm) if cm is not None else None, cap, _ptr(sums), _ptr(counts), kp, vp,
+                                                         nulls, _ptr(first_rows), C.byref(ng)))
+    G = ng.value
+    acc = _abi.DOUBLE if values is not None and values.type_id in (_abi.FLOAT, _abi.DOUBLE) else (
+        _abi.INT64 if values is None or values.type_id in (_abi.INT8, _abi.INT16, _abi.INT32, _abi.INT64) else _abi.UINT64)
+    out_keys = [DeviceArray(k.type_id, kb, vb if nulls[i] else None, G, 0, nulls[i]) for i, (k, kb, vb) in enumerate(zip(keys, kbufs, vbufs))]
+    return G, DeviceArray(acc, sums, None, G), DeviceArray(_abi.INT64, counts, None, G), out_keys, first_rows
+
+
 _BOOL_OPS = {"invert": _abi.INVERT, "and": _abi.AND, "and_not": _abi.AND_NOT, "or": _abi.OR, "xor": _abi.XOR,
              "and_kleene": _abi.AND_KLEENE, "and_not_kleene": _abi.AND_NOT_KLEENE, "or_kleene": _abi.OR_KLEENE}
 

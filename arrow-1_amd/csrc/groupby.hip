@@ -581,9 +581,19 @@ constexpr int kPartThreads = 1024;
 constexpr int kPartRows = 8192;          // rows per tile of the partition pass (8 per thread)
 constexpr uint32_t kRecKeyNull = 0x80000000u, kRecValValid = 0x40000000u, kRecRowMask = 0x3FFFFFFFu;
 
+// Several key columns packed into one key word (amdarrow_filter_groupby_multi): column c contributes
+// code = value - bias (or null_code for a null) at bit `shift`; the codes of all columns fit 32 bits.
+constexpr int kMaxPackedKeys = 4;
+struct KeyPack {
+  int ncols;
+  const void* data[kMaxPackedKeys]; const uint8_t* valid[kMaxPackedKeys]; int64_t off[kMaxPackedKeys];
+  int load_bits[kMaxPackedKeys]; int is_signed[kMaxPackedKeys]; int shift[kMaxPackedKeys]; int bits[kMaxPackedKeys];
+  uint32_t null_code[kMaxPackedKeys]; uint64_t bias[kMaxPackedKeys];
+};
 struct FastArgs {
   const void* k_data; const uint8_t* k_valid; int64_t k_off; int k_bits;
-  int k_load_bits;    // width of the key column in memory (== k_bits, or 64 for a range-compressed int64 column)
+  int k_load_bits;    // width of the key column in memory (== k_bits, or 64 for a range-compressed int64 column; 0 = `pack`)
+  KeyPack pack;
   uint64_t k_bias;    // subtracted from a 64-bit key: x = key - min(key) fits k_bits = 32
   ValueCol v; int has_values;
   const uint8_t* m_data; const uint8_t* m_valid; int64_t m_off;
@@ -615,7 +625,32 @@ __device__ __forceinline__ uint64_t FastMaskWord(const FastArgs& a, int64_t row0
   }
   return w;
 }
+__device__ __forceinline__ uint64_t PackedKey(const KeyPack& p, int64_t row) {
+  uint64_t x = 0;
+#pragma unroll
+  for (int c = 0; c < kMaxPackedKeys; ++c) {
+    if (c >= p.ncols) break;
+    const int64_t i = p.off[c] + row;
+    uint64_t code;
+    if (p.valid[c] && !GetBit(p.valid[c], i)) {
+      code = p.null_code[c];
+    } else {
+      uint64_t raw;
+      switch (p.load_bits[c]) {
+        case 1: raw = GetBit(reinterpret_cast<const uint8_t*>(p.data[c]), i); break;
+        case 8: raw = p.is_signed[c] ? uint64_t(int64_t(reinterpret_cast<const int8_t*>(p.data[c])[i])) : reinterpret_cast<const uint8_t*>(p.data[c])[i]; break;
+        case 16: raw = p.is_signed[c] ? uint64_t(int64_t(reinterpret_cast<const int16_t*>(p.data[c])[i])) : reinterpret_cast<const uint16_t*>(p.data[c])[i]; break;
+        case 32: raw = p.is_signed[c] ? uint64_t(int64_t(reinterpret_cast<const int32_t*>(p.data[c])[i])) : reinterpret_cast<const uint32_t*>(p.data[c])[i]; break;
+        default: raw = reinterpret_cast<const uint64_t*>(p.data[c])[i]; break;
+      }
+      code = raw - p.bias[c];
+    }
+    x |= code << p.shift[c];
+  }
+  return x;
+}
 __device__ __forceinline__ uint64_t FastKeyBits(const FastArgs& a, int64_t row) {
+  if (a.k_load_bits == 0) return PackedKey(a.pack, row);
   switch (a.k_load_bits) {
     case 1: return GetBit(reinterpret_cast<const uint8_t*>(a.k_data), a.k_off + row);
     case 8: return reinterpret_cast<const uint8_t*>(a.k_data)[a.k_off + row];
@@ -2142,10 +2177,14 @@ int amdarrow_hash_aggregate(amdarrow_ctx* ctx, int func, const amdarrow_array* v
   return rc;
 }
 
-int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, const amdarrow_array* keys,
-                            const amdarrow_array* mask, int64_t group_capacity, void* out_sums, int64_t* out_counts,
-                            void* out_keys, uint8_t* out_key_validity, uint32_t* out_first_rows,
-                            int64_t* out_num_groups) {
+}  // extern "C"
+
+// The fused Filter -> GroupBy.  `pack` != nullptr: `keys` is a stand-in UINT32 column whose values are the packed
+// codes of several real columns (PackedKey); the caller holds ctx->mu and decodes out_keys afterwards.
+static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, const amdarrow_array* keys,
+                             const amdarrow_array* mask, int64_t group_capacity, void* out_sums, int64_t* out_counts,
+                             void* out_keys, uint8_t* out_key_validity, uint32_t* out_first_rows,
+                             int64_t* out_num_groups, const KeyPack* pack) {
   const int64_t n = keys->length;
   *out_num_groups = 0;
   if (values && values->length != n) return SetError(AMDARROW_INVALID, "Array arguments must all be the same length");
@@ -2158,14 +2197,15 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
   if (n == 0) return AMDARROW_OK;
   KeySpec ks;
   AA_TRY(MakeKeySpec(1, keys, nullptr, &ks));
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::unique_lock<std::mutex> lock(ctx->mu, std::defer_lock);
+  if (!pack) lock.lock();
   const KeySpec ks_generic = ks;  // as the reference encodes the column; used by the generic path
   // An int64 / uint64 key column whose values span less than 2^32 (ids, dates, small integers --
   // most integer key columns) is range-compressed onto 32 bits: x = key - min.  One extra pass over
   // the keys (min / max) buys the partitioned LDS paths instead of the global-atomic table.
-  int k_load_bits = ks.col[0].bits;
+  int k_load_bits = pack ? 0 : ks.col[0].bits;
   uint64_t k_bias = 0;
-  if (ks.total_bits == 64 && (keys->type_id == AMDARROW_INT64 || keys->type_id == AMDARROW_UINT64) &&
+  if (!pack && ks.total_bits == 64 && (keys->type_id == AMDARROW_INT64 || keys->type_id == AMDARROW_UINT64) &&
       n >= (int64_t(1) << 18) && n < (int64_t(1) << 30) && !getenv("AMDARROW_GROUPBY_NO_RANGE_COMPRESSION")) {
     amdarrow_agg kr;
     AA_TRY(AggregateLocked(ctx, keys, &kr));
@@ -2188,13 +2228,14 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
   const bool fast_ok = ks.total_bits <= 32 && n >= (int64_t(1) << 18) && n < (int64_t(1) << 30);
   int path = fast_ok ? 3 : 0;  // 3 = local pre-aggregation with the partition path queued behind it
   if (const char* env = getenv("AMDARROW_GROUPBY_PATH")) path = std::min(path, atoi(env));
+  if (pack && path == 0) return SetError(AMDARROW_NOT_IMPLEMENTED, "group-by: packed keys need the partitioned paths");
   // Path 3 first tries to pre-aggregate every row range in LDS and looks for heavy hitters; with many
   // evenly spread groups both give up (~60 us of kernels and launches for nothing).  A call of the
   // same shape as the last one that went that way starts at the partition path directly; if its
   // capacity assumption then fails (the data changed character) the call starts over at path 3, and
   // every 16th hinted call takes path 3 anyway so that a change for the better is noticed too.
   amdarrow_ctx::GroupByHint shape;
-  shape.n = n; shape.key_type = keys->type_id; shape.value_type = values ? values->type_id : 0;
+  shape.n = n; shape.key_type = pack ? 1000 + pack->ncols : keys->type_id; shape.value_type = values ? values->type_id : 0;
   shape.has_mask = mask != nullptr; shape.has_value_validity = values && values->validity != nullptr;
   auto& hint = ctx->gb_hint;
   bool hinted = false;
@@ -2212,6 +2253,8 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
   constexpr int kMaxFlags = 1024;
   int sub_bits = 0;  // 2 after a partition's LDS table overflowed: four sub-problems, up to ~7 M groups
   for (;; --path) {
+    if (pack && path == 0)  // the generic table reads the real columns: the caller falls back to the batch-wise Grouper
+      return SetError(AMDARROW_CAPACITY_ERROR, "group-by: more groups than the partitioned paths hold for packed keys");
     const bool fast = path > 0;
     const int nsub = (fast && path == 2) ? 1 << sub_bits : 1;
     const uint64_t T = fast ? uint64_t(nsub) * kP * kSlots
@@ -2290,6 +2333,7 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
       FastArgs fa{};
       fa.k_data = keys->values; fa.k_valid = keys->validity; fa.k_off = keys->offset; fa.k_bits = ks.total_bits;
       fa.k_load_bits = k_load_bits; fa.k_bias = k_bias;
+      if (pack) fa.pack = *pack;
       fa.v = v; fa.has_values = values ? 1 : 0;
       fa.m_data = m_data; fa.m_valid = m_valid; fa.m_off = m_off;
       fa.n = n; fa.nblocks = nblocks; fa.rows_per_block = rows_per_block;
@@ -2431,6 +2475,139 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
     break;
   }
   // no trailing synchronise: *out_num_groups is final, the output arrays are stream-ordered
+  return AMDARROW_OK;
+}
+
+// Packed group keys -> the key columns (GetUniques per column, hash_aggregate.cc:410-428): one group per lane,
+// a wave's validity word by ballot.
+struct UnpackCols { void* values[kMaxPackedKeys]; uint64_t* validity[kMaxPackedKeys]; int width[kMaxPackedKeys]; };
+__global__ __launch_bounds__(256) void k_decode_packed_keys(const uint32_t* packed, int64_t G, KeyPack p, UnpackCols o,
+                                                            unsigned long long* null_counts /* slotted, one counter per column */) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwords = (G + 63) >> 6;
+  for (int64_t w = (int64_t(blockIdx.x) * 256 + threadIdx.x) >> 6; w < nwords; w += (int64_t(gridDim.x) * 256) >> 6) {
+    const int64_t g = (w << 6) + lane;
+    const uint32_t x = g < G ? packed[g] : 0u;
+    for (int c = 0; c < p.ncols; ++c) {
+      const uint32_t code = p.bits[c] >= 32 ? x : ((x >> p.shift[c]) & ((1u << p.bits[c]) - 1u));
+      const bool valid = g < G && !(p.valid[c] && code == p.null_code[c]);
+      const uint64_t v = valid ? uint64_t(code) + p.bias[c] : 0;
+      const uint64_t m = __ballot(valid);
+      if (o.width[c] == 1) {
+        const uint64_t bits = __ballot(valid && (v & 1));
+        if (lane == 0) reinterpret_cast<uint64_t*>(o.values[c])[w] = bits;
+      } else if (g < G) {
+        switch (o.width[c]) {
+          case 8: static_cast<uint8_t*>(o.values[c])[g] = static_cast<uint8_t>(v); break;
+          case 16: static_cast<uint16_t*>(o.values[c])[g] = static_cast<uint16_t>(v); break;
+          case 32: static_cast<uint32_t*>(o.values[c])[g] = static_cast<uint32_t>(v); break;
+          default: static_cast<uint64_t*>(o.values[c])[g] = v; break;
+        }
+      }
+      if (lane == 0) {
+        o.validity[c][w] = m;
+        const int64_t left = G - (w << 6);
+        const unsigned long long nulls = (left >= 64 ? 64 : left) - __popcll(m);
+        if (nulls) atomicAdd(CounterSlot(null_counts) + c, nulls);
+      }
+    }
+  }
+}
+
+extern "C" {
+
+int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, const amdarrow_array* keys,
+                            const amdarrow_array* mask, int64_t group_capacity, void* out_sums, int64_t* out_counts,
+                            void* out_keys, uint8_t* out_key_validity, uint32_t* out_first_rows,
+                            int64_t* out_num_groups) {
+  return FilterGroupByImpl(ctx, values, keys, mask, group_capacity, out_sums, out_counts, out_keys, out_key_validity, out_first_rows,
+                           out_num_groups, nullptr);
+}
+
+int amdarrow_filter_groupby_multi(amdarrow_ctx* ctx, const amdarrow_array* values, const amdarrow_array* keys, int nkeys,
+                                  const amdarrow_array* mask, int64_t group_capacity, void* out_sums, int64_t* out_counts,
+                                  void* const* out_keys, uint8_t* const* out_key_validity, int64_t* out_key_null_counts,
+                                  uint32_t* out_first_rows, int64_t* out_num_groups) {
+  *out_num_groups = 0;
+  if (nkeys < 1 || nkeys > kMaxPackedKeys) return SetError(AMDARROW_NOT_IMPLEMENTED, "group-by: 1 to 4 packed key columns");
+  const int64_t n = keys[0].length;
+  for (int c = 0; c < nkeys; ++c) {
+    if (keys[c].length != n) return SetError(AMDARROW_INVALID, "Array arguments must all be the same length");
+    const int t = keys[c].type_id;
+    if (t == AMDARROW_FLOAT || t == AMDARROW_DOUBLE || BitWidth(t) < 0)
+      return SetError(AMDARROW_NOT_IMPLEMENTED, "group-by: packed keys are integer or boolean columns");
+    out_key_null_counts[c] = 0;
+  }
+  if (n == 0) return AMDARROW_OK;
+  if (n < (int64_t(1) << 18) || n >= (int64_t(1) << 30))
+    return SetError(AMDARROW_NOT_IMPLEMENTED, "group-by: packed keys take the partitioned paths (2^18 <= rows < 2^30)");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  // plan: one pass per key column for its range (the aggregate kernel's min / max), bits = log2(range [+ a code for null])
+  KeyPack p{};
+  p.ncols = nkeys;
+  int total = 0;
+  for (int c = 0; c < nkeys; ++c) {
+    const amdarrow_array& k = keys[c];
+    amdarrow_agg r;
+    AA_TRY(AggregateLocked(ctx, &k, &r));
+    const bool has_null = k.validity && k.null_count != 0 && r.valid_count < n;
+    const uint64_t span = r.valid_count > 0 ? r.max - r.min : 0;  // wrap-around difference: exact for both signednesses
+    if (span >= 0xFFFFFFFEull) return SetError(AMDARROW_NOT_IMPLEMENTED, "group-by: key range too wide to pack");
+    const uint64_t codes = (r.valid_count > 0 ? span + 1 : 0) + (has_null ? 1 : 0);
+    int bits = 0;
+    while (bits < 33 && (uint64_t(1) << bits) < codes) ++bits;
+    p.data[c] = k.values; p.valid[c] = has_null ? k.validity : nullptr; p.off[c] = k.offset;
+    p.load_bits[c] = BitWidth(k.type_id);
+    p.is_signed[c] = k.type_id == AMDARROW_INT8 || k.type_id == AMDARROW_INT16 || k.type_id == AMDARROW_INT32 || k.type_id == AMDARROW_INT64;
+    p.bias[c] = r.valid_count > 0 ? r.min : 0;
+    p.null_code[c] = static_cast<uint32_t>(r.valid_count > 0 ? span + 1 : 0);
+    p.bits[c] = bits;
+    p.shift[c] = total;
+    total += bits;
+    if (total > 32) return SetError(AMDARROW_NOT_IMPLEMENTED, "group-by: the key columns need more than 32 bits together");
+  }
+  // the single-key machinery on a stand-in column of packed codes
+  const int64_t bound = group_capacity < n ? group_capacity : n;
+  uint32_t* packed = nullptr;
+  uint8_t* dummy_validity = nullptr;
+  AA_HIP(hipMalloc(reinterpret_cast<void**>(&packed), 4 * static_cast<size_t>(bound) + 64));
+  if (hipMalloc(reinterpret_cast<void**>(&dummy_validity), static_cast<size_t>(bound) / 8 + 64) != hipSuccess) {
+    (void)hipFree(packed);
+    return SetError(AMDARROW_OUT_OF_MEMORY, "group-by: scratch for packed keys");
+  }
+  amdarrow_array stand_in{};
+  stand_in.values = nullptr; stand_in.validity = nullptr; stand_in.length = n; stand_in.offset = 0;
+  stand_in.type_id = AMDARROW_UINT32; stand_in.null_count = 0;
+  int64_t G = 0;
+  int rc = FilterGroupByImpl(ctx, values, &stand_in, mask, group_capacity, out_sums, out_counts, packed, dummy_validity, out_first_rows,
+                             &G, &p);
+  if (rc == AMDARROW_OK && G > 0) {
+    void* base;
+    rc = Scratch(ctx, kCounterBytes, &base);
+    if (rc == AMDARROW_OK) {
+      auto* counters = static_cast<unsigned long long*>(base);
+      rc = ClearCounters(ctx, counters);
+      UnpackCols o{};
+      for (int c = 0; c < nkeys; ++c) {
+        o.values[c] = out_keys[c];
+        o.validity[c] = reinterpret_cast<uint64_t*>(out_key_validity[c]);
+        o.width[c] = BitWidth(keys[c].type_id);
+      }
+      if (rc == AMDARROW_OK) {
+        hipLaunchKernelGGL(k_decode_packed_keys, dim3(GridFor(G, 256, ctx->num_cus * 8)), dim3(256), 0, ctx->stream, packed, G, p, o,
+                           counters);
+        unsigned long long nulls[kMaxPackedKeys] = {0, 0, 0, 0};
+        rc = ReadCounters(ctx, counters, nkeys, nulls);
+        for (int c = 0; c < nkeys; ++c) out_key_null_counts[c] = static_cast<int64_t>(nulls[c]);
+      }
+    }
+  }
+  const hipError_t e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(packed);
+  (void)hipFree(dummy_validity);
+  AA_TRY(rc);
+  AA_HIP(e);
+  *out_num_groups = G;
   return AMDARROW_OK;
 }
 

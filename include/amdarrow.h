@@ -228,6 +228,20 @@ int amdarrow_hash_aggregate(amdarrow_ctx* ctx, int func, const amdarrow_array* v
                             const uint32_t* ids, int64_t num_groups, int count_mode,
                             void* out_values, uint8_t* out_validity, amdarrow_out* out);
 
+/* The fused Filter -> GroupBy over SEVERAL key columns (GrouperImpl with one KeyEncoder per column,
+ * hash_aggregate.cc:313-437; rows of the result as amdarrow_filter_groupby, one keys / validity buffer per key column
+ * plus its null count).  The columns' values are packed into one 32-bit key word: column c contributes
+ * value - min(column c), with one more code for null, in just enough bits for its range (one min / max pass per key
+ * column).  AMDARROW_NOT_IMPLEMENTED when that cannot be done -- float keys, more than 4 columns, ranges that need more
+ * than 32 bits together, fewer than 2^18 rows -- and AMDARROW_CAPACITY_ERROR beyond the partitioned tables (~7 M
+ * groups): the caller then takes the Grouper + hash_accumulate route, which handles every shape. */
+int amdarrow_filter_groupby_multi(amdarrow_ctx* ctx, const amdarrow_array* values,
+                                  const amdarrow_array* keys, int nkeys, const amdarrow_array* mask,
+                                  int64_t group_capacity, void* out_sums, int64_t* out_counts,
+                                  void* const* out_keys, uint8_t* const* out_key_validity,
+                                  int64_t* out_key_null_counts, uint32_t* out_first_rows,
+                                  int64_t* out_num_groups);
+
 /* The device half of the multi-GPU group-by merge (protocol in arrow-1_amd/dist.py): the
  * reference has no counterpart -- its GroupBy is single-process (hash_aggregate.cc:890-966); the
  * merged table is what that GroupBy returns on the concatenated shards, first-appearance order

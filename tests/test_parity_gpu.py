@@ -1011,3 +1011,62 @@ def test_call_function_names_of_the_widened_rows(gpu, oracle):
     assert compute.call_function(ctx, "and_kleene", [up(m), up(m)]).length == 5000
     with pytest.raises(_abi.AmdArrowError):
         compute.call_function(ctx, "no_such_function", [up(a)])
+
+
+# ---- fused GroupBy over several key columns (packed key word) ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["two-int32", "int8+int16+bool", "nulls", "int64-narrow+uint8", "many-groups", "negative"])
+def test_filter_groupby_multi_key_packed(gpu, oracle, shape):
+    """Key columns packed into one key word on the device against the oracle's multi-column Grouper + hash_sum /
+    hash_count over the filtered rows: same groups, same first-appearance order, same per-column uniques."""
+    from arrow1_amd import compute
+    from gpu_api import up
+    rng = np.random.default_rng(500)
+    n = 600_000
+    if shape == "two-int32":
+        keys = [Arr(INT32, rng.integers(0, 300, n)), Arr(INT32, rng.integers(1000, 1400, n))]
+    elif shape == "int8+int16+bool":
+        keys = [Arr(INT8, rng.integers(-5, 6, n)), Arr(INT16, rng.integers(-300, 300, n)), Arr(BOOL, rng.random(n) < .5)]
+    elif shape == "nulls":
+        keys = [Arr(INT32, rng.integers(0, 50, n), rng.random(n) > .1), Arr(UINT16, rng.integers(0, 40, n), rng.random(n) > .2),
+                Arr(INT32, np.zeros(n, np.int32), np.zeros(n, bool))]
+    elif shape == "int64-narrow+uint8":
+        keys = [Arr(INT64, rng.integers(10**12, 10**12 + 5000, n)), Arr(UINT8, rng.integers(0, 200, n))]
+    elif shape == "many-groups":
+        keys = [Arr(INT32, rng.integers(0, 2000, n)), Arr(INT32, rng.integers(0, 1000, n))]
+    else:
+        keys = [Arr(INT64, rng.integers(-2**40, -2**40 + 100, n)), Arr(INT32, rng.integers(-2**31, -2**31 + 100, n))]
+    v = R(rng, INT64, n, .02, 0)
+    m = rng.random(n) < .6
+    G, sums, counts, okeys, first = compute.filter_groupby_multi(gpu.ctx, up(v), [up(k) for k in keys], up(Arr(BOOL, m)), 1 << 21)
+    # the oracle on the filtered rows
+    sel = np.nonzero(m)[0]
+    fk = [Arr(k.type_id, k.data[sel], None if k.valid is None else k.valid[sel]) for k in keys]
+    fv = Arr(INT64, v.data[sel], None if v.valid is None else v.valid[sel])
+    ids, ng, uniq = oracle.group_ids([fk])
+    assert G == ng
+    es = oracle.hash_aggregate("sum", fv, ids[0], ng)
+    ec = oracle.hash_aggregate("count", fv, ids[0], ng)
+    assert np.array_equal(sums.values_numpy(), es.values.view(np.int64))
+    assert np.array_equal(counts.values_numpy(), ec.values)
+    for c, (uv, uvalid, unull) in enumerate(uniq):
+        got_valid = okeys[c].validity_numpy() if okeys[c].validity is not None else np.ones(G, bool)
+        assert np.array_equal(got_valid, uvalid[:G] if len(uvalid) else got_valid), (shape, c)
+        assert okeys[c].null_count == unull
+        gv = okeys[c].values_numpy()
+        assert np.array_equal(np.asarray(gv)[got_valid], np.asarray(uv)[uvalid.astype(bool)]), (shape, c)
+
+
+@pytest.mark.gpu
+def test_filter_groupby_multi_key_refusals(gpu):
+    from arrow1_amd import _abi, compute
+    from gpu_api import up
+    rng = np.random.default_rng(501)
+    n = 300_000
+    wide = [Arr(INT32, rng.integers(0, 2**20, n)), Arr(INT32, rng.integers(0, 2**20, n))]  # 40 bits together
+    v = up(Arr(INT64, rng.integers(0, 9, n)))
+    for keys in (wide, [Arr(DOUBLE, rng.random(n)), Arr(INT32, rng.integers(0, 9, n))], [Arr(INT32, np.zeros(100, np.int32))] * 2):
+        vv = v if keys[0].length == n else up(Arr(INT64, np.zeros(100, np.int64)))
+        with pytest.raises(_abi.AmdArrowError) as ei:
+            compute.filter_groupby_multi(gpu.ctx, vv, [up(k) for k in keys], None, 1 << 20)
+        assert ei.value.code == 10  # NotImplemented: the caller takes the Grouper route
