@@ -583,6 +583,8 @@ constexpr uint32_t kRecKeyNull = 0x80000000u, kRecValValid = 0x40000000u, kRecRo
 
 // Several key columns packed into one key word (amdarrow_filter_groupby_multi): column c contributes
 // code = value - bias (or null_code for a null) at bit `shift`; the codes of all columns fit 32 bits.
+// k_pack_keys materialises the packed column once (12 bytes per row for two int32 columns) and the
+// single-key machinery -- the specialised scatter included -- runs on it unchanged.
 constexpr int kMaxPackedKeys = 4;
 struct KeyPack {
   int ncols;
@@ -592,8 +594,7 @@ struct KeyPack {
 };
 struct FastArgs {
   const void* k_data; const uint8_t* k_valid; int64_t k_off; int k_bits;
-  int k_load_bits;    // width of the key column in memory (== k_bits, or 64 for a range-compressed int64 column; 0 = `pack`)
-  KeyPack pack;
+  int k_load_bits;    // width of the key column in memory (== k_bits, or 64 for a range-compressed int64 column)
   uint64_t k_bias;    // subtracted from a 64-bit key: x = key - min(key) fits k_bits = 32
   ValueCol v; int has_values;
   const uint8_t* m_data; const uint8_t* m_valid; int64_t m_off;
@@ -650,7 +651,6 @@ __device__ __forceinline__ uint64_t PackedKey(const KeyPack& p, int64_t row) {
   return x;
 }
 __device__ __forceinline__ uint64_t FastKeyBits(const FastArgs& a, int64_t row) {
-  if (a.k_load_bits == 0) return PackedKey(a.pack, row);
   switch (a.k_load_bits) {
     case 1: return GetBit(reinterpret_cast<const uint8_t*>(a.k_data), a.k_off + row);
     case 8: return reinterpret_cast<const uint8_t*>(a.k_data)[a.k_off + row];
@@ -2179,12 +2179,12 @@ int amdarrow_hash_aggregate(amdarrow_ctx* ctx, int func, const amdarrow_array* v
 
 }  // extern "C"
 
-// The fused Filter -> GroupBy.  `pack` != nullptr: `keys` is a stand-in UINT32 column whose values are the packed
-// codes of several real columns (PackedKey); the caller holds ctx->mu and decodes out_keys afterwards.
+// The fused Filter -> GroupBy.  `locked`: the caller already holds ctx->mu (the multi-key entry point, which runs
+// this on its column of packed key codes).
 static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, const amdarrow_array* keys,
                              const amdarrow_array* mask, int64_t group_capacity, void* out_sums, int64_t* out_counts,
                              void* out_keys, uint8_t* out_key_validity, uint32_t* out_first_rows,
-                             int64_t* out_num_groups, const KeyPack* pack) {
+                             int64_t* out_num_groups, bool locked) {
   const int64_t n = keys->length;
   *out_num_groups = 0;
   if (values && values->length != n) return SetError(AMDARROW_INVALID, "Array arguments must all be the same length");
@@ -2198,14 +2198,14 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
   KeySpec ks;
   AA_TRY(MakeKeySpec(1, keys, nullptr, &ks));
   std::unique_lock<std::mutex> lock(ctx->mu, std::defer_lock);
-  if (!pack) lock.lock();
+  if (!locked) lock.lock();
   const KeySpec ks_generic = ks;  // as the reference encodes the column; used by the generic path
   // An int64 / uint64 key column whose values span less than 2^32 (ids, dates, small integers --
   // most integer key columns) is range-compressed onto 32 bits: x = key - min.  One extra pass over
   // the keys (min / max) buys the partitioned LDS paths instead of the global-atomic table.
-  int k_load_bits = pack ? 0 : ks.col[0].bits;
+  int k_load_bits = ks.col[0].bits;
   uint64_t k_bias = 0;
-  if (!pack && ks.total_bits == 64 && (keys->type_id == AMDARROW_INT64 || keys->type_id == AMDARROW_UINT64) &&
+  if (ks.total_bits == 64 && (keys->type_id == AMDARROW_INT64 || keys->type_id == AMDARROW_UINT64) &&
       n >= (int64_t(1) << 18) && n < (int64_t(1) << 30) && !getenv("AMDARROW_GROUPBY_NO_RANGE_COMPRESSION")) {
     amdarrow_agg kr;
     AA_TRY(AggregateLocked(ctx, keys, &kr));
@@ -2228,14 +2228,13 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
   const bool fast_ok = ks.total_bits <= 32 && n >= (int64_t(1) << 18) && n < (int64_t(1) << 30);
   int path = fast_ok ? 3 : 0;  // 3 = local pre-aggregation with the partition path queued behind it
   if (const char* env = getenv("AMDARROW_GROUPBY_PATH")) path = std::min(path, atoi(env));
-  if (pack && path == 0) return SetError(AMDARROW_NOT_IMPLEMENTED, "group-by: packed keys need the partitioned paths");
   // Path 3 first tries to pre-aggregate every row range in LDS and looks for heavy hitters; with many
   // evenly spread groups both give up (~60 us of kernels and launches for nothing).  A call of the
   // same shape as the last one that went that way starts at the partition path directly; if its
   // capacity assumption then fails (the data changed character) the call starts over at path 3, and
   // every 16th hinted call takes path 3 anyway so that a change for the better is noticed too.
   amdarrow_ctx::GroupByHint shape;
-  shape.n = n; shape.key_type = pack ? 1000 + pack->ncols : keys->type_id; shape.value_type = values ? values->type_id : 0;
+  shape.n = n; shape.key_type = keys->type_id; shape.value_type = values ? values->type_id : 0;
   shape.has_mask = mask != nullptr; shape.has_value_validity = values && values->validity != nullptr;
   auto& hint = ctx->gb_hint;
   bool hinted = false;
@@ -2253,8 +2252,6 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
   constexpr int kMaxFlags = 1024;
   int sub_bits = 0;  // 2 after a partition's LDS table overflowed: four sub-problems, up to ~7 M groups
   for (;; --path) {
-    if (pack && path == 0)  // the generic table reads the real columns: the caller falls back to the batch-wise Grouper
-      return SetError(AMDARROW_CAPACITY_ERROR, "group-by: more groups than the partitioned paths hold for packed keys");
     const bool fast = path > 0;
     const int nsub = (fast && path == 2) ? 1 << sub_bits : 1;
     const uint64_t T = fast ? uint64_t(nsub) * kP * kSlots
@@ -2333,7 +2330,6 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
       FastArgs fa{};
       fa.k_data = keys->values; fa.k_valid = keys->validity; fa.k_off = keys->offset; fa.k_bits = ks.total_bits;
       fa.k_load_bits = k_load_bits; fa.k_bias = k_bias;
-      if (pack) fa.pack = *pack;
       fa.v = v; fa.has_values = values ? 1 : 0;
       fa.m_data = m_data; fa.m_valid = m_valid; fa.m_off = m_off;
       fa.n = n; fa.nblocks = nblocks; fa.rows_per_block = rows_per_block;
@@ -2478,6 +2474,57 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
   return AMDARROW_OK;
 }
 
+// The packed key column: one uint32 per row (PackedKey).  Four rows per thread and step; the raw values of every
+// column are requested before any is used (the width switch is uniform: one branch per column, four loads inside).
+__global__ __launch_bounds__(256) void k_pack_keys(KeyPack p, int64_t n, uint32_t* out) {
+  constexpr int kU = 4;
+  for (int64_t base = (int64_t(blockIdx.x) * 256) * kU; base < n; base += int64_t(gridDim.x) * 256 * kU) {
+    uint64_t raw[kMaxPackedKeys][kU];
+    bool ok[kMaxPackedKeys][kU];
+#pragma unroll
+    for (int c = 0; c < kMaxPackedKeys; ++c) {
+      if (c >= p.ncols) break;
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int64_t r = base + u * 256 + threadIdx.x;
+        ok[c][u] = !p.valid[c] || GetBit(p.valid[c], p.off[c] + (r < n ? r : n - 1));
+      }
+      const int64_t o = p.off[c];
+#define AA_RAW(T, EXT)                                                                                   \
+  _Pragma("unroll") for (int u = 0; u < kU; ++u) {                                                       \
+    const int64_t r = base + u * 256 + threadIdx.x;                                                      \
+    raw[c][u] = static_cast<uint64_t>(static_cast<EXT>(reinterpret_cast<const T*>(p.data[c])[o + (r < n ? r : n - 1)])); \
+  }
+      switch (p.load_bits[c]) {
+        case 1:
+#pragma unroll
+          for (int u = 0; u < kU; ++u) {
+            const int64_t r = base + u * 256 + threadIdx.x;
+            raw[c][u] = GetBit(reinterpret_cast<const uint8_t*>(p.data[c]), o + (r < n ? r : n - 1));
+          }
+          break;
+        case 8: if (p.is_signed[c]) { AA_RAW(int8_t, int64_t) } else { AA_RAW(uint8_t, uint64_t) } break;
+        case 16: if (p.is_signed[c]) { AA_RAW(int16_t, int64_t) } else { AA_RAW(uint16_t, uint64_t) } break;
+        case 32: if (p.is_signed[c]) { AA_RAW(int32_t, int64_t) } else { AA_RAW(uint32_t, uint64_t) } break;
+        default: AA_RAW(uint64_t, uint64_t) break;
+      }
+#undef AA_RAW
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t r = base + u * 256 + threadIdx.x;
+      uint64_t x = 0;
+#pragma unroll
+      for (int c = 0; c < kMaxPackedKeys; ++c) {
+        if (c >= p.ncols) break;
+        const uint64_t code = ok[c][u] ? raw[c][u] - p.bias[c] : uint64_t(p.null_code[c]);
+        x |= code << p.shift[c];
+      }
+      if (r < n) out[r] = static_cast<uint32_t>(x);
+    }
+  }
+}
+
 // Packed group keys -> the key columns (GetUniques per column, hash_aggregate.cc:410-428): one group per lane,
 // a wave's validity word by ballot.
 struct UnpackCols { void* values[kMaxPackedKeys]; uint64_t* validity[kMaxPackedKeys]; int width[kMaxPackedKeys]; };
@@ -2521,7 +2568,7 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
                             void* out_keys, uint8_t* out_key_validity, uint32_t* out_first_rows,
                             int64_t* out_num_groups) {
   return FilterGroupByImpl(ctx, values, keys, mask, group_capacity, out_sums, out_counts, out_keys, out_key_validity, out_first_rows,
-                           out_num_groups, nullptr);
+                           out_num_groups, /*locked=*/false);
 }
 
 int amdarrow_filter_groupby_multi(amdarrow_ctx* ctx, const amdarrow_array* values, const amdarrow_array* keys, int nkeys,
@@ -2539,8 +2586,7 @@ int amdarrow_filter_groupby_multi(amdarrow_ctx* ctx, const amdarrow_array* value
     out_key_null_counts[c] = 0;
   }
   if (n == 0) return AMDARROW_OK;
-  if (n < (int64_t(1) << 18) || n >= (int64_t(1) << 30))
-    return SetError(AMDARROW_NOT_IMPLEMENTED, "group-by: packed keys take the partitioned paths (2^18 <= rows < 2^30)");
+  if (n >= (int64_t(1) << 32) - 1) return SetError(AMDARROW_NOT_IMPLEMENTED, "group-by: 2^32 rows or more per call");
   std::lock_guard<std::mutex> lock(ctx->mu);
   // plan: one pass per key column for its range (the aggregate kernel's min / max), bits = log2(range [+ a code for null])
   KeyPack p{};
@@ -2566,21 +2612,28 @@ int amdarrow_filter_groupby_multi(amdarrow_ctx* ctx, const amdarrow_array* value
     total += bits;
     if (total > 32) return SetError(AMDARROW_NOT_IMPLEMENTED, "group-by: the key columns need more than 32 bits together");
   }
-  // the single-key machinery on a stand-in column of packed codes
+  // the single-key machinery on the column of packed codes (grow-only buffer of the context: codes of the rows, then of
+  // the groups, then a validity bitmap nobody reads)
   const int64_t bound = group_capacity < n ? group_capacity : n;
-  uint32_t* packed = nullptr;
-  uint8_t* dummy_validity = nullptr;
-  AA_HIP(hipMalloc(reinterpret_cast<void**>(&packed), 4 * static_cast<size_t>(bound) + 64));
-  if (hipMalloc(reinterpret_cast<void**>(&dummy_validity), static_cast<size_t>(bound) / 8 + 64) != hipSuccess) {
-    (void)hipFree(packed);
-    return SetError(AMDARROW_OUT_OF_MEMORY, "group-by: scratch for packed keys");
+  const size_t need = 4 * static_cast<size_t>(n) + 4 * static_cast<size_t>(bound) + static_cast<size_t>(bound) / 8 + 512;
+  if (ctx->pack_cap < need) {
+    if (ctx->pack_buf) (void)hipFree(ctx->pack_buf);
+    ctx->pack_buf = nullptr;
+    ctx->pack_cap = 0;
+    AA_HIP(hipMalloc(&ctx->pack_buf, need));
+    ctx->pack_cap = need;
   }
+  auto* codes = static_cast<uint32_t*>(ctx->pack_buf);
+  uint32_t* packed = codes + ((n + 63) / 64) * 64;
+  uint8_t* dummy_validity = reinterpret_cast<uint8_t*>(packed + ((bound + 63) / 64) * 64);
+  hipLaunchKernelGGL(k_pack_keys, dim3(GridFor(n, 1024, ctx->num_cus * 8)), dim3(256), 0, ctx->stream, p, n, codes);
+  AA_HIP(hipGetLastError());
   amdarrow_array stand_in{};
-  stand_in.values = nullptr; stand_in.validity = nullptr; stand_in.length = n; stand_in.offset = 0;
+  stand_in.values = codes; stand_in.validity = nullptr; stand_in.length = n; stand_in.offset = 0;
   stand_in.type_id = AMDARROW_UINT32; stand_in.null_count = 0;
   int64_t G = 0;
   int rc = FilterGroupByImpl(ctx, values, &stand_in, mask, group_capacity, out_sums, out_counts, packed, dummy_validity, out_first_rows,
-                             &G, &p);
+                             &G, /*locked=*/true);
   if (rc == AMDARROW_OK && G > 0) {
     void* base;
     rc = Scratch(ctx, kCounterBytes, &base);
@@ -2603,8 +2656,6 @@ int amdarrow_filter_groupby_multi(amdarrow_ctx* ctx, const amdarrow_array* value
     }
   }
   const hipError_t e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(packed);
-  (void)hipFree(dummy_validity);
   AA_TRY(rc);
   AA_HIP(e);
   *out_num_groups = G;

@@ -52,6 +52,7 @@ class Status {
   bool IsKeyError() const { return code_ == StatusCode::KeyError; }
   bool IsIndexError() const { return code_ == StatusCode::IndexError; }
   bool IsNotImplemented() const { return code_ == StatusCode::NotImplemented; }
+  bool IsCapacityError() const { return code_ == StatusCode::CapacityError; }
   std::string ToString() const;
 
  private:

@@ -736,6 +736,37 @@ static int RunGpu() {
     }
     CHECK(internal::GroupBy({Datum(DevBool(pool, {1, 0}))}, {Datum(Dev<int64_t>(pool, int64(), {V(int64_t, 1), V(int64_t, 2)}))},
                             {{"hash_min_max", nullptr}}, &ctx).status().IsNotImplemented());  // :674-676
+    // two key columns: the packed fused path (large input) against the batch-wise Grouper path -- same rows
+    {
+      const int64_t nn = 400000;
+      std::vector<Opt<int64_t>> av; std::vector<Opt<int32_t>> k1; std::vector<Opt<int16_t>> k2;
+      uint64_t st = 12345;
+      auto rnd = [&]() { st = st * 6364136223846793005ULL + 1442695040888963407ULL; return st >> 33; };
+      for (int64_t i = 0; i < nn; ++i) {
+        av.push_back(rnd() % 50 == 0 ? N(int64_t) : V(int64_t, int64_t(rnd() % 2001) - 1000));
+        k1.push_back(rnd() % 40 == 0 ? N(int32_t) : V(int32_t, int32_t(rnd() % 300) + 7000));
+        k2.push_back(V(int16_t, int16_t(rnd() % 90) - 45));
+      }
+      auto a2 = Dev<int64_t>(pool, int64(), av);
+      auto ka = Dev<int32_t>(pool, int32(), k1);
+      auto kb = Dev<int16_t>(pool, int16(), k2);
+      const std::vector<internal::Aggregate> ag = {{"hash_sum", nullptr}, {"hash_count", nullptr}};
+      auto fused = internal::GroupBy({Datum(a2), Datum(a2)}, {Datum(ka), Datum(kb)}, ag, &ctx);
+      setenv("AMDARROW_GROUPBY_BATCHWISE", "1", 1);
+      auto batch = internal::GroupBy({Datum(a2), Datum(a2)}, {Datum(ka), Datum(kb)}, ag, &ctx);
+      unsetenv("AMDARROW_GROUPBY_BATCHWISE");
+      CHECK_OK(fused.status());
+      CHECK_OK(batch.status());
+      if (fused.ok() && batch.ok()) {
+        CHECK(fused->length == batch->length && fused->length > 20000);
+        CHECK(fused->field_names == batch->field_names && fused->field_names.back() == "key_1");
+        CHECK(Same(Host<int64_t>(pool, *fused->columns[0]), Host<int64_t>(pool, *batch->columns[0])));
+        CHECK(Same(Host<int64_t>(pool, *fused->columns[1]), Host<int64_t>(pool, *batch->columns[1])));
+        CHECK(Same(Host<int32_t>(pool, *fused->columns[2]), Host<int32_t>(pool, *batch->columns[2])));
+        CHECK(Same(Host<int16_t>(pool, *fused->columns[3]), Host<int16_t>(pool, *batch->columns[3])));
+        CHECK(fused->columns[2]->null_count == batch->columns[2]->null_count && fused->columns[3]->buffers[0] == nullptr);
+      }
+    }
     auto bad = internal::GroupBy({Datum(argument)}, {Datum(key)}, {{"hash_sum", nullptr}, {"hash_count", nullptr}}, &ctx);
     CHECK(bad.status().IsInvalid());  // aggregates.size() != arguments.size() (:811-815)
     CHECK(CallFunction("hash_sum", {Datum(argument), Datum(key), Datum(key)}, &ctx).status().IsNotImplemented());

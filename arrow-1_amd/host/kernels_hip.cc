@@ -1186,16 +1186,22 @@ namespace {
 // chunked inputs split into batches, other aggregates) takes the Grouper + per-kernel consume path.
 struct FusedRun {
   const ArrayData* column;
-  std::shared_ptr<Buffer> sums, counts, keys, key_validity, first_rows;
+  std::shared_ptr<Buffer> sums, counts, first_rows;
+  std::vector<std::shared_ptr<Buffer>> keys, key_validity;  // one per key column
+  std::vector<int64_t> key_nulls;
 };
 int HashFuncOf(const std::string& name) {
   return name == "hash_sum" ? AMDARROW_HASH_SUM : name == "hash_count" ? AMDARROW_HASH_COUNT : name == "hash_mean" ? AMDARROW_HASH_MEAN : -1;
 }
 bool CanFuseGroupBy(const std::vector<Datum>& arguments, const std::vector<Datum>& keys, const std::vector<Aggregate>& aggregates,
                     ExecContext* ctx) {
-  if (keys.size() != 1 || !keys[0].is_array() || arguments.empty()) return false;
+  if (keys.empty() || keys.size() > 4 || !keys[0].is_array() || arguments.empty()) return false;
   const ArrayData& key = *keys[0].array();
   if (key.length == 0 || key.length > ctx->exec_chunksize() || key.type->bit_width() < 0) return false;
+  for (const auto& k : keys) {  // several keys: packed into one key word on the device (integer / boolean columns)
+    if (!k.is_array() || k.array()->length != key.length || k.array()->type->bit_width() < 0) return false;
+    if (keys.size() > 1 && is_floating(k.array()->type->id())) return false;
+  }
   for (size_t i = 0; i < arguments.size(); ++i) {
     if (!arguments[i].is_array() || arguments[i].array()->length != key.length) return false;
     if (arguments[i].array()->type->bit_width() < 0) return false;
@@ -1215,7 +1221,9 @@ Result<GroupByResult> FusedGroupBy(const std::vector<Datum>& arguments, const st
   KernelContext kctx(ctx);
   const ArrayData& key = *keys[0].array();
   const int64_t n = key.length;
-  amdarrow_array k = key.abi();
+  const int nkeys = static_cast<int>(keys.size());
+  std::vector<amdarrow_array> k;
+  for (const auto& kd : keys) k.push_back(kd.array()->abi());
   std::vector<FusedRun> runs;
   std::vector<int> run_of(arguments.size());
   int64_t num_groups = 0;
@@ -1233,14 +1241,27 @@ Result<GroupByResult> FusedGroupBy(const std::vector<Datum>& arguments, const st
       run.column = col;
       AMD_ASSIGN_OR_RAISE(run.sums, kctx.Allocate(8 * cap));
       AMD_ASSIGN_OR_RAISE(run.counts, kctx.Allocate(8 * cap));
-      AMD_ASSIGN_OR_RAISE(run.keys, kctx.Allocate(ValueBytes(*key.type, cap) + 8));
-      AMD_ASSIGN_OR_RAISE(run.key_validity, kctx.AllocateBitmap(cap));
+      std::vector<void*> kp;
+      std::vector<uint8_t*> vp;
+      for (int c = 0; c < nkeys; ++c) {
+        AMD_ASSIGN_OR_RAISE(auto kb, kctx.Allocate(ValueBytes(*keys[c].array()->type, cap) + 8));
+        AMD_ASSIGN_OR_RAISE(auto vb, kctx.AllocateBitmap(cap));
+        kp.push_back(kb->mutable_data());
+        vp.push_back(vb->mutable_data());
+        run.keys.push_back(kb);
+        run.key_validity.push_back(vb);
+      }
+      run.key_nulls.assign(nkeys, -1);
       AMD_ASSIGN_OR_RAISE(run.first_rows, kctx.Allocate(4 * cap));
       amdarrow_array v = col->abi();
       int64_t g = 0;
-      const int rc = amdarrow_filter_groupby(kctx.abi(), &v, &k, nullptr, cap, run.sums->mutable_data(),
-                                             reinterpret_cast<int64_t*>(run.counts->mutable_data()), run.keys->mutable_data(),
-                                             run.key_validity->mutable_data(), reinterpret_cast<uint32_t*>(run.first_rows->mutable_data()), &g);
+      const int rc = nkeys == 1
+          ? amdarrow_filter_groupby(kctx.abi(), &v, &k[0], nullptr, cap, run.sums->mutable_data(),
+                                    reinterpret_cast<int64_t*>(run.counts->mutable_data()), kp[0], vp[0],
+                                    reinterpret_cast<uint32_t*>(run.first_rows->mutable_data()), &g)
+          : amdarrow_filter_groupby_multi(kctx.abi(), &v, k.data(), nkeys, nullptr, cap, run.sums->mutable_data(),
+                                          reinterpret_cast<int64_t*>(run.counts->mutable_data()), kp.data(), vp.data(),
+                                          run.key_nulls.data(), reinterpret_cast<uint32_t*>(run.first_rows->mutable_data()), &g);
       if (rc == AMDARROW_CAPACITY_ERROR && cap < n) { too_small = true; break; }
       if (rc != AMDARROW_OK) return Status::FromAbi(rc);
       num_groups = g;  // identical for every column: the grouping only looks at the keys
@@ -1272,16 +1293,21 @@ Result<GroupByResult> FusedGroupBy(const std::vector<Datum>& arguments, const st
     result.field_names.push_back(aggregates[i].function);
     result.columns.push_back(ArrayData::Make(ot, num_groups, {o.has_validity ? nbuf : nullptr, vbuf}, o.null_count));
   }
-  // key_0: the bitmap exists only when a null key exists (FixedWidthKeyEncoder::Decode, hash_aggregate.cc:64-92)
+  // key_k: the bitmap exists only when a null key exists (FixedWidthKeyEncoder::Decode, hash_aggregate.cc:64-92)
   const FusedRun& r0 = runs[0];
-  int64_t valid_keys = num_groups;
-  if (num_groups > 0) {
-    const int rc = amdarrow_count_set_bits(kctx.abi(), r0.key_validity->data(), 0, num_groups, &valid_keys);
-    if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  for (int c = 0; c < nkeys; ++c) {
+    int64_t nulls = r0.key_nulls[c];
+    if (nulls < 0) {  // the single-key entry point does not report it
+      int64_t valid_keys = num_groups;
+      if (num_groups > 0) {
+        const int rc = amdarrow_count_set_bits(kctx.abi(), r0.key_validity[c]->data(), 0, num_groups, &valid_keys);
+        if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+      }
+      nulls = num_groups - valid_keys;
+    }
+    result.field_names.push_back("key_" + std::to_string(c));
+    result.columns.push_back(ArrayData::Make(keys[c].array()->type, num_groups, {nulls > 0 ? r0.key_validity[c] : nullptr, r0.keys[c]}, nulls));
   }
-  result.field_names.push_back("key_0");
-  result.columns.push_back(ArrayData::Make(key.type, num_groups, {valid_keys < num_groups ? r0.key_validity : nullptr, r0.keys},
-                                           num_groups - valid_keys));
   return result;
 }
 }  // namespace
@@ -1291,8 +1317,12 @@ Result<GroupByResult> GroupBy(const std::vector<Datum>& arguments, const std::ve
   if (aggregates.size() != arguments.size())  // GetKernels :811-815
     return Status::Invalid(std::to_string(aggregates.size()) + " aggregate functions were specified but " +
                            std::to_string(arguments.size()) + " arguments were provided.");
-  if (CanFuseGroupBy(arguments, keys, aggregates, ctx) && !getenv("AMDARROW_GROUPBY_BATCHWISE"))
-    return FusedGroupBy(arguments, keys, aggregates, ctx);
+  if (CanFuseGroupBy(arguments, keys, aggregates, ctx) && !getenv("AMDARROW_GROUPBY_BATCHWISE")) {
+    auto fused = FusedGroupBy(arguments, keys, aggregates, ctx);
+    // several keys: the packed path declines shapes it does not take (too wide together, too few rows, too many groups)
+    const bool declined = keys.size() > 1 && !fused.ok() && (fused.status().IsNotImplemented() || fused.status().IsCapacityError());
+    if (!declined) return fused;
+  }
   std::vector<const HashAggregateKernel*> kernels;
   std::vector<std::unique_ptr<KernelState>> states;
   std::vector<const FunctionOptions*> opts;

@@ -46,6 +46,7 @@ WORKLOADS = {
     "take_random_i64": "Take int64 + validity by uint32 indices (uniform random, M = s*N of them)",
     "sort_u64": "sort_indices uint64 full range",
     "sort_f64": "sort_indices float64 U[0,1) + 0.1% NaN + 1% null",
+    "groupby_2key_i64": "Filter(mask 50%) -> GroupBy{hash_sum,hash_count}(int64) by TWO int32 key columns (1000 x 1000 groups)",
     "filter_utf8": "Filter of a utf8 column (lengths U[0,16], mean 8 bytes; 32-bit offsets), Bernoulli(s) mask, DROP",
     "sort_2key": "sort_indices of a batch by (int32 key over --groups values ascending, int64 + validity descending)",
     "hash_agg_f64": "GroupBy sum/count over float64 (p_null .01), 1M int32 keys",
@@ -97,6 +98,15 @@ def make_inputs(workload, n, dev, rank, sel):
         vals[torch.rand(n, device=dev, generator=gen) < 0.001] = float("nan")
         d["values"] = device.DeviceArray(_abi.DOUBLE, vals.view(torch.uint8), device_bitmap(n, 0.99, gen, dev), n, 0, -1)
         d["_keep"] = (vals,)
+    elif workload == "groupby_2key_i64":
+        vals = torch.randint(-100, 101, (n,), dtype=torch.int64, device=dev, generator=gen)
+        k1 = torch.randint(0, 1000, (n,), dtype=torch.int32, device=dev, generator=gen)
+        k2 = torch.randint(50_000, 51_000, (n,), dtype=torch.int32, device=dev, generator=gen)
+        d["values"] = device.DeviceArray(_abi.INT64, vals.view(torch.uint8), None, n)
+        d["k1"] = device.DeviceArray(_abi.INT32, k1.view(torch.uint8), None, n)
+        d["k2"] = device.DeviceArray(_abi.INT32, k2.view(torch.uint8), None, n)
+        d["mask"] = device.DeviceArray(_abi.BOOL, device_bitmap(n, sel, gen, dev), None, n)
+        d["_keep"] = (vals, k1, k2)
     elif workload == "filter_utf8":
         lens = torch.randint(0, 17, (n,), dtype=torch.int32, device=dev, generator=gen)
         off = torch.zeros(n + 1, dtype=torch.int32, device=dev)
@@ -141,6 +151,7 @@ def bytes_per_row(workload, sel):
     return {"filter_groupby_sum_i64": 12.125, "filter_i64": 8.25 + 8.125 * sel, "take_i64": 20.25 * sel,
             "take_random_i64": 20.25 * sel, "sort_u64": 16.0, "sort_f64": 16.0, "hash_agg_f64": 12.125, "compare_i64": 16.25,
             "sort_2key": 20.125,  # both key columns + validity in, uint64 indices out
+            "groupby_2key_i64": 16.125,  # values + two key columns + mask
             "filter_utf8": 4 + 8 + 0.125 + sel * (4 + 8),  # offsets + bytes (mean 8) + mask in, offsets + bytes out
             "mask_and_kleene": 0.75, "agg_f64": 8.125}[workload]  # 2 x (data + validity) bits in, data + validity bits out
 
@@ -189,6 +200,8 @@ def make_step(workload, ctx, inp, sel, world, rank):
             per = (chunks.length + NUM_CHUNKS - 1) // NUM_CHUNKS
             chunks = [chunks.slice(i * per, min(per, chunks.length - i * per)) for i in range(NUM_CHUNKS)]
         return lambda: compute.sort_indices(ctx, chunks)
+    if workload == "groupby_2key_i64":
+        return lambda: compute.filter_groupby_multi(ctx, inp["values"], [inp["k1"], inp["k2"]], inp["mask"], 1 << 21)
     if workload == "filter_utf8":
         return lambda: compute.binary_filter(ctx, inp["values"], inp["mask"])
     if workload == "sort_2key":
@@ -389,7 +402,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"filter_groupby_sum_i64": "int64", "filter_i64": "u64", "take_i64": "u64",
                                             "take_random_i64": "u64", "sort_u64": "u64", "sort_f64": "f64", "hash_agg_f64": "f64",
-                                            "compare_i64": "int64", "mask_and_kleene": "u64", "agg_f64": "f64", "sort_2key": "u64", "filter_utf8": "u8"}[args.workload],
+                                            "compare_i64": "int64", "mask_and_kleene": "u64", "agg_f64": "f64", "sort_2key": "u64", "filter_utf8": "u8", "groupby_2key_i64": "int64"}[args.workload],
             "data": "synthetic (device-generated, seed 0x0ff1ce + rank; HBM-resident before timing)",
             "config": {"workload": args.workload + ": " + WORKLOADS[args.workload], "rows_per_gpu": n,
                        "selectivity": sel, "groups": NUM_GROUPS, "sharding": "row-range, %d shard(s)" % world},

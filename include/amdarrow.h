@@ -232,9 +232,10 @@ int amdarrow_hash_aggregate(amdarrow_ctx* ctx, int func, const amdarrow_array* v
  * hash_aggregate.cc:313-437; rows of the result as amdarrow_filter_groupby, one keys / validity buffer per key column
  * plus its null count).  The columns' values are packed into one 32-bit key word: column c contributes
  * value - min(column c), with one more code for null, in just enough bits for its range (one min / max pass per key
- * column).  AMDARROW_NOT_IMPLEMENTED when that cannot be done -- float keys, more than 4 columns, ranges that need more
- * than 32 bits together, fewer than 2^18 rows -- and AMDARROW_CAPACITY_ERROR beyond the partitioned tables (~7 M
- * groups): the caller then takes the Grouper + hash_accumulate route, which handles every shape. */
+ * column), the packed column is materialised once (4 bytes per row) and the single-key machinery runs on it; the
+ * group keys are decoded back into their columns at the end.  AMDARROW_NOT_IMPLEMENTED when the columns cannot be
+ * packed -- float keys, more than 4 columns, ranges that need more than 32 bits together: the caller then takes the
+ * Grouper + hash_accumulate route, which handles every shape. */
 int amdarrow_filter_groupby_multi(amdarrow_ctx* ctx, const amdarrow_array* values,
                                   const amdarrow_array* keys, int nkeys, const amdarrow_array* mask,
                                   int64_t group_capacity, void* out_sums, int64_t* out_counts,
