@@ -679,8 +679,8 @@ __global__ __launch_bounds__(kPartThreads) void k_part_hist(FastArgs a, uint32_t
       sel[j] = (w >> lane) & 1;
       x[j] = 0;
       if (sel[j]) {
-        const bool kn = a.k_valid && !GetBit(a.k_valid, a.k_off + row);
-        x[j] = kn ? (uint64_t(1) << a.k_bits) : FastKeyBits(a, row);
+        const bool kn = a.k_valid && !GetBit(a.k_valid, a.k_off + row);  // (64-bit keys come here without nulls)
+        x[j] = kn ? (uint64_t(1) << (a.k_bits & 63)) : FastKeyBits(a, row);
       }
     }
 #pragma unroll
@@ -695,20 +695,27 @@ __global__ __launch_bounds__(kPartThreads) void k_part_hist(FastArgs a, uint32_t
 // records are staged in LDS grouped by partition, so every partition leaves as one contiguous
 // run; successive tiles of a block append to the same regions, which keeps the partially
 // written lines in this CU's L2 until they are complete.
-__global__ __launch_bounds__(kPartThreads) void k_part_scatter(FastArgs a, const uint32_t* offsets, uint4* records) {
+// WIDE: 64-bit keys that do not range-compress (ids, hashes).  The record keeps its 16 bytes (x = the key's
+// low word) and the key's high word travels in a parallel array `hi_words`, same order; tiles are half as
+// long so that both stages fit the LDS.
+template <bool WIDE>
+__global__ __launch_bounds__(kPartThreads) void k_part_scatter(FastArgs a, const uint32_t* offsets, uint4* records, uint32_t* hi_words) {
+  constexpr int kTileRows = WIDE ? kPartRows / 2 : kPartRows;
   __shared__ unsigned int s_cnt[kP];
   __shared__ uint32_t s_off[kP];
   __shared__ uint32_t s_cur[kP];
   __shared__ uint32_t s_scan[8];
-  __shared__ uint4 s_rec[kPartRows];
+  __shared__ uint4 s_rec[kTileRows];
+  __shared__ uint32_t s_hi[WIDE ? kTileRows : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int kIters = kPartRows / kPartThreads;  // 8
+  constexpr int kIters = kTileRows / kPartThreads;  // 8 (4 when WIDE)
   if (tid < kP) { s_cnt[tid] = 0; s_cur[tid] = offsets[int64_t(tid) * a.nblocks + blockIdx.x]; }
   __syncthreads();
   const int64_t lo = int64_t(blockIdx.x) * a.rows_per_block;
   const int64_t hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
-  for (int64_t tile0 = lo; tile0 < hi; tile0 += kPartRows) {
+  for (int64_t tile0 = lo; tile0 < hi; tile0 += kTileRows) {
     uint32_t rx[kIters], rflags[kIters], rrank[kIters];
+    uint32_t rhi[WIDE ? kIters : 1];
     uint64_t rval[kIters];
     int rpart[kIters];
     // phase 1a: issue every load of the tile (mask word, key, value) before anything waits
@@ -721,7 +728,9 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(FastArgs a, const
       if ((w >> lane) & 1) {
         rpart[j] = 0;
         const bool kn = a.k_valid && !GetBit(a.k_valid, a.k_off + row);
-        rx[j] = kn ? 0u : static_cast<uint32_t>(FastKeyBits(a, row));
+        const uint64_t kx = kn ? 0u : FastKeyBits(a, row);
+        rx[j] = static_cast<uint32_t>(kx);
+        if (WIDE) rhi[WIDE ? j : 0] = static_cast<uint32_t>(kx >> 32);
         uint32_t f = static_cast<uint32_t>(row) | (kn ? kRecKeyNull : 0u);
         if (a.has_values && (!a.v.valid || GetBit(a.v.valid, a.v.off + row))) {
           bool is_double;
@@ -735,7 +744,8 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(FastArgs a, const
 #pragma unroll
     for (int j = 0; j < kIters; ++j) {
       if (rpart[j] >= 0) {
-        const uint64_t x = (rflags[j] & kRecKeyNull) ? (uint64_t(1) << a.k_bits) : uint64_t(rx[j]);
+        const uint64_t x = WIDE ? ((uint64_t(rhi[WIDE ? j : 0]) << 32) | rx[j])
+                                : ((rflags[j] & kRecKeyNull) ? (uint64_t(1) << a.k_bits) : uint64_t(rx[j]));
         const int p = static_cast<int>(Fmix64(x) >> (64 - kPBits));
         rpart[j] = p;
         rrank[j] = atomicAdd(&s_cnt[p], 1u);
@@ -762,15 +772,18 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(FastArgs a, const
         r.x = rx[j]; r.y = rflags[j];
         r.z = static_cast<uint32_t>(rval[j]); r.w = static_cast<uint32_t>(rval[j] >> 32);
         s_rec[s_off[rpart[j]] + rrank[j]] = r;
+        if (WIDE) s_hi[WIDE ? s_off[rpart[j]] + rrank[j] : 0] = rhi[WIDE ? j : 0];
       }
     }
     __syncthreads();
     const uint32_t total = s_off[kP - 1] + s_cnt[kP - 1];
     for (uint32_t i = tid; i < total; i += kPartThreads) {
       const uint4 r = s_rec[i];
-      const uint64_t x = (r.y & kRecKeyNull) ? (uint64_t(1) << a.k_bits) : uint64_t(r.x);
+      const uint64_t x = WIDE ? ((uint64_t(s_hi[WIDE ? i : 0]) << 32) | r.x)
+                              : ((r.y & kRecKeyNull) ? (uint64_t(1) << a.k_bits) : uint64_t(r.x));
       const int p = static_cast<int>(Fmix64(x) >> (64 - kPBits));
       records[s_cur[p] + (i - s_off[p])] = r;
+      if (WIDE) hi_words[s_cur[p] + (i - s_off[p])] = s_hi[WIDE ? i : 0];
     }
     __syncthreads();
     if (tid < kP) { s_cur[tid] += s_cnt[tid]; s_cnt[tid] = 0; }
@@ -780,7 +793,8 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(FastArgs a, const
 
 // One workgroup per partition: aggregate its records in an LDS hash table, then publish the
 // table as slice p of the global GroupTable (T = kP * kSlots) for the shared numbering/emit.
-__global__ __launch_bounds__(kPartThreads) void k_part_aggregate(const uint4* records, const uint32_t* offsets,
+template <bool WIDE>
+__global__ __launch_bounds__(kPartThreads) void k_part_aggregate(const uint4* records, const uint32_t* hi_words, const uint32_t* offsets,
                                                                  int nblocks, int k_bits, int acc_double, GroupTable t,
                                                                  unsigned int* overflow) {
   __shared__ unsigned long long s_h[kSlots];
@@ -799,19 +813,23 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate(const uint4* re
   constexpr int kUnroll = 4;
   for (int64_t i0 = lo + tid; i0 < hi; i0 += int64_t(kUnroll) * kPartThreads) {
     uint4 rec[kUnroll];
+    uint32_t rec_hi[WIDE ? kUnroll : 1];
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const int64_t i = i0 + int64_t(u) * kPartThreads;
       rec[u] = make_uint4(0, 0, 0, 0);
       if (i < hi) rec[u] = records[i];
+      if (WIDE) rec_hi[WIDE ? u : 0] = i < hi ? hi_words[i] : 0u;
     }
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const int64_t i = i0 + int64_t(u) * kPartThreads;
       if (i >= hi) break;
       const uint4 r = rec[u];
-      const uint64_t x = (r.y & kRecKeyNull) ? (uint64_t(1) << k_bits) : uint64_t(r.x);
+      const uint64_t x = WIDE ? ((uint64_t(rec_hi[WIDE ? u : 0]) << 32) | r.x)
+                              : ((r.y & kRecKeyNull) ? (uint64_t(1) << k_bits) : uint64_t(r.x));
       const uint64_t h = Fmix64(x);
+      if (WIDE && h == kEmpty) { failed = true; continue; }  // the one key that hashes onto the free marker: generic path
       uint32_t slot = static_cast<uint32_t>(h) & (kSlots - 1);
       bool found = false;
       for (int probes = 0; probes < kSlots; ++probes) {
@@ -2227,6 +2245,11 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
   // global table.  Each falls back to the next when its capacity assumption fails.
   const bool fast_ok = ks.total_bits <= 32 && n >= (int64_t(1) << 18) && n < (int64_t(1) << 30);
   int path = fast_ok ? 3 : 0;  // 3 = local pre-aggregation with the partition path queued behind it
+  // 64-bit keys that did not range-compress (ids, hashes; doubles by their bits) and hold no null: the exact two-pass
+  // partition path with the key's high word in a parallel array, instead of the global-atomic table
+  const bool wide = !fast_ok && ks.total_bits == 64 && !(keys->validity && keys->null_count != 0) &&
+                    n >= (int64_t(1) << 18) && n < (int64_t(1) << 30) && !getenv("AMDARROW_GROUPBY_NO_WIDE");
+  if (wide) path = 1;
   if (const char* env = getenv("AMDARROW_GROUPBY_PATH")) path = std::min(path, atoi(env));
   // Path 3 first tries to pre-aggregate every row range in LDS and looks for heavy hitters; with many
   // evenly spread groups both give up (~60 us of kernels and launches for nothing).  A call of the
@@ -2289,6 +2312,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
     const size_t rec_bytes = path >= 2 ? std::max(16 * static_cast<size_t>(cap) * kP * nblocks, LocalStageBytes(nblocks_local))
                            : path == 1 ? 16 * static_cast<size_t>(n) : 0;
     const size_t off_rec = c.Take(rec_bytes);
+    const size_t off_hi = c.Take(path == 1 && wide ? 4 * static_cast<size_t>(n) : 0);
     // heavy-hitter scratch (path 3 only)
     const int nwg_hot = path == 3 ? nblocks_local : 0;
     const size_t off_hot_cand = c.Take(4 * size_t(nwg_hot) * kHotPerWg);
@@ -2395,10 +2419,16 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
         hipLaunchKernelGGL(k_part_hist, dim3(nblocks), dim3(kPartThreads), 0, ctx->stream, fa, hist);
         AA_HIP(hipGetLastError());
         AA_TRY(ScanU32InPlace(ctx, hist, hist_n, sums, sumoff));
-        hipLaunchKernelGGL(k_part_scatter, dim3(nblocks), dim3(kPartThreads), 0, ctx->stream, fa, hist, records);
-        AA_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_part_aggregate, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nblocks,
-                           ks.total_bits, acc_double, t, misc);
+        auto* hi_words = reinterpret_cast<uint32_t*>(b + off_hi);
+        if (wide) {
+          hipLaunchKernelGGL(k_part_scatter<true>, dim3(nblocks), dim3(kPartThreads), 0, ctx->stream, fa, hist, records, hi_words);
+          hipLaunchKernelGGL(k_part_aggregate<true>, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hi_words, hist, nblocks,
+                             ks.total_bits, acc_double, t, misc);
+        } else {
+          hipLaunchKernelGGL(k_part_scatter<false>, dim3(nblocks), dim3(kPartThreads), 0, ctx->stream, fa, hist, records, hi_words);
+          hipLaunchKernelGGL(k_part_aggregate<false>, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hi_words, hist, nblocks,
+                             ks.total_bits, acc_double, t, misc);
+        }
         AA_HIP(hipGetLastError());
       }
     } else {

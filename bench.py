@@ -37,6 +37,7 @@ NUM_GROUPS = 1_000_000  # --groups
 NUM_CHUNKS = 1  # --chunks (sort workloads)
 HOT_FRAC = 0.0  # --hot-frac (headline workload: this share of the rows carries ONE key)
 KEY_BITS = 32   # --key-bits (headline workload: 64 = int64 key column)
+WIDE_KEYS = False  # --wide-keys (with --key-bits 64: the keys span the whole 64-bit range)
 
 WORKLOADS = {
     # name: (description, algorithmic bytes per row as a function of selectivity)
@@ -78,7 +79,10 @@ def make_inputs(workload, n, dev, rank, sel):
         keys = torch.randint(0, NUM_GROUPS, (n,), dtype=kdt, device=dev, generator=gen)
         if HOT_FRAC > 0:  # a heavy hitter among many distinct keys (skew)
             keys[torch.rand(n, device=dev, generator=gen) < HOT_FRAC] = 7
-        if KEY_BITS == 64:
+        if KEY_BITS == 64 and WIDE_KEYS:  # ids / hashes: NUM_GROUPS distinct values spread over the whole 64-bit range
+            pool = torch.randint(-2**63, 2**63 - 1, (NUM_GROUPS,), dtype=torch.int64, device=dev, generator=gen)
+            keys = pool[keys]
+        elif KEY_BITS == 64:
             keys += 1_700_000_000_000  # e.g. millisecond timestamps / large ids: wide values, narrow range
         d["values"] = device.DeviceArray(_abi.INT64, vals.view(torch.uint8), None, n)
         d["keys"] = device.DeviceArray(kid, keys.view(torch.uint8), None, n)
@@ -337,10 +341,12 @@ def main():
     ap.add_argument("--groups", type=int, default=1_000_000, help="distinct group keys (tuning aid; the headline is 1M)")
     ap.add_argument("--hot-frac", type=float, default=0.0, help="headline workload: share of rows that carry one hot key")
     ap.add_argument("--key-bits", type=int, default=32, choices=[32, 64], help="headline workload: width of the key column")
+    ap.add_argument("--wide-keys", action="store_true", help="with --key-bits 64: distinct keys spread over the whole int64 range")
     ap.add_argument("--chunks", type=int, default=1, help="sort workloads: present the rows as this many equal chunks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
-    global NUM_GROUPS, NUM_CHUNKS, KEY_BITS, HOT_FRAC
+    global NUM_GROUPS, NUM_CHUNKS, KEY_BITS, HOT_FRAC, WIDE_KEYS
+    WIDE_KEYS = args.wide_keys
     HOT_FRAC = args.hot_frac
     KEY_BITS = args.key_bits
     NUM_GROUPS = args.groups

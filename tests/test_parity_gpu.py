@@ -1075,3 +1075,28 @@ def test_filter_groupby_multi_key_refusals(gpu):
                                                              None, 16)
     assert G == 3 and sums.values_numpy().tolist() == [40, 60, 50] and counts.values_numpy().tolist() == [2, 2, 1]
     assert okeys[0].values_numpy().tolist() == [3, 1, 2] and okeys[1].validity_numpy().tolist() == [True, True, False]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["int64-ids", "uint64-hashes", "double-keys", "too-many-groups", "nullable-keys"])
+def test_filter_groupby_wide_64bit_keys(gpu, oracle, shape):
+    """64-bit keys that do not range-compress take the exact two-pass partition path with the key's high word in a
+    parallel array (nullable keys and more groups than its tables hold end on the generic table): the reference's rows."""
+    rng = np.random.default_rng(600)
+    n = 700_000
+    if shape == "uint64-hashes":
+        pool = rng.integers(0, 2**64, 50_000, dtype=np.uint64)
+        k = Arr(orc.UINT64, pool[rng.integers(0, len(pool), n)])
+    elif shape == "double-keys":
+        pool = rng.standard_normal(20_000) * 1e100
+        pool[:3] = [0.0, -0.0, np.nan]
+        k = Arr(DOUBLE, pool[rng.integers(0, len(pool), n)])
+    elif shape == "too-many-groups":
+        k = Arr(INT64, rng.integers(-2**62, 2**62, n))  # ~700 k distinct keys in 512 partitions of <= ~3.5 k slots: fits or falls back
+    else:
+        pool = rng.integers(-2**63, 2**63 - 1, 80_000)
+        k = Arr(INT64, pool[rng.integers(0, len(pool), n)], (rng.random(n) > .05) if shape == "nullable-keys" else None)
+    v = R(rng, INT64, n, .02, 0)
+    m = R(rng, BOOL, n, 0.0, 0)
+    for x, y in zip(oracle.filter_groupby_sum(v, k, m), gpu.filter_groupby_sum(v, k, m)):
+        assert np.array_equal(x, y, equal_nan=(shape == "double-keys" and x.dtype == np.float64)), shape
