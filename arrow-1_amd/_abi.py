@@ -82,6 +82,7 @@ SYMBOLS = {
     "amdarrow_grouper_create": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(_P)]),
     "amdarrow_grouper_destroy": (C.c_int, [_P]),
     "amdarrow_grouper_consume": (C.c_int, [_P, _A, _P]),
+    "amdarrow_grouper_lookup": (C.c_int, [_P, _A, _P]),
     "amdarrow_grouper_num_groups": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "amdarrow_grouper_uniques": (C.c_int, [_P, C.c_int, _P, _P, _O]),
     "amdarrow_hash_aggregate": (C.c_int, [_P, C.c_int, _A, _P, C.c_int64, C.c_int, _P, _P, _O]),

@@ -377,13 +377,21 @@ __global__ __launch_bounds__(kThreads) void k_unpack_groups(const ulonglong4* pa
 }
 
 // Grouper pass 2: out_ids[row] = ids[slot(key(row))]
-__global__ __launch_bounds__(kThreads) void k_lookup_ids(KeySpec ks, int64_t n, GroupTable t, uint32_t* out_ids) {
+__global__ __launch_bounds__(kThreads) void k_lookup_ids(KeySpec ks, int64_t n, GroupTable t, uint32_t* out_ids,
+                                                         unsigned long long* misses /* slotted counter or null */) {
+  unsigned long long missed = 0;
   for (int64_t row = int64_t(blockIdx.x) * kThreads + threadIdx.x; row < n; row += int64_t(gridDim.x) * kThreads) {
     uint64_t x;
     int64_t idx;
     if (EncodeKey(ks, row, &x)) idx = static_cast<int64_t>(t.mask) + 1;
     else idx = FindOrInsert(t, Fmix64(x), false);
-    out_ids[row] = idx >= 0 ? t.ids[idx] : kNoRow;
+    const uint32_t id = idx >= 0 ? t.ids[idx] : kNoRow;
+    out_ids[row] = id;
+    missed += id == kNoRow;
+  }
+  if (misses) {
+    missed = WaveReduceSum64(missed);
+    if ((threadIdx.x & 63) == 0 && missed) atomicAdd(CounterSlot(misses), missed);
   }
 }
 // Grouper growth: re-insert the known groups (x per id) into a fresh table.
@@ -2103,10 +2111,38 @@ int amdarrow_grouper_consume(amdarrow_grouper* g, const amdarrow_array* keys, ui
   AA_HIP(hipMemsetAsync(t.first, 0xFF, 4 * (t.mask + 3), ctx->stream));
   // pass 2: ids per row
   hipLaunchKernelGGL(k_lookup_ids, dim3(GridFor(n, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, ks, n, t,
-                     out_ids);
+                     out_ids, static_cast<unsigned long long*>(nullptr));
   AA_HIP(hipGetLastError());
   g->num_groups += static_cast<uint32_t>(new_groups);
   AA_HIP(hipStreamSynchronize(ctx->stream));
+  return AMDARROW_OK;
+}
+
+/* Ids of rows whose keys are all known already (Grouper::Consume without the growth: no table is sized for n new
+ * groups, nothing is inserted).  A key that is not in the table is an error (AMDARROW_KEY_ERROR). */
+int amdarrow_grouper_lookup(amdarrow_grouper* g, const amdarrow_array* keys, uint32_t* out_ids) {
+  amdarrow_ctx* ctx = g->ctx;
+  const int64_t n = keys[0].length;
+  for (int k = 0; k < g->nkeys; ++k) {
+    if (keys[k].type_id != g->types[k]) return SetError(AMDARROW_TYPE_ERROR, "grouper: key type differs from Make()");
+    if (keys[k].length != n) return SetError(AMDARROW_INVALID, "Array arguments must all be the same length");
+  }
+  if (n == 0) return AMDARROW_OK;
+  if (g->T == 0 || g->num_groups == 0) return SetError(AMDARROW_KEY_ERROR, "grouper: lookup in an empty grouper");
+  KeySpec ks;
+  AA_TRY(MakeKeySpec(g->nkeys, keys, nullptr, &ks));
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  GroupTable t = BindTable(g->table_mem, g->tm, g->T, true);
+  void* base;
+  AA_TRY(Scratch(ctx, kCounterBytes, &base));
+  auto* counters = static_cast<unsigned long long*>(base);
+  AA_TRY(ClearCounters(ctx, counters));
+  hipLaunchKernelGGL(k_lookup_ids, dim3(GridFor(n, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, ks, n, t, out_ids,
+                     counters);
+  AA_HIP(hipGetLastError());
+  unsigned long long missed = 0;
+  AA_TRY(ReadCounters(ctx, counters, 1, &missed));
+  if (missed) return SetError(AMDARROW_KEY_ERROR, "grouper: " + std::to_string(missed) + " rows hold keys the grouper has not seen");
   return AMDARROW_OK;
 }
 

@@ -691,6 +691,7 @@ class Grouper {
   ~Grouper();
   static Result<std::unique_ptr<Grouper>> Make(const std::vector<ValueDescr>& descrs, ExecContext* ctx);
   Result<Datum> Consume(const ExecBatch& batch);  // uint32 group ids, first-appearance order
+  Result<Datum> Lookup(const ExecBatch& batch);   // ids of rows whose keys are all known: no growth, KeyError otherwise
   Result<ExecBatch> GetUniques();
   uint32_t num_groups() const;
 

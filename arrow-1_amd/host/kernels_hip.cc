@@ -1044,6 +1044,17 @@ Result<Datum> Grouper::Consume(const ExecBatch& batch) {
   if (rc != AMDARROW_OK) return Status::FromAbi(rc);
   return Datum(ArrayData::Make(uint32(), batch.length, {nullptr, buf}, 0));
 }
+Result<Datum> Grouper::Lookup(const ExecBatch& batch) {
+  std::vector<amdarrow_array> keys;
+  for (const auto& v : batch.values) {
+    if (!v.is_array()) return Status::NotImplemented("Grouper::Lookup: array keys only");
+    keys.push_back(v.array()->abi());
+  }
+  AMD_ASSIGN_OR_RAISE(auto buf, AllocateBuffer(4 * batch.length, ctx_->memory_pool()));
+  const int rc = amdarrow_grouper_lookup(impl_, keys.data(), reinterpret_cast<uint32_t*>(buf->mutable_data()));
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  return Datum(ArrayData::Make(uint32(), batch.length, {nullptr, buf}, 0));
+}
 uint32_t Grouper::num_groups() const {
   uint32_t n = 0;
   amdarrow_grouper_num_groups(impl_, &n);
@@ -1193,6 +1204,15 @@ struct FusedRun {
 int HashFuncOf(const std::string& name) {
   return name == "hash_sum" ? AMDARROW_HASH_SUM : name == "hash_count" ? AMDARROW_HASH_COUNT : name == "hash_mean" ? AMDARROW_HASH_MEAN : -1;
 }
+bool IsFusedAggregate(const Aggregate& a) {
+  const int func = HashFuncOf(a.function);
+  if (func < 0) return false;
+  if (func == AMDARROW_HASH_COUNT) {
+    const auto* co = static_cast<const CountOptions*>(a.options);
+    if (co && co->count_mode != CountOptions::COUNT_NON_NULL) return false;
+  }
+  return true;
+}
 bool CanFuseGroupBy(const std::vector<Datum>& arguments, const std::vector<Datum>& keys, const std::vector<Aggregate>& aggregates,
                     ExecContext* ctx) {
   if (keys.empty() || keys.size() > 4 || !keys[0].is_array() || arguments.empty()) return false;
@@ -1205,13 +1225,11 @@ bool CanFuseGroupBy(const std::vector<Datum>& arguments, const std::vector<Datum
   for (size_t i = 0; i < arguments.size(); ++i) {
     if (!arguments[i].is_array() || arguments[i].array()->length != key.length) return false;
     if (arguments[i].array()->type->bit_width() < 0) return false;
-    const int func = HashFuncOf(aggregates[i].function);
-    if (func < 0) return false;
-    if (func == AMDARROW_HASH_COUNT) {
-      const auto* co = static_cast<const CountOptions*>(aggregates[i].options);
-      if (co && co->count_mode != CountOptions::COUNT_NON_NULL) return false;
-    } else if (arguments[i].array()->type->id() == Type::BOOL && func != AMDARROW_HASH_COUNT) {
-      continue;  // sum / mean of booleans: supported (uint64 accumulator)
+    // hash_sum / hash_count(non-null) / hash_mean ride the fused pass; any other hash aggregate (hash_min_max,
+    // hash_count of nulls) is served afterwards through per-row group ids (FusedGroupBy) -- it only has to exist
+    if (!IsFusedAggregate(aggregates[i])) {
+      auto f = ctx->func_registry()->GetFunction(aggregates[i].function);
+      if (!f.ok() || (*f)->kind() != Function::HASH_AGGREGATE) return false;
     }
   }
   return true;
@@ -1232,7 +1250,11 @@ Result<GroupByResult> FusedGroupBy(const std::vector<Datum>& arguments, const st
     const int64_t cap = attempt == 0 ? std::min<int64_t>(n, int64_t(1) << 22) : n;
     runs.clear();
     bool too_small = false;
+    bool any_fused = false;
+    for (const auto& a : aggregates) any_fused = any_fused || IsFusedAggregate(a);
     for (size_t i = 0; i < arguments.size() && !too_small; ++i) {
+      // a column needs its own fused pass only for an aggregate that rides it; without any, the first column's pass does the grouping
+      if (!IsFusedAggregate(aggregates[i]) && (any_fused || i > 0)) { run_of[i] = -1; continue; }
       const ArrayData* col = arguments[i].array().get();
       int found = -1;
       for (size_t r = 0; r < runs.size(); ++r) if (runs[r].column == col) found = static_cast<int>(r);
@@ -1272,7 +1294,59 @@ Result<GroupByResult> FusedGroupBy(const std::vector<Datum>& arguments, const st
   }
   GroupByResult result;
   result.length = num_groups;
+  // the key columns: a bitmap exists only when a null key exists (FixedWidthKeyEncoder::Decode, hash_aggregate.cc:64-92)
+  std::vector<std::shared_ptr<ArrayData>> key_columns;
+  {
+    const FusedRun& r0 = runs[0];
+    for (int c = 0; c < nkeys; ++c) {
+      int64_t nulls = r0.key_nulls[c];
+      if (nulls < 0) {  // the single-key entry point does not report it
+        int64_t valid_keys = num_groups;
+        if (num_groups > 0) {
+          const int rc = amdarrow_count_set_bits(kctx.abi(), r0.key_validity[c]->data(), 0, num_groups, &valid_keys);
+          if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+        }
+        nulls = num_groups - valid_keys;
+      }
+      key_columns.push_back(ArrayData::Make(keys[c].array()->type, num_groups, {nulls > 0 ? r0.key_validity[c] : nullptr, r0.keys[c]}, nulls));
+    }
+  }
+  Datum row_ids;  // per-row group ids, built on first need: a Grouper fed the unique keys (ids 0..G-1 in this order), then every row
   for (size_t i = 0; i < arguments.size(); ++i) {
+    if (!IsFusedAggregate(aggregates[i])) {
+      if (row_ids.kind() == Datum::NONE) {
+        std::vector<ValueDescr> descrs;
+        std::vector<Datum> uniq, all;
+        for (int c = 0; c < nkeys; ++c) {
+          descrs.push_back(ValueDescr::Array(keys[c].array()->type));
+          uniq.push_back(Datum(key_columns[c]));
+          all.push_back(keys[c]);
+        }
+        AMD_ASSIGN_OR_RAISE(auto grouper, Grouper::Make(descrs, ctx));
+        if (num_groups > 0) {
+          AMD_ASSIGN_OR_RAISE(auto ub, ExecBatch::Make(uniq));
+          AMD_ASSIGN_OR_RAISE(Datum ignored, grouper->Consume(ub));
+          (void)ignored;
+        }
+        AMD_ASSIGN_OR_RAISE(auto ab, ExecBatch::Make(all));
+        if (num_groups > 0) { AMD_ASSIGN_OR_RAISE(row_ids, grouper->Lookup(ab)); }
+        else { AMD_ASSIGN_OR_RAISE(row_ids, grouper->Consume(ab)); }
+        if (static_cast<int64_t>(grouper->num_groups()) != num_groups) return Status::Invalid("GroupBy: group ids disagree with the fused grouping");
+      }
+      AMD_ASSIGN_OR_RAISE(auto function, ctx->func_registry()->GetFunction(aggregates[i].function));
+      auto* hf = static_cast<const HashAggregateFunction*>(function.get());
+      AMD_ASSIGN_OR_RAISE(const HashAggregateKernel* kernel,
+                          hf->DispatchExact({ValueDescr::Array(arguments[i].type()), ValueDescr::Array(uint32()), ValueDescr::Scalar(uint32())}));
+      const FunctionOptions* o = aggregates[i].options ? aggregates[i].options : function->default_options();
+      AMD_ASSIGN_OR_RAISE(auto state, kernel->init(&kctx, arguments[i].type(), o));
+      ExecBatch batch({arguments[i], row_ids, Datum(Scalar::Make(uint32(), static_cast<uint32_t>(num_groups)))}, n);
+      AMD_RETURN_NOT_OK(kernel->consume(&kctx, state.get(), batch));
+      Datum out;
+      AMD_RETURN_NOT_OK(kernel->finalize(&kctx, state.get(), &out));
+      result.field_names.push_back(aggregates[i].function);
+      result.columns.push_back(out.array());
+      continue;
+    }
     const FusedRun& run = runs[run_of[i]];
     const int func = HashFuncOf(aggregates[i].function);
     const Type::type in = arguments[i].array()->type->id();
@@ -1293,20 +1367,9 @@ Result<GroupByResult> FusedGroupBy(const std::vector<Datum>& arguments, const st
     result.field_names.push_back(aggregates[i].function);
     result.columns.push_back(ArrayData::Make(ot, num_groups, {o.has_validity ? nbuf : nullptr, vbuf}, o.null_count));
   }
-  // key_k: the bitmap exists only when a null key exists (FixedWidthKeyEncoder::Decode, hash_aggregate.cc:64-92)
-  const FusedRun& r0 = runs[0];
   for (int c = 0; c < nkeys; ++c) {
-    int64_t nulls = r0.key_nulls[c];
-    if (nulls < 0) {  // the single-key entry point does not report it
-      int64_t valid_keys = num_groups;
-      if (num_groups > 0) {
-        const int rc = amdarrow_count_set_bits(kctx.abi(), r0.key_validity[c]->data(), 0, num_groups, &valid_keys);
-        if (rc != AMDARROW_OK) return Status::FromAbi(rc);
-      }
-      nulls = num_groups - valid_keys;
-    }
     result.field_names.push_back("key_" + std::to_string(c));
-    result.columns.push_back(ArrayData::Make(keys[c].array()->type, num_groups, {nulls > 0 ? r0.key_validity[c] : nullptr, r0.keys[c]}, nulls));
+    result.columns.push_back(key_columns[c]);
   }
   return result;
 }

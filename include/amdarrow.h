@@ -216,6 +216,10 @@ int amdarrow_grouper_create(amdarrow_ctx* ctx, int nkeys, const int* key_type_id
                             amdarrow_grouper** out);
 int amdarrow_grouper_destroy(amdarrow_grouper* g);
 int amdarrow_grouper_consume(amdarrow_grouper* g, const amdarrow_array* keys, uint32_t* out_ids);
+/* Ids of rows whose keys the grouper has all seen (no counterpart in the reference, whose Consume always may insert,
+ * :358-408): nothing is inserted and no table is sized for `length` new groups -- what a caller that knows the groups
+ * (the fused GroupBy serving hash_min_max through ids) needs.  AMDARROW_KEY_ERROR if some key is unknown. */
+int amdarrow_grouper_lookup(amdarrow_grouper* g, const amdarrow_array* keys, uint32_t* out_ids);
 int amdarrow_grouper_num_groups(amdarrow_grouper* g, uint32_t* out_num_groups);
 /* GetUniques (:410-428): key column k -> num_groups values + validity bitmap. */
 int amdarrow_grouper_uniques(amdarrow_grouper* g, int k, void* out_values,
