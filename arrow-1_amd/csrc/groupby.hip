@@ -101,7 +101,9 @@ struct GroupTable {
 __device__ __forceinline__ int64_t FindOrInsert(const GroupTable& t, uint64_t h, bool insert) {
   if (h == kEmpty) return static_cast<int64_t>(t.mask) + 2;
   uint64_t idx = h & t.mask;
-  for (uint64_t probes = 0; probes <= t.mask; ++probes) {
+  // A chain this long does not occur below ~90 % load: the table is (nearly) full -- report it instead of walking it
+  const uint64_t limit = t.mask < 4095 ? t.mask : 4095;
+  for (uint64_t probes = 0; probes <= limit; ++probes) {
     unsigned long long cur = t.hkeys[idx];
     if (cur == h) return static_cast<int64_t>(idx);
     if (cur == kEmpty) {
@@ -2056,8 +2058,21 @@ int amdarrow_grouper_consume(amdarrow_grouper* g, const amdarrow_array* keys, ui
   KeySpec ks;
   AA_TRY(MakeKeySpec(g->nkeys, keys, nullptr, &ks));
   std::lock_guard<std::mutex> lock(ctx->mu);
-  // grow the table so that (known + possible new) groups stay under 50 % load
-  const uint64_t need = NextPow2(2 * (static_cast<uint64_t>(g->num_groups) + static_cast<uint64_t>(n)));
+  // Grow the table so that (known + possible new) groups stay under 50 % load.  Every row of the batch COULD be a
+  // new group, but sizing for that costs gigabytes per 50 M-row batch (allocation, clearing, re-insertion) when
+  // the batch usually brings few: start with room for 1 M (or as many as are known) new groups and come back
+  // with 16x more when the insert pass reports a full table -- the groups it inserted on the way have no id yet
+  // and vanish with the old table.
+  uint64_t room = static_cast<uint64_t>(n);
+  if (room > (uint64_t(1) << 20) && !getenv("AMDARROW_GROUPER_SIZE_FOR_BATCH"))
+    room = std::max<uint64_t>(uint64_t(1) << 20, 2 * static_cast<uint64_t>(g->num_groups));
+  if (room > static_cast<uint64_t>(n)) room = static_cast<uint64_t>(n);
+  int64_t new_groups = 0;
+  GroupTable t{};
+  RankMem r{};
+  for (bool retry = true; retry;) {
+  retry = false;
+  const uint64_t need = NextPow2(2 * (static_cast<uint64_t>(g->num_groups) + room));
   if (need > g->T) {
     char* mem; TableMem tm;
     AA_TRY(GrouperAllocTable(g, need, &mem, &tm));
@@ -2073,8 +2088,8 @@ int amdarrow_grouper_consume(amdarrow_grouper* g, const amdarrow_array* keys, ui
     AA_HIP(hipFree(g->table_mem));
     g->table_mem = mem; g->tm = tm; g->T = need;
   }
-  if (g->num_groups + static_cast<uint64_t>(n) > g->gx_cap) {
-    const uint64_t cap = NextPow2(2 * (g->num_groups + static_cast<uint64_t>(n)));
+  if (g->num_groups + room > g->gx_cap) {
+    const uint64_t cap = NextPow2(2 * (g->num_groups + room));
     unsigned long long* ngx;
     AA_HIP(hipMalloc(reinterpret_cast<void**>(&ngx), 8 * cap));
     if (g->num_groups) AA_HIP(hipMemcpyAsync(ngx, g->gx, 8ull * g->num_groups, hipMemcpyDeviceToDevice, ctx->stream));
@@ -2082,14 +2097,14 @@ int amdarrow_grouper_consume(amdarrow_grouper* g, const amdarrow_array* keys, ui
     if (g->gx) AA_HIP(hipFree(g->gx));
     g->gx = ngx; g->gx_cap = cap;
   }
-  GroupTable t = BindTable(g->table_mem, g->tm, g->T, true);
+  t = BindTable(g->table_mem, g->tm, g->T, true);
   Carver c;
   size_t roff[4];
   CarveRank(&c, n, roff);
   const size_t off_flag = c.Take(256);
   void* base;
   AA_TRY(Scratch(ctx, c.off, &base));
-  RankMem r = BindRank(static_cast<char*>(base), roff, n);
+  r = BindRank(static_cast<char*>(base), roff, n);
   auto* overflow = reinterpret_cast<unsigned int*>(static_cast<char*>(base) + off_flag);
   AA_HIP(hipMemsetAsync(overflow, 0, 4, ctx->stream));
   // pass 1: insert keys, first_row = min(row) on every slot touched
@@ -2099,8 +2114,17 @@ int amdarrow_grouper_consume(amdarrow_grouper* g, const amdarrow_array* keys, ui
                      overflow);
   AA_HIP(hipGetLastError());
   // rank the NEW groups (no id yet) by first row; old groups just reset their first_row
-  int64_t new_groups = 0;
   AA_TRY(RankFirstRows(ctx, t, /*only_unassigned=*/1, r, &new_groups));
+  unsigned int full = 0;
+  AA_TRY(ReadBack(ctx, overflow, 4, &full));
+  if (full || static_cast<uint64_t>(new_groups) > room) {
+    if (room >= static_cast<uint64_t>(n)) return SetError(AMDARROW_CAPACITY_ERROR, "grouper: table full");
+    room = std::min<uint64_t>(static_cast<uint64_t>(n), room * 16);
+    // force a fresh table even if the size class does not change: the failed pass left id-less entries behind
+    g->T = 0;
+    retry = true;
+  }
+  }  // sizing attempts
   EmitArgs e{};
   e.t = t; e.nslots = static_cast<int64_t>(t.mask) + 3; e.bitmap = r.bitmap; e.prefix = r.prefix;
   e.capacity = static_cast<int64_t>(g->gx_cap); e.id_base = g->num_groups; e.only_unassigned = 1;

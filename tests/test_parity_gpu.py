@@ -1100,3 +1100,19 @@ def test_filter_groupby_wide_64bit_keys(gpu, oracle, shape):
     m = R(rng, BOOL, n, 0.0, 0)
     for x, y in zip(oracle.filter_groupby_sum(v, k, m), gpu.filter_groupby_sum(v, k, m)):
         assert np.array_equal(x, y, equal_nan=(shape == "double-keys" and x.dtype == np.float64)), shape
+
+
+@pytest.mark.gpu
+def test_grouper_large_batches_grow_optimistically(gpu, oracle):
+    """Batches above 1 M rows size the table for 1 M new groups first and come back with more when that was too few:
+    a low-cardinality batch (no retry), an all-distinct 2.5 M-row batch (retry), then a batch mixing known and new keys."""
+    rng = np.random.default_rng(700)
+    b1 = Arr(INT64, rng.integers(0, 5000, 2_000_000))
+    b2 = Arr(INT64, rng.permutation(2_500_000) + 10_000)
+    b3 = Arr(INT64, np.concatenate([rng.integers(0, 5000, 600_000), rng.permutation(1_500_000) + 5_000_000, rng.integers(10_000, 20_000, 400_000)]))
+    want_ids, want_ng, want_u = oracle.group_ids([[b1], [b2], [b3]])
+    got_ids, got_ng, got_u = gpu.group_ids([[b1], [b2], [b3]])
+    assert got_ng == want_ng
+    for a, b in zip(got_ids, want_ids):
+        assert np.array_equal(a, b)
+    assert np.array_equal(got_u[0][0], want_u[0][0])
