@@ -78,6 +78,7 @@ SYMBOLS = {
     "amdarrow_validity_test": (C.c_int, [_P, C.c_int, _A, _P, _O]),
     "amdarrow_is_nan": (C.c_int, [_P, _A, _P, _P, _O]),
     "amdarrow_fill_null": (C.c_int, [_P, _A, _P, _P, _P, _O]),
+    "amdarrow_cast_numeric": (C.c_int, [_P, _A, C.c_int, C.c_int, _P]),
     "amdarrow_aggregate": (C.c_int, [_P, _A, _P]),
     "amdarrow_grouper_create": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(_P)]),
     "amdarrow_grouper_destroy": (C.c_int, [_P]),

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _abi
-from ._abi import (BOOL, DROP, EMIT_NULL, ASCENDING, DESCENDING, COut, CArray, AmdArrowError, check)
+from ._abi import (BOOL, UINT8, INT8, UINT16, INT16, UINT32, INT32, UINT64, INT64, FLOAT, DOUBLE, DROP, EMIT_NULL, ASCENDING, DESCENDING, COut, CArray, AmdArrowError, check)
 from .device import Context, DeviceArray, alloc_bytes, bit_width, NP_OF
 
 _CMP = {"equal": _abi.EQ, "not_equal": _abi.NE, "greater": _abi.GT, "greater_equal": _abi.GE,
@@ -186,13 +186,66 @@ def _binary(ctx, fn, op, lhs, rhs, out_type):
     return DeviceArray(ot, out_v, out_b, out.length, 0, out.null_count)
 
 
+_INT_BITS = {UINT8: 8, INT8: 8, UINT16: 16, INT16: 16, UINT32: 32, INT32: 32, UINT64: 64, INT64: 64}
+_SIGNED = (INT8, INT16, INT32, INT64)
+
+
+def common_numeric(type_a, type_b):
+    """CommonNumeric (codegen_internal.cc:220-268): the type both operands of a binary compare / arithmetic
+    call are cast to when no kernel matches exactly; None when one of them is not a number."""
+    ts = (type_a, type_b)
+    if any(t not in _INT_BITS and t not in (FLOAT, DOUBLE) for t in ts):
+        return None
+    if DOUBLE in ts:
+        return DOUBLE
+    if FLOAT in ts:
+        return FLOAT
+    ws = max([_INT_BITS[t] for t in ts if t in _SIGNED], default=0)
+    wu = max([_INT_BITS[t] for t in ts if t not in _SIGNED], default=0)
+    if ws == 0:
+        return {64: UINT64, 32: UINT32, 16: UINT16}.get(wu, INT8)  # sic (:252)
+    if ws <= wu:
+        ws = 1 << wu.bit_length()  # NextPower2(wu + 1)
+    return INT64 if ws >= 64 else {32: INT32, 16: INT16}.get(ws, INT8)
+
+
+def cast(ctx, a, to_type, safe=True):
+    """Number -> number cast (scalar_cast_numeric.cc:38-50, 203-262; CastOptions::Safe unless safe=False).
+    The result shares the input's validity buffer (and keeps its offset into it)."""
+    dev = a.values.device
+    out_v = alloc_bytes(_values_bytes(to_type, a.length), dev)
+    c = a.c()
+    check(ctx.lib, ctx.lib.amdarrow_cast_numeric(ctx.handle, C.byref(c), int(to_type), int(bool(safe)), _ptr(out_v)))
+    if a.validity is None:
+        return DeviceArray(to_type, out_v, None, a.length, 0, 0)
+    if a.offset % 8 == 0:
+        return DeviceArray(to_type, out_v, a.validity[a.offset // 8:], a.length, 0, a.null_count)
+    # a validity view that does not start on a byte: values re-based in front of element 0 is not expressible with
+    # one buffer per array here, so the bits are normalised to offset 0 (is_valid gives exactly that bitmap)
+    bits = is_valid(ctx, a)
+    return DeviceArray(to_type, out_v, bits.values, a.length, 0, a.null_count)
+
+
+def _implicitly_cast(ctx, lhs, rhs):
+    """Function::Execute's implicit casts (function.cc:175-176, cast.cc:228-243) behind CompareFunction /
+    ArithmeticFunction::DispatchBest (scalar_compare.cc:75-98, scalar_arithmetic.cc:389-412)."""
+    if not (isinstance(lhs, DeviceArray) and isinstance(rhs, DeviceArray)) or lhs.type_id == rhs.type_id:
+        return lhs, rhs
+    t = common_numeric(lhs.type_id, rhs.type_id)
+    if t is None:
+        raise NotImplementedError("no kernel matching input types (%d, %d)" % (lhs.type_id, rhs.type_id))
+    return (lhs if lhs.type_id == t else cast(ctx, lhs, t)), (rhs if rhs.type_id == t else cast(ctx, rhs, t))
+
+
 def compare(ctx, op, lhs, rhs):
     """equal / not_equal / greater / greater_equal / less / less_equal -- scalar_compare.cc:100-171."""
+    lhs, rhs = _implicitly_cast(ctx, lhs, rhs)
     return _binary(ctx, ctx.lib.amdarrow_compare, op, lhs, rhs, BOOL)
 
 
 def arith(ctx, op, lhs, rhs):
     """add / subtract / multiply / divide [+ _checked] -- scalar_arithmetic.cc:69-251."""
+    lhs, rhs = _implicitly_cast(ctx, lhs, rhs)
     return _binary(ctx, ctx.lib.amdarrow_arith, op, lhs, rhs, None)
 
 

@@ -16,6 +16,8 @@
 
 #include <cstring>
 #include <limits>
+#include <string>
+#include <type_traits>
 
 namespace amdarrow {
 
@@ -322,9 +324,101 @@ __global__ __launch_bounds__(kThreads) void k_fill_null(const U* values, const u
   }
 }
 
+// ---- cast between numbers (scalar_cast_numeric.cc:38-58, 203-262) ---------------------------------------
+// One pass: convert and, for CastOptions::Safe, test the SOURCE value against [lo, hi] (the reference
+// checks the whole input first -- IntegersCanFit / CheckForIntegerToFloatingTruncation -- and then
+// converts; a failing call returns no output either way).  first_bad = lowest offending valid slot.
+template <typename In, typename Out>
+__global__ __launch_bounds__(kThreads) void k_cast(const In* values, const uint8_t* valid, int64_t off, int64_t n, Out* out,
+                                                   int check, In lo, In hi, unsigned long long* first_bad) {
+  unsigned long long bad = ~0ull;
+  for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < n; i += int64_t(gridDim.x) * kThreads) {
+    const In v = values[off + i];
+    out[i] = static_cast<Out>(v);
+    if (check && (v < lo || v > hi) && (valid == nullptr || GetBit(valid, off + i)) && bad == ~0ull) bad = i;
+  }
+  if (bad != ~0ull) atomicMin(first_bad, bad);
+}
+
 }  // namespace amdarrow
 
 using namespace amdarrow;
+
+// cast (numbers).  Bounds of the safe mode, in the source type: integer -> integer GetSafeMinMax
+// (util/int_util.cc:826-912: the intersection of the two ranges), integer -> floating the whole
+// numbers the target represents exactly (FloatingIntegerBound, scalar_cast_numeric.cc:188-209).
+namespace {
+template <typename In> struct CastBounds { In lo, hi; bool check; };
+template <typename In>
+CastBounds<In> SafeBounds(int to) {
+  using L = std::numeric_limits<In>;
+  CastBounds<In> b{L::lowest(), L::max(), false};
+  if constexpr (std::is_integral<In>::value) {
+    __int128 lo = L::lowest(), hi = L::max(), tlo = 0, thi = 0;
+    switch (to) {
+      case AMDARROW_UINT8: thi = UINT8_MAX; break;
+      case AMDARROW_INT8: tlo = INT8_MIN; thi = INT8_MAX; break;
+      case AMDARROW_UINT16: thi = UINT16_MAX; break;
+      case AMDARROW_INT16: tlo = INT16_MIN; thi = INT16_MAX; break;
+      case AMDARROW_UINT32: thi = UINT32_MAX; break;
+      case AMDARROW_INT32: tlo = INT32_MIN; thi = INT32_MAX; break;
+      case AMDARROW_UINT64: thi = UINT64_MAX; break;
+      case AMDARROW_INT64: tlo = INT64_MIN; thi = INT64_MAX; break;
+      case AMDARROW_FLOAT: thi = 1ll << 24; tlo = -thi; if (sizeof(In) < 4) { tlo = lo; thi = hi; } break;
+      default: thi = 1ll << 53; tlo = -thi; if (sizeof(In) < 8) { tlo = lo; thi = hi; } break;
+    }
+    if (tlo > lo) lo = tlo;
+    if (thi < hi) hi = thi;
+    b.check = lo != L::lowest() || hi != L::max();
+    b.lo = static_cast<In>(lo); b.hi = static_cast<In>(hi);
+  }
+  return b;
+}
+template <typename In, typename Out>
+int CastTo(amdarrow_ctx* ctx, const amdarrow_array* a, int to, int safe, void* out_values) {
+  const CastBounds<In> b = SafeBounds<In>(to);
+  const int check = safe && b.check;
+  void* base;
+  AA_TRY(Scratch(ctx, 256, &base));
+  auto* first_bad = static_cast<unsigned long long*>(base);
+  if (check) AA_HIP(hipMemsetAsync(first_bad, 0xff, 8, ctx->stream));
+  const int64_t n = a->length;
+  hipLaunchKernelGGL((k_cast<In, Out>), dim3(GridFor(n, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream,
+                     static_cast<const In*>(a->values), MayHaveNulls(a) ? a->validity : nullptr, a->offset, n,
+                     static_cast<Out*>(out_values), check, b.lo, b.hi, first_bad);
+  AA_HIP(hipGetLastError());
+  if (check) {
+    unsigned long long bad = 0;
+    AA_TRY(ReadBack(ctx, first_bad, 8, &bad));
+    if (bad != ~0ull) {
+      In v;
+      AA_TRY(ReadBack(ctx, static_cast<const In*>(a->values) + a->offset + bad, sizeof(In), &v));
+      return SetError(AMDARROW_INVALID, "Integer value " + std::to_string(v) + " not in range: " + std::to_string(b.lo) +
+                                            " to " + std::to_string(b.hi));  // int_util.cc:614-618
+    }
+  }
+  return AMDARROW_OK;
+}
+template <typename In>
+int CastFrom(amdarrow_ctx* ctx, const amdarrow_array* a, int to, int safe, void* out_values) {
+  if (std::is_floating_point<In>::value && to != AMDARROW_FLOAT && to != AMDARROW_DOUBLE)
+    return SetError(AMDARROW_NOT_IMPLEMENTED, "cast: floating point to integer");
+  switch (to) {
+    case AMDARROW_UINT8: return CastTo<In, uint8_t>(ctx, a, to, safe, out_values);
+    case AMDARROW_INT8: return CastTo<In, int8_t>(ctx, a, to, safe, out_values);
+    case AMDARROW_UINT16: return CastTo<In, uint16_t>(ctx, a, to, safe, out_values);
+    case AMDARROW_INT16: return CastTo<In, int16_t>(ctx, a, to, safe, out_values);
+    case AMDARROW_UINT32: return CastTo<In, uint32_t>(ctx, a, to, safe, out_values);
+    case AMDARROW_INT32: return CastTo<In, int32_t>(ctx, a, to, safe, out_values);
+    case AMDARROW_UINT64: return CastTo<In, uint64_t>(ctx, a, to, safe, out_values);
+    case AMDARROW_INT64: return CastTo<In, int64_t>(ctx, a, to, safe, out_values);
+    case AMDARROW_FLOAT: return CastTo<In, float>(ctx, a, to, safe, out_values);
+    case AMDARROW_DOUBLE: return CastTo<In, double>(ctx, a, to, safe, out_values);
+    default: return SetError(AMDARROW_NOT_IMPLEMENTED, "cast: target type");
+  }
+}
+}  // namespace
+
 
 extern "C" {
 
@@ -578,6 +672,24 @@ int amdarrow_fill_null(amdarrow_ctx* ctx, const amdarrow_array* a, const void* f
                      reinterpret_cast<uint64_t*>(out_validity));
   AA_HIP(hipGetLastError());
   return AMDARROW_OK;
+}
+
+int amdarrow_cast_numeric(amdarrow_ctx* ctx, const amdarrow_array* a, int to_type_id, int safe, void* out_values) {
+  if (a->length == 0) return AMDARROW_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  switch (a->type_id) {
+    case AMDARROW_UINT8: return CastFrom<uint8_t>(ctx, a, to_type_id, safe, out_values);
+    case AMDARROW_INT8: return CastFrom<int8_t>(ctx, a, to_type_id, safe, out_values);
+    case AMDARROW_UINT16: return CastFrom<uint16_t>(ctx, a, to_type_id, safe, out_values);
+    case AMDARROW_INT16: return CastFrom<int16_t>(ctx, a, to_type_id, safe, out_values);
+    case AMDARROW_UINT32: return CastFrom<uint32_t>(ctx, a, to_type_id, safe, out_values);
+    case AMDARROW_INT32: return CastFrom<int32_t>(ctx, a, to_type_id, safe, out_values);
+    case AMDARROW_UINT64: return CastFrom<uint64_t>(ctx, a, to_type_id, safe, out_values);
+    case AMDARROW_INT64: return CastFrom<int64_t>(ctx, a, to_type_id, safe, out_values);
+    case AMDARROW_FLOAT: return CastFrom<float>(ctx, a, to_type_id, safe, out_values);
+    case AMDARROW_DOUBLE: return CastFrom<double>(ctx, a, to_type_id, safe, out_values);
+    default: return SetError(AMDARROW_NOT_IMPLEMENTED, "cast: source type");
+  }
 }
 
 }  // extern "C"

@@ -107,10 +107,15 @@ class DataType {
   int bit_width() const;
   std::string ToString() const;
   bool Equals(const DataType& o) const { return id_ == o.id_; }
+  // DictionaryType::value_type (type.h:1360-1400); null for the other types and for dictionary_()
+  const std::shared_ptr<DataType>& value_type() const { return value_type_; }
+  void set_value_type(std::shared_ptr<DataType> t) { value_type_ = std::move(t); }
 
  private:
   Type::type id_;
+  std::shared_ptr<DataType> value_type_;
 };
+std::shared_ptr<DataType> null();
 std::shared_ptr<DataType> boolean();
 std::shared_ptr<DataType> uint8();
 std::shared_ptr<DataType> int8();
@@ -124,6 +129,7 @@ std::shared_ptr<DataType> float32();
 std::shared_ptr<DataType> float64();
 std::shared_ptr<DataType> struct_();  // field list carried by the StructScalar itself
 std::shared_ptr<DataType> dictionary_();  // dictionary(int32(), <type of ArrayData::dictionary>)
+std::shared_ptr<DataType> dictionary(std::shared_ptr<DataType> value_type);  // dictionary(int32(), value_type), type.h:1360
 std::shared_ptr<DataType> binary();
 std::shared_ptr<DataType> utf8();
 inline bool is_binary_like(Type::type id) { return id == Type::BINARY || id == Type::STRING; }  // type_traits.h
@@ -378,6 +384,21 @@ struct TakeOptions : public FunctionOptions {
   static TakeOptions NoBoundsCheck() { return TakeOptions(false); }
   bool boundscheck = true;
 };
+struct CastOptions : public FunctionOptions {  // cast.h:41-70 (the flags the number casts read)
+  static CastOptions Safe(std::shared_ptr<DataType> to_type = nullptr) {
+    CastOptions o;
+    o.to_type = std::move(to_type);
+    return o;
+  }
+  static CastOptions Unsafe(std::shared_ptr<DataType> to_type = nullptr) {
+    CastOptions o;
+    o.to_type = std::move(to_type);
+    o.allow_int_overflow = o.allow_float_truncate = true;
+    return o;
+  }
+  std::shared_ptr<DataType> to_type;
+  bool allow_int_overflow = false, allow_float_truncate = false;
+};
 enum class SortOrder { Ascending, Descending };
 struct ArraySortOptions : public FunctionOptions {
   explicit ArraySortOptions(SortOrder order = SortOrder::Ascending) : order(order) {}
@@ -594,6 +615,9 @@ class ScalarFunction : public Function {
   Status AddKernel(ScalarKernel kernel);
   int num_kernels() const override { return static_cast<int>(kernels_.size()); }
   Result<const ScalarKernel*> DispatchExact(const std::vector<ValueDescr>& values) const;
+  // function.h:186-193 / function.cc:152-155: the kernel for `values` after implicit conversions, which are written
+  // back into `values` (Execute casts the arguments to them, function.cc:175-176).  Default: DispatchExact.
+  virtual Result<const ScalarKernel*> DispatchBest(std::vector<ValueDescr>* values) const { return DispatchExact(*values); }
   Result<Datum> Execute(const std::vector<Datum>& args, const FunctionOptions* options, ExecContext* ctx) const override;
 
  private:
@@ -730,6 +754,19 @@ Result<Datum> NthToIndices(const Datum& values, int64_t n, ExecContext* ctx);   
 Result<Datum> Unique(const Datum& values, ExecContext* ctx);                                   // api_vector.cc:115-118
 Result<Datum> ValueCounts(const Datum& values, ExecContext* ctx);                              // api_vector.cc:130-133
 Result<Datum> DictionaryEncode(const Datum& values, const DictionaryEncodeOptions& options, ExecContext* ctx);  // :120-124
+// cast.h:128-160.  Numbers <-> numbers (not floating point -> integer), null -> numbers, dictionary -> its value type.
+Result<Datum> Cast(const Datum& value, const CastOptions& options, ExecContext* ctx);
+Result<Datum> Cast(const Datum& value, std::shared_ptr<DataType> to_type, const CastOptions& options, ExecContext* ctx);
+namespace internal {
+// codegen_internal.cc:190-268, the DispatchBest helpers
+std::shared_ptr<DataType> CommonNumeric(const std::vector<ValueDescr>& descrs);
+void EnsureDictionaryDecoded(std::vector<ValueDescr>* descrs);
+void ReplaceNullWithOtherType(std::vector<ValueDescr>* descrs);
+void ReplaceTypes(const std::shared_ptr<DataType>& type, std::vector<ValueDescr>* descrs);
+// cast.cc:228-243: the arguments cast (safely) to the descriptors DispatchBest settled on
+Result<std::vector<Datum>> Cast(std::vector<Datum> datums, const std::vector<ValueDescr>& descrs, ExecContext* ctx);
+void RegisterScalarCast(FunctionRegistry* registry);  // "cast" (cast.cc:120-160)
+}  // namespace internal
 Result<Datum> Compare(const Datum& left, const Datum& right, CompareOperator op, ExecContext* ctx);
 Result<Datum> Add(const Datum& left, const Datum& right, ArithmeticOptions options, ExecContext* ctx);
 Result<Datum> Subtract(const Datum& left, const Datum& right, ArithmeticOptions options, ExecContext* ctx);

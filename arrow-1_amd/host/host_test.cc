@@ -39,7 +39,36 @@ static std::shared_ptr<ArrayData> HostInt32(const std::vector<int32_t>& v) {
   return ArrayData::Make(int32(), static_cast<int64_t>(v.size()), {nullptr, Buffer::WrapHost(copy->data(), 4 * copy->size())}, 0);
 }
 
+// CheckDispatchBest (scalar_arithmetic_test.cc:863-895, 920-922; scalar_compare_test.cc:454-481, the numeric rows):
+// the descriptors DispatchBest settles on.  No device involved.
+static void DispatchBestTests() {
+  auto* registry = GetFunctionRegistry();
+  struct Row { std::shared_ptr<DataType> a, b, want; };
+  const std::vector<Row> rows = {
+      {int32(), int32(), int32()},   {int32(), null(), int32()},    {null(), int32(), int32()},    {int32(), int8(), int32()},
+      {int32(), int16(), int32()},   {int32(), int64(), int64()},   {int32(), uint8(), int32()},   {int32(), uint16(), int32()},
+      {int32(), uint32(), int64()},  {int32(), uint64(), int64()},  {uint8(), uint8(), uint8()},   {uint8(), uint16(), uint16()},
+      {int32(), float32(), float32()}, {float32(), int64(), float32()}, {float64(), int32(), float64()},
+      {dictionary(float64()), float64(), float64()}, {dictionary(float64()), int16(), float64()}, {int8(), uint64(), int64()}};
+  for (const char* name : {"add", "subtract", "multiply", "divide", "add_checked", "subtract_checked", "multiply_checked",
+                           "divide_checked", "equal", "not_equal", "less", "less_equal", "greater", "greater_equal"}) {
+    auto fr = registry->GetFunction(name);
+    CHECK_OK(fr.status());
+    if (!fr.ok()) continue;
+    auto* f = static_cast<const ScalarFunction*>(fr->get());
+    for (const auto& r : rows) {
+      std::vector<ValueDescr> d{ValueDescr::Array(r.a), ValueDescr::Array(r.b)};
+      auto k = f->DispatchBest(&d);
+      CHECK_OK(k.status());
+      CHECK(d[0].type->id() == r.want->id() && d[1].type->id() == r.want->id());
+    }
+    std::vector<ValueDescr> d{ValueDescr::Array(boolean()), ValueDescr::Array(int8())};  // nothing to meet at
+    CHECK(f->DispatchBest(&d).status().IsNotImplemented());
+  }
+}
+
 static int RunCpu() {
+  DispatchBestTests();
   // ---- registry semantics (registry.cc:35-110; registry_test.cc) ----
   auto registry = FunctionRegistry::Make();
   CHECK(registry->num_functions() == 0);
@@ -629,6 +658,97 @@ static void TabularTests(const std::shared_ptr<MemoryPool>& pool, ExecContext* c
   }
 }
 
+// AddWithImplicitCasts / ...Uint64EdgeCase (scalar_arithmetic_test.cc:897-933), GreaterWithImplicitCasts
+// (scalar_compare_test.cc:494-520) and explicit casts (cast_test.cc: safe / unsafe integer and floating cases).
+static void PromotionTests(const std::shared_ptr<MemoryPool>& pool, ExecContext* ctx) {
+  auto i32 = Dev<int32_t>(pool, int32(), {V(int32_t, 0), V(int32_t, 1), V(int32_t, 2), N(int32_t)});
+  auto f64 = Dev<double>(pool, float64(), {V(double, 0.25), V(double, 0.5), V(double, 0.75), V(double, 1.0)});
+  auto r = CallFunction("add", {Datum(i32), Datum(f64)}, ctx);
+  CHECK_OK(r.status());
+  if (r.ok()) CHECK(r->type()->id() == Type::DOUBLE && Same(Host<double>(pool, *r->array()), {V(double, 0.25), V(double, 1.5), V(double, 2.75), N(double)}));
+  auto i8 = Dev<int8_t>(pool, int8(), {V(int8_t, -16), V(int8_t, 0), V(int8_t, 16), N(int8_t)});
+  auto u32 = Dev<uint32_t>(pool, uint32(), {V(uint32_t, 3), V(uint32_t, 4), V(uint32_t, 5), V(uint32_t, 7)});
+  r = CallFunction("add", {Datum(i8), Datum(u32)}, ctx);
+  CHECK_OK(r.status());
+  if (r.ok()) CHECK(r->type()->id() == Type::INT64 && Same(Host<int64_t>(pool, *r->array()), {V(int64_t, -13), V(int64_t, 4), V(int64_t, 21), N(int64_t)}));
+  {  // dictionary(int32, int32) [8, 6, 3, null, 2] + uint32 -> int64 [11, 10, 8, null, 2]
+    auto values = Dev<int32_t>(pool, int32(), {V(int32_t, 8), V(int32_t, 6), V(int32_t, 3), N(int32_t), V(int32_t, 2)});
+    auto enc = DictionaryEncode(Datum(values), DictionaryEncodeOptions(), ctx);
+    CHECK_OK(enc.status());
+    auto rhs = Dev<uint32_t>(pool, uint32(), {V(uint32_t, 3), V(uint32_t, 4), V(uint32_t, 5), V(uint32_t, 7), V(uint32_t, 0)});
+    if (enc.ok()) {
+      r = CallFunction("add", {*enc, Datum(rhs)}, ctx);
+      CHECK_OK(r.status());
+      if (r.ok()) CHECK(r->type()->id() == Type::INT64 && Same(Host<int64_t>(pool, *r->array()), {V(int64_t, 11), V(int64_t, 10), V(int64_t, 8), N(int64_t), V(int64_t, 2)}));
+      r = CallFunction("greater", {*enc, Datum(rhs)}, ctx);  // :507-510 shape
+      CHECK_OK(r.status());
+      if (r.ok()) CHECK(HostBool(pool, *r->array()) == (std::vector<int>{1, 1, 0, -1, 1}));
+    }
+  }
+  {  // int32 + NullArray(4) -> int32 [null, null, null, null]
+    auto nulls = ArrayData::Make(null(), 4, {nullptr}, 4);
+    r = CallFunction("add", {Datum(i32), Datum(nulls)}, ctx);
+    CHECK_OK(r.status());
+    if (r.ok()) CHECK(r->type()->id() == Type::INT32 && Same(Host<int32_t>(pool, *r->array()), {N(int32_t), N(int32_t), N(int32_t), N(int32_t)}));
+    r = CallFunction("greater", {Datum(i32), Datum(nulls)}, ctx);  // :512-514
+    CHECK_OK(r.status());
+    if (r.ok()) CHECK(HostBool(pool, *r->array()) == (std::vector<int>{-1, -1, -1, -1}));
+  }
+  {  // the uint64 edge: int64 is as wide as the promotion goes
+    auto m1 = Dev<int8_t>(pool, int8(), {V(int8_t, -1)});
+    auto z = Dev<uint64_t>(pool, uint64(), {V(uint64_t, 0)});
+    r = CallFunction("add", {Datum(m1), Datum(z)}, ctx);
+    CHECK_OK(r.status());
+    if (r.ok()) CHECK(r->type()->id() == Type::INT64 && Same(Host<int64_t>(pool, *r->array()), {V(int64_t, -1)}));
+    auto m64 = Dev<int64_t>(pool, int64(), {V(int64_t, -1)});
+    auto big = Dev<uint64_t>(pool, uint64(), {V(uint64_t, 18446744073709551615ull)});
+    r = CallFunction("add", {Datum(m64), Datum(big)}, ctx);
+    CHECK(r.status().IsInvalid());
+    CHECK(r.status().message() == "Integer value 18446744073709551615 not in range: 0 to 9223372036854775807");
+  }
+  // greater with implicit casts
+  r = CallFunction("greater", {Datum(i32), Datum(Dev<double>(pool, float64(), {V(double, 0.5), V(double, 1.0), V(double, 1.5), V(double, 2.0)}))}, ctx);
+  CHECK_OK(r.status());
+  if (r.ok()) CHECK(HostBool(pool, *r->array()) == (std::vector<int>{0, 0, 1, -1}));
+  r = CallFunction("greater", {Datum(i8), Datum(u32)}, ctx);
+  CHECK_OK(r.status());
+  if (r.ok()) CHECK(HostBool(pool, *r->array()) == (std::vector<int>{0, 0, 1, -1}));
+  r = CallFunction("greater", {Datum(i8), Datum(Dev<uint8_t>(pool, uint8(), {V(uint8_t, 255), V(uint8_t, 254), V(uint8_t, 1), V(uint8_t, 0)}))}, ctx);
+  CHECK_OK(r.status());
+  if (r.ok()) CHECK(HostBool(pool, *r->array()) == (std::vector<int>{0, 0, 1, -1}));
+  // an array against a scalar of another type: both are cast (the scalar on the host)
+  r = CallFunction("add", {Datum(i8), Datum(Scalar::Make<int32_t>(int32(), 1000))}, ctx);
+  CHECK_OK(r.status());
+  if (r.ok()) CHECK(r->type()->id() == Type::INT32 && Same(Host<int32_t>(pool, *r->array()), {V(int32_t, 984), V(int32_t, 1000), V(int32_t, 1016), N(int32_t)}));
+  // sliced operands keep their validity
+  r = CallFunction("multiply", {Datum(i8->Slice(1, 3)), Datum(f64->Slice(0, 3))}, ctx);
+  CHECK_OK(r.status());
+  if (r.ok()) CHECK(Same(Host<double>(pool, *r->array()), {V(double, 0.0), V(double, 8.0), N(double)}));
+  // explicit casts
+  auto wide = Dev<int64_t>(pool, int64(), {V(int64_t, 1), V(int64_t, -2), N(int64_t), V(int64_t, 1099511627776ll)});
+  r = Cast(Datum(wide), int32(), CastOptions::Safe(), ctx);
+  CHECK(r.status().IsInvalid() && r.status().message() == "Integer value 1099511627776 not in range: -2147483648 to 2147483647");
+  r = Cast(Datum(wide), int32(), CastOptions::Unsafe(), ctx);
+  CHECK_OK(r.status());
+  if (r.ok()) CHECK(Same(Host<int32_t>(pool, *r->array()), {V(int32_t, 1), V(int32_t, -2), N(int32_t), V(int32_t, 0)}));
+  r = Cast(Datum(wide->Slice(0, 3)), int8(), CastOptions::Safe(), ctx);
+  CHECK_OK(r.status());
+  if (r.ok()) CHECK(Same(Host<int8_t>(pool, *r->array()), {V(int8_t, 1), V(int8_t, -2), N(int8_t)}));
+  CastOptions to_f32 = CastOptions::Safe(float32());
+  r = CallFunction("cast", {Datum(wide)}, &to_f32, ctx);
+  CHECK(r.status().IsInvalid() && r.status().message() == "Integer value 1099511627776 not in range: -16777216 to 16777216");
+  r = Cast(Datum(wide), float64(), CastOptions::Safe(), ctx);
+  CHECK_OK(r.status());
+  if (r.ok()) CHECK(Same(Host<double>(pool, *r->array()), {V(double, 1), V(double, -2), N(double), V(double, 1099511627776.0)}));
+  CHECK(Cast(Datum(f64), int32(), CastOptions::Safe(), ctx).status().IsNotImplemented());
+  CHECK(CallFunction("cast", {Datum(wide)}, ctx).status().IsInvalid());  // no to_type
+  auto chunked = std::make_shared<ChunkedArray>(std::vector<std::shared_ptr<ArrayData>>{i8, i8->Slice(2, 2)}, int8());
+  r = Cast(Datum(chunked), int64(), CastOptions::Safe(), ctx);
+  CHECK_OK(r.status());
+  if (r.ok()) CHECK(r->kind() == Datum::CHUNKED_ARRAY && r->chunked_array()->num_chunks() == 2 &&
+                    Same(Host<int64_t>(pool, *r->chunked_array()->chunk(1)), {V(int64_t, 16), N(int64_t)}));
+}
+
 static int RunGpu() {
   auto pool_r = MemoryPool::Make(0);
   if (!pool_r.ok()) { fprintf(stderr, "no device: %s\n", pool_r.status().ToString().c_str()); return 2; }
@@ -989,6 +1109,7 @@ static int RunGpu() {
     }
   }
   TabularTests(pool, &ctx);
+  PromotionTests(pool, &ctx);
   CHECK(pool->bytes_allocated() >= 0 && pool->max_memory() > 0);  // the MemoryPool counters (memory_pool.h:38-105)
   printf("host_test gpu: %d checks, %d failures\n", g_checks, g_failures);
   return g_failures ? 1 : 0;

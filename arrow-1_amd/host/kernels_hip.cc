@@ -774,10 +774,31 @@ HashAggregateKernel MakeHashMinMaxKernel() {
   return k;
 }
 
+// CompareFunction::DispatchBest (scalar_compare.cc:75-98) and ArithmeticFunction::DispatchBest
+// (scalar_arithmetic.cc:389-412): exact match first; else dictionaries decoded, a null operand takes the other's
+// type, numbers meet at CommonNumeric.  (The timestamp / binary promotions of the comparison concern types that are
+// not on this path.)  Function::Execute then casts the arguments.
+struct PromotingFunction : ScalarFunction {
+  using ScalarFunction::ScalarFunction;
+  Result<const ScalarKernel*> DispatchBest(std::vector<ValueDescr>* values) const override {
+    AMD_RETURN_NOT_OK(CheckArity(static_cast<int>(values->size())));
+    auto exact = DispatchExact(*values);
+    if (exact.ok()) return exact;
+    EnsureDictionaryDecoded(values);
+    if (values->size() == 2) {  // "Only promote types for binary functions"
+      ReplaceNullWithOtherType(values);
+      if (auto type = CommonNumeric(*values)) ReplaceTypes(type, values);
+    }
+    return DispatchExact(*values);
+  }
+};
+using CompareFunction = PromotingFunction;
+using ArithmeticFunction = PromotingFunction;
+
 template <typename Fn>
 void AddBinaryFunctions(FunctionRegistry* registry, const char* const* names, int n, bool compare, Fn make_exec) {
   for (int op = 0; op < n; ++op) {
-    auto func = std::make_shared<ScalarFunction>(names[op], Arity::Binary());
+    auto func = std::make_shared<PromotingFunction>(names[op], Arity::Binary());
     for (Type::type t : kNumeric) {
       ScalarKernel k;
       k.signature.in_types = {InputType::Exact(t), InputType::Exact(t)};

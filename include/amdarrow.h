@@ -208,6 +208,17 @@ int amdarrow_arith(amdarrow_ctx* ctx, int op, const amdarrow_array* lhs,
                    const void* lhs_scalar, const amdarrow_array* rhs, const void* rhs_scalar,
                    void* out_values, uint8_t* out_validity, amdarrow_out* out);
 
+/* cast between numbers: compute/kernels/scalar_cast_numeric.cc:38-50 (CastIntegerToInteger,
+ * CastFloatingToFloating) and :203-262 (CastIntegerToFloating) -- what Function::Execute's implicit casts
+ * (function.cc:175-176, cast.cc:228-243, after DispatchBest / CommonNumeric codegen_internal.cc:220-268)
+ * and an explicit "cast" run.  out_values: values.length elements of to_type_id at element offset 0; the
+ * result's validity IS the input's (a slice of it), so none is written.  safe != 0 = CastOptions::Safe:
+ * AMDARROW_INVALID "Integer value V not in range: L to U" for the first valid slot that the target cannot
+ * hold (int_util.cc:600-618; integer -> floating: |V| <= 2^24 / 2^53).  Floating point -> integer is
+ * AMDARROW_NOT_IMPLEMENTED (its out-of-range conversion is undefined behaviour in the reference, :53-60). */
+int amdarrow_cast_numeric(amdarrow_ctx* ctx, const amdarrow_array* values, int to_type_id, int safe,
+                          void* out_values);
+
 /* ---- hash_aggregate.cc ---------------------------------------------------------------------- */
 /* Grouper (hash_aggregate.cc:313-437): keys -> dense uint32 ids in FIRST-APPEARANCE order,
  * stateful across Consume calls.  Key columns: fixed width, total <= 8 value bytes. */

@@ -860,14 +860,177 @@ int orc_propagate_nulls(const orc_array* a, const orc_array* b, uint8_t* out_val
     }                                                                                     \
     if (v) set_bit(out_bits, i);                                                          \
   }
+/* ---- e3: implicit promotion and the casts behind it ---------------------------------------- */
+/* CommonNumeric, codegen_internal.cc:220-268 (both types numeric, no half float; else -1). */
+static int int_bits(int t) {
+  switch (t) {
+    case ORC_UINT8: case ORC_INT8: return 8;
+    case ORC_UINT16: case ORC_INT16: return 16;
+    case ORC_UINT32: case ORC_INT32: return 32;
+    default: return 64;
+  }
+}
+int orc_common_numeric(int a, int b) {
+  const int ts[2] = {a, b};
+  for (int i = 0; i < 2; ++i)
+    if (!is_float(ts[i]) && !is_signed_int(ts[i]) && !is_unsigned_int(ts[i])) return -1;
+  if (a == ORC_DOUBLE || b == ORC_DOUBLE) return ORC_DOUBLE;
+  if (a == ORC_FLOAT || b == ORC_FLOAT) return ORC_FLOAT;
+  int ws = 0, wu = 0;
+  for (int i = 0; i < 2; ++i) {
+    int* w = is_signed_int(ts[i]) ? &ws : &wu;
+    if (int_bits(ts[i]) > *w) *w = int_bits(ts[i]);
+  }
+  if (ws == 0) { /* :247-253 */
+    if (wu >= 64) return ORC_UINT64;
+    if (wu == 32) return ORC_UINT32;
+    if (wu == 16) return ORC_UINT16;
+    return ORC_INT8; /* sic, :252 */
+  }
+  if (ws <= wu) { /* NextPower2(wu + 1), :255-257 */
+    ws = 1;
+    while (ws < wu + 1) ws <<= 1;
+  }
+  if (ws >= 64) return ORC_INT64;
+  if (ws == 32) return ORC_INT32;
+  if (ws == 16) return ORC_INT16;
+  return ORC_INT8;
+}
+
+/* Number -> number casts, scalar_cast_numeric.cc: CastIntegerToInteger :38-45 (IntegersCanFit,
+ * util/int_util.cc:914-948 with the bounds of GetSafeMinMax :826-912), CastFloatingToFloating
+ * :47-50, CastIntegerToFloating :251-262 (CheckForIntegerToFloatingTruncation :211-249); the
+ * conversion itself is static_cast (CastNumberToNumberUnsafe, scalar_cast_internal.cc).  The check
+ * runs over the whole input first and names the first valid offending slot (int_util.cc:600-692). */
+typedef struct { __int128 lo, hi; } range128;
+static range128 int_range(int t) {
+  range128 r = {0, 0};
+  switch (t) {
+    case ORC_UINT8: r.hi = UINT8_MAX; break;
+    case ORC_INT8: r.lo = INT8_MIN; r.hi = INT8_MAX; break;
+    case ORC_UINT16: r.hi = UINT16_MAX; break;
+    case ORC_INT16: r.lo = INT16_MIN; r.hi = INT16_MAX; break;
+    case ORC_UINT32: r.hi = UINT32_MAX; break;
+    case ORC_INT32: r.lo = INT32_MIN; r.hi = INT32_MAX; break;
+    case ORC_UINT64: r.hi = UINT64_MAX; break;
+    default: r.lo = INT64_MIN; r.hi = INT64_MAX; break;
+  }
+  return r;
+}
+static __int128 load_int128(const orc_array* a, int64_t i) {
+  const int64_t k = a->offset + i;
+  switch (a->type_id) {
+    case ORC_UINT8: return ((const uint8_t*)a->values)[k];
+    case ORC_INT8: return ((const int8_t*)a->values)[k];
+    case ORC_UINT16: return ((const uint16_t*)a->values)[k];
+    case ORC_INT16: return ((const int16_t*)a->values)[k];
+    case ORC_UINT32: return ((const uint32_t*)a->values)[k];
+    case ORC_INT32: return ((const int32_t*)a->values)[k];
+    case ORC_UINT64: return ((const uint64_t*)a->values)[k];
+    default: return ((const int64_t*)a->values)[k];
+  }
+}
+static void print_int128(char* buf, __int128 v) { /* std::to_string of the source type */
+  if (v < 0) sprintf(buf, "%lld", (long long)v);
+  else sprintf(buf, "%llu", (unsigned long long)v);
+}
+static void store_number(void* out, int64_t i, int to, __int128 iv, double fv, int from_float, int src_unsigned64) {
+  switch (to) {
+    case ORC_UINT8: ((uint8_t*)out)[i] = (uint8_t)(uint64_t)iv; break;
+    case ORC_INT8: ((int8_t*)out)[i] = (int8_t)(uint8_t)(uint64_t)iv; break;
+    case ORC_UINT16: ((uint16_t*)out)[i] = (uint16_t)(uint64_t)iv; break;
+    case ORC_INT16: ((int16_t*)out)[i] = (int16_t)(uint16_t)(uint64_t)iv; break;
+    case ORC_UINT32: ((uint32_t*)out)[i] = (uint32_t)(uint64_t)iv; break;
+    case ORC_INT32: ((int32_t*)out)[i] = (int32_t)(uint32_t)(uint64_t)iv; break;
+    case ORC_UINT64: ((uint64_t*)out)[i] = (uint64_t)iv; break;
+    case ORC_INT64: ((int64_t*)out)[i] = (int64_t)(uint64_t)iv; break;
+    case ORC_FLOAT: /* one rounding, from the source's own 64-bit widening */
+      ((float*)out)[i] = from_float ? (float)fv : src_unsigned64 ? (float)(uint64_t)iv : (float)(int64_t)iv; break;
+    default:
+      ((double*)out)[i] = from_float ? fv : src_unsigned64 ? (double)(uint64_t)iv : (double)(int64_t)iv; break;
+  }
+}
+int orc_cast_numeric(const orc_array* a, int to, int safe, void* out_values) {
+  const int from = a->type_id;
+  const int from_int = is_signed_int(from) || is_unsigned_int(from);
+  const int to_int = is_signed_int(to) || is_unsigned_int(to);
+  if (!from_int && !is_float(from)) return fail(ORC_NOT_IMPLEMENTED, "cast: source type");
+  if (!to_int && !is_float(to)) return fail(ORC_NOT_IMPLEMENTED, "cast: target type");
+  if (is_float(from) && to_int) return fail(ORC_NOT_IMPLEMENTED, "cast: floating point to integer");
+  if (from_int && safe) {
+    range128 src = int_range(from), dst;
+    if (to_int) dst = int_range(to);
+    else { /* FloatingIntegerBound :188-199; small integers are always exact :213-230 */
+      const int exact_bits = to == ORC_FLOAT ? 24 : 53;
+      dst.hi = (__int128)1 << exact_bits; dst.lo = -dst.hi;
+      if (int_bits(from) < (to == ORC_FLOAT ? 32 : 64)) dst = src;
+    }
+    range128 b = src;
+    if (dst.lo > b.lo) b.lo = dst.lo;
+    if (dst.hi < b.hi) b.hi = dst.hi;
+    if (b.lo != src.lo || b.hi != src.hi) {
+      for (int64_t i = 0; i < a->length; ++i) {
+        const __int128 v = load_int128(a, i);
+        if ((v < b.lo || v > b.hi) && slot_valid(a, i)) {
+          char msg[224], sv[48], sl[48], sh[48];
+          print_int128(sv, v); print_int128(sl, b.lo); print_int128(sh, b.hi);
+          sprintf(msg, "Integer value %s not in range: %s to %s", sv, sl, sh);
+          return fail(ORC_INVALID, msg);
+        }
+      }
+    }
+  }
+  for (int64_t i = 0; i < a->length; ++i) {
+    if (from_int) store_number(out_values, i, to, load_int128(a, i), 0, 0, from == ORC_UINT64);
+    else {
+      const double fv = from == ORC_FLOAT ? (double)((const float*)a->values)[a->offset + i] : ((const double*)a->values)[a->offset + i];
+      store_number(out_values, i, to, 0, fv, 1, 0);
+    }
+  }
+  return ORC_OK;
+}
+
+/* Function::Execute's implicit casts for a binary call on two arrays of different numeric types
+ * (function.cc:175-176 -> cast.cc:228-243 with CastOptions::Safe, after CompareFunction /
+ * ArithmeticFunction::DispatchBest, scalar_compare.cc:75-98 / scalar_arithmetic.cc:389-412):
+ * both operands become arrays of the common type sharing their validity.  0 = nothing to do. */
+static int promote_pair(const orc_array* lhs, const orc_array* rhs, orc_array* pl, orc_array* pr, void** bl, void** br, int* rc) {
+  *bl = *br = NULL; *rc = ORC_OK;
+  if (!lhs || !rhs || lhs->type_id == rhs->type_id) return 0;
+  const int t = orc_common_numeric(lhs->type_id, rhs->type_id);
+  if (t < 0) { *rc = fail(ORC_NOT_IMPLEMENTED, "no kernel matching input types"); return 1; }
+  const orc_array* in[2] = {lhs, rhs};
+  orc_array* outp[2] = {pl, pr};
+  void** bufs[2] = {bl, br};
+  for (int k = 0; k < 2; ++k) {
+    *outp[k] = *in[k];
+    if (in[k]->type_id == t) continue;
+    *bufs[k] = calloc((size_t)in[k]->length + 1, 8);
+    *rc = orc_cast_numeric(in[k], t, 1, *bufs[k]);
+    if (*rc != ORC_OK) return 1;
+    /* the cast output starts at element 0, the validity view keeps its offset: re-base the values */
+    const size_t width = (size_t)(is_float(t) ? (t == ORC_FLOAT ? 32 : 64) : int_bits(t)) / 8;
+    outp[k]->type_id = t;
+    outp[k]->values = (const char*)*bufs[k] - (size_t)in[k]->offset * width;
+  }
+  return 1;
+}
+
 int orc_compare(int op, const orc_array* lhs, const void* ls, const orc_array* rhs, const void* rs,
                 uint8_t* out_bits, uint8_t* out_validity, orc_out* out) {
   if (!lhs && !rhs) return fail(ORC_INVALID, "compare: need at least one array operand");
   if (lhs && rhs && lhs->length != rhs->length)
     return fail(ORC_INVALID, "Array arguments must all be the same length");
+  {
+    orc_array pl, pr; void *bl, *br; int rc;
+    if (promote_pair(lhs, rhs, &pl, &pr, &bl, &br, &rc)) {
+      if (rc == ORC_OK) rc = orc_compare(op, &pl, ls, &pr, rs, out_bits, out_validity, out);
+      free(bl); free(br);
+      return rc;
+    }
+  }
   const int64_t n = lhs ? lhs->length : rhs->length;
   const int t = lhs ? lhs->type_id : rhs->type_id;
-  if (lhs && rhs && lhs->type_id != rhs->type_id) return fail(ORC_NOT_IMPLEMENTED, "compare: implicit casts are out of scope");
   propagate(lhs, rhs, n, out_validity, out);
   memset(out_bits, 0, bytes_for_bits(n)); /* GenerateBitsUnrolled leaves trailing bits 0 */
   switch (t) {
@@ -942,7 +1105,14 @@ int orc_arith(int op, const orc_array* lhs, const void* ls, const orc_array* rhs
   if (!lhs && !rhs) return fail(ORC_INVALID, "arith: need at least one array operand");
   if (lhs && rhs && lhs->length != rhs->length)
     return fail(ORC_INVALID, "Array arguments must all be the same length");
-  if (lhs && rhs && lhs->type_id != rhs->type_id) return fail(ORC_NOT_IMPLEMENTED, "arith: implicit casts are out of scope");
+  {
+    orc_array pl, pr; void *bl, *br; int rc;
+    if (promote_pair(lhs, rhs, &pl, &pr, &bl, &br, &rc)) {
+      if (rc == ORC_OK) rc = orc_arith(op, &pl, ls, &pr, rs, out_values, out_validity, out);
+      free(bl); free(br);
+      return rc;
+    }
+  }
   const int64_t n = lhs ? lhs->length : rhs->length;
   const int t = lhs ? lhs->type_id : rhs->type_id;
   propagate(lhs, rhs, n, out_validity, out);

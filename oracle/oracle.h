@@ -199,6 +199,16 @@ int orc_arith(int op, const orc_array* lhs, const void* lhs_scalar, const orc_ar
               const void* rhs_scalar, void* out_values, uint8_t* out_validity,
               orc_out* out);
 
+/* e3: implicit promotion.  orc_compare / orc_arith accept two ARRAYS of different numeric types and
+ * do what Function::Execute does: DispatchBest (scalar_compare.cc:75-98, scalar_arithmetic.cc:389-412)
+ * picks CommonNumeric (codegen_internal.cc:220-268), both operands are cast with CastOptions::Safe
+ * (cast.cc:228-243).  orc_common_numeric returns the type id or -1; orc_cast_numeric is the
+ * number -> number cast (scalar_cast_numeric.cc:38-50, 203-262): out_values = length elements of
+ * to_type at element 0, validity is the input's; safe: ORC_INVALID "Integer value V not in range:
+ * L to U" (int_util.cc:600-618); floating -> integer is not restated (UB out of range, :53-60). */
+int orc_common_numeric(int type_a, int type_b);
+int orc_cast_numeric(const orc_array* values, int to_type, int safe, void* out_values);
+
 /* ---- mask-building scalars ------------------------------------------------
  * Boolean kernels, scalar_boolean.cc:30-566.  Operand i is a boolean array (lhs / rhs
  * non-NULL) or a scalar given by its state (ORC_SCALAR_FALSE / TRUE / NULL); at least one

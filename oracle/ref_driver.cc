@@ -20,6 +20,8 @@
 #include "arrow/compute/api_aggregate.h"
 #include "arrow/compute/api_scalar.h"
 #include "arrow/compute/api_vector.h"
+#include "arrow/compute/cast.h"
+#include "arrow/compute/cast_internal.h"
 #include "arrow/compute/exec.h"
 #include "arrow/compute/exec_internal.h"
 #include "arrow/compute/function.h"
@@ -443,6 +445,56 @@ int ref_binary_filter(const orc_binary* values, const orc_array* filter, int nul
   return 0;
 }
 
+// ---- e3: implicit promotion and the casts behind it -----------------------------------------
+int ref_common_numeric(int a, int b) {  // through ArithmeticFunction::DispatchBest of "add"
+  std::vector<ValueDescr> d{ValueDescr::Array(TypeOf(a)), ValueDescr::Array(TypeOf(b))};
+  auto f = Ctx()->func_registry()->GetFunction("add");
+  if (!f.ok()) return -1;
+  auto k = (*f)->DispatchBest(&d);
+  if (!k.ok() || !d[0].type->Equals(*d[1].type)) return -1;
+  for (int id = ORC_UINT8; id <= ORC_DOUBLE; ++id)
+    if (id != 10 && TypeOf(id)->Equals(*d[0].type)) return id;
+  return -1;
+}
+// The reference's number -> number CastFunction, taken from GetNumericCasts() directly: Cast() /
+// CallFunction("cast") would initialise the whole cast table (cast.cc:47-60), whose string / nested /
+// temporal / dictionary families are not part of this build (ref_build.mk).
+static Result<Datum> NumericCast(const Datum& in, int to, bool safe) {
+  static const auto casts = arrow::compute::internal::GetNumericCasts();
+  auto type = TypeOf(to);
+  CastOptions o = safe ? CastOptions::Safe(type) : CastOptions::Unsafe(type);
+  for (const auto& f : casts)
+    if (f->out_type_id() == type->id()) return f->Execute({in}, &o, Ctx());
+  return Status::NotImplemented("cast to ", type->ToString());
+}
+int ref_cast_numeric(const orc_array* a, int to, int safe, void* out_values) {
+  auto res = NumericCast(Datum(Wrap(a)), to, safe != 0);
+  if (!res.ok()) return Fail(res.status());
+  const ArrayData& d = *res->array();
+  const int64_t w = bit_width(d.type->id()) / 8;
+  if (d.length > 0) memcpy(out_values, d.buffers[1]->data() + d.offset * w, static_cast<size_t>(d.length * w));
+  return 0;
+}
+// Function::Execute (function.cc:157-201) for two arrays of different types, step by step with the
+// reference's own pieces: DispatchBest rewrites the descriptors, each argument whose type changed is
+// cast safely (cast.cc:228-243), the call then matches a kernel exactly.
+static Status ImplicitlyCast(const char* name, Datum* l, Datum* r) {
+  if (!l->is_array() || !r->is_array() || l->type()->Equals(*r->type())) return Status::OK();
+  std::vector<ValueDescr> d{l->descr(), r->descr()};
+  ARROW_ASSIGN_OR_RAISE(auto f, Ctx()->func_registry()->GetFunction(name));
+  ARROW_RETURN_NOT_OK(f->DispatchBest(&d).status());
+  Datum* args[2] = {l, r};
+  for (int k = 0; k < 2; ++k) {
+    if (d[k].type->Equals(*args[k]->type())) continue;
+    int to = -1;
+    for (int id = ORC_UINT8; id <= ORC_DOUBLE; ++id)
+      if (id != 10 && TypeOf(id)->Equals(*d[k].type)) to = id;
+    if (to < 0) return Status::NotImplemented("implicit cast to ", d[k].type->ToString());
+    ARROW_ASSIGN_OR_RAISE(*args[k], NumericCast(*args[k], to, true));
+  }
+  return Status::OK();
+}
+
 static const char* kCmpNames[] = {"equal", "not_equal", "greater", "greater_equal", "less", "less_equal"};
 static const char* kArithNames[] = {"add", "subtract", "multiply", "divide",
                                     "add_checked", "subtract_checked", "multiply_checked", "divide_checked"};
@@ -452,6 +504,8 @@ static int Binary(const char* name, const orc_array* lhs, const void* ls, const 
   const int t = lhs ? lhs->type_id : rhs->type_id;
   Datum l = lhs ? Datum(Wrap(lhs)) : Datum(WrapScalar(t, ls));
   Datum r = rhs ? Datum(Wrap(rhs)) : Datum(WrapScalar(t, rs));
+  auto st = ImplicitlyCast(name, &l, &r);
+  if (!st.ok()) return Fail(st);
   auto res = CallFunction(name, {l, r}, nullptr, Ctx());
   if (!res.ok()) return Fail(res.status());
   Export(*res->array(), out_values, out_validity, out);

@@ -213,6 +213,41 @@ def iter_cases():
             yield ("value_counts", {}, [a])
             for ne in (0, 1):
                 yield ("dictionary_encode", dict(null_encoding=ne), [a])
+    # ---- e3: implicit promotion (scalar_arithmetic_test.cc:863-933 DispatchBest / AddWithImplicitCasts /
+    # ...Uint64EdgeCase, scalar_compare_test.cc:454-520) and the number -> number casts behind it
+    # (cast_test.cc IntegerSignedToSigned / ...ToFloating / overflow cases): every ordered pair of types ----
+    for ta in NUMERIC:
+        for tb in NUMERIC:
+            if ta == tb:
+                continue
+            a = R(rng, ta, 100, 0.2, 3, lo=-5, hi=5)
+            b = R(rng, tb, 100, 0.1, 6, lo=1, hi=5)
+            k = (ta * 13 + tb) % 6
+            yield ("compare", dict(op=k), [a, b])
+            yield ("compare", dict(op=(k + 3) % 6), [a, b])
+            yield ("arith", dict(op=k % 4), [a, b])
+            yield ("arith", dict(op=4 + (k + 1) % 4), [a, b])
+            if tb in (FLOAT, DOUBLE) or ta not in (FLOAT, DOUBLE):
+                yield ("cast", dict(to=tb, safe=1), [a])
+                # full-range values: the safe cast names the first valid value that does not fit, a null slot
+                # may hold anything; the unsafe one wraps / rounds
+                if ta in (FLOAT, DOUBLE):
+                    w = R(rng, ta, 120, 0.1, 5, lo=-1e30, hi=1e30)
+                else:
+                    info = np.iinfo(orc.NP_OF[ta])
+                    w = R(rng, ta, 120, 0.1, 5, lo=info.min, hi=info.max)
+                yield ("cast", dict(to=tb, safe=1), [w])
+                yield ("cast", dict(to=tb, safe=0), [w])
+                d = a.data.copy()
+                d[10] = w.data[7]
+                v = np.ones(len(d), bool) if a.valid is None else a.valid.copy()
+                v[10] = False
+                yield ("cast", dict(to=tb, safe=1), [Arr(ta, d, v, 3, 100)])
+    # the uint64 edge: int64 is as wide as the promotion goes (scalar_arithmetic_test.cc:920-933)
+    yield ("arith", dict(op=0), [Arr(orc.INT8, np.array([-1], np.int8)), Arr(orc.UINT64, np.array([0], np.uint64))])
+    yield ("arith", dict(op=0), [Arr(orc.INT64, np.array([-1])), Arr(orc.UINT64, np.array([2**64 - 1], np.uint64))])
+    yield ("compare", dict(op=2), [Arr(orc.UINT64, np.array([2**63, 5], np.uint64), np.array([False, True])),
+                                   Arr(orc.INT16, np.array([3, 7], np.int16))])
 
 
 def run_case(api, op, params, arrs):
@@ -282,6 +317,8 @@ def run_case(api, op, params, arrs):
             return res(api.compare(params["op"], arrs[0], rhs))
         if op == "arith":
             return res(api.arith(params["op"], arrs[0], arrs[1]))
+        if op == "cast":
+            return {"values": api.cast(arrs[0], params["to"], bool(params["safe"])).view(np.uint8)}
         if op == "boolean":
             if params.get("has_lhs_scalar"):
                 return res(api.boolean(params["op"], params["lhs_scalar"], arrs[0]))

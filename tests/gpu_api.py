@@ -137,6 +137,13 @@ class GpuApi:
         f = lambda x: up(x) if isinstance(x, orc.Arr) else x  # noqa: E731
         return self._wrap(lambda: down(compute.arith(self.ctx, op, f(lhs), f(rhs))))
 
+    def common_numeric(self, type_a, type_b):
+        t = compute.common_numeric(type_a, type_b)
+        return -1 if t is None else t
+
+    def cast(self, a, to_type, safe=True):
+        return self._wrap(lambda: compute.cast(self.ctx, up(a), to_type, safe).values_numpy()[:a.length])
+
     # ---- mask-building scalars ----
     @staticmethod
     def _down_full(d):

@@ -444,6 +444,8 @@ class Api:
 
         la, ls, keep1 = operand(lhs)
         ra, rs, keep2 = operand(rhs)
+        if isinstance(lhs, Arr) and isinstance(rhs, Arr) and lhs.type_id != rhs.type_id:
+            t = self.common_numeric(lhs.type_id, rhs.type_id)  # e3: implicit promotion
         ot = t if out_type is None else out_type
         ov = np.zeros((n + 64) * 8 + 16, np.uint8)
         ob = np.zeros(n // 8 + 16, np.uint8)
@@ -451,6 +453,17 @@ class Api:
         self._check(self._f(name)(op, la, ls, ra, rs, ov.ctypes.data_as(C.c_void_p), ob.ctypes.data_as(C.c_void_p),
                                   C.byref(out)))
         return self._result(ot, ov, ob, out)
+
+    def common_numeric(self, type_a, type_b):
+        """CommonNumeric (codegen_internal.cc:220-268) -> type id, -1 if there is none"""
+        return int(self._f("common_numeric")(int(type_a), int(type_b)))
+
+    def cast(self, a, to_type, safe=True):
+        """number -> number cast: the converted values (the validity is the input's)"""
+        out_v = np.zeros(a.length * 8 + 16, np.uint8)
+        c = a.c()
+        self._check(self._f("cast_numeric")(C.byref(c), int(to_type), int(bool(safe)), out_v.ctypes.data_as(C.c_void_p)))
+        return out_v[:a.length * bit_width(to_type) // 8].view(NP_OF[to_type]).copy()
 
     def compare(self, op, lhs, rhs):
         return self._binary("compare", op, lhs, rhs, BOOL)
@@ -555,7 +568,7 @@ def random_arr(rng, type_id, n, null_prob=0.0, offset=0, lo=None, hi=None, null_
         info = np.iinfo(NP_OF[type_id])
         a = max(info.min, -100 if lo is None else lo)
         b = min(info.max, 100 if hi is None else hi)
-        data = rng.integers(a, b, m, endpoint=True)
+        data = rng.integers(a, b, m, endpoint=True, dtype=np.uint64) if b > 2**63 - 1 else rng.integers(a, b, m, endpoint=True)
     valid = None
     if null_prob > 0 or force_validity:
         valid = rng.random(m) >= null_prob

@@ -1116,3 +1116,41 @@ def test_grouper_large_batches_grow_optimistically(gpu, oracle):
     for a, b in zip(got_ids, want_ids):
         assert np.array_equal(a, b)
     assert np.array_equal(got_u[0][0], want_u[0][0])
+
+
+@pytest.mark.gpu
+def test_casts_and_implicit_promotion_large(gpu, oracle):
+    """e3 at sizes beyond one grid stride: number -> number casts (safe / unsafe, sliced, nulls hiding values that do
+    not fit), the first offending value in the error, and compare / arithmetic on operands of different types."""
+    rng = np.random.default_rng(901)
+    n = 1_000_003
+    for ta, tb in [(orc.INT64, orc.INT32), (orc.INT32, orc.INT64), (orc.UINT64, orc.INT64), (orc.INT64, DOUBLE), (orc.UINT32, FLOAT),
+                   (orc.INT8, orc.UINT16), (FLOAT, DOUBLE), (DOUBLE, FLOAT), (orc.UINT16, orc.INT8), (orc.INT16, DOUBLE)]:
+        small = R(rng, ta, n, 0.1, 5, lo=0, hi=100)
+        assert np.array_equal(gpu.cast(small, tb).view(np.uint8), oracle.cast(small, tb).view(np.uint8))
+        if ta in (FLOAT, DOUBLE):
+            continue
+        info = np.iinfo(orc.NP_OF[ta])
+        wide = R(rng, ta, n, 0.1, 3, lo=info.min, hi=info.max)
+        assert np.array_equal(gpu.cast(wide, tb, safe=False).view(np.uint8), oracle.cast(wide, tb, safe=False).view(np.uint8))
+        outcome = []
+        for api in (gpu, oracle):
+            try:
+                outcome.append(api.cast(wide, tb).tobytes())
+            except orc.StatusError as e:
+                outcome.append((e.code, e.msg))
+        assert outcome[0] == outcome[1]
+        # the only value that does not fit sits under a null
+        d = small.data.copy()
+        v = small.valid.copy()
+        d[n // 2] = wide.data[0]
+        v[n // 2] = False
+        hidden = Arr(ta, d, v, 5, n)
+        assert np.array_equal(gpu.cast(hidden, tb).view(np.uint8), oracle.cast(hidden, tb).view(np.uint8))
+    a = R(rng, orc.INT32, n, 0.05, 3, lo=-1000, hi=1000)
+    for tb, op in [(orc.INT64, 0), (DOUBLE, 2), (orc.UINT8, 1), (orc.UINT32, 6), (FLOAT, 3)]:
+        b = R(rng, tb, n, 0.05, 6, lo=1, hi=100)
+        for fn in ("arith", "compare"):
+            k = op if fn == "arith" else op % 6
+            want, got = getattr(oracle, fn)(k, a, b), getattr(gpu, fn)(k, a, b)
+            assert got.type_id == want.type_id and got.same(want), (fn, k, tb)
