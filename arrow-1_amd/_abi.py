@@ -86,6 +86,7 @@ SYMBOLS = {
     "amdarrow_grouper_lookup": (C.c_int, [_P, _A, _P]),
     "amdarrow_grouper_num_groups": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "amdarrow_grouper_uniques": (C.c_int, [_P, C.c_int, _P, _P, _O]),
+    "amdarrow_make_groupings": (C.c_int, [_P, _P, C.c_int64, C.c_uint32, _P, _P]),
     "amdarrow_hash_aggregate": (C.c_int, [_P, C.c_int, _A, _P, C.c_int64, C.c_int, _P, _P, _O]),
     "amdarrow_dense_merge_scatter": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, _P, _P]),
     "amdarrow_dense_merge_order": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int64,

@@ -322,6 +322,20 @@ def aggregate(ctx, a):
     return out.valid_count, out.sum, out.min, out.max
 
 
+def make_groupings(ctx, ids, num_groups):
+    """Grouper::MakeGroupings (hash_aggregate.cc:979-1018): ids = uint32 DeviceArray without nulls -> the two buffers
+    (offsets int32[num_groups + 1], indices int32[n]) of the ListArray listing every group's rows in row order."""
+    if ids.null_count != 0 and ids.validity is not None:
+        raise AmdArrowError(4, "MakeGroupings with null ids")
+    dev = ids.values.device
+    n = ids.length
+    off = torch.empty(num_groups + 1, dtype=torch.int32, device=dev)
+    idx = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    check(ctx.lib, ctx.lib.amdarrow_make_groupings(ctx.handle, ids.values.data_ptr() + 4 * ids.offset, n, num_groups,
+                                                   off.data_ptr(), idx.data_ptr()))
+    return off, idx[:n]
+
+
 def hash_aggregate(ctx, func, values, ids, num_groups, count_mode=0):
     """One HashAggregateKernel (hash_sum / hash_count / hash_mean) over (values, ids, num_groups).
     `ids`: torch.int32/uint32 tensor on the device."""

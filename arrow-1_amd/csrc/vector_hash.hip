@@ -49,6 +49,25 @@ __global__ __launch_bounds__(kVThreads) void k_dictionary_indices(const uint32_t
   if (lane == 0 && nulls) atomicAdd(CounterSlot(counters), nulls);
 }
 
+// Grouper::MakeGroupings (hash_aggregate.cc:979-1018) from the stable sort of the ids: position i of the sorted
+// order holds row sorted[i] -- that IS the grouping's value i -- and group g starts where the sorted ids first
+// reach g.  The thread at a boundary writes the offsets of every group that starts there (the empty ones between
+// the previous id and this one included); the last position also closes the groups behind the largest id.
+__global__ __launch_bounds__(kVThreads) void k_groupings_from_sorted(const uint32_t* ids, const uint64_t* sorted, int64_t n,
+                                                                    uint32_t num_groups, int32_t* out_offsets,
+                                                                    int32_t* out_indices, unsigned int* bad) {
+  for (int64_t i = int64_t(blockIdx.x) * kVThreads + threadIdx.x; i < n; i += int64_t(gridDim.x) * kVThreads) {
+    const uint64_t row = sorted[i];
+    out_indices[i] = static_cast<int32_t>(row);
+    const uint32_t g = ids[row];
+    if (g >= num_groups) { *bad = 1; continue; }
+    const int64_t first = i == 0 ? 0 : int64_t(ids[sorted[i - 1]]) + 1;
+    for (int64_t k = first; k <= int64_t(g); ++k) out_offsets[k] = static_cast<int32_t>(i);
+    if (i == n - 1)
+      for (int64_t k = int64_t(g) + 1; k <= int64_t(num_groups); ++k) out_offsets[k] = static_cast<int32_t>(n);
+  }
+}
+
 }  // namespace amdarrow
 
 using namespace amdarrow;
@@ -79,4 +98,39 @@ extern "C" int amdarrow_dictionary_indices(amdarrow_ctx* ctx, const uint32_t* id
   out->null_count = static_cast<int64_t>(nn);
   out->has_validity = nn > 0;  // the builder materialises a bitmap only once a null was appended
   return AMDARROW_OK;
+}
+
+extern "C" int amdarrow_make_groupings(amdarrow_ctx* ctx, const uint32_t* ids, int64_t n, uint32_t num_groups,
+                                       int32_t* out_offsets, int32_t* out_indices) {
+  using namespace amdarrow;
+  if (n < 0 || n > INT32_MAX) return SetError(AMDARROW_INVALID, "MakeGroupings: more rows than int32 offsets address");
+  if (n == 0) {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    AA_HIP(hipMemsetAsync(out_offsets, 0, 4 * (static_cast<size_t>(num_groups) + 1), ctx->stream));
+    return AMDARROW_OK;
+  }
+  uint64_t* sorted = nullptr;
+  AA_HIP(hipMalloc(reinterpret_cast<void**>(&sorted), 8 * static_cast<size_t>(n)));
+  amdarrow_array chunk;
+  chunk.values = ids; chunk.validity = nullptr; chunk.length = n; chunk.offset = 0;
+  chunk.type_id = AMDARROW_UINT32; chunk.null_count = 0;
+  int rc = amdarrow_sort_indices(ctx, &chunk, 1, AMDARROW_ASCENDING, sorted);  // stable: rows of a group stay in row order
+  if (rc == AMDARROW_OK) {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    void* base;
+    rc = Scratch(ctx, 256, &base);
+    if (rc == AMDARROW_OK) {
+      auto* bad = static_cast<unsigned int*>(base);
+      hipError_t e = hipMemsetAsync(bad, 0, 4, ctx->stream);
+      hipLaunchKernelGGL(k_groupings_from_sorted, dim3(GridFor(n, kVThreads, ctx->num_cus * 8)), dim3(kVThreads), 0, ctx->stream,
+                         ids, sorted, n, num_groups, out_offsets, out_indices, bad);
+      if (e == hipSuccess) e = hipGetLastError();
+      unsigned int flag = 0;
+      if (e != hipSuccess) rc = SetError(AMDARROW_UNKNOWN_ERROR, hipGetErrorString(e));
+      else rc = ReadBack(ctx, bad, 4, &flag);  // also orders the free below after the kernel
+      if (rc == AMDARROW_OK && flag) rc = SetError(AMDARROW_INVALID, "MakeGroupings: an id is not below num_groups");
+    }
+  }
+  (void)hipFree(sorted);
+  return rc;
 }

@@ -98,7 +98,8 @@ struct Type {
   enum type { NA = 0, BOOL = 1, UINT8, INT8, UINT16, INT16, UINT32, INT32, UINT64, INT64, HALF_FLOAT, FLOAT, DOUBLE,
               STRUCT,       // the {min, max} / {values, counts} results
               DICTIONARY,   // dictionary_encode's result: int32 indices + ArrayData::dictionary
-              BINARY, STRING }; // 32-bit offsets; buffers = validity | offsets | data (Filter / Take only)
+              BINARY, STRING,   // 32-bit offsets; buffers = validity | offsets | data (Filter / Take only)
+              LIST };           // list<...> with int32 offsets: Grouper::MakeGroupings / ApplyGroupings; buffers = validity | offsets, child_data[0] = the values
 };
 class DataType {
  public:
@@ -130,6 +131,7 @@ std::shared_ptr<DataType> float64();
 std::shared_ptr<DataType> struct_();  // field list carried by the StructScalar itself
 std::shared_ptr<DataType> dictionary_();  // dictionary(int32(), <type of ArrayData::dictionary>)
 std::shared_ptr<DataType> dictionary(std::shared_ptr<DataType> value_type);  // dictionary(int32(), value_type), type.h:1360
+std::shared_ptr<DataType> list_();  // list(<type of child_data[0]>)
 std::shared_ptr<DataType> binary();
 std::shared_ptr<DataType> utf8();
 inline bool is_binary_like(Type::type id) { return id == Type::BINARY || id == Type::STRING; }  // type_traits.h
@@ -718,6 +720,12 @@ class Grouper {
   Result<Datum> Lookup(const ExecBatch& batch);   // ids of rows whose keys are all known: no growth, KeyError otherwise
   Result<ExecBatch> GetUniques();
   uint32_t num_groups() const;
+  // api_aggregate.h:360-377 / hash_aggregate.cc:979-1018: list<int32>[num_groups], element g = the rows whose id is g,
+  // in row order.  ids: uint32 without nulls ("MakeGroupings with null ids" otherwise).
+  static Result<std::shared_ptr<ArrayData>> MakeGroupings(const ArrayData& ids, uint32_t num_groups, ExecContext* ctx);
+  // api_aggregate.h:379-395 / hash_aggregate.cc:968-977: list<array.type> with the groupings' offsets over
+  // take(array, groupings' values)
+  static Result<std::shared_ptr<ArrayData>> ApplyGroupings(const ArrayData& groupings, const ArrayData& array, ExecContext* ctx);
 
  private:
   Grouper() = default;

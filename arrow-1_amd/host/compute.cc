@@ -41,9 +41,9 @@ std::string DataType::ToString() const {
   return names[id_];
 }
 std::shared_ptr<DataType> TypeFromId(Type::type id) {
-  static std::shared_ptr<DataType> types[17];
+  static std::shared_ptr<DataType> types[18];
   static std::once_flag once;
-  std::call_once(once, [] { for (int i = 0; i < 17; ++i) types[i] = std::make_shared<DataType>(static_cast<Type::type>(i)); });
+  std::call_once(once, [] { for (int i = 0; i < 18; ++i) types[i] = std::make_shared<DataType>(static_cast<Type::type>(i)); });
   return types[id];
 }
 std::shared_ptr<DataType> boolean() { return TypeFromId(Type::BOOL); }
@@ -55,6 +55,7 @@ std::shared_ptr<DataType> dictionary(std::shared_ptr<DataType> value_type) {
   return t;
 }
 std::shared_ptr<DataType> null() { return TypeFromId(Type::NA); }
+std::shared_ptr<DataType> list_() { return TypeFromId(Type::LIST); }
 std::shared_ptr<DataType> binary() { return TypeFromId(Type::BINARY); }
 std::shared_ptr<DataType> utf8() { return TypeFromId(Type::STRING); }
 std::shared_ptr<DataType> uint8() { return TypeFromId(Type::UINT8); }

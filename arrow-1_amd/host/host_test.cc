@@ -749,6 +749,43 @@ static void PromotionTests(const std::shared_ptr<MemoryPool>& pool, ExecContext*
                     Same(Host<int64_t>(pool, *r->chunked_array()->chunk(1)), {V(int64_t, 16), N(int64_t)}));
 }
 
+// Grouper.MakeGroupings (hash_aggregate_test.cc:423-452): the literals, ApplyGroupings on the ids, null ids.
+static void GroupingsTests(const std::shared_ptr<MemoryPool>& pool, ExecContext* ctx) {
+  struct Case { std::vector<uint32_t> ids; std::vector<std::vector<int32_t>> want; };
+  const std::vector<Case> cases = {{{}, {{}}},
+                                   {{0, 0, 0}, {{0, 1, 2}}},
+                                   {{0, 0, 0, 1, 1, 2}, {{0, 1, 2}, {3, 4}, {5}, {}}},
+                                   {{2, 1, 2, 1, 1, 2}, {{}, {1, 3, 4}, {0, 2, 5}, {}, {}}},
+                                   {{2, 2, 5, 5, 2, 3}, {{}, {}, {0, 1, 4}, {5}, {}, {2, 3}, {}, {}}}};
+  for (const auto& c : cases) {
+    std::vector<Opt<uint32_t>> items;
+    for (uint32_t v : c.ids) items.push_back(V(uint32_t, v));
+    auto ids = Dev<uint32_t>(pool, uint32(), items);
+    const uint32_t ng = static_cast<uint32_t>(c.want.size());
+    auto g = compute::internal::Grouper::MakeGroupings(*ids, ng, ctx);
+    CHECK_OK(g.status());
+    if (!g.ok()) continue;
+    CHECK((*g)->type->id() == Type::LIST && (*g)->length == ng && (*g)->child_data.size() == 1);
+    auto off = Host<int32_t>(pool, *ArrayData::Make(int32(), ng + 1, {nullptr, (*g)->buffers[1]}, 0));
+    auto idx = Host<int32_t>(pool, *(*g)->child_data[0]);
+    auto grouped = compute::internal::Grouper::ApplyGroupings(**g, *ids, ctx);
+    CHECK_OK(grouped.status());
+    std::vector<Opt<uint32_t>> gid;
+    if (grouped.ok()) gid = Host<uint32_t>(pool, *(*grouped)->child_data[0]);
+    for (uint32_t k = 0; k < ng; ++k) {
+      std::vector<int32_t> got;
+      for (int32_t i = off[k].v; i < off[k + 1].v; ++i) {
+        got.push_back(idx[i].v);
+        if (grouped.ok()) CHECK(gid[i].v == k);
+      }
+      CHECK(got == c.want[k]);
+    }
+  }
+  auto with_null = Dev<uint32_t>(pool, uint32(), {V(uint32_t, 0), N(uint32_t), V(uint32_t, 1)});
+  auto st = compute::internal::Grouper::MakeGroupings(*with_null, 5, ctx).status();
+  CHECK(st.IsInvalid() && st.message() == "MakeGroupings with null ids");
+}
+
 static int RunGpu() {
   auto pool_r = MemoryPool::Make(0);
   if (!pool_r.ok()) { fprintf(stderr, "no device: %s\n", pool_r.status().ToString().c_str()); return 2; }
@@ -1110,6 +1147,7 @@ static int RunGpu() {
   }
   TabularTests(pool, &ctx);
   PromotionTests(pool, &ctx);
+  GroupingsTests(pool, &ctx);
   CHECK(pool->bytes_allocated() >= 0 && pool->max_memory() > 0);  // the MemoryPool counters (memory_pool.h:38-105)
   printf("host_test gpu: %d checks, %d failures\n", g_checks, g_failures);
   return g_failures ? 1 : 0;

@@ -1076,6 +1076,33 @@ Result<Datum> Grouper::Lookup(const ExecBatch& batch) {
   if (rc != AMDARROW_OK) return Status::FromAbi(rc);
   return Datum(ArrayData::Make(uint32(), batch.length, {nullptr, buf}, 0));
 }
+Result<std::shared_ptr<ArrayData>> Grouper::MakeGroupings(const ArrayData& ids, uint32_t num_groups, ExecContext* ctx) {
+  if (ids.type->id() != Type::UINT32) return Status::Invalid("MakeGroupings: ids must be uint32");
+  if (ids.null_count != 0 && ids.buffers[0]) {
+    AMD_ASSIGN_OR_RAISE(Datum valid_count, CallFunction("count", {Datum(std::make_shared<ArrayData>(ids))}, ctx));
+    int64_t valid = 0;
+    memcpy(&valid, &valid_count.scalar()->bits, 8);
+    if (valid != ids.length) return Status::Invalid("MakeGroupings with null ids");  // :982-984
+  }
+  const auto& pool = ctx->memory_pool();
+  AMD_ASSIGN_OR_RAISE(auto offsets, AllocateBuffer(4 * (static_cast<int64_t>(num_groups) + 1), pool));
+  AMD_ASSIGN_OR_RAISE(auto indices, AllocateBuffer(4 * std::max<int64_t>(ids.length, 1), pool));
+  const int rc = amdarrow_make_groupings(pool->ctx(), reinterpret_cast<const uint32_t*>(ids.buffers[1]->data()) + ids.offset, ids.length,
+                                         num_groups, reinterpret_cast<int32_t*>(offsets->mutable_data()),
+                                         reinterpret_cast<int32_t*>(indices->mutable_data()));
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  auto out = ArrayData::Make(list_(), num_groups, {nullptr, offsets}, 0);
+  out->child_data = {ArrayData::Make(int32(), ids.length, {nullptr, indices}, 0)};
+  return out;
+}
+Result<std::shared_ptr<ArrayData>> Grouper::ApplyGroupings(const ArrayData& groupings, const ArrayData& array, ExecContext* ctx) {
+  if (groupings.type->id() != Type::LIST || groupings.child_data.size() != 1) return Status::Invalid("ApplyGroupings: groupings must be list<int32>");
+  AMD_ASSIGN_OR_RAISE(Datum sorted, Take(Datum(std::make_shared<ArrayData>(array)), Datum(groupings.child_data[0]),
+                                         TakeOptions::NoBoundsCheck(), ctx));
+  auto out = std::make_shared<ArrayData>(groupings);
+  out->child_data = {sorted.array()};
+  return out;
+}
 uint32_t Grouper::num_groups() const {
   uint32_t n = 0;
   amdarrow_grouper_num_groups(impl_, &n);

@@ -235,6 +235,12 @@ int amdarrow_grouper_num_groups(amdarrow_grouper* g, uint32_t* out_num_groups);
 /* GetUniques (:410-428): key column k -> num_groups values + validity bitmap. */
 int amdarrow_grouper_uniques(amdarrow_grouper* g, int k, void* out_values,
                              uint8_t* out_validity, amdarrow_out* out);
+/* Grouper::MakeGroupings (hash_aggregate.cc:979-1018, api_aggregate.h:360-377): the ListArray<int32> that lists, per
+ * group, the rows carrying its id in row order -- given as its two buffers.  ids: device uint32[n], every id <
+ * num_groups (AMDARROW_INVALID otherwise; the reference only DCHECKs); out_offsets: int32[num_groups + 1];
+ * out_indices: int32[n].  ApplyGroupings (:968-977) is take(values, out_indices) under the same offsets. */
+int amdarrow_make_groupings(amdarrow_ctx* ctx, const uint32_t* ids, int64_t n, uint32_t num_groups,
+                            int32_t* out_offsets, int32_t* out_indices);
 /* One HashAggregateKernel consume+finalize over one batch (hash_aggregate.cc:466-622,
  * 928-960): func = AMDARROW_HASH_{SUM,COUNT,MEAN}; `ids` device uint32[values.length];
  * out_values: num_groups x 8 bytes (int64 / uint64 / double per FindAccumulatorType,

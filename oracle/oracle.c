@@ -1436,3 +1436,26 @@ int64_t orc_filter_groupby_sum(const orc_array* values, const orc_array* keys, c
   free(fv); free(fk); free(fvv); free(fkv); free(ids);
   return ng;
 }
+
+/* Grouper::MakeGroupings, hash_aggregate.cc:979-1018: count the rows of every id (:990-994), exclusive
+ * prefix sum (:995-1001), then a stable scatter of the row numbers through a copy of the offsets
+ * (:1004-1013) -- a counting sort of the rows by id. */
+int orc_make_groupings(const uint32_t* ids, int64_t n, uint32_t num_groups, int32_t* out_offsets,
+                       int32_t* out_indices) {
+  for (int64_t i = 0; i < n; ++i)
+    if (ids[i] >= num_groups) return fail(ORC_INVALID, "MakeGroupings: an id is not below num_groups");
+  memset(out_offsets, 0, sizeof(int32_t) * ((size_t)num_groups + 1));
+  for (int64_t i = 0; i < n; ++i) out_offsets[ids[i]] += 1;
+  int32_t length = 0;
+  for (uint32_t g = 0; g < num_groups; ++g) {
+    const int32_t c = out_offsets[g];
+    out_offsets[g] = length;
+    length += c;
+  }
+  out_offsets[num_groups] = length;
+  int32_t* cursor = (int32_t*)malloc(sizeof(int32_t) * ((size_t)num_groups + 1));
+  memcpy(cursor, out_offsets, sizeof(int32_t) * ((size_t)num_groups + 1));
+  for (int64_t i = 0; i < n; ++i) out_indices[cursor[ids[i]]++] = (int32_t)i;
+  free(cursor);
+  return ORC_OK;
+}

@@ -199,6 +199,11 @@ int orc_arith(int op, const orc_array* lhs, const void* lhs_scalar, const orc_ar
               const void* rhs_scalar, void* out_values, uint8_t* out_validity,
               orc_out* out);
 
+/* Grouper::MakeGroupings (hash_aggregate.cc:979-1018): offsets int32[num_groups + 1] and values int32[n] of
+ * the ListArray listing each group's rows in row order.  ORC_INVALID if an id >= num_groups (DCHECK there). */
+int orc_make_groupings(const uint32_t* ids, int64_t n, uint32_t num_groups, int32_t* out_offsets,
+                       int32_t* out_indices);
+
 /* e3: implicit promotion.  orc_compare / orc_arith accept two ARRAYS of different numeric types and
  * do what Function::Execute does: DispatchBest (scalar_compare.cc:75-98, scalar_arithmetic.cc:389-412)
  * picks CommonNumeric (codegen_internal.cc:220-268), both operands are cast with CastOptions::Safe

@@ -521,6 +521,19 @@ int ref_arith(int op, const orc_array* lhs, const void* ls, const orc_array* rhs
   return Binary(kArithNames[op], lhs, ls, rhs, rs, out_values, out_validity, out);
 }
 
+int ref_make_groupings(const uint32_t* ids, int64_t n, uint32_t num_groups, int32_t* out_offsets, int32_t* out_indices) {
+  for (int64_t i = 0; i < n; ++i)
+    if (ids[i] >= num_groups) { g_err = "MakeGroupings: an id is not below num_groups"; return ORC_INVALID; }  // DCHECK in the reference
+  UInt32Array arr(n, Buffer::Wrap(ids, static_cast<size_t>(n)));
+  auto res = compute::internal::Grouper::MakeGroupings(arr, num_groups, Ctx());
+  if (!res.ok()) return Fail(res.status());
+  const ListArray& l = **res;
+  memcpy(out_offsets, l.raw_value_offsets(), sizeof(int32_t) * (static_cast<size_t>(num_groups) + 1));
+  const auto& v = static_cast<const Int32Array&>(*l.values());
+  if (n > 0) memcpy(out_indices, v.raw_values(), sizeof(int32_t) * static_cast<size_t>(n));
+  return 0;
+}
+
 // ---- mask-building scalars -------------------------------------------------
 static const char* kBoolNames[] = {"invert", "and", "and_not", "or", "xor", "and_kleene", "and_not_kleene", "or_kleene"};
 

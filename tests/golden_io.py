@@ -248,6 +248,10 @@ def iter_cases():
     yield ("arith", dict(op=0), [Arr(orc.INT64, np.array([-1])), Arr(orc.UINT64, np.array([2**64 - 1], np.uint64))])
     yield ("compare", dict(op=2), [Arr(orc.UINT64, np.array([2**63, 5], np.uint64), np.array([False, True])),
                                    Arr(orc.INT16, np.array([3, 7], np.int16))])
+    # ---- Grouper::MakeGroupings (hash_aggregate_test.cc:423-452 has literals only): random ids, empty groups at
+    # both ends and in between, one group, no rows ----
+    for n, ng, hi in [(0, 3, 1), (1, 1, 0), (500, 8, 7), (500, 64, 40), (3000, 1000, 999), (3000, 5000, 4999), (777, 2, 0)]:
+        yield ("make_groupings", dict(num_groups=ng), [Arr(orc.UINT32, rng.integers(0, hi, n, endpoint=True))])
 
 
 def run_case(api, op, params, arrs):
@@ -317,6 +321,9 @@ def run_case(api, op, params, arrs):
             return res(api.compare(params["op"], arrs[0], rhs))
         if op == "arith":
             return res(api.arith(params["op"], arrs[0], arrs[1]))
+        if op == "make_groupings":
+            off, idx = api.make_groupings(arrs[0].values(), params["num_groups"])
+            return {"offsets": np.asarray(off, np.int32), "indices": np.asarray(idx, np.int32)}
         if op == "cast":
             return {"values": api.cast(arrs[0], params["to"], bool(params["safe"])).view(np.uint8)}
         if op == "boolean":

@@ -137,6 +137,12 @@ class GpuApi:
         f = lambda x: up(x) if isinstance(x, orc.Arr) else x  # noqa: E731
         return self._wrap(lambda: down(compute.arith(self.ctx, op, f(lhs), f(rhs))))
 
+    def make_groupings(self, ids, num_groups):
+        def run():
+            off, idx = compute.make_groupings(self.ctx, up(orc.Arr(orc.UINT32, np.asarray(ids, np.uint32))), num_groups)
+            return off.cpu().numpy(), idx.cpu().numpy()
+        return self._wrap(run)
+
     def common_numeric(self, type_a, type_b):
         t = compute.common_numeric(type_a, type_b)
         return -1 if t is None else t

@@ -163,6 +163,12 @@ def run_all(api, skip_grouper_multi_batch=False):
                     check(grp["source"] + " dictionary", logical(dic.values, np.ones(dic.length, bool)), expect(t, c["dictionary"]))
                     check(grp["source"] + " indices", logical(i.values, i.validity() if i.has_validity else np.ones(i.length, bool)),
                           expect(orc.INT32, c["indices"]))
+    for grp in lit["make_groupings"]:
+        for c in grp["cases"]:
+            off, idx = api.make_groupings(np.array(c["ids"], np.uint32), len(c["groupings"]))
+            got = [idx[off[g]:off[g + 1]].tolist() for g in range(len(c["groupings"]))]
+            if got != c["groupings"]:
+                fails.append("%s %s: got %s" % (grp["source"], c["ids"], got))
     for grp in lit["grouper"]:
         for t in TYPE_GROUPS[grp["types"]]:
             batches = [[arr(t, b["keys"])] for b in grp["batches"]]

@@ -408,6 +408,15 @@ class Api:
         finally:
             self._f("grouper_free")(C.c_void_p(g))
 
+    def make_groupings(self, ids, num_groups):
+        """Grouper::MakeGroupings -> (offsets int32[num_groups + 1], indices int32[n])"""
+        ids = np.ascontiguousarray(ids, np.uint32)
+        off = np.zeros(num_groups + 1, np.int32)
+        idx = np.zeros(max(len(ids), 1), np.int32)
+        self._check(self._f("make_groupings")(ids.ctypes.data_as(C.c_void_p), C.c_int64(len(ids)), C.c_uint32(num_groups),
+                                              off.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p)))
+        return off, idx[:len(ids)]
+
     def hash_aggregate(self, func, values, ids, num_groups, count_mode=0):
         """func: 'sum' | 'count' | 'mean'.  Returns Result with 8-byte values viewed per out type."""
         fid = {"sum": 0, "count": 1, "mean": 2}[func]

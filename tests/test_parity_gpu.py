@@ -1154,3 +1154,16 @@ def test_casts_and_implicit_promotion_large(gpu, oracle):
             k = op if fn == "arith" else op % 6
             want, got = getattr(oracle, fn)(k, a, b), getattr(gpu, fn)(k, a, b)
             assert got.type_id == want.type_id and got.same(want), (fn, k, tb)
+
+
+@pytest.mark.gpu
+def test_make_groupings_large(gpu, oracle):
+    """Grouper::MakeGroupings at sizes where the sort behind it takes its multi-pass paths: dense ids, sparse ids with
+    long runs of empty groups, a single group, and an id that is not below num_groups."""
+    rng = np.random.default_rng(77)
+    for n, ng, hi in [(2_000_000, 1000, 999), (1_500_000, 3_000_000, 2_999_999), (300_000, 1, 0), (100_000, 1 << 20, 5)]:
+        ids = rng.integers(0, hi, n, endpoint=True).astype(np.uint32)
+        want, got = oracle.make_groupings(ids, ng), gpu.make_groupings(ids, ng)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (n, ng)
+    with pytest.raises(orc.StatusError):
+        gpu.make_groupings(np.array([0, 7, 1], np.uint32), 7)
