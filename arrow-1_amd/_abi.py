@@ -6,6 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libamdarrow.so")
 
+POWER, POWER_CHECKED, NEGATE, NEGATE_CHECKED = 8, 9, 10, 11  # after add ... divide_checked (0-7)
 BOOL, UINT8, INT8, UINT16, INT16, UINT32, INT32, UINT64, INT64, FLOAT, DOUBLE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12
 DROP, EMIT_NULL = 0, 1
 ASCENDING, DESCENDING = 0, 1

@@ -243,8 +243,16 @@ def compare(ctx, op, lhs, rhs):
     return _binary(ctx, ctx.lib.amdarrow_compare, op, lhs, rhs, BOOL)
 
 
-def arith(ctx, op, lhs, rhs):
-    """add / subtract / multiply / divide [+ _checked] -- scalar_arithmetic.cc:69-251."""
+def arith(ctx, op, lhs, rhs=None):
+    """add / subtract / multiply / divide [+ _checked], power[_checked], negate[_checked] (unary: rhs unused) --
+    scalar_arithmetic.cc:69-356."""
+    if op >= _abi.NEGATE:
+        dev, n = lhs.values.device, lhs.length
+        out_v = alloc_bytes(_values_bytes(lhs.type_id, n), dev)
+        out_b = alloc_bytes((n + 7) // 8, dev)
+        out, c = COut(), lhs.c()
+        check(ctx.lib, ctx.lib.amdarrow_arith(ctx.handle, op, C.byref(c), None, None, None, _ptr(out_v), _ptr(out_b), C.byref(out)))
+        return DeviceArray(lhs.type_id, out_v, out_b, out.length, 0, out.null_count)
     lhs, rhs = _implicitly_cast(ctx, lhs, rhs)
     return _binary(ctx, ctx.lib.amdarrow_arith, op, lhs, rhs, None)
 

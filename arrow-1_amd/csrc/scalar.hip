@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kThreads) void k_compare(int op, Operand l, Operand
 
 // error word: (row << 2 | kind), max over rows => the LAST failing row decides the message,
 // as *st is overwritten per failing element in the reference loops.
-enum { kErrOverflow = 1, kErrDivZero = 2 };
+enum { kErrOverflow = 1, kErrDivZero = 2, kErrNegativePower = 3 };
 
 template <typename T, typename U, bool kSigned>
 __device__ __forceinline__ T IntOp(int op, T l, T r, bool valid, int* err) {
@@ -86,11 +86,40 @@ __device__ __forceinline__ T IntOp(int op, T l, T r, bool valid, int* err) {
     case AMDARROW_ADD: return static_cast<T>(static_cast<U>(static_cast<U>(l) + static_cast<U>(r)));
     case AMDARROW_SUB: return static_cast<T>(static_cast<U>(static_cast<U>(l) - static_cast<U>(r)));
     case AMDARROW_MUL: return static_cast<T>(static_cast<uint64_t>(static_cast<U>(l)) * static_cast<uint64_t>(static_cast<U>(r)));
+    case AMDARROW_NEGATE: return static_cast<T>(static_cast<U>(~static_cast<U>(l) + 1));  // :253-268 (SafeSignedNegate wraps)
+    case AMDARROW_POWER: {  // Power::IntegerPower :296-318: right to left in uint64, every slot
+      if (kSigned && r < 0) { *err = kErrNegativePower; return 0; }
+      uint64_t base = static_cast<uint64_t>(l), exp = static_cast<uint64_t>(r), pow = 1;
+      while (exp) {
+        pow *= (exp & 1) ? base : 1;
+        base *= base;
+        exp >>= 1;
+      }
+      return static_cast<T>(pow);
+    }
     default: break;
   }
   if (!valid) return 0;  // ScalarBinaryNotNull::WriteNull
   T res = 0;
   switch (op) {
+    case AMDARROW_NEGATE_CHECKED:  // NegateWithOverflow :270-279 (signed only)
+      if (__builtin_sub_overflow(static_cast<T>(0), l, &res)) *err = kErrOverflow;
+      break;
+    case AMDARROW_POWER_CHECKED: {  // :322-351: left to right with overflow checks
+      if (kSigned && r < 0) { *err = kErrNegativePower; return 0; }
+      if (r == 0) return 1;
+      bool overflow = false;
+      uint64_t bitmask = 1ull << (63 - __clzll(static_cast<long long>(static_cast<uint64_t>(r))));
+      T pow = 1;
+      while (bitmask) {
+        overflow |= __builtin_mul_overflow(pow, pow, &pow);
+        if (static_cast<uint64_t>(r) & bitmask) overflow |= __builtin_mul_overflow(pow, l, &pow);
+        bitmask >>= 1;
+      }
+      if (overflow) *err = kErrOverflow;
+      res = pow;
+      break;
+    }
     case AMDARROW_ADD_CHECKED: if (__builtin_add_overflow(l, r, &res)) *err = kErrOverflow; break;
     case AMDARROW_SUB_CHECKED: if (__builtin_sub_overflow(l, r, &res)) *err = kErrOverflow; break;
     case AMDARROW_MUL_CHECKED: if (__builtin_mul_overflow(l, r, &res)) *err = kErrOverflow; break;
@@ -104,16 +133,23 @@ __device__ __forceinline__ T IntOp(int op, T l, T r, bool valid, int* err) {
   }
   return res;
 }
+// std::pow (:314-318).  float32 goes through the double-precision pow and one rounding: within 1 ulp of the host
+// libm's powf; float64 is ocml's pow (<= 2 ulp from the correctly rounded value glibc returns).
+template <typename T> __device__ __forceinline__ T PowAs(T l, T r) { return static_cast<T>(pow(static_cast<double>(l), static_cast<double>(r))); }
 template <typename T>
 __device__ __forceinline__ T FloatOp(int op, T l, T r, bool valid, int* err) {
   switch (op) {
     case AMDARROW_ADD: return l + r;
     case AMDARROW_SUB: return l - r;
     case AMDARROW_MUL: return l * r;
+    case AMDARROW_NEGATE: return -l;
+    case AMDARROW_POWER: return PowAs<T>(l, r);
     default: break;
   }
   if (!valid) return 0;
   switch (op) {
+    case AMDARROW_NEGATE_CHECKED: return -l;
+    case AMDARROW_POWER_CHECKED: return PowAs<T>(l, r);
     case AMDARROW_ADD_CHECKED: return l + r;
     case AMDARROW_SUB_CHECKED: return l - r;
     case AMDARROW_MUL_CHECKED: return l * r;
@@ -130,7 +166,7 @@ __global__ __launch_bounds__(kThreads) void k_arith(int op, Operand l, Operand r
   unsigned long long my_err = 0;
   for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < n; i += int64_t(gridDim.x) * kThreads) {
     const T a = LoadOp<T>(l, i), b = LoadOp<T>(r, i);
-    const bool valid = op < AMDARROW_DIV ? true : GetBit(out_valid, i);
+    const bool valid = (op < AMDARROW_DIV || op == AMDARROW_POWER || op == AMDARROW_NEGATE) ? true : GetBit(out_valid, i);
     int err = 0;
     T res;
     if constexpr (kKind == 2) res = FloatOp<T>(op, a, b, valid, &err);
@@ -457,9 +493,14 @@ int amdarrow_arith(amdarrow_ctx* ctx, int op, const amdarrow_array* lhs, const v
                    const amdarrow_array* rhs, const void* rhs_scalar, void* out_values, uint8_t* out_validity,
                    amdarrow_out* out) {
   int type; int64_t n;
+  if (op < AMDARROW_ADD || op > AMDARROW_NEGATE_CHECKED) return SetError(AMDARROW_INVALID, "arith: bad operator");
+  static const uint64_t zero = 0;
+  if (op >= AMDARROW_NEGATE) { rhs = nullptr; rhs_scalar = &zero; }  // unary: the right operand is not read
   AA_TRY(CheckBinary(lhs, lhs_scalar, rhs, rhs_scalar, &type, &n));
   if (type == AMDARROW_BOOL) return SetError(AMDARROW_NOT_IMPLEMENTED, "arithmetic on boolean");
-  if (op < AMDARROW_ADD || op > AMDARROW_DIV_CHECKED) return SetError(AMDARROW_INVALID, "arith: bad operator");
+  if (op == AMDARROW_NEGATE_CHECKED && (type == AMDARROW_UINT8 || type == AMDARROW_UINT16 || type == AMDARROW_UINT32 || type == AMDARROW_UINT64))
+    return SetError(AMDARROW_NOT_IMPLEMENTED, "Function negate_checked has no kernel matching input types (array[uint" +
+                                                  std::to_string(BitWidth(type)) + "])");  // :454-466: none registered
   std::lock_guard<std::mutex> lock(ctx->mu);
   AA_TRY(Propagate(ctx, lhs, rhs, n, out_validity, out));
   if (n == 0) return AMDARROW_OK;
@@ -490,7 +531,8 @@ int amdarrow_arith(amdarrow_ctx* ctx, int op, const amdarrow_array* lhs, const v
   if (can_fail) {
     unsigned long long e = 0;
     AA_TRY(ReadBack(ctx, err_word, 8, &e));
-    if (e) return SetError(AMDARROW_INVALID, (e & 3) == kErrDivZero ? "divide by zero" : "overflow");
+    if (e) return SetError(AMDARROW_INVALID, (e & 3) == kErrDivZero ? "divide by zero" :
+                           (e & 3) == kErrNegativePower ? "integers to negative integer powers are not allowed" : "overflow");
   }
   return AMDARROW_OK;
 }

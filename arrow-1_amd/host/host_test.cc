@@ -724,6 +724,41 @@ static void PromotionTests(const std::shared_ptr<MemoryPool>& pool, ExecContext*
   r = CallFunction("multiply", {Datum(i8->Slice(1, 3)), Datum(f64->Slice(0, 3))}, ctx);
   CHECK_OK(r.status());
   if (r.ok()) CHECK(Same(Host<double>(pool, *r->array()), {V(double, 0.0), V(double, 8.0), N(double)}));
+  // negate / power (scalar_arithmetic_test.cc:479-592, 708-861 literals)
+  r = CallFunction("negate", {Datum(i8)}, ctx);
+  CHECK_OK(r.status());
+  if (r.ok()) CHECK(Same(Host<int8_t>(pool, *r->array()), {V(int8_t, 16), V(int8_t, 0), V(int8_t, -16), N(int8_t)}));
+  r = CallFunction("negate", {Datum(u32)}, ctx);  // unsigned: ~x + 1
+  CHECK_OK(r.status());
+  if (r.ok()) CHECK(Same(Host<uint32_t>(pool, *r->array()), {V(uint32_t, 4294967293u), V(uint32_t, 4294967292u), V(uint32_t, 4294967291u), V(uint32_t, 4294967289u)}));
+  auto mins = Dev<int8_t>(pool, int8(), {V(int8_t, -128), V(int8_t, 127)});
+  r = CallFunction("negate", {Datum(mins)}, ctx);  // wraps
+  CHECK_OK(r.status());
+  if (r.ok()) CHECK(Same(Host<int8_t>(pool, *r->array()), {V(int8_t, -128), V(int8_t, -127)}));
+  r = CallFunction("negate_checked", {Datum(mins)}, ctx);
+  CHECK(r.status().IsInvalid() && r.status().message() == "overflow");
+  CHECK(CallFunction("negate_checked", {Datum(u32)}, ctx).status().IsNotImplemented());
+  auto base = Dev<int32_t>(pool, int32(), {V(int32_t, 2), V(int32_t, -3), N(int32_t), V(int32_t, 7)});
+  auto expo = Dev<int32_t>(pool, int32(), {V(int32_t, 10), V(int32_t, 3), V(int32_t, 2), V(int32_t, 0)});
+  r = CallFunction("power", {Datum(base), Datum(expo)}, ctx);
+  CHECK_OK(r.status());
+  if (r.ok()) CHECK(Same(Host<int32_t>(pool, *r->array()), {V(int32_t, 1024), V(int32_t, -27), N(int32_t), V(int32_t, 1)}));
+  r = CallFunction("power", {Datum(base), Datum(Scalar::Make<int32_t>(int32(), -1))}, ctx);
+  CHECK(r.status().IsInvalid() && r.status().message() == "integers to negative integer powers are not allowed");
+  r = CallFunction("power_checked", {Datum(base), Datum(Scalar::Make<int32_t>(int32(), 40))}, ctx);
+  CHECK(r.status().IsInvalid() && r.status().message() == "overflow");
+  r = CallFunction("power", {Datum(base), Datum(Scalar::Make<int32_t>(int32(), 40))}, ctx);  // wraps in uint64
+  CHECK_OK(r.status());
+  if (r.ok()) CHECK(Same(Host<int32_t>(pool, *r->array()), {V(int32_t, 0), V(int32_t, int32_t(12157665459056928801ull)), N(int32_t), V(int32_t, int32_t(12233820880559894977ull))}));
+  r = CallFunction("power", {Datum(f64), Datum(Scalar::Make<double>(float64(), 2.0))}, ctx);
+  CHECK_OK(r.status());
+  if (r.ok()) {  // pow(): within 2 ulp of the host libm (include/amdarrow.h)
+    auto got = Host<double>(pool, *r->array());
+    const double want[4] = {0.0625, 0.25, 0.5625, 1.0};
+    for (int i = 0; i < 4; ++i) CHECK(got[i].valid && std::fabs(got[i].v - want[i]) <= want[i] * 4.5e-16);
+  }
+  r = CallFunction("power", {Datum(i8), Datum(f64)}, ctx);  // promoted to float64 first
+  CHECK(r.ok() && r->type()->id() == Type::DOUBLE);
   // explicit casts
   auto wide = Dev<int64_t>(pool, int64(), {V(int64_t, 1), V(int64_t, -2), N(int64_t), V(int64_t, 1099511627776ll)});
   r = Cast(Datum(wide), int32(), CastOptions::Safe(), ctx);

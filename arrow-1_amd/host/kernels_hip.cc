@@ -216,6 +216,21 @@ Status ExecArith(KernelContext* ctx, const ExecBatch& batch, Datum* out) {
   return Status::OK();
 }
 
+// negate / negate_checked (scalar_arithmetic.cc:253-294): ScalarUnary / ScalarUnaryNotNull over one array
+template <int kOp>
+Status ExecNegate(KernelContext* ctx, const ExecBatch& batch, Datum* out) {
+  if (!batch[0].is_array()) return Status::NotImplemented("negate of a scalar is left to the CPU caller");
+  const amdarrow_array a = batch[0].array()->abi();
+  auto type = batch[0].type();
+  AMD_ASSIGN_OR_RAISE(auto vbuf, ctx->Allocate(ValueBytes(*type, a.length)));
+  AMD_ASSIGN_OR_RAISE(auto nbuf, ctx->AllocateBitmap(a.length));
+  amdarrow_out o;
+  const int rc = amdarrow_arith(ctx->abi(), kOp, &a, nullptr, nullptr, nullptr, vbuf->mutable_data(), nbuf->mutable_data(), &o);
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  *out = Datum(ArrayData::Make(type, o.length, {nbuf, vbuf}, o.null_count));
+  return Status::OK();
+}
+
 // ---- mask-building scalars: scalar_boolean.cc / scalar_validity.cc / scalar_fill_null.cc ----
 int ScalarState(const Scalar& s) {
   return !s.is_valid ? AMDARROW_SCALAR_NULL : (s.bits & 0xFF) ? AMDARROW_SCALAR_TRUE : AMDARROW_SCALAR_FALSE;
@@ -926,8 +941,24 @@ void RegisterScalarComparison(FunctionRegistry* registry) {
 }
 void RegisterScalarArithmetic(FunctionRegistry* registry) {
   static const char* names[] = {"add", "subtract", "multiply", "divide",
-                                "add_checked", "subtract_checked", "multiply_checked", "divide_checked"};
-  AddBinaryFunctions(registry, names, 8, false, [](int op) { return PickArith<0, 1, 2, 3, 4, 5, 6, 7>(op); });
+                                "add_checked", "subtract_checked", "multiply_checked", "divide_checked",
+                                "power", "power_checked"};
+  AddBinaryFunctions(registry, names, 10, false, [](int op) { return PickArith<0, 1, 2, 3, 4, 5, 6, 7, 8, 9>(op); });
+  // MakeUnaryArithmeticFunction<Negate> over every number type, MakeUnarySignedArithmeticFunctionNotNull<NegateChecked>
+  // over the signed and floating ones (:437-466, 589-596)
+  for (int checked = 0; checked < 2; ++checked) {
+    auto func = std::make_shared<PromotingFunction>(checked ? "negate_checked" : "negate", Arity::Unary());
+    for (Type::type t : kNumeric) {
+      if (checked && is_integer(t) && !is_signed_integer(t)) continue;
+      ScalarKernel k;
+      k.signature.in_types = {InputType::Exact(t)};
+      k.signature.out_type = FirstArgOut();
+      k.exec = checked ? ExecNegate<AMDARROW_NEGATE_CHECKED> : ExecNegate<AMDARROW_NEGATE>;
+      k.can_write_into_slices = false;
+      (void)func->AddKernel(std::move(k));
+    }
+    (void)registry->AddFunction(std::move(func));
+  }
 }
 
 template <int... kOps>

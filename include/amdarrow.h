@@ -52,7 +52,9 @@ enum { AMDARROW_EQ = 0, AMDARROW_NE, AMDARROW_GT, AMDARROW_GE, AMDARROW_LT, AMDA
 /* add/subtract/multiply/divide[_checked], compute/kernels/scalar_arithmetic.cc:69-251 */
 enum {
   AMDARROW_ADD = 0, AMDARROW_SUB, AMDARROW_MUL, AMDARROW_DIV,
-  AMDARROW_ADD_CHECKED, AMDARROW_SUB_CHECKED, AMDARROW_MUL_CHECKED, AMDARROW_DIV_CHECKED
+  AMDARROW_ADD_CHECKED, AMDARROW_SUB_CHECKED, AMDARROW_MUL_CHECKED, AMDARROW_DIV_CHECKED,
+  AMDARROW_POWER, AMDARROW_POWER_CHECKED,  /* scalar_arithmetic.cc:296-356 */
+  AMDARROW_NEGATE, AMDARROW_NEGATE_CHECKED /* :253-294; unary: rhs / rhs_scalar are ignored (may be NULL) */
 };
 enum { AMDARROW_HASH_SUM = 0, AMDARROW_HASH_COUNT = 1, AMDARROW_HASH_MEAN = 2 };
 
@@ -203,7 +205,10 @@ int amdarrow_compare(amdarrow_ctx* ctx, int op, const amdarrow_array* lhs,
                      uint8_t* out_bits, uint8_t* out_validity, amdarrow_out* out);
 /* Unchecked add/sub/mul write every slot (ScalarBinary, codegen_internal.h:758-824);
  * divide and *_checked write 0 at null slots (ScalarBinaryNotNull, :828-932) and fail with
- * AMDARROW_INVALID "overflow" / "divide by zero". */
+ * AMDARROW_INVALID "overflow" / "divide by zero".  power is unchecked in the same sense (every slot, integer
+ * powers wrap in uint64) yet fails with "integers to negative integer powers are not allowed" for a negative
+ * exponent in ANY slot, as the reference does; floating point powers are pow(): float64 within 2 ulp, float32
+ * within 1 ulp of the reference's libm result (everything else on this entry point is bit-exact). */
 int amdarrow_arith(amdarrow_ctx* ctx, int op, const amdarrow_array* lhs,
                    const void* lhs_scalar, const amdarrow_array* rhs, const void* rhs_scalar,
                    void* out_values, uint8_t* out_validity, amdarrow_out* out);

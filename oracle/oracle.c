@@ -1067,6 +1067,25 @@ int orc_compare(int op, const orc_array* lhs, const void* ls, const orc_array* r
       case ORC_ADD: res = (T)((U)l + (U)r); break;                                        \
       case ORC_SUB: res = (T)((U)l - (U)r); break;                                        \
       case ORC_MUL: res = (T)((uint64_t)(U)l * (uint64_t)(U)r); break; /* :145-185 */      \
+      case ORC_NEGATE: res = (T)(U)(~(U)l + 1); break; /* :259-267 */                      \
+      case ORC_NEGATE_CHECKED: if (!valid) break; /* :270-279 */                          \
+        if (__builtin_sub_overflow((T)0, l, &res)) err = "overflow"; break;               \
+      case ORC_POWER: /* :296-318, every slot */                                          \
+        if (SIGNED && r < (T)0) { err = kNegPower; res = 0; break; }                      \
+        res = (T)integer_power((uint64_t)l, (uint64_t)r); break;                          \
+      case ORC_POWER_CHECKED: if (!valid) break; /* :322-351 */                           \
+        if (SIGNED && r < (T)0) { err = kNegPower; res = 0; break; }                      \
+        if (r == 0) { res = 1; break; }                                                   \
+        { int ovf = 0; T pw = 1;                                                          \
+          uint64_t bitmask = 1ull << (63 - __builtin_clzll((uint64_t)r));                 \
+          while (bitmask) {                                                               \
+            ovf |= __builtin_mul_overflow(pw, pw, &pw);                                   \
+            if ((uint64_t)r & bitmask) ovf |= __builtin_mul_overflow(pw, l, &pw);         \
+            bitmask >>= 1;                                                                \
+          }                                                                               \
+          if (ovf) err = "overflow";                                                      \
+          res = pw; }                                                                     \
+        break;                                                                            \
       case ORC_ADD_CHECKED: if (!valid) break;                                            \
         if (__builtin_add_overflow(l, r, &res)) err = "overflow"; break;                  \
       case ORC_SUB_CHECKED: if (!valid) break;                                            \
@@ -1083,7 +1102,7 @@ int orc_compare(int op, const orc_array* lhs, const void* ls, const orc_array* r
     }                                                                                     \
     ((T*)out_values)[i] = res;                                                            \
   }
-#define ARITH_FLT(T)                                                                      \
+#define ARITH_FLT(T, POWFN)                                                                    \
   for (int64_t i = 0; i < n; ++i) {                                                       \
     const int valid = get_bit(out_validity, i);                                           \
     const T l = LOAD_AS(T, lhs, ls, i), r = LOAD_AS(T, rhs, rs, i);                       \
@@ -1091,6 +1110,10 @@ int orc_compare(int op, const orc_array* lhs, const void* ls, const orc_array* r
     switch (op) {                                                                         \
       case ORC_ADD: res = l + r; break; case ORC_SUB: res = l - r; break;                 \
       case ORC_MUL: res = l * r; break;                                                   \
+      case ORC_NEGATE: res = -l; break;                                                   \
+      case ORC_NEGATE_CHECKED: if (valid) res = -l; break;                                \
+      case ORC_POWER: res = (T)POWFN(l, r); break;                           /* :314-318 */ \
+      case ORC_POWER_CHECKED: if (valid) res = (T)POWFN(l, r); break;                     \
       case ORC_ADD_CHECKED: if (valid) res = l + r; break;                                \
       case ORC_SUB_CHECKED: if (valid) res = l - r; break;                                \
       case ORC_MUL_CHECKED: if (valid) res = l * r; break;                                \
@@ -1100,8 +1123,27 @@ int orc_compare(int op, const orc_array* lhs, const void* ls, const orc_array* r
     }                                                                                     \
     ((T*)out_values)[i] = res;                                                            \
   }
+static const char* const kNegPower = "integers to negative integer powers are not allowed";
+static uint64_t integer_power(uint64_t base, uint64_t exp) { /* Power::IntegerPower :298-307 */
+  uint64_t pow = 1;
+  while (exp) {
+    pow *= (exp & 1) ? base : 1;
+    base *= base;
+    exp >>= 1;
+  }
+  return pow;
+}
 int orc_arith(int op, const orc_array* lhs, const void* ls, const orc_array* rhs, const void* rs,
               void* out_values, uint8_t* out_validity, orc_out* out) {
+  static const uint64_t zero = 0;
+  if (op < ORC_ADD || op > ORC_NEGATE_CHECKED) return fail(ORC_INVALID, "arith: bad operator");
+  if (op >= ORC_NEGATE) { rhs = NULL; rs = &zero; } /* unary kernels, :437-466 */
+  if (op == ORC_NEGATE_CHECKED && lhs && is_unsigned_int(lhs->type_id))
+  { /* :454-466: no kernel is registered -> DispatchExact's NoMatchingKernel (function.cc:112-125) */
+    static char msg[128];
+    sprintf(msg, "Function negate_checked has no kernel matching input types (array[uint%d])", int_bits(lhs->type_id));
+    return fail(ORC_NOT_IMPLEMENTED, msg);
+  }
   if (!lhs && !rhs) return fail(ORC_INVALID, "arith: need at least one array operand");
   if (lhs && rhs && lhs->length != rhs->length)
     return fail(ORC_INVALID, "Array arguments must all be the same length");
@@ -1126,8 +1168,8 @@ int orc_arith(int op, const orc_array* lhs, const void* ls, const orc_array* rhs
     case ORC_INT32: ARITH_INT(int32_t, uint32_t, 1, INT32_MIN) break;
     case ORC_UINT64: ARITH_INT(uint64_t, uint64_t, 0, 0) break;
     case ORC_INT64: ARITH_INT(int64_t, uint64_t, 1, INT64_MIN) break;
-    case ORC_FLOAT: ARITH_FLT(float) break;
-    case ORC_DOUBLE: ARITH_FLT(double) break;
+    case ORC_FLOAT: ARITH_FLT(float, powf) break;
+    case ORC_DOUBLE: ARITH_FLT(double, pow) break;
     default: return fail(ORC_NOT_IMPLEMENTED, "arith: type");
   }
   if (err) return fail(ORC_INVALID, err);

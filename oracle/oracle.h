@@ -66,7 +66,9 @@ enum { ORC_COUNT_NON_NULL = 0, ORC_COUNT_NULL = 1 };  /* CountOptions::Mode */
 enum { ORC_EQ = 0, ORC_NE, ORC_GT, ORC_GE, ORC_LT, ORC_LE };
 enum {
   ORC_ADD = 0, ORC_SUB, ORC_MUL, ORC_DIV,
-  ORC_ADD_CHECKED, ORC_SUB_CHECKED, ORC_MUL_CHECKED, ORC_DIV_CHECKED
+  ORC_ADD_CHECKED, ORC_SUB_CHECKED, ORC_MUL_CHECKED, ORC_DIV_CHECKED,
+  ORC_POWER, ORC_POWER_CHECKED,   /* scalar_arithmetic.cc:296-356 */
+  ORC_NEGATE, ORC_NEGATE_CHECKED  /* :253-294; unary: rhs / rhs_scalar ignored */
 };
 
 int orc_bit_width(int type_id);

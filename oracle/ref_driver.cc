@@ -497,7 +497,8 @@ static Status ImplicitlyCast(const char* name, Datum* l, Datum* r) {
 
 static const char* kCmpNames[] = {"equal", "not_equal", "greater", "greater_equal", "less", "less_equal"};
 static const char* kArithNames[] = {"add", "subtract", "multiply", "divide",
-                                    "add_checked", "subtract_checked", "multiply_checked", "divide_checked"};
+                                    "add_checked", "subtract_checked", "multiply_checked", "divide_checked",
+                                    "power", "power_checked", "negate", "negate_checked"};
 
 static int Binary(const char* name, const orc_array* lhs, const void* ls, const orc_array* rhs,
                   const void* rs, void* out_values, uint8_t* out_validity, orc_out* out) {
@@ -518,6 +519,12 @@ int ref_compare(int op, const orc_array* lhs, const void* ls, const orc_array* r
 }
 int ref_arith(int op, const orc_array* lhs, const void* ls, const orc_array* rhs, const void* rs,
               void* out_values, uint8_t* out_validity, orc_out* out) {
+  if (op >= ORC_NEGATE) {  // unary
+    auto res = CallFunction(kArithNames[op], {Datum(Wrap(lhs))}, nullptr, Ctx());
+    if (!res.ok()) return Fail(res.status());
+    Export(*res->array(), out_values, out_validity, out);
+    return 0;
+  }
   return Binary(kArithNames[op], lhs, ls, rhs, rs, out_values, out_validity, out);
 }
 

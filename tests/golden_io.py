@@ -248,6 +248,31 @@ def iter_cases():
     yield ("arith", dict(op=0), [Arr(orc.INT64, np.array([-1])), Arr(orc.UINT64, np.array([2**64 - 1], np.uint64))])
     yield ("compare", dict(op=2), [Arr(orc.UINT64, np.array([2**63, 5], np.uint64), np.array([False, True])),
                                    Arr(orc.INT16, np.array([3, 7], np.int16))])
+    # ---- negate / power [+ _checked] (scalar_arithmetic_test.cc:479-592 Negate*, :708-861 Power*): wrap-around and
+    # overflow at the type's edges, negative exponents (also under a null: the unchecked kernel visits every slot) ----
+    for t in NUMERIC:
+        a = R(rng, t, 200, 0.2, 3, lo=-6, hi=6)
+        if t in (FLOAT, DOUBLE):
+            e = R(rng, t, 200, 0.1, 5, lo=-3, hi=3)
+            edge = Arr(t, np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.5, -2.0, 1e30], orc.NP_OF[t]))
+            edge_e = Arr(t, np.array([0.0, -1.0, 2.0, 3.0, 0.0, np.inf, 0.5, 4.0], orc.NP_OF[t]))
+        else:
+            info = np.iinfo(orc.NP_OF[t])
+            e = R(rng, t, 200, 0.1, 5, lo=0, hi=3)
+            edge = Arr(t, np.array([info.min, info.max, 0, 1, 2, 3, 7, info.max // 2], orc.NP_OF[t]),
+                       np.array([1, 1, 1, 1, 0, 1, 1, 1], bool))
+            edge_e = Arr(t, np.array([1, 1, 0, info.max, 9, 40, 2, 2], orc.NP_OF[t]))
+        for op in (10, 11):
+            yield ("arith", dict(op=op), [a])
+            yield ("arith", dict(op=op), [edge])
+        for op in (8, 9):
+            yield ("arith", dict(op=op), [a, e])
+            yield ("arith", dict(op=op), [edge, edge_e])
+        if t in (orc.INT8, orc.INT16, orc.INT32, orc.INT64):
+            neg = Arr(t, np.array([2, 3, 4], orc.NP_OF[t]))
+            yield ("arith", dict(op=8), [neg, Arr(t, np.array([1, -1, 2], orc.NP_OF[t]))])
+            yield ("arith", dict(op=9), [neg, Arr(t, np.array([1, -1, 2], orc.NP_OF[t]), np.array([1, 0, 1], bool))])
+            yield ("arith", dict(op=8), [neg, Arr(t, np.array([1, -1, 2], orc.NP_OF[t]), np.array([1, 0, 1], bool))])
     # ---- Grouper::MakeGroupings (hash_aggregate_test.cc:423-452 has literals only): random ids, empty groups at
     # both ends and in between, one group, no rows ----
     for n, ng, hi in [(0, 3, 1), (1, 1, 0), (500, 8, 7), (500, 64, 40), (3000, 1000, 999), (3000, 5000, 4999), (777, 2, 0)]:
@@ -320,7 +345,12 @@ def run_case(api, op, params, arrs):
             rhs = arrs[1] if len(arrs) > 1 else params["rhs_scalar"]
             return res(api.compare(params["op"], arrs[0], rhs))
         if op == "arith":
-            return res(api.arith(params["op"], arrs[0], arrs[1]))
+            r = api.arith(params["op"], arrs[0], arrs[1] if len(arrs) > 1 else None)
+            if params["op"] == 11 and r.has_validity:
+                # negate_checked: ScalarUnaryNotNull skips null slots (codegen_internal.h:622-631 "++out_data"), what
+                # they hold in the reference is whatever the allocation held -> compared as 0
+                r.values = np.where(r.validity(), r.values, np.zeros(1, r.values.dtype))
+            return res(r)
         if op == "make_groupings":
             off, idx = api.make_groupings(arrs[0].values(), params["num_groups"])
             return {"offsets": np.asarray(off, np.int32), "indices": np.asarray(idx, np.int32)}

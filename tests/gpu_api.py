@@ -133,7 +133,7 @@ class GpuApi:
         f = lambda x: up(x) if isinstance(x, orc.Arr) else x  # noqa: E731
         return self._wrap(lambda: down(compute.compare(self.ctx, op, f(lhs), f(rhs))))
 
-    def arith(self, op, lhs, rhs):
+    def arith(self, op, lhs, rhs=None):
         f = lambda x: up(x) if isinstance(x, orc.Arr) else x  # noqa: E731
         return self._wrap(lambda: down(compute.arith(self.ctx, op, f(lhs), f(rhs))))
 

@@ -196,6 +196,9 @@ class StatusError(Exception):
         self.code, self.msg = code, msg
 
 
+POWER, POWER_CHECKED, NEGATE, NEGATE_CHECKED = 8, 9, 10, 11
+
+
 def build_oracle():
     """gcc-compile oracle/oracle.c -> oracle/liboracle.so (seconds)."""
     so = os.path.join(ROOT, "oracle", "liboracle.so")
@@ -477,7 +480,15 @@ class Api:
     def compare(self, op, lhs, rhs):
         return self._binary("compare", op, lhs, rhs, BOOL)
 
-    def arith(self, op, lhs, rhs):
+    def arith(self, op, lhs, rhs=None):
+        """op 0-7 add ... divide_checked, 8 / 9 power[_checked], 10 / 11 negate[_checked] (unary: rhs unused)"""
+        if op >= NEGATE:
+            ov = np.zeros((lhs.length + 64) * 8 + 16, np.uint8)
+            ob = np.zeros(lhs.length // 8 + 16, np.uint8)
+            out, c = COut(), lhs.c()
+            self._check(self._f("arith")(op, C.byref(c), None, None, None, ov.ctypes.data_as(C.c_void_p), ob.ctypes.data_as(C.c_void_p),
+                                         C.byref(out)))
+            return self._result(lhs.type_id, ov, ob, out)
         return self._binary("arith", op, lhs, rhs, None)
 
     # ---- SURVEY 8f.1: mask-building scalars ----

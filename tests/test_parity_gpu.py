@@ -42,6 +42,13 @@ def test_committed_reference_outputs(gpu):
             if op == "hash_min_max" and arrs[0].type_id in (FLOAT, DOUBLE):
                 is_f64 = "f4" if arrs[0].type_id == FLOAT else "f8"  # float extremes: equal as values
             ok, msg = golden_io.same_output(got, want, float_tol=is_f64)
+            if not ok and op == "arith" and params["op"] in (8, 9) and arrs[0].type_id in (FLOAT, DOUBLE):
+                # pow(): the device's libm against the host's -- float64 within 2 ulp, float32 within 1 ulp
+                # (include/amdarrow.h); everything but the values bit-exact
+                dt, tol = (np.float32, 2.0 ** -23) if arrs[0].type_id == FLOAT else (np.float64, 2.0 ** -51)
+                rest = {k: v for k, v in got.items() if k != "values"}, {k: v for k, v in want.items() if k != "values"}
+                ok = golden_io.same_output(*rest)[0] and np.allclose(got["values"].view(dt), want["values"].view(dt), rtol=tol, atol=0,
+                                                                      equal_nan=True)
         if not ok:
             bad.append("case %d %s %s: %s" % (i, op, params, msg))
     assert not bad, "\n".join(bad[:20])
