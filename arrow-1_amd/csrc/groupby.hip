@@ -1989,10 +1989,13 @@ __global__ __launch_bounds__(kThreads) void k_local_merge(LocalStage st, int64_t
 using namespace amdarrow;
 
 // ---- Grouper ------------------------------------------------------------------------------------------
+constexpr int kMaxWideKeys = 16;
+struct WideGrouper;
 struct amdarrow_grouper {
   amdarrow_ctx* ctx;
   int nkeys;
-  int types[kMaxKeys];
+  int types[kMaxWideKeys];
+  WideGrouper* wide = nullptr;  // key rows that do not fit one 64-bit word: see WideGrouper
   KeySpec spec;              // shifts/bits only (data pointers are per batch)
   uint64_t T = 0;            // table slots
   char* table_mem = nullptr; // hkeys | first | sums(unused) | counts(unused) | ids
@@ -2003,6 +2006,13 @@ struct amdarrow_grouper {
   uint32_t* wide_null_id = nullptr;  // device word
 };
 
+extern "C" {
+int amdarrow_grouper_create(amdarrow_ctx* ctx, int nkeys, const int* key_type_ids, amdarrow_grouper** out);
+int amdarrow_grouper_destroy(amdarrow_grouper* g);
+int amdarrow_grouper_consume(amdarrow_grouper* g, const amdarrow_array* keys, uint32_t* out_ids);
+int amdarrow_grouper_lookup(amdarrow_grouper* g, const amdarrow_array* keys, uint32_t* out_ids);
+int amdarrow_grouper_uniques(amdarrow_grouper* g, int k, void* out_values, uint8_t* out_validity, amdarrow_out* out);
+}
 static int GrouperAllocTable(amdarrow_grouper* g, uint64_t T, char** mem, TableMem* tm) {
   Carver c;
   CarveTable(&c, T, true, tm);
@@ -2010,11 +2020,167 @@ static int GrouperAllocTable(amdarrow_grouper* g, uint64_t T, char** mem, TableM
   return ClearTable(g->ctx, BindTable(*mem, *tm, T, true), true);
 }
 
+// ---- key rows wider than one 64-bit word (KeyEncoder rows of any width, hash_aggregate.cc:48-311, 313-437) ----
+// The packed-word table above holds keys of up to 64 - nkeys value bits.  Wider rows are grouped by composition,
+// every step exact: each key column gets its own single-column grouper (values -> dense ids), and the row's ids are
+// folded left to right, pairs[j] grouping the 64-bit word (ids so far | ids of column j + 1 << 32).  Equal rows
+// have equal id tuples and vice versa, every grouper numbers in first-appearance order and keeps its state across
+// Consume calls, so the last pair grouper's ids ARE the reference's group ids.  GetUniques walks the pair
+// dictionaries back down to the column's ids and gathers the column grouper's uniques through them.
+struct WideGrouper {
+  std::vector<amdarrow_grouper*> cols, pairs;
+  uint32_t* ids = nullptr;             // (ncols + 1) x cap row ids
+  unsigned long long* packed = nullptr;  // cap pair words
+  int64_t cap = 0;
+};
+__global__ __launch_bounds__(kThreads) void k_pack_id_pair(const uint32_t* lo, const uint32_t* hi, int64_t n, unsigned long long* out) {
+  for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < n; i += int64_t(gridDim.x) * kThreads)
+    out[i] = static_cast<unsigned long long>(lo[i]) | (static_cast<unsigned long long>(hi[i]) << 32);
+}
+// out[i] = one half of pair word of group (lst ? lst[i] : i)
+__global__ __launch_bounds__(kThreads) void k_pair_half(const unsigned long long* pair_words, const uint32_t* lst, int64_t n, int high,
+                                                        uint32_t* out) {
+  for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < n; i += int64_t(gridDim.x) * kThreads) {
+    const unsigned long long x = pair_words[lst ? lst[i] : static_cast<uint32_t>(i)];
+    out[i] = high ? static_cast<uint32_t>(x >> 32) : static_cast<uint32_t>(x);
+  }
+}
+static void WideDestroy(amdarrow_grouper* g) {
+  if (!g->wide) return;
+  for (auto* c : g->wide->cols) amdarrow_grouper_destroy(c);
+  for (auto* c : g->wide->pairs) amdarrow_grouper_destroy(c);
+  if (g->wide->ids) (void)hipFree(g->wide->ids);
+  if (g->wide->packed) (void)hipFree(g->wide->packed);
+  delete g->wide;
+  g->wide = nullptr;
+}
+static int WideCreate(amdarrow_ctx* ctx, int nkeys, const int* types, amdarrow_grouper** out) {
+  auto* g = new amdarrow_grouper;
+  g->ctx = ctx;
+  g->nkeys = nkeys;
+  for (int k = 0; k < nkeys; ++k) g->types[k] = types[k];
+  g->wide = new WideGrouper;
+  int rc = AMDARROW_OK;
+  for (int k = 0; k < nkeys && rc == AMDARROW_OK; ++k) {
+    amdarrow_grouper* c = nullptr;
+    rc = amdarrow_grouper_create(ctx, 1, &types[k], &c);
+    if (rc == AMDARROW_OK) g->wide->cols.push_back(c);
+  }
+  const int pair_type = AMDARROW_UINT64;
+  for (int j = 0; j + 1 < nkeys && rc == AMDARROW_OK; ++j) {
+    amdarrow_grouper* c = nullptr;
+    rc = amdarrow_grouper_create(ctx, 1, &pair_type, &c);
+    if (rc == AMDARROW_OK) g->wide->pairs.push_back(c);
+  }
+  if (rc != AMDARROW_OK) { WideDestroy(g); delete g; return rc; }
+  *out = g;
+  return AMDARROW_OK;
+}
+static int WideIds(amdarrow_grouper* g, const amdarrow_array* keys, uint32_t* out_ids, bool insert) {
+  amdarrow_ctx* ctx = g->ctx;
+  WideGrouper* w = g->wide;
+  const int K = g->nkeys;
+  const int64_t n = keys[0].length;
+  for (int k = 0; k < K; ++k) {
+    if (keys[k].type_id != g->types[k]) return SetError(AMDARROW_TYPE_ERROR, "grouper: key type differs from Make()");
+    if (keys[k].length != n) return SetError(AMDARROW_INVALID, "Array arguments must all be the same length");
+  }
+  if (n == 0) return AMDARROW_OK;
+  if (n > w->cap) {
+    AA_HIP(hipStreamSynchronize(ctx->stream));
+    if (w->ids) (void)hipFree(w->ids);
+    if (w->packed) (void)hipFree(w->packed);
+    w->ids = nullptr; w->packed = nullptr; w->cap = 0;
+    AA_HIP(hipMalloc(reinterpret_cast<void**>(&w->ids), 4 * static_cast<size_t>(K + 1) * static_cast<size_t>(n)));
+    AA_HIP(hipMalloc(reinterpret_cast<void**>(&w->packed), 8 * static_cast<size_t>(n)));
+    w->cap = n;
+  }
+  for (int k = 0; k < K; ++k)
+    AA_TRY(insert ? amdarrow_grouper_consume(w->cols[k], &keys[k], w->ids + k * w->cap)
+                  : amdarrow_grouper_lookup(w->cols[k], &keys[k], w->ids + k * w->cap));
+  const uint32_t* cur = w->ids;
+  for (int j = 0; j + 1 < K; ++j) {
+    {
+      std::lock_guard<std::mutex> lock(ctx->mu);
+      hipLaunchKernelGGL(k_pack_id_pair, dim3(GridFor(n, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, cur,
+                         w->ids + (j + 1) * w->cap, n, w->packed);
+      AA_HIP(hipGetLastError());
+    }
+    amdarrow_array pa;
+    pa.values = w->packed; pa.validity = nullptr; pa.length = n; pa.offset = 0; pa.type_id = AMDARROW_UINT64; pa.null_count = 0;
+    uint32_t* dst = j + 2 == K ? out_ids : w->ids + K * w->cap;
+    AA_TRY(insert ? amdarrow_grouper_consume(w->pairs[j], &pa, dst) : amdarrow_grouper_lookup(w->pairs[j], &pa, dst));
+    cur = dst;
+  }
+  g->num_groups = w->pairs.back()->num_groups;
+  return AMDARROW_OK;
+}
+static int WideUniques(amdarrow_grouper* g, int k, void* out_values, uint8_t* out_validity, amdarrow_out* out) {
+  amdarrow_ctx* ctx = g->ctx;
+  WideGrouper* w = g->wide;
+  const int K = g->nkeys;
+  const int64_t G = g->num_groups;
+  out->length = G; out->null_count = 0; out->has_validity = 0;
+  if (G == 0) return AMDARROW_OK;
+  amdarrow_grouper* child = w->cols[k];
+  const int64_t Gc = child->num_groups;
+  char* mem = nullptr;
+  const size_t words = 8 * (static_cast<size_t>(G) + 8), bits = (static_cast<size_t>(std::max(G, Gc)) / 64 + 2) * 8;
+  const size_t lst_bytes = 8 * ((static_cast<size_t>(G) + 9) / 2), child_bytes = 8 * (static_cast<size_t>(Gc) + 8);
+  AA_HIP(hipMalloc(reinterpret_cast<void**>(&mem), words + bits + 2 * lst_bytes + child_bytes + bits));
+  auto* pair_words = reinterpret_cast<unsigned long long*>(mem);
+  auto* scratch_bits = reinterpret_cast<uint8_t*>(mem + words);
+  uint32_t* lst_buf[2] = {reinterpret_cast<uint32_t*>(mem + words + bits), reinterpret_cast<uint32_t*>(mem + words + bits + lst_bytes)};
+  char* child_values = mem + words + bits + 2 * lst_bytes;
+  auto* child_valid = reinterpret_cast<uint8_t*>(child_values + child_bytes);
+  int rc = AMDARROW_OK;
+  const uint32_t* lst = nullptr;  // identity over the G groups
+  uint32_t* col_ids = nullptr;
+  for (int j = K - 2; j >= 0 && rc == AMDARROW_OK && !col_ids; --j) {
+    amdarrow_out po;
+    rc = amdarrow_grouper_uniques(w->pairs[j], 0, pair_words, scratch_bits, &po);
+    if (rc != AMDARROW_OK) break;
+    const int high = k == j + 1;
+    uint32_t* dst = lst_buf[j & 1];
+    {
+      std::lock_guard<std::mutex> lock(ctx->mu);
+      hipLaunchKernelGGL(k_pair_half, dim3(GridFor(G, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, pair_words, lst, G,
+                         high, dst);
+      if (hipGetLastError() != hipSuccess) rc = SetError(AMDARROW_UNKNOWN_ERROR, "k_pair_half launch");
+    }
+    if (high || j == 0) col_ids = dst;  // j == 0 and not high: the low half is column 0's ids
+    lst = dst;
+  }
+  if (rc == AMDARROW_OK) {
+    amdarrow_out co;
+    rc = amdarrow_grouper_uniques(child, 0, child_values, child_valid, &co);
+    if (rc == AMDARROW_OK) {
+      amdarrow_array va, ia;
+      va.values = child_values; va.validity = co.has_validity ? child_valid : nullptr; va.length = Gc; va.offset = 0;
+      va.type_id = g->types[k]; va.null_count = co.null_count;
+      ia.values = col_ids; ia.validity = nullptr; ia.length = G; ia.offset = 0; ia.type_id = AMDARROW_UINT32; ia.null_count = 0;
+      amdarrow_out to;
+      rc = amdarrow_take(ctx, &va, &ia, /*boundscheck=*/0, out_values, out_validity, &to);
+      if (rc == AMDARROW_OK) { out->null_count = to.null_count; out->has_validity = to.null_count > 0; }
+    }
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(mem);
+  return rc;
+}
+
 extern "C" {
 
 int amdarrow_grouper_create(amdarrow_ctx* ctx, int nkeys, const int* key_type_ids, amdarrow_grouper** out) {
   KeySpec ks;
-  AA_TRY(MakeKeySpec(nkeys, nullptr, key_type_ids, &ks));
+  {
+    const int rc = MakeKeySpec(nkeys, nullptr, key_type_ids, &ks);
+    if (rc != AMDARROW_OK) {
+      bool fixed_width = nkeys >= 2 && nkeys <= kMaxWideKeys;
+      for (int k = 0; fixed_width && k < nkeys; ++k) fixed_width = BitWidth(key_type_ids[k]) >= 0;
+      return fixed_width ? WideCreate(ctx, nkeys, key_type_ids, out) : rc;
+    }
+  }
   auto* g = new amdarrow_grouper;
   g->ctx = ctx;
   g->nkeys = nkeys;
@@ -2034,6 +2200,7 @@ int amdarrow_grouper_create(amdarrow_ctx* ctx, int nkeys, const int* key_type_id
 int amdarrow_grouper_destroy(amdarrow_grouper* g) {
   if (!g) return AMDARROW_OK;
   (void)hipStreamSynchronize(g->ctx->stream);
+  WideDestroy(g);
   if (g->table_mem) (void)hipFree(g->table_mem);
   if (g->gx) (void)hipFree(g->gx);
   if (g->wide_null_id) (void)hipFree(g->wide_null_id);
@@ -2047,6 +2214,7 @@ int amdarrow_grouper_num_groups(amdarrow_grouper* g, uint32_t* out) {
 }
 
 int amdarrow_grouper_consume(amdarrow_grouper* g, const amdarrow_array* keys, uint32_t* out_ids) {
+  if (g->wide) return WideIds(g, keys, out_ids, /*insert=*/true);
   amdarrow_ctx* ctx = g->ctx;
   const int64_t n = keys[0].length;
   for (int k = 0; k < g->nkeys; ++k) {
@@ -2145,6 +2313,7 @@ int amdarrow_grouper_consume(amdarrow_grouper* g, const amdarrow_array* keys, ui
 /* Ids of rows whose keys are all known already (Grouper::Consume without the growth: no table is sized for n new
  * groups, nothing is inserted).  A key that is not in the table is an error (AMDARROW_KEY_ERROR). */
 int amdarrow_grouper_lookup(amdarrow_grouper* g, const amdarrow_array* keys, uint32_t* out_ids) {
+  if (g->wide) return WideIds(g, keys, out_ids, /*insert=*/false);
   amdarrow_ctx* ctx = g->ctx;
   const int64_t n = keys[0].length;
   for (int k = 0; k < g->nkeys; ++k) {
@@ -2173,6 +2342,7 @@ int amdarrow_grouper_lookup(amdarrow_grouper* g, const amdarrow_array* keys, uin
 int amdarrow_grouper_uniques(amdarrow_grouper* g, int k, void* out_values, uint8_t* out_validity, amdarrow_out* out) {
   amdarrow_ctx* ctx = g->ctx;
   if (k < 0 || k >= g->nkeys) return SetError(AMDARROW_INVALID, "grouper_uniques: no such key column");
+  if (g->wide) return WideUniques(g, k, out_values, out_validity, out);
   out->length = g->num_groups;
   out->null_count = 0;
   out->has_validity = 0;

@@ -758,7 +758,30 @@ Result<Datum> ScalarFunction::Execute(const std::vector<Datum>& args_in, const F
   // function.cc:175-176: the best kernel, then the arguments cast to the descriptors it settled on
   const std::vector<ValueDescr> given = descrs;
   AMD_ASSIGN_OR_RAISE(const ScalarKernel* kernel, DispatchBest(&descrs));
-  if (all_scalar) return Status::NotImplemented("Function " + name_ + ": all-scalar execution is left to the CPU caller");
+  if (all_scalar) {
+    // exec.cc:553-716: a call whose arguments are all scalars yields a scalar.  The kernels here are array kernels, so
+    // the first argument becomes a one-element array and the element of the result is boxed again.
+    std::vector<Datum> lifted = args_in;
+    const Scalar& s0 = *args_in[0].scalar();
+    if (s0.type->bit_width() < 1) return Status::NotImplemented("Function " + name_ + ": scalar of type " + s0.type->ToString());
+    const uint8_t valid_bit = s0.is_valid ? 1 : 0;
+    uint64_t bits = s0.bits;
+    AMD_ASSIGN_OR_RAISE(auto one, ArrayFromHost(ctx->memory_pool(), s0.type, &bits, 1, &valid_bit, s0.is_valid ? 0 : 1));
+    lifted[0] = Datum(one);
+    AMD_ASSIGN_OR_RAISE(Datum r, Execute(lifted, options, ctx));
+    if (!r.is_array() || r.array()->length != 1) return Status::Invalid("scalar execution did not yield one value");
+    const ArrayData& a = *r.array();
+    if (a.type->bit_width() < 1) return Status::NotImplemented("Function " + name_ + ": scalar result of type " + a.type->ToString());
+    uint64_t value = 0;
+    uint8_t vbit = 1;
+    AMD_RETURN_NOT_OK(CopyValuesToHost(a, ctx->memory_pool(), &value, &vbit));
+    auto out = std::make_shared<Scalar>();
+    out->type = a.type;
+    out->is_valid = (vbit & 1) != 0;
+    out->bits = a.type->bit_width() == 1 ? (value & 1) : value;
+    if (!out->is_valid) out->bits = 0;
+    return Datum(out);
+  }
   std::vector<Datum> cast_args;
   bool changed = false;
   for (size_t i = 0; i < descrs.size(); ++i) changed |= descrs[i].type.get() != given[i].type.get();

@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <map>
+#include <tuple>
 #include <cstdio>
 #include <cstring>
 #include <limits>
@@ -759,6 +761,24 @@ static void PromotionTests(const std::shared_ptr<MemoryPool>& pool, ExecContext*
   }
   r = CallFunction("power", {Datum(i8), Datum(f64)}, ctx);  // promoted to float64 first
   CHECK(r.ok() && r->type()->id() == Type::DOUBLE);
+  {  // scalar (x) scalar -> scalar (ScalarBinary's fourth shape, codegen_internal.h:758-824; exec.cc:553-716)
+    auto three = Datum(Scalar::Make<int32_t>(int32(), 3)), four = Datum(Scalar::Make<int32_t>(int32(), 4));
+    r = CallFunction("add", {three, four}, ctx);
+    CHECK_OK(r.status());
+    if (r.ok()) CHECK(r->is_scalar() && r->scalar()->is_valid && r->type()->id() == Type::INT32 && static_cast<int32_t>(r->scalar()->bits) == 7);
+    r = CallFunction("greater", {four, three}, ctx);
+    CHECK(r.ok() && r->is_scalar() && r->type()->id() == Type::BOOL && r->scalar()->is_valid && r->scalar()->bits == 1);
+    r = CallFunction("multiply", {three, Datum(Scalar::MakeNull(int32()))}, ctx);
+    CHECK(r.ok() && r->is_scalar() && !r->scalar()->is_valid);
+    r = CallFunction("add", {Datum(Scalar::Make<int8_t>(int8(), -5)), four}, ctx);  // promoted to int32
+    CHECK(r.ok() && r->is_scalar() && r->type()->id() == Type::INT32 && static_cast<int32_t>(r->scalar()->bits) == -1);
+    r = CallFunction("divide", {three, Datum(Scalar::Make<int32_t>(int32(), 0))}, ctx);
+    CHECK(r.status().IsInvalid() && r.status().message() == "divide by zero");
+    r = CallFunction("is_null", {Datum(Scalar::MakeNull(float64()))}, ctx);
+    CHECK(r.ok() && r->is_scalar() && r->scalar()->is_valid && r->scalar()->bits == 1);
+    r = CallFunction("negate", {three}, ctx);
+    CHECK(r.ok() && r->is_scalar() && static_cast<int32_t>(r->scalar()->bits) == -3);
+  }
   // explicit casts
   auto wide = Dev<int64_t>(pool, int64(), {V(int64_t, 1), V(int64_t, -2), N(int64_t), V(int64_t, 1099511627776ll)});
   r = Cast(Datum(wide), int32(), CastOptions::Safe(), ctx);
@@ -819,6 +839,48 @@ static void GroupingsTests(const std::shared_ptr<MemoryPool>& pool, ExecContext*
   auto with_null = Dev<uint32_t>(pool, uint32(), {V(uint32_t, 0), N(uint32_t), V(uint32_t, 1)});
   auto st = compute::internal::Grouper::MakeGroupings(*with_null, 5, ctx).status();
   CHECK(st.IsInvalid() && st.message() == "MakeGroupings with null ids");
+}
+
+// GroupBy over key rows wider than 64 bits ({int64, float64, int64}: the composed Grouper), against a host map.
+static void WideKeyGroupByTests(const std::shared_ptr<MemoryPool>& pool, ExecContext* ctx) {
+  const int64_t n = 50000;
+  std::vector<Opt<int64_t>> v, ka, kc;
+  std::vector<Opt<double>> kb;
+  uint64_t st = 99;
+  auto rnd = [&]() { st = st * 6364136223846793005ULL + 1442695040888963407ULL; return st >> 33; };
+  for (int64_t i = 0; i < n; ++i) {
+    v.push_back(V(int64_t, int64_t(rnd() % 1000)));
+    ka.push_back(rnd() % 30 == 0 ? N(int64_t) : V(int64_t, (int64_t(rnd() % 7) - 3) * 4000000000000ll));
+    kb.push_back(V(double, double(rnd() % 5) * 0.5));
+    kc.push_back(V(int64_t, int64_t(rnd() % 3) << 40));
+  }
+  auto r = internal::GroupBy({Datum(Dev<int64_t>(pool, int64(), v))},
+                             {Datum(Dev<int64_t>(pool, int64(), ka)), Datum(Dev<double>(pool, float64(), kb)), Datum(Dev<int64_t>(pool, int64(), kc))},
+                             {{"hash_sum", nullptr}}, ctx);
+  CHECK_OK(r.status());
+  if (!r.ok()) return;
+  struct Key { bool a_valid; int64_t a; double b; int64_t c; bool operator<(const Key& o) const { return std::tie(a_valid, a, b, c) < std::tie(o.a_valid, o.a, o.b, o.c); } };
+  std::map<Key, std::pair<int64_t, int64_t>> want;  // key -> (first row, sum)
+  for (int64_t i = 0; i < n; ++i) {
+    Key k{ka[i].valid, ka[i].valid ? ka[i].v : 0, kb[i].v, kc[i].v};
+    auto it = want.find(k);
+    if (it == want.end()) want[k] = {i, v[i].v};
+    else it->second.second += v[i].v;
+  }
+  CHECK(r->length == static_cast<int64_t>(want.size()) && r->columns.size() == 4);
+  auto sums = Host<int64_t>(pool, *r->columns[0]);
+  auto ga = Host<int64_t>(pool, *r->columns[1]);
+  auto gb = Host<double>(pool, *r->columns[2]);
+  auto gc = Host<int64_t>(pool, *r->columns[3]);
+  int64_t last_first = -1;
+  bool ok = true;
+  for (int64_t g = 0; g < r->length && ok; ++g) {
+    Key k{ga[g].valid, ga[g].valid ? ga[g].v : 0, gb[g].v, gc[g].v};
+    auto it = want.find(k);
+    ok = it != want.end() && it->second.second == sums[g].v && it->second.first > last_first;  // first-appearance order
+    if (ok) last_first = it->second.first;
+  }
+  CHECK(ok);
 }
 
 static int RunGpu() {
@@ -1183,6 +1245,7 @@ static int RunGpu() {
   TabularTests(pool, &ctx);
   PromotionTests(pool, &ctx);
   GroupingsTests(pool, &ctx);
+  WideKeyGroupByTests(pool, &ctx);
   CHECK(pool->bytes_allocated() >= 0 && pool->max_memory() > 0);  // the MemoryPool counters (memory_pool.h:38-105)
   printf("host_test gpu: %d checks, %d failures\n", g_checks, g_failures);
   return g_failures ? 1 : 0;

@@ -1174,3 +1174,39 @@ def test_make_groupings_large(gpu, oracle):
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (n, ng)
     with pytest.raises(orc.StatusError):
         gpu.make_groupings(np.array([0, 7, 1], np.uint32), 7)
+
+
+@pytest.mark.gpu
+def test_grouper_key_rows_wider_than_64_bits(gpu, oracle):
+    """KeyEncoder rows of any fixed width (hash_aggregate_test.cc:339-420 use {utf8, int64}, {float64, utf8, int64} and
+    four-column keys; the fixed-width shapes of those): ids in first-appearance order over several Consume calls and
+    the decoded uniques of every column, nulls, NaNs and both zeros included."""
+    rng = np.random.default_rng(4242)
+
+    def col(t, n, distinct, null_prob):
+        if t == BOOL:
+            return R(rng, BOOL, n, null_prob, 0)
+        if t in (FLOAT, DOUBLE):
+            pool = np.concatenate([rng.uniform(-5, 5, distinct), [np.nan, 0.0, -0.0]]).astype(orc.NP_OF[t])
+        else:
+            info = np.iinfo(orc.NP_OF[t])
+            pool = rng.integers(info.min, info.max, distinct, endpoint=True, dtype=np.int64 if info.min < 0 else np.uint64).astype(orc.NP_OF[t])
+        data = pool[rng.integers(0, len(pool), n)]
+        valid = (rng.random(n) >= null_prob) if null_prob > 0 else None
+        return Arr(t, data, valid)
+
+    shapes = [([orc.INT64, orc.INT64], 40), ([DOUBLE, orc.INT64, orc.INT32], 12), ([orc.INT64, orc.UINT32, orc.INT16, INT8, BOOL], 6),
+              ([orc.UINT64, DOUBLE, orc.INT64, FLOAT], 5), ([INT8, INT8, INT8, INT8, INT8], 4)]
+    for types, distinct in shapes:
+        for null_prob in (0.0, 0.15):
+            batches = [[col(t, n, distinct, null_prob) for t in types] for n in (5000, 1, 70_000)]
+            want_ids, want_ng, want_u = oracle.group_ids(batches)
+            got_ids, got_ng, got_u = gpu.group_ids(batches)
+            assert got_ng == want_ng, (types, null_prob)
+            for a, b in zip(got_ids, want_ids):
+                assert np.array_equal(a, b), (types, null_prob)
+            for k, ((gv, gb, gn), (wv, wb, wn)) in enumerate(zip(got_u, want_u)):
+                assert gn == wn and np.array_equal(gb[:got_ng], wb[:want_ng]), (types, k)
+                v = np.asarray(wb[:want_ng], bool)
+                ga, wa = np.asarray(gv)[:got_ng][v], np.asarray(wv)[:want_ng][v]
+                assert np.array_equal(ga.view(np.uint8) if ga.dtype != bool else ga, wa.view(np.uint8) if wa.dtype != bool else wa), (types, k)
