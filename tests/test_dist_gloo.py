@@ -1,6 +1,7 @@
 """CPU, world_size 2, gloo: the sharded group-by protocol of arrow-1_amd/dist.py with the
 oracle standing in for the kernels.  Checks that row-range shards + all-gather + re-aggregation
 reproduce the single-process GroupBy row for row (first-appearance order included)."""
+import datetime
 import os
 import sys
 
@@ -13,12 +14,35 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    """a port nobody listens on right now (bind to 0, read it back) instead of one derived from the pid"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _join_all(procs, seconds):
+    """join with a deadline; whatever is still running afterwards is killed so that a stuck rendezvous can never keep
+    the test session alive, then the exit codes are checked"""
+    try:
+        for p in procs:
+            p.join(seconds)
+    finally:
+        stuck = [p for p in procs if p.is_alive()]
+        for p in stuck:
+            p.kill()
+        for p in stuck:
+            p.join(10)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
 def _worker(rank, world, port, n, null_keys, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    tdist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     import orc
     from __graft_entry__ import load_package
     load_package()
@@ -71,13 +95,12 @@ def _worker(rank, world, port, n, null_keys, q):
 def test_sharded_groupby_matches_single_process(null_keys):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000 + (1 if null_keys else 0)
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, 20_000, null_keys, q)) for r in range(2)]
     for p in procs:
+        p.daemon = True
         p.start()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    _join_all(procs, 120)
     assert q.get(timeout=5) is True
 
 
@@ -87,7 +110,7 @@ def _sort_worker(rank, world, port, n, case, q):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    tdist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     import orc
     from __graft_entry__ import load_package
     load_package()
@@ -146,16 +169,15 @@ def test_sharded_sort_indices_matches_single_process(case, world):
     import orc  # noqa: F401  (type ids in the case tuples are orc's)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() * 7 + hash(case) % 97 + world) % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_sort_worker, args=(r, world, port, 6000, case, q)) for r in range(world)]
     for p in procs:
+        p.daemon = True
         p.start()
     got = {}
     for _ in range(world + 1):
         r, arr, _ = q.get(timeout=60)
         got[r] = arr
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    _join_all(procs, 120)
     merged = np.concatenate([got[r] for r in range(world)])
     assert np.array_equal(merged, got[-1]), case

@@ -3,6 +3,7 @@ merge) with TWO ranks sharing one GPU.  RCCL refuses two ranks per device, so th
 through gloo here (CUDA tensors staged by gloo); everything else -- the fused HIP kernel per shard,
 the dense scatter, the ordering, the stream/event choreography -- is the code `bench.py --gpus N`
 runs under RCCL."""
+import datetime
 import os
 import sys
 
@@ -15,13 +16,36 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
+def _free_port():
+    """a port nobody listens on right now (bind to 0, read it back) instead of one derived from the pid"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _join_all(procs, seconds):
+    """join with a deadline; whatever is still running afterwards is killed so that a stuck rendezvous can never keep
+    the test session alive, then the exit codes are checked"""
+    try:
+        for p in procs:
+            p.join(seconds)
+    finally:
+        stuck = [p for p in procs if p.is_alive()]
+        for p in stuck:
+            p.kill()
+        for p in stuck:
+            p.join(10)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
 def _worker(rank, world, port, n, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as tdist
-    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    tdist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     torch.cuda.set_device(0)
     import orc
     from __graft_entry__ import load_package
@@ -62,13 +86,12 @@ def _worker(rank, world, port, n, q):
 def test_two_ranks_one_gpu_dense_merge():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29650 + os.getpid() % 300
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, 700_000, q)) for r in range(2)]
     for p in procs:
+        p.daemon = True
         p.start()
-    for p in procs:
-        p.join(300)
-        assert p.exitcode == 0
+    _join_all(procs, 300)
     assert q.get(timeout=5) is True
 
 
@@ -78,7 +101,7 @@ def _sort_worker(rank, world, port, n, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as tdist
-    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    tdist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     torch.cuda.set_device(0)
     import orc
     from __graft_entry__ import load_package
@@ -120,11 +143,10 @@ def test_two_ranks_one_gpu_sharded_sort():
     one device (collectives over gloo): the concatenated result is sort_indices of the whole column."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 30650 + os.getpid() % 300
+    port = _free_port()
     procs = [ctx.Process(target=_sort_worker, args=(r, 2, port, 300_000, q)) for r in range(2)]
     for p in procs:
+        p.daemon = True
         p.start()
-    for p in procs:
-        p.join(300)
-        assert p.exitcode == 0
+    _join_all(procs, 300)
     assert q.get(timeout=5) is True
