@@ -18,6 +18,7 @@
 #include <limits>
 
 #include "amdarrow_compute.h"
+#include "expression.h"
 
 using namespace amdarrow;           // NOLINT
 using namespace amdarrow::compute;  // NOLINT
@@ -883,6 +884,52 @@ static void WideKeyGroupByTests(const std::shared_ptr<MemoryPool>& pool, ExecCon
   CHECK(ok);
 }
 
+// Expression + the scanner's per-batch step (expression_test.cc: Bind / ExecuteScalarExpression cases; scanner.cc:456-500)
+static void ExpressionTests(const std::shared_ptr<MemoryPool>& pool, ExecContext* ctx) {
+  auto a = Dev<int32_t>(pool, int32(), {V(int32_t, 1), V(int32_t, 5), N(int32_t), V(int32_t, 3), V(int32_t, 9), V(int32_t, 4)});
+  auto b = Dev<double>(pool, float64(), {V(double, 0.5), V(double, 1.5), V(double, 2.5), N(double), V(double, 4.5), V(double, 5.5)});
+  auto c = Dev<int64_t>(pool, int64(), {V(int64_t, 10), V(int64_t, 20), V(int64_t, 30), V(int64_t, 40), V(int64_t, 50), V(int64_t, 60)});
+  auto sch = schema({field("a", int32()), field("b", float64()), field("c", int64())});
+  auto batch = RecordBatch::Make(sch, 6, {a, b, c});
+  // a > 2 and b is valid  (int32 column against an int64 literal: promoted by DispatchBest)
+  Expression filter = and_(greater(field_ref("a"), literal<int64_t>(int64(), 2)), is_valid(field_ref("b")));
+  Expression projection = project({field_ref("c"), call("add", {field_ref("a"), field_ref("b")})}, {"c", "a_plus_b"});
+  CHECK(ExecuteScalarExpression(filter, Datum(batch), ctx).status().message() == "Cannot Execute unbound expression.");
+  CHECK(FieldsInExpression(filter) == (std::vector<std::string>{"a", "b"}) && !filter.IsBound());
+  auto bf = filter.Bind(*sch, ctx);
+  auto bp = projection.Bind(*sch, ctx);
+  CHECK_OK(bf.status());
+  CHECK_OK(bp.status());
+  if (!bf.ok() || !bp.ok()) return;
+  CHECK(bf->IsBound() && bf->type()->id() == Type::BOOL && bp->type()->id() == Type::STRUCT);
+  CHECK(bp->call()->arguments[1].type()->id() == Type::DOUBLE);  // int32 + float64
+  CHECK(field_ref("nope").Bind(*sch, ctx)->type()->id() == Type::NA);
+  CHECK(call("no_such_function", {field_ref("a")}).Bind(*sch, ctx).status().IsKeyError());
+  auto mask = ExecuteScalarExpression(*bf, Datum(batch), ctx);
+  CHECK_OK(mask.status());
+  if (mask.ok()) CHECK(HostBool(pool, *mask->array()) == (std::vector<int>{0, 1, -1, 0, 1, 1}));  // Kleene: null and true = null, true and false = false
+  auto out = FilterAndProjectRecordBatch(batch, *bf, *bp, ctx);
+  CHECK_OK(out.status());
+  if (out.ok()) {
+    CHECK((*out)->num_rows() == 3 && (*out)->num_columns() == 2 && (*out)->schema()->field(1).name == "a_plus_b");
+    CHECK(Same(Host<int64_t>(pool, *(*out)->column(0)), {V(int64_t, 20), V(int64_t, 50), V(int64_t, 60)}));
+    CHECK(Same(Host<double>(pool, *(*out)->column(1)), {V(double, 6.5), V(double, 13.5), V(double, 9.5)}));
+  }
+  // a literal filter keeps everything or nothing (scanner.cc:468-478)
+  auto all = FilterAndProjectRecordBatch(batch, literal<uint8_t>(boolean(), 1), *bp, ctx);
+  auto none = FilterAndProjectRecordBatch(batch, literal<uint8_t>(boolean(), 0), *bp, ctx);
+  CHECK(all.ok() && (*all)->num_rows() == 6);
+  CHECK(none.ok() && (*none)->num_rows() == 0);
+  // or_ / not_ / equal over several fields
+  auto e2 = or_(not_(less_equal(field_ref("c"), literal<int64_t>(int64(), 40))), equal(field_ref("a"), literal<int32_t>(int32(), 1))).Bind(*sch, ctx);
+  CHECK_OK(e2.status());
+  if (e2.ok()) {
+    auto m2 = ExecuteScalarExpression(*e2, Datum(batch), ctx);
+    CHECK_OK(m2.status());
+    if (m2.ok()) CHECK(HostBool(pool, *m2->array()) == (std::vector<int>{1, 0, -1, 0, 1, 1}));
+  }
+}
+
 static int RunGpu() {
   auto pool_r = MemoryPool::Make(0);
   if (!pool_r.ok()) { fprintf(stderr, "no device: %s\n", pool_r.status().ToString().c_str()); return 2; }
@@ -1246,6 +1293,7 @@ static int RunGpu() {
   PromotionTests(pool, &ctx);
   GroupingsTests(pool, &ctx);
   WideKeyGroupByTests(pool, &ctx);
+  ExpressionTests(pool, &ctx);
   CHECK(pool->bytes_allocated() >= 0 && pool->max_memory() > 0);  // the MemoryPool counters (memory_pool.h:38-105)
   printf("host_test gpu: %d checks, %d failures\n", g_checks, g_failures);
   return g_failures ? 1 : 0;
