@@ -17,7 +17,8 @@ _CMP = {"equal": _abi.EQ, "not_equal": _abi.NE, "greater": _abi.GT, "greater_equ
         "less": _abi.LT, "less_equal": _abi.LE}
 _ARITH = {"add": _abi.ADD, "subtract": _abi.SUB, "multiply": _abi.MUL, "divide": _abi.DIV,
           "add_checked": _abi.ADD_CHECKED, "subtract_checked": _abi.SUB_CHECKED,
-          "multiply_checked": _abi.MUL_CHECKED, "divide_checked": _abi.DIV_CHECKED}
+          "multiply_checked": _abi.MUL_CHECKED, "divide_checked": _abi.DIV_CHECKED,
+          "power": _abi.POWER, "power_checked": _abi.POWER_CHECKED, "negate": _abi.NEGATE, "negate_checked": _abi.NEGATE_CHECKED}
 _AGG = {"hash_sum": _abi.HASH_SUM, "hash_count": _abi.HASH_COUNT, "hash_mean": _abi.HASH_MEAN}
 
 
@@ -622,7 +623,11 @@ def call_function(ctx, name, args, options=None):
     if name in _CMP:
         return compare(ctx, _CMP[name], args[0], args[1])
     if name in _ARITH:
-        return arith(ctx, _ARITH[name], args[0], args[1])
+        return arith(ctx, _ARITH[name], args[0], args[1] if len(args) > 1 else None)
+    if name == "cast":  # options: {"to_type": type id, "safe": bool} (CastOptions)
+        if not options or options.get("to_type") is None:
+            raise AmdArrowError(4, "Cast requires that options be passed with the to_type populated")
+        return cast(ctx, args[0], options["to_type"], options.get("safe", True))
     if name in _AGG:
         # function.cc:193-195: hash aggregates cannot be called directly
         raise AmdArrowError(10, "Direct execution of HASH_AGGREGATE functions")
