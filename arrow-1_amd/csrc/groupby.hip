@@ -1289,6 +1289,294 @@ __global__ __launch_bounds__(kFThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
   }
 }
 
+// ---- scatter with per-partition LDS bins --------------------------------------------------------
+// Same contract as k_part_scatter_fast (headline shape, private [workgroup][partition][cap] regions,
+// whole 64-byte sectors only), without the per-tile scan / compact staging / per-record partition
+// look-ups: every partition owns a BIN of kBinSlots records in LDS.  A selected row's LDS atomic on
+// the bin's counter IS its slot; after one barrier four lanes per partition copy the bin's complete
+// sectors to the region tail and move the (at most three) left-over records to the bin's front.  Two
+// LDS barriers per tile instead of four, no scan, and the loads are 16 bytes per lane: a thread owns
+// R consecutive rows (one key vector, R / 2 value vectors, one nibble of the mask).
+// A row whose bin is full (arrivals are Poisson with mean tile rows x selectivity / 512; more than
+// 13 in one tile is rare by choice of R) goes to the partition's SPILL list instead: segment
+// `nblocks` of the same region array, filled through a global atomic counter (counts[p][nblocks]).
+// The aggregate kernel reads it as one more segment.
+constexpr int kBinSlots = 16;
+constexpr int kBThreads = 1024;
+constexpr unsigned int kOverflowRegionWord = 1;  // == kOverflowRegion (status[0])
+struct BinShared {
+  unsigned int cnt[kP];  // records in the bin (runs past kBinSlots while a tile is ranked: the excess was spilled)
+  uint32_t cur[kP];      // records of this workgroup's region already written (a multiple of 4)
+  uint4 bin[kP * kBinSlots];
+};
+// A bin is four 64-byte sectors; sector s of bin p lives at physical sector s ^ (p & 2 ? 3 : 0).  The flush
+// reads bins with eight lanes per partition, and the hardware serves a ds_read_b128 in the lane groups
+// {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32): with this swizzle the four (partition, sector) pairs
+// of every group fall into four different 16-bank groups.
+__device__ __forceinline__ uint32_t BinIndex(uint32_t p, uint32_t slot) {
+  return p * kBinSlots + ((((slot >> 2) ^ ((p & 2u) ? 3u : 0u)) & 3u) << 2) + (slot & 3u);
+}
+
+// One tile's loads as they arrive: nothing is computed from them before the tile is staged (a use would
+// make the wave wait for the load right where it was issued).
+using BinU32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+using BinU32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+using BinU64x2 = __attribute__((ext_vector_type(2))) unsigned long long;
+template <int R> struct BinTile;
+template <> struct BinTile<4> {
+  BinU32x4 kv; BinU64x2 va, vb; uint32_t m0, m1, v0, v1;
+  __device__ __forceinline__ uint32_t k(int j) const { return kv[j]; }
+  __device__ __forceinline__ uint64_t v(int j) const { return j < 2 ? va[j] : vb[j - 2]; }
+};
+template <> struct BinTile<2> {
+  BinU32x2 kv; BinU64x2 va; uint32_t m0, m1, v0, v1;
+  __device__ __forceinline__ uint32_t k(int j) const { return kv[j]; }
+  __device__ __forceinline__ uint64_t v(int j) const { return va[j]; }
+};
+
+// R consecutive bits of a bitmap starting at bit `pos` (R <= 4, any alignment) arrive as two bytes;
+// `last_byte` is the last byte that holds a bit of the buffer.
+__device__ __forceinline__ void LoadBitBytes(const uint8_t* __restrict__ bm, int64_t pos, int64_t last_byte, uint32_t* b0,
+                                             uint32_t* b1) {
+  const int64_t i0 = pos >> 3;
+  const int64_t i1 = i0 + 1 <= last_byte ? i0 + 1 : last_byte;
+  *b0 = bm[i0];
+  *b1 = bm[i1];
+}
+template <int R>
+__device__ __forceinline__ uint32_t FewBits(uint32_t b0, uint32_t b1, int64_t pos) {
+  return ((b0 | (b1 << 8)) >> (pos & 7)) & ((1u << R) - 1u);
+}
+
+// A whole tile (every row below hi): 16-byte loads, unconditional.
+template <bool MASK, bool VVALID, int R>
+__device__ __forceinline__ void BinLoadTile(const FastArgs& a, const uint32_t* __restrict__ keys,
+                                            const uint64_t* __restrict__ vals, int64_t tile0, int tid, BinTile<R>& t) {
+  const int64_t r0 = tile0 + int64_t(tid) * R;
+  if constexpr (R == 4) {
+    t.kv = __builtin_nontemporal_load(reinterpret_cast<const BinU32x4*>(keys + r0));
+    t.va = __builtin_nontemporal_load(reinterpret_cast<const BinU64x2*>(vals + r0));
+    t.vb = __builtin_nontemporal_load(reinterpret_cast<const BinU64x2*>(vals + r0 + 2));
+  } else {
+    t.kv = __builtin_nontemporal_load(reinterpret_cast<const BinU32x2*>(keys + r0));
+    t.va = __builtin_nontemporal_load(reinterpret_cast<const BinU64x2*>(vals + r0));
+  }
+  if (MASK) LoadBitBytes(a.m_data, a.m_off + r0, (a.m_off + a.n - 1) >> 3, &t.m0, &t.m1);
+  if (VVALID) LoadBitBytes(a.v.valid, a.v.off + r0, (a.v.off + a.n - 1) >> 3, &t.v0, &t.v1);
+}
+// The last, partial tile of the last block: one row at a time, addresses kept inside the buffers.
+template <bool MASK, bool VVALID, int R>
+__device__ __forceinline__ void BinLoadTail(const FastArgs& a, const uint32_t* __restrict__ keys,
+                                            const uint64_t* __restrict__ vals, int64_t tile0, int64_t hi, int tid,
+                                            BinTile<R>& t) {
+  const int64_t r0 = tile0 + int64_t(tid) * R;
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int64_t rc = r0 + j < hi ? r0 + j : hi - 1;
+    t.kv[j] = keys[rc];
+    if (j < 2) t.va[j] = vals[rc];
+    if constexpr (R == 4) { if (j >= 2) t.vb[j - 2] = vals[rc]; }
+  }
+  const int64_t rb = r0 < hi ? r0 : hi - 1;
+  if (MASK) LoadBitBytes(a.m_data, a.m_off + rb, (a.m_off + a.n - 1) >> 3, &t.m0, &t.m1);
+  if (VVALID) LoadBitBytes(a.v.valid, a.v.off + rb, (a.v.off + a.n - 1) >> 3, &t.v0, &t.v1);
+}
+
+// Rank + stage: the slot of a selected row is what the LDS atomic on its bin's counter returns.
+template <bool MASK, bool VVALID, int R>
+__device__ __forceinline__ void BinStageTile(BinShared& sh, const FastArgs& a, const BinTile<R>& t, int64_t tile0, int64_t hi,
+                                             int tid, int64_t cap, uint4* __restrict__ regions,
+                                             uint32_t* __restrict__ counts, unsigned int* overflow) {
+  const int64_t r0 = tile0 + int64_t(tid) * R;
+  const int64_t left = hi - r0;
+  const uint32_t live = left >= R ? (1u << R) - 1u : (left > 0 ? (1u << left) - 1u : 0u);
+  const int64_t rb = left > 0 ? r0 : hi - 1;  // where the bitmap bytes were fetched (bits beyond hi are dropped by `live`)
+  const uint32_t mbits = MASK ? (FewBits<R>(t.m0, t.m1, a.m_off + rb) & live) : live;
+  const uint32_t vbits = VVALID ? FewBits<R>(t.v0, t.v1, a.v.off + rb) : live;
+  uint32_t part[R], slot[R];
+  bool sel[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const uint32_t h = Fmix32(t.k(j));
+    sel[j] = ((mbits >> j) & 1u) && InSub(h, a.sub_bits, a.sub_id);
+    part[j] = PartOf(h, a.sub_bits);
+    slot[j] = 0;
+    if (sel[j]) slot[j] = atomicAdd(&sh.cnt[part[j]], 1u);
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    if (!sel[j]) continue;
+    const bool vvalid = (vbits >> j) & 1u;
+    const uint64_t v = vvalid ? t.v(j) : 0;
+    uint4 q;
+    q.x = t.k(j);
+    q.y = static_cast<uint32_t>(r0 + j) | (vvalid ? kRecValValid : 0u);
+    q.z = static_cast<uint32_t>(v); q.w = static_cast<uint32_t>(v >> 32);
+    if (slot[j] < static_cast<uint32_t>(kBinSlots)) {
+      sh.bin[BinIndex(part[j], slot[j])] = q;
+    } else {  // the bin is full until the next flush: the partition's spill list takes the record
+      const uint32_t at = atomicAdd(&counts[int64_t(part[j]) * (a.nblocks + 1) + a.nblocks], 1u);
+      if (at < cap) regions[(int64_t(a.nblocks) * kP + part[j]) * cap + at] = q;
+      else __hip_atomic_store(overflow, kOverflowRegionWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// Flush: eight lanes per partition; whole 128-byte lines (kBinUnit records) leave, the rest moves to the
+// front of the bin.  Measured with the kernel's access pattern and no LDS work at all (exp/membench.hip): the
+// input stream next to 64-byte region writes runs at 4.7 TB/s, next to 128-byte writes at 6.0 TB/s.
+constexpr int kBinUnit = 8;
+__device__ __forceinline__ void BinFlush(BinShared& sh, int tid, int64_t cap, uint4* __restrict__ my_regions,
+                                         unsigned int* overflow) {
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+  const uint32_t ll = tid & (kBinUnit - 1);
+#pragma unroll
+  for (int round = 0; round < kP / (kBThreads / kBinUnit); ++round) {
+    const uint32_t p = (tid / kBinUnit) + round * (kBThreads / kBinUnit);
+    const uint32_t raw = sh.cnt[p];
+    const uint32_t c = raw < static_cast<uint32_t>(kBinSlots) ? raw : static_cast<uint32_t>(kBinSlots);
+    const uint32_t nfull = c & ~uint32_t(kBinUnit - 1), left = c & uint32_t(kBinUnit - 1);
+    const uint32_t cur = sh.cur[p];
+    const bool ok = cur + nfull <= cap;
+    uint4* dst = my_regions + int64_t(p) * cap + cur + ll;
+#pragma unroll
+    for (uint32_t s = 0; s < kBinSlots / kBinUnit; ++s) {
+      if (kBinUnit * s < nfull && ok) {
+        const uint4 q = sh.bin[BinIndex(p, kBinUnit * s + ll)];
+        const u32x4 v = {q.x, q.y, q.z, q.w};
+#if defined(BIN_DEBUG_NOSTORE)
+        asm volatile("" :: "v"(v));
+#elif defined(BIN_DEBUG_PLAINSTORE)
+        *reinterpret_cast<u32x4*>(dst + kBinUnit * s) = v;
+#else
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + kBinUnit * s));
+#endif
+      }
+    }
+    uint4 keep;
+    const bool move = nfull > 0 && ll < left;  // (nfull == 8 here: a full bin leaves nothing behind)
+    if (move) keep = sh.bin[BinIndex(p, nfull + ll)];
+    if (move) sh.bin[BinIndex(p, ll)] = keep;  // (LDS operations of one wave execute in order: every read above is done)
+    if (ll == 0 && nfull > 0) {
+      sh.cnt[p] = left;
+      if (ok) sh.cur[p] = cur + nfull;
+      else __hip_atomic_store(overflow, kOverflowRegionWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// The tile loop of one workgroup over its row range, R rows per thread and tile.
+template <bool MASK, bool VVALID, int R>
+__device__ __forceinline__ void BinRun(BinShared& sh, const FastArgs& a, int64_t lo, int64_t hi, int64_t cap,
+                                       uint4* __restrict__ regions, uint4* __restrict__ my_regions,
+                                       uint32_t* __restrict__ counts, unsigned int* overflow) {
+  constexpr int kRows = kBThreads * R;
+  const int tid = threadIdx.x;
+  const uint32_t* keys = reinterpret_cast<const uint32_t*>(a.k_data) + a.k_off;
+  const uint64_t* vals = reinterpret_cast<const uint64_t*>(a.v.data) + a.v.off;
+  // Three register sets: tile X is staged while the loads of X+1 and X+2 are in flight.  Per tile:
+  //   stage(X) | barrier | wait for X+1 | flush(X) | issue X+3 | barrier
+  // The wait sits BEFORE the flush stores, where the only younger memory operations are the loads of
+  // X+2 (an exact vmcnt): behind the flush it would also wait for the flush's own stores.
+  BinTile<R> t0{}, t1{}, t2{};
+#define AA_TOUCH(T) do { asm volatile("" :: "v"(T.kv), "v"(T.va)); if constexpr (R == 4) asm volatile("" :: "v"(T.vb)); \
+                         if (MASK) asm volatile("" :: "v"(T.m0), "v"(T.m1)); if (VVALID) asm volatile("" :: "v"(T.v0), "v"(T.v1)); } while (0)
+  // Every prefetch is issued unconditionally -- past the last whole tile it fetches that tile again
+  // and the result is dropped -- so that the number of loads in flight at each wait is a constant
+  // the compiler can count (a conditional load makes it wait for everything).
+#define AA_BIN_STEP(CUR, NEXT, TILE0)                                                                  \
+  do {                                                                                                   \
+    BinStageTile<MASK, VVALID, R>(sh, a, CUR, (TILE0), hi, tid, cap, regions, counts, overflow);         \
+    LdsBarrier();                                                                                        \
+    AA_TOUCH(NEXT);                                                                                      \
+    BinFlush(sh, tid, cap, my_regions, overflow);                                                        \
+    BinLoadTile<MASK, VVALID, R>(a, keys, vals, (TILE0) + 3 * kRows <= last_whole ? (TILE0) + 3 * kRows : last_whole, tid, CUR); \
+    LdsBarrier();                                                                                        \
+  } while (0)
+  int64_t tile0 = lo;
+  if (lo + kRows <= hi) {
+    const int64_t last_whole = lo + ((hi - lo) / kRows - 1) * kRows;
+    BinLoadTile<MASK, VVALID, R>(a, keys, vals, lo, tid, t0);
+    BinLoadTile<MASK, VVALID, R>(a, keys, vals, lo + kRows <= last_whole ? lo + kRows : last_whole, tid, t1);
+    BinLoadTile<MASK, VVALID, R>(a, keys, vals, lo + 2 * kRows <= last_whole ? lo + 2 * kRows : last_whole, tid, t2);
+    AA_TOUCH(t0);  // (the loop body starts with its first tile complete on every path into it)
+    // whole tiles, three per trip (a trip ends with the register sets back in phase); no exit from
+    // inside a trip: with one the compiler sees paths into the loop head on which t0 was just reloaded
+    for (; tile0 + 2 * kRows <= last_whole; tile0 += 3 * kRows) {
+      AA_BIN_STEP(t0, t1, tile0);
+      AA_BIN_STEP(t1, t2, tile0 + kRows);
+      AA_BIN_STEP(t2, t0, tile0 + 2 * kRows);
+    }
+    if (tile0 <= last_whole) {
+      AA_BIN_STEP(t0, t1, tile0);
+      tile0 += kRows;
+      if (tile0 <= last_whole) {
+        AA_BIN_STEP(t1, t2, tile0);
+        tile0 += kRows;
+      }
+    }
+  }
+  if (tile0 < hi) {  // the partial tile at the end of the input
+    BinLoadTail<MASK, VVALID, R>(a, keys, vals, tile0, hi, tid, t0);
+    BinStageTile<MASK, VVALID, R>(sh, a, t0, tile0, hi, tid, cap, regions, counts, overflow);
+    LdsBarrier();
+    BinFlush(sh, tid, cap, my_regions, overflow);
+  }
+#undef AA_BIN_STEP
+#undef AA_TOUCH
+}
+
+// A bin takes what is left of the last line (< 8 records) plus a tile's arrivals, Poisson with mean
+// tile rows x selectivity / 512.  4096-row tiles spill 0.06 % of the records at 50 % selectivity and
+// 0.6 % at 75 % (mean 6); denser input runs on 2048-row tiles (mean <= 4).  Every workgroup decides for
+// itself from the mask bits of its first rows.
+constexpr int kBinSampleWords = 256;  // 64-bit words of the workgroup's mask range that are counted
+template <bool MASK, bool VVALID>
+__global__ __launch_bounds__(kBThreads) void k_part_scatter_bins(FastArgs a, int64_t cap, uint4* regions, uint32_t* counts,
+                                                                 unsigned int* overflow, const unsigned int* run_if,
+                                                                 const unsigned int* skip_if) {
+  if (run_if && !*run_if) return;  // the local path already built the table
+  if (skip_if && *skip_if) return;  // the launch on the mask without the hot rows does the work
+  __shared__ BinShared sh;
+  __shared__ unsigned int s_sample;
+  const int tid = threadIdx.x;
+  if (tid < kP) { sh.cnt[tid] = 0; sh.cur[tid] = 0; }
+  if (tid == 0) s_sample = 0;
+  __syncthreads();
+  const int64_t lo = int64_t(blockIdx.x) * a.rows_per_block;
+  const int64_t hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
+  uint4* const my_regions = regions + int64_t(blockIdx.x) * kP * cap;
+  bool dense = true;  // no mask: every row is selected
+  if (MASK) {
+    const int64_t sample_rows = hi - lo < 64 * kBinSampleWords ? hi - lo : 64 * kBinSampleWords;
+    if (tid < kBinSampleWords) {
+      const int64_t r = lo + 64 * int64_t(tid);
+      const int64_t left = lo + sample_rows - r;
+      if (left > 0) {
+        const uint64_t w = LoadBits64(a.m_data, a.m_off + r, left >= 64 ? 64 : static_cast<int>(left));
+        atomicAdd(&s_sample, static_cast<unsigned int>(__popcll(w)));
+      }
+    }
+    __syncthreads();
+    dense = 3 * int64_t(s_sample) > 2 * sample_rows;  // more than two thirds of the rows selected
+  }
+  if (dense) BinRun<MASK, VVALID, 2>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow);
+  else BinRun<MASK, VVALID, 4>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow);
+  __syncthreads();
+  if (tid < kP) {
+    // what is left of every partition's last line, and the region fills
+    const uint32_t left = sh.cnt[tid], cur = sh.cur[tid];  // left < kBinUnit after a flush
+    const bool ok = cur + left <= cap;
+    if (ok) {
+      uint4* dst = my_regions + int64_t(tid) * cap + cur;
+      for (uint32_t k = 0; k < left; ++k) dst[k] = sh.bin[BinIndex(tid, k)];
+    } else {
+      __hip_atomic_store(overflow, kOverflowRegionWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    counts[int64_t(tid) * (a.nblocks + 1) + blockIdx.x] = ok ? cur + left : 0;
+  }
+}
+
 // One workgroup per partition; every wave walks whole regions (segments) of the partition.
 // LDS table: 32-bit tags (fmix32 of the key, a bijection, so tag equality is key equality),
 // 0xFFFFFFFF = free; the null key and the one key whose tag equals the free marker live in
@@ -1432,6 +1720,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
   {
     const int b = wave + kWaves * lane;
     if (b < nblocks) my_cnt = counts[int64_t(p) * nblocks + b];
+    if (my_cnt > cap) my_cnt = static_cast<uint32_t>(cap);  // (a spill list that overflowed; the attempt is abandoned anyway)
   }
   for (int s = tid; s < kSlots + 2; s += kPartThreads) { s_tag[s] = kTagFree; s_sum[s] = 0; s_first[s] = kNoRow; s_cnt[s] = 0; }
   if (tid == 0) { s_groups = 0; s_abort = 0; }
@@ -1448,6 +1737,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
     if (jb) {
       const int b = wave + kWaves * (jb + lane);
       my_cnt = b < nblocks ? counts[int64_t(p) * nblocks + b] : 0;
+      if (my_cnt > cap) my_cnt = static_cast<uint32_t>(cap);
     }
     const int left = (nblocks - wave - kWaves * jb + kWaves - 1) / kWaves;
     const int nseg = left < 64 ? left : 64;
@@ -1482,6 +1772,9 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
   __syncthreads();
   if (*abort_lds || __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // nothing reads the table
   const int64_t g0 = slice0 + int64_t(p) * kSlots;
+#ifdef AGG_DEBUG_NOWRITE
+  if (s_tag[tid] != 12345) return;
+#endif
   for (int s = tid; s < kSlots; s += kPartThreads) {
     const unsigned int tag = s_tag[s];
     // the shared numbering / emit kernels speak fmix64 of the packed key word
@@ -1491,7 +1784,9 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
     t.sums[g0 + s] = s_sum[s];
     t.counts[g0 + s] = s_cnt[s];
     // mark the group's first row for the first-appearance numbering (was a separate kernel)
+#ifndef AGG_DEBUG_NOMARK
     if (fr != kNoRow) atomicOr(&first_bitmap[fr >> 6], 1ull << (fr & 63));
+#endif
   }
   // side slots -> two spare regular slots of the global table: partition p's slice is only
   // kSlotLimit full, so the (at most two) extra groups go to free slots of the slice.
@@ -1937,8 +2232,11 @@ __global__ __launch_bounds__(kDThreads) void k_local_aggregate(FastArgs a, int a
 
 // Zero the first-row bitmap, the status words and the per-workgroup flags in one launch.
 __global__ __launch_bounds__(kThreads) void k_prepare(unsigned long long* bitmap, int64_t nwords, unsigned int* status,
-                                                      unsigned int* wg_flags, int nflags, unsigned int* hot_cand_n) {
+                                                      unsigned int* wg_flags, int nflags, unsigned int* hot_cand_n,
+                                                      uint32_t* spill_counts /* counts[p][stride - 1], or null */, int spill_stride) {
   for (int64_t w = int64_t(blockIdx.x) * kThreads + threadIdx.x; w < nwords; w += int64_t(gridDim.x) * kThreads) bitmap[w] = 0;
+  if (blockIdx.x == 1 % gridDim.x && spill_counts)
+    for (int p = threadIdx.x; p < kP; p += kThreads) spill_counts[int64_t(p) * spill_stride + spill_stride - 1] = 0;
   if (blockIdx.x == 0) {
     if (threadIdx.x < 8) status[threadIdx.x] = threadIdx.x == 4 ? kNoRow : 0u;
     for (int i = threadIdx.x; i < nflags; i += kThreads) { wg_flags[i] = 0; if (hot_cand_n) hot_cand_n[i] = 0; }
@@ -2498,6 +2796,10 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
   }
   const bool headline_shape = ks.total_bits == 32 && k_load_bits == 32 && !keys->validity && values &&
                               BitWidth(values->type_id) == 64 && !m_valid;
+  // the bin scatter loads 16-byte vectors: keys and values must start on a 16-byte boundary
+  const bool use_bins = headline_shape && !getenv("AMDARROW_GROUPBY_NO_BINS") &&
+                        (reinterpret_cast<uintptr_t>(keys->values) + 4 * static_cast<uintptr_t>(keys->offset)) % 16 == 0 &&
+                        (reinterpret_cast<uintptr_t>(values->values) + 8 * static_cast<uintptr_t>(values->offset)) % 16 == 0;
   GroupTable t{};
   RankMem r{};
   unsigned long long* gx = nullptr;
@@ -2521,15 +2823,15 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
     int64_t rows_per_block = 0, rows_per_block_local = 0, cap = 0, hist_n = 0;
     if (path >= 2) {
       // the specialised scatter runs two 512-thread workgroups per CU on 3584-row tiles
-      const int64_t tile = headline_shape ? kFRows : kDRows;
-      nblocks = static_cast<int>(std::min<int64_t>(ctx->num_cus * (headline_shape ? 1024 / kFThreads : 1), (n + tile - 1) / tile));
+      const int64_t tile = use_bins ? kBThreads * 4 : headline_shape ? kFRows : kDRows;
+      nblocks = static_cast<int>(std::min<int64_t>(ctx->num_cus * (headline_shape && !use_bins ? 1024 / kFThreads : 1), (n + tile - 1) / tile));
       rows_per_block = (((n + nblocks - 1) / nblocks + tile - 1) / tile) * tile;
       nblocks_local = static_cast<int>(std::min<int64_t>(ctx->num_cus, (n + kDRows - 1) / kDRows));
       rows_per_block_local = (((n + nblocks_local - 1) / nblocks_local + kDRows - 1) / kDRows) * kDRows;
       const double mean = static_cast<double>(rows_per_block) / kP / nsub;
       // room for a key of up to ~0.25 % of the rows next to the uniform share (hotter keys are taken out before the scatter)
-      cap = (static_cast<int64_t>(mean * 2.0 + 8.0 * std::sqrt(mean) + 32.0) + 3) & ~int64_t(3);  // whole 64-byte sectors
-      hist_n = int64_t(kP) * nblocks;
+      cap = (static_cast<int64_t>(mean * 2.0 + 8.0 * std::sqrt(mean) + 32.0) + 7) & ~int64_t(7);  // whole 128-byte lines
+      hist_n = int64_t(kP) * (nblocks + (use_bins ? 1 : 0));  // bins: one more segment per partition, the spill list
     } else if (path == 1) {
       nblocks = static_cast<int>(std::min<int64_t>(ctx->num_cus, (n + kPartRows - 1) / kPartRows));
       rows_per_block = (((n + nblocks - 1) / nblocks + kPartRows - 1) / kPartRows) * kPartRows;
@@ -2539,7 +2841,8 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
     const size_t off_hist = c.Take(4 * hist_n);
     const size_t off_sums = c.Take(4 * scan_nb);
     const size_t off_sumoff = c.Take(8 * (scan_nb + 1));
-    const size_t rec_bytes = path >= 2 ? std::max(16 * static_cast<size_t>(cap) * kP * nblocks, LocalStageBytes(nblocks_local))
+    const int nseg = nblocks + (path >= 2 && use_bins ? 1 : 0);  // segments per partition the aggregate walks
+    const size_t rec_bytes = path >= 2 ? std::max(16 * static_cast<size_t>(cap) * kP * nseg, LocalStageBytes(nblocks_local))
                            : path == 1 ? 16 * static_cast<size_t>(n) : 0;
     const size_t off_rec = c.Take(rec_bytes);
     const size_t off_hi = c.Take(path == 1 && wide ? 4 * static_cast<size_t>(n) : 0);
@@ -2573,7 +2876,8 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
     if (nblocks > kMaxFlags || nblocks_local > kMaxFlags) return SetError(AMDARROW_INVALID, "group-by: more workgroups than flag words");
     hipLaunchKernelGGL(k_prepare, dim3(GridFor(r.nwords, kThreads, ctx->num_cus * 4)), dim3(kThreads), 0, ctx->stream, r.bitmap,
                        r.nwords, misc, wg_flags, nblocks_local > nblocks ? nblocks_local : nblocks,
-                       path == 3 ? hot.cand_n : static_cast<unsigned int*>(nullptr));
+                       path == 3 ? hot.cand_n : static_cast<unsigned int*>(nullptr),
+                       path >= 2 && use_bins ? reinterpret_cast<uint32_t*>(b + off_hist) : static_cast<uint32_t*>(nullptr), nseg);
     AA_HIP(hipGetLastError());
 
     if (fast) {
@@ -2625,7 +2929,13 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
         fa.sub_bits = nsub > 1 ? sub_bits : 0; fa.sub_id = static_cast<uint32_t>(sub);
         FastArgs fh = fa;  // the same scatter on the mask k_hot_aggregate wrote
         fh.m_data = hot.alt_mask; fh.m_valid = nullptr; fh.m_off = 0;
-        if (headline_shape) {
+        if (use_bins) {
+#define AA_BINS(MM, VV, ARGS, RUN, SKIP) hipLaunchKernelGGL((k_part_scatter_bins<MM, VV>), dim3(nblocks), dim3(kBThreads), 0, ctx->stream, ARGS, cap, records, hist, misc, RUN, SKIP)
+          if (M && V) AA_BINS(true, true, fa, run_if, use_hot); else if (M) AA_BINS(true, false, fa, run_if, use_hot);
+          else if (V) AA_BINS(false, true, fa, run_if, use_hot); else AA_BINS(false, false, fa, run_if, use_hot);
+          if (use_hot) { if (V) AA_BINS(true, true, fh, use_hot, nullptr); else AA_BINS(true, false, fh, use_hot, nullptr); }
+#undef AA_BINS
+        } else if (headline_shape) {
 #define AA_FAST(MM, VV, ARGS, RUN, SKIP) hipLaunchKernelGGL((k_part_scatter_fast<MM, VV>), dim3(nblocks), dim3(kFThreads), 0, ctx->stream, ARGS, cap, records, hist, misc, RUN, SKIP)
           if (M && V) AA_FAST(true, true, fa, run_if, use_hot); else if (M) AA_FAST(true, false, fa, run_if, use_hot);
           else if (V) AA_FAST(false, true, fa, run_if, use_hot); else AA_FAST(false, false, fa, run_if, use_hot);
@@ -2639,7 +2949,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
                                misc, use_hot, static_cast<const unsigned int*>(nullptr));
         }
         AA_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_part_aggregate_direct, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nblocks,
+        hipLaunchKernelGGL(k_part_aggregate_direct, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nseg,
                            cap, ks.total_bits, acc_double, t, r.bitmap, misc, run_if, int64_t(sub) * kP * kSlots,
                            sub == 0 ? static_cast<int64_t>(T) : int64_t(0));
         AA_HIP(hipGetLastError());
