@@ -612,6 +612,9 @@ struct FastArgs {
   // Sub-problems (more than ~1.8 M groups): the top sub_bits hash bits select one of 2^sub_bits
   // passes over the input, each with its own 512 partitions (the NEXT 9 bits) and table slice.
   int sub_bits; uint32_t sub_id;
+  // bin scatter only: keys are compared / partitioned as k ^ k_flip (0x80000000 for signed keys: value order as
+  // unsigned order); the smallest / largest selected key lands in key_minmax[0 / 1] (atomicMin / atomicMax)
+  uint32_t k_flip; unsigned int* key_minmax;
 };
 __device__ __forceinline__ uint32_t PartOf(uint32_t h, int sub_bits) { return (h << sub_bits) >> (32 - kPBits); }
 __device__ __forceinline__ bool InSub(uint32_t h, int sub_bits, uint32_t sub_id) {
@@ -1322,6 +1325,11 @@ __device__ __forceinline__ uint32_t BinIndex(uint32_t p, uint32_t slot) {
 using BinU32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 using BinU32x2 = __attribute__((ext_vector_type(2))) unsigned int;
 using BinU64x2 = __attribute__((ext_vector_type(2))) unsigned long long;
+// Partition of a key in the bin scatter: its low 9 bits XOR nine hashed bits of the rest.  (partition, key >> 9)
+// names the key, and key >> 9 spans a small range when the keys do -- small enough, for key ranges up to
+// 2 M, to index the partition's LDS table directly (k_part_aggregate_piped) instead of hashing into it --
+// while keys that share their low bits (multiples of 512, say) are still spread by the hashed part.
+__device__ __forceinline__ uint32_t BinPartOf(uint32_t kk) { return (kk & (kP - 1)) ^ (((kk >> kPBits) * 0x9E3779B1u) >> (32 - kPBits)); }
 template <int R> struct BinTile;
 template <> struct BinTile<4> {
   BinU32x4 kv; BinU64x2 va, vb; uint32_t m0, m1, v0, v1;
@@ -1386,7 +1394,8 @@ __device__ __forceinline__ void BinLoadTail(const FastArgs& a, const uint32_t* _
 template <bool MASK, bool VVALID, int R>
 __device__ __forceinline__ void BinStageTile(BinShared& sh, const FastArgs& a, const BinTile<R>& t, int64_t tile0, int64_t hi,
                                              int tid, int64_t cap, uint4* __restrict__ regions,
-                                             uint32_t* __restrict__ counts, unsigned int* overflow) {
+                                             uint32_t* __restrict__ counts, unsigned int* overflow, uint32_t& kmin,
+                                             uint32_t& kmax) {
   const int64_t r0 = tile0 + int64_t(tid) * R;
   const int64_t left = hi - r0;
   const uint32_t live = left >= R ? (1u << R) - 1u : (left > 0 ? (1u << left) - 1u : 0u);
@@ -1397,11 +1406,16 @@ __device__ __forceinline__ void BinStageTile(BinShared& sh, const FastArgs& a, c
   bool sel[R];
 #pragma unroll
   for (int j = 0; j < R; ++j) {
-    const uint32_t h = Fmix32(t.k(j));
-    sel[j] = ((mbits >> j) & 1u) && InSub(h, a.sub_bits, a.sub_id);
-    part[j] = PartOf(h, a.sub_bits);
+    const uint32_t kk = t.k(j) ^ a.k_flip;
+    sel[j] = (mbits >> j) & 1u;
+    if (a.sub_bits) sel[j] = sel[j] && InSub(Fmix32(t.k(j)), a.sub_bits, a.sub_id);  // (uniform branch: sub-problems only)
+    part[j] = BinPartOf(kk);
     slot[j] = 0;
-    if (sel[j]) slot[j] = atomicAdd(&sh.cnt[part[j]], 1u);
+    if (sel[j]) {
+      slot[j] = atomicAdd(&sh.cnt[part[j]], 1u);
+      kmin = kk < kmin ? kk : kmin;
+      kmax = kk > kmax ? kk : kmax;
+    }
   }
 #pragma unroll
   for (int j = 0; j < R; ++j) {
@@ -1444,13 +1458,7 @@ __device__ __forceinline__ void BinFlush(BinShared& sh, int tid, int64_t cap, ui
       if (kBinUnit * s < nfull && ok) {
         const uint4 q = sh.bin[BinIndex(p, kBinUnit * s + ll)];
         const u32x4 v = {q.x, q.y, q.z, q.w};
-#if defined(BIN_DEBUG_NOSTORE)
-        asm volatile("" :: "v"(v));
-#elif defined(BIN_DEBUG_PLAINSTORE)
-        *reinterpret_cast<u32x4*>(dst + kBinUnit * s) = v;
-#else
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + kBinUnit * s));
-#endif
       }
     }
     uint4 keep;
@@ -1469,7 +1477,7 @@ __device__ __forceinline__ void BinFlush(BinShared& sh, int tid, int64_t cap, ui
 template <bool MASK, bool VVALID, int R>
 __device__ __forceinline__ void BinRun(BinShared& sh, const FastArgs& a, int64_t lo, int64_t hi, int64_t cap,
                                        uint4* __restrict__ regions, uint4* __restrict__ my_regions,
-                                       uint32_t* __restrict__ counts, unsigned int* overflow) {
+                                       uint32_t* __restrict__ counts, unsigned int* overflow, uint32_t& kmin, uint32_t& kmax) {
   constexpr int kRows = kBThreads * R;
   const int tid = threadIdx.x;
   const uint32_t* keys = reinterpret_cast<const uint32_t*>(a.k_data) + a.k_off;
@@ -1486,7 +1494,7 @@ __device__ __forceinline__ void BinRun(BinShared& sh, const FastArgs& a, int64_t
   // the compiler can count (a conditional load makes it wait for everything).
 #define AA_BIN_STEP(CUR, NEXT, TILE0)                                                                  \
   do {                                                                                                   \
-    BinStageTile<MASK, VVALID, R>(sh, a, CUR, (TILE0), hi, tid, cap, regions, counts, overflow);         \
+    BinStageTile<MASK, VVALID, R>(sh, a, CUR, (TILE0), hi, tid, cap, regions, counts, overflow, kmin, kmax); \
     LdsBarrier();                                                                                        \
     AA_TOUCH(NEXT);                                                                                      \
     BinFlush(sh, tid, cap, my_regions, overflow);                                                        \
@@ -1518,7 +1526,7 @@ __device__ __forceinline__ void BinRun(BinShared& sh, const FastArgs& a, int64_t
   }
   if (tile0 < hi) {  // the partial tile at the end of the input
     BinLoadTail<MASK, VVALID, R>(a, keys, vals, tile0, hi, tid, t0);
-    BinStageTile<MASK, VVALID, R>(sh, a, t0, tile0, hi, tid, cap, regions, counts, overflow);
+    BinStageTile<MASK, VVALID, R>(sh, a, t0, tile0, hi, tid, cap, regions, counts, overflow, kmin, kmax);
     LdsBarrier();
     BinFlush(sh, tid, cap, my_regions, overflow);
   }
@@ -1538,10 +1546,10 @@ __global__ __launch_bounds__(kBThreads) void k_part_scatter_bins(FastArgs a, int
   if (run_if && !*run_if) return;  // the local path already built the table
   if (skip_if && *skip_if) return;  // the launch on the mask without the hot rows does the work
   __shared__ BinShared sh;
-  __shared__ unsigned int s_sample;
+  __shared__ unsigned int s_sample, s_kmin, s_kmax;
   const int tid = threadIdx.x;
   if (tid < kP) { sh.cnt[tid] = 0; sh.cur[tid] = 0; }
-  if (tid == 0) s_sample = 0;
+  if (tid == 0) { s_sample = 0; s_kmin = 0xFFFFFFFFu; s_kmax = 0; }
   __syncthreads();
   const int64_t lo = int64_t(blockIdx.x) * a.rows_per_block;
   const int64_t hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
@@ -1560,9 +1568,20 @@ __global__ __launch_bounds__(kBThreads) void k_part_scatter_bins(FastArgs a, int
     __syncthreads();
     dense = 3 * int64_t(s_sample) > 2 * sample_rows;  // more than two thirds of the rows selected
   }
-  if (dense) BinRun<MASK, VVALID, 2>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow);
-  else BinRun<MASK, VVALID, 4>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow);
+  uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
+  if (dense) BinRun<MASK, VVALID, 2>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow, kmin, kmax);
+  else BinRun<MASK, VVALID, 4>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow, kmin, kmax);
+  {  // the range of the selected keys: wave, workgroup (LDS), device -- two device atomics per workgroup
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const uint32_t omin = __shfl_xor(kmin, d, 64), omax = __shfl_xor(kmax, d, 64);
+      kmin = omin < kmin ? omin : kmin;
+      kmax = omax > kmax ? omax : kmax;
+    }
+    if ((tid & 63) == 0 && kmin <= kmax) { atomicMin(&s_kmin, kmin); atomicMax(&s_kmax, kmax); }
+  }
   __syncthreads();
+  if (tid == 0 && s_kmin <= s_kmax) { atomicMin(&a.key_minmax[0], s_kmin); atomicMax(&a.key_minmax[1], s_kmax); }
   if (tid < kP) {
     // what is left of every partition's last line, and the region fills
     const uint32_t left = sh.cnt[tid], cur = sh.cur[tid];  // left < kBinUnit after a flush
@@ -1627,6 +1646,7 @@ __device__ __forceinline__ int ProbeInsert(unsigned int* s_tag, unsigned int* s_
 constexpr int kAggUnroll = 4;                  // records per lane and step (local path)
 constexpr int kPaUnroll = 4;                   // records per lane and step (partition aggregate; 5: +5 %, 6 spills: +10 %)
 constexpr int kAggStep = 64 * kPaUnroll;       // records per wave and step of the partition aggregate
+constexpr int kMaxSegments = 1024 + 1;        // scatter workgroups (kMaxFlags) + the spill list
 
 // Issue the (unconditional, clamped) streaming loads of one step: records [i0, i0 + kAggStep) of `seg`.
 template <int N>
@@ -1813,6 +1833,242 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
 }
 
 
+// ---- the partition aggregate, pipelined three steps deep -------------------------------------------------------
+// Same table, same output as k_part_aggregate_direct (which it replaces behind the bin scatter).  Measured on
+// that kernel: 127 us to stream the 0.8 GB of records without folding them, 100 us more for the fold -- the two
+// did not overlap, with two steps in flight per wave the stream ran at the speed of one dependent round trip
+// per step -- and 55 us of the fold were the first ~2 k records of every partition, all inserts, each going
+// through the serial probe loop.  Here a wave keeps three steps in flight (the loads are unconditional, so
+// the compiler counts them: vmcnt(8) before a fold), and the first insertion attempt of a step's records is
+// one compare-and-swap per record on the first free entry of the buckets already fetched, all issued
+// together; only a lost race enters the probe loop.
+struct AggIter { int k; uint32_t i0, cnt; };
+// The probe loop as a real call: inlined, the twelve copies of it (four records x three register sets) made
+// the streaming loop several times the size of the instruction cache's share of one CU.
+__device__ __attribute__((noinline)) int ProbeInsertCold(unsigned int* s_tag, unsigned int* s_groups, uint32_t h) {
+  return ProbeInsert(s_tag, s_groups, h, h & (kBuckets - 1), (h >> kBucketBits) & (kBuckets - 1), kSlotLimit);
+}
+template <int N>
+__device__ __forceinline__ bool AggFoldFast(const uint4 (&rec)[N], const bool (&live)[N], int acc_double,
+                                            unsigned int* s_tag, unsigned long long* s_sum, uint32_t* s_first,
+                                            unsigned int* s_cnt, unsigned int* s_groups) {
+  bool ok = true;
+  uint32_t h[N];
+  int slot[N], target[N];
+  uint4 home1[N], home2[N];
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    h[u] = Fmix32(rec[u].x);
+    home1[u] = *reinterpret_cast<const uint4*>(&s_tag[(h[u] & (kBuckets - 1)) * kBucket]);
+    home2[u] = *reinterpret_cast<const uint4*>(&s_tag[((h[u] >> kBucketBits) & (kBuckets - 1)) * kBucket]);
+  }
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    target[u] = -1;
+    if (!live[u]) { slot[u] = -2; continue; }
+    if (rec[u].y & kRecKeyNull) slot[u] = kSideNull;
+    else if (h[u] == kTagFree) slot[u] = kSideFree;
+    else {
+      const uint32_t b1 = h[u] & (kBuckets - 1), b2 = (h[u] >> kBucketBits) & (kBuckets - 1);
+      const int j1 = MatchBucket(home1[u], h[u]), j2 = MatchBucket(home2[u], h[u]);
+      if (j1 >= 0) slot[u] = static_cast<int>(b1 * kBucket) + j1;
+      else if (j2 >= 0) slot[u] = static_cast<int>(b2 * kBucket) + j2;
+      else {
+        // a new key (or one inserted since the buckets were read): aim at the first free entry in probe order
+        slot[u] = -3;
+        const int f1 = MatchBucket(home1[u], kTagFree), f2 = MatchBucket(home2[u], kTagFree);
+        if (f1 >= 0) target[u] = static_cast<int>(b1 * kBucket) + f1;
+        else if (f2 >= 0) target[u] = static_cast<int>(b2 * kBucket) + f2;
+      }
+    }
+  }
+  unsigned int old[N];
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    old[u] = 0;
+    if (target[u] >= 0) old[u] = atomicCAS(&s_tag[target[u]], kTagFree, h[u]);
+  }
+  unsigned int added = 0;  // (wave-uniform: counted with ballots, no cross-lane data movement)
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    const bool won = slot[u] == -3 && target[u] >= 0 && old[u] == kTagFree;
+    added += static_cast<unsigned int>(__popcll(__ballot(won)));
+    if (slot[u] != -3) continue;
+    if (target[u] >= 0 && (old[u] == kTagFree || old[u] == h[u])) {
+      slot[u] = target[u];
+    } else {  // both buckets full, or another key took the entry meanwhile
+      slot[u] = ProbeInsertCold(s_tag, s_groups, h[u]);
+    }
+  }
+  // one counter update per wave (the count only decides when the table is called full)
+  if (added && LaneId() == 0) atomicAdd(s_groups, added);
+#ifdef AGG_DEBUG_NOACC
+  return ok;
+#endif
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    if (slot[u] == -2) continue;
+    if (slot[u] < 0) { ok = false; continue; }
+    const uint4 r = rec[u];
+    atomicMin(&s_first[slot[u]], r.y & kRecRowMask);
+    if (r.y & kRecValValid) {
+      const unsigned long long bits = (static_cast<unsigned long long>(r.w) << 32) | r.z;
+      if (acc_double) atomicAdd(reinterpret_cast<double*>(&s_sum[slot[u]]), __longlong_as_double(bits));
+      else atomicAdd(&s_sum[slot[u]], bits);
+      atomicAdd(&s_cnt[slot[u]], 1u);
+    }
+  }
+  return ok;
+}
+
+__global__ __launch_bounds__(kPartThreads) void k_part_aggregate_piped(const uint4* regions, const uint32_t* counts,
+                                                                       int nblocks, int64_t cap, int k_bits,
+                                                                       int acc_double, GroupTable t,
+                                                                       unsigned long long* first_bitmap,
+                                                                       unsigned int* overflow, const unsigned int* run_if,
+                                                                       int64_t slice0, int64_t total_slots,
+                                                                       const unsigned int* key_minmax, uint32_t k_flip,
+                                                                       const unsigned int* hashed_if /* optional device word */) {
+  __shared__ __attribute__((aligned(16))) unsigned int s_tag[kSlots + 4];
+  __shared__ unsigned long long s_sum[kSlots + 2];
+  __shared__ uint32_t s_first[kSlots + 2];
+  __shared__ unsigned int s_cnt[kSlots + 2];
+  __shared__ uint32_t s_fill[kMaxSegments];
+  __shared__ unsigned int s_groups;
+  __shared__ unsigned int s_abort;
+  if (run_if && !*run_if) return;  // the local path already built the table
+  if (__hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // the scatter gave up
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform values stay in scalar registers: uniform loop control)
+  const int p = blockIdx.x;
+  constexpr int kWaves = kPartThreads / 64;
+  for (int b = tid; b < nblocks; b += kPartThreads) {
+    const uint32_t c = counts[int64_t(p) * nblocks + b];
+    s_fill[b] = c > cap ? static_cast<uint32_t>(cap) : c;  // (a spill list that overflowed; the attempt is abandoned anyway)
+  }
+  for (int s = tid; s < kSlots + 2; s += kPartThreads) { s_tag[s] = kTagFree; s_sum[s] = 0; s_first[s] = kNoRow; s_cnt[s] = 0; }
+  if (tid == 0) { s_groups = 0; s_abort = 0; }
+  // Keys of a small range (key >> 9 spans at most kSlots values): the slot IS (key >> 9) - base, no tags, no
+  // probing -- the fold is three LDS atomics per record.  The hashed fold costs ~100 vector instructions per
+  // record (two bucket compares, the finaliser's multiplies): 127 us of issue slots per 100 M rows, which is
+  // what kept it from hiding under the record stream.
+  const uint32_t key_lo = key_minmax[0], key_hi = key_minmax[1];
+  const uint32_t dbase = key_lo >> kPBits;
+  // (heavy hitters taken out before the scatter are injected into free slots of the finished table later: a
+  // directly indexed slice may have none, so calls with heavy hitters keep the hashed table, at most 87.5 % full)
+  const bool direct = key_lo <= key_hi && (key_hi >> kPBits) - dbase < static_cast<uint32_t>(kSlots) &&
+                      !(hashed_if && *hashed_if);
+  __syncthreads();
+  // (relaxed atomic loads, not volatile ones: a volatile access makes the compiler drain every counter, i.e. the prefetched steps)
+  auto aborted = [&]() { return __hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; };
+  const int nseg = wave < nblocks ? (nblocks - wave + kWaves - 1) / kWaves : 0;  // this wave's segments: wave, wave + 16, ...
+  if (nseg > 0) {
+    const int64_t seg_stride = int64_t(kWaves) * kP * cap;
+    const uint4* seg0 = regions + (int64_t(wave) * kP + p) * cap;  // segment k: seg0 + k * seg_stride
+    // the step after `it`; empty segments are skipped; k == nseg: past the end (such a step loads record 0 of
+    // the wave's first segment slot and folds nothing)
+    auto advance = [&](AggIter it) -> AggIter {
+      it.i0 += kAggStep;
+      if (it.i0 >= it.cnt) {
+        it.i0 = 0;
+        do { ++it.k; it.cnt = it.k < nseg ? __builtin_amdgcn_readfirstlane(s_fill[wave + kWaves * it.k]) : 0u; } while (it.k < nseg && it.cnt == 0);
+      }
+      return it;
+    };
+    auto load = [&](uint4 (&r)[kPaUnroll], const AggIter& it) {
+      const bool in = it.k < nseg;
+      AggLoad(r, seg0 + (in ? it.k : 0) * seg_stride, in ? it.i0 : 0u, in ? it.cnt : 0u, lane);
+    };
+    bool failed = false;
+    auto fold = [&](const uint4 (&r)[kPaUnroll], const AggIter& it) {
+      bool live[kPaUnroll];
+#pragma unroll
+      for (int u = 0; u < kPaUnroll; ++u) live[u] = it.k < nseg && it.i0 + lane + 64 * u < it.cnt;
+#ifdef AGG_DEBUG_NOFOLD
+#pragma unroll
+      for (int u = 0; u < kPaUnroll; ++u) asm volatile("" :: "v"(r[u].x), "v"(r[u].y), "v"(r[u].z), "v"(r[u].w));
+#else
+      if (direct) {
+#pragma unroll
+        for (int u = 0; u < kPaUnroll; ++u) {
+          if (!live[u]) continue;
+          const uint32_t slot = ((r[u].x ^ k_flip) >> kPBits) - dbase;
+          atomicMin(&s_first[slot], r[u].y & kRecRowMask);
+          if (r[u].y & kRecValValid) {
+            const unsigned long long bits = (static_cast<unsigned long long>(r[u].w) << 32) | r[u].z;
+            if (acc_double) atomicAdd(reinterpret_cast<double*>(&s_sum[slot]), __longlong_as_double(bits));
+            else atomicAdd(&s_sum[slot], bits);
+            atomicAdd(&s_cnt[slot], 1u);
+          }
+        }
+      } else {
+        failed |= !AggFold(r, live, acc_double, s_tag, s_sum, s_first, s_cnt, &s_groups);
+      }
+#endif
+    };
+    AggIter i0{-1, 0, 0};
+    i0 = advance(i0);  // the first step of the first non-empty segment
+    AggIter i1 = advance(i0), i2 = advance(i1);
+    uint4 r0[kPaUnroll], r1[kPaUnroll], r2[kPaUnroll];
+    load(r0, i0); load(r1, i1); load(r2, i2);
+    while (i0.k < nseg) {  // three steps per trip, no exit inside (steps past the end fold nothing)
+      fold(r0, i0); i0 = advance(i2); load(r0, i0);
+      fold(r1, i1); i1 = advance(i0); load(r1, i1);
+      fold(r2, i2); i2 = advance(i1); load(r2, i2);
+      const bool full = aborted() || __hip_atomic_load(&s_groups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > kSlotLimit;
+      if (__any(failed || full)) {
+        if (lane == 0) {
+          __hip_atomic_store(&s_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(overflow, kOverflowTable, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  if (aborted() || __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // nothing reads the table
+  const int64_t g0 = slice0 + int64_t(p) * kSlots;
+  for (int s = tid; s < kSlots; s += kPartThreads) {
+    const uint32_t fr = s_first[s];
+    // the shared numbering / emit kernels speak fmix64 of the packed key word
+    if (direct) {
+      // the key of (partition p, slot s): high part s + base, low part p XOR the high part's hashed bits (BinPartOf)
+      const uint32_t high = static_cast<uint32_t>(s) + dbase;
+      const uint32_t kk = (high << kPBits) | (static_cast<uint32_t>(p) ^ ((high * 0x9E3779B1u) >> (32 - kPBits)));
+      t.hkeys[g0 + s] = fr == kNoRow ? kEmpty : Fmix64(uint64_t(kk ^ k_flip));
+    } else {
+      const unsigned int tag = s_tag[s];
+      t.hkeys[g0 + s] = tag == kTagFree ? kEmpty : Fmix64(uint64_t(Fmix32Inv(tag)));
+    }
+    t.first[g0 + s] = fr;
+    t.sums[g0 + s] = s_sum[s];
+    t.counts[g0 + s] = s_cnt[s];
+    // mark the group's first row for the first-appearance numbering
+    if (fr != kNoRow) atomicOr(&first_bitmap[fr >> 6], 1ull << (fr & 63));
+  }
+  // side slots -> two spare regular slots of the global table (see k_part_aggregate_direct)
+  __syncthreads();
+  if (tid == 0) {
+    for (int side = kSideNull; side <= kSideFree; ++side) {
+      if (s_first[side] == kNoRow) continue;
+      const uint64_t x = side == kSideNull ? (uint64_t(1) << k_bits) : uint64_t(Fmix32Inv(kTagFree));
+      for (int s = 0; s < kSlots; ++s) {
+        if (s_tag[s] == kTagFree) {
+          s_tag[s] = 0;  // claimed (value irrelevant from here on)
+          t.hkeys[g0 + s] = Fmix64(x); t.first[g0 + s] = s_first[side]; t.sums[g0 + s] = s_sum[side];
+          t.counts[g0 + s] = s_cnt[side];
+          atomicOr(&first_bitmap[s_first[side] >> 6], 1ull << (s_first[side] & 63));
+          break;
+        }
+      }
+    }
+  }
+  if (p == 0 && tid < 2 && total_slots > 0) {  // the two special slots behind the last slice stay empty on this path
+    const int64_t T = total_slots;
+    t.hkeys[T + tid] = kEmpty; t.first[T + tid] = kNoRow; t.sums[T + tid] = 0; t.counts[T + tid] = 0;
+  }
+}
+
 // ---- local path: per-workgroup LDS pre-aggregation ----------------------------------------------------
 // When a workgroup's row range holds few distinct keys (low-cardinality or clustered keys) the
 // records never need to leave the CU: every workgroup folds its rows straight into the LDS table
@@ -1847,7 +2103,7 @@ __device__ __forceinline__ void LocalInit(LocalShared& sh, int tid) {
   __syncthreads();
 }
 __device__ __forceinline__ void LocalGiveUp(LocalShared& sh, unsigned int* wg_flags) {
-  if ((threadIdx.x & 63) == 0) { sh.stop = 1; wg_flags[blockIdx.x] = 1; }
+  if ((threadIdx.x & 63) == 0) { __hip_atomic_store(&sh.stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); wg_flags[blockIdx.x] = 1; }
 }
 __device__ __forceinline__ void LocalWriteOut(const LocalShared& sh, const LocalStage& st, int tid) {
   const int64_t base = int64_t(blockIdx.x) * kStageSlots;
@@ -2168,22 +2424,23 @@ __global__ __launch_bounds__(kDThreads) void k_local_aggregate_fast(FastArgs a, 
     *vword = VVALID ? (CombineBits(a.v.valid, a.v.off + mrow_c, nbits > 0 ? nbits : 1, vraw) & live) : live;
   };
   uint64_t mw, vw;
-  volatile unsigned int* stop = &sh.stop;
+  // (a relaxed atomic load, not a volatile one: a volatile access drains every counter, i.e. the prefetched tile)
+  auto stopped = [&]() { return __hip_atomic_load(&sh.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; };
   if (lo < hi) FastLoadTile<MASK, VVALID>(a, keys, vals, lo, hi, wave, lane, kxA, kvA, mA, vA);
   for (int64_t tile0 = lo; tile0 < hi; tile0 += 2 * kLRows) {
     const bool has_b = tile0 + kLRows < hi;
     if (has_b) FastLoadTile<MASK, VVALID>(a, keys, vals, tile0 + kLRows, hi, wave, lane, kxB, kvB, mB, vB);
-    if (*stop) break;
+    if (stopped()) break;
     words(tile0, mA, vA, &mw, &vw);
     if (__any(!LocalFoldFast<VVALID>(sh, tile0, wave, lane, acc_double, kxA, kvA, mw, vw))) { LocalGiveUp(sh, wg_flags); break; }
     if (!has_b) break;
     if (tile0 + 2 * kLRows < hi) FastLoadTile<MASK, VVALID>(a, keys, vals, tile0 + 2 * kLRows, hi, wave, lane, kxA, kvA, mA, vA);
-    if (*stop) break;
+    if (stopped()) break;
     words(tile0 + kLRows, mB, vB, &mw, &vw);
     if (__any(!LocalFoldFast<VVALID>(sh, tile0 + kLRows, wave, lane, acc_double, kxB, kvB, mw, vw))) { LocalGiveUp(sh, wg_flags); break; }
   }
   __syncthreads();
-  if (*stop) {  // a stale staging table is never read: the merge is gated on the flags
+  if (stopped()) {  // a stale staging table is never read: the merge is gated on the flags
     ReportHotCandidates(sh, hot, tid);
     return;
   }
@@ -2200,13 +2457,14 @@ __global__ __launch_bounds__(kDThreads) void k_local_aggregate(FastArgs a, int a
   const int64_t hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
   constexpr int kIters = kDRows / kDThreads;
   static_assert(kIters % kAggUnroll == 0, "tile rows per thread");
-  volatile unsigned int* stop = &sh.stop;
+  // (a relaxed atomic load, not a volatile one: a volatile access drains every counter, i.e. the prefetched tile)
+  auto stopped = [&]() { return __hip_atomic_load(&sh.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; };
   TileRegs t;
   if (lo < hi) LoadTile(a, lo, hi, tid, lane, &t);
   for (int64_t tile0 = lo; tile0 < hi; tile0 += kDRows) {
     const TileRegs c = t;
     if (tile0 + kDRows < hi) LoadTile(a, tile0 + kDRows, hi, tid, lane, &t);
-    if (*stop) break;
+    if (stopped()) break;
     bool ok = true;
 #pragma unroll
     for (int g = 0; g < kIters; g += kAggUnroll) {
@@ -2223,7 +2481,7 @@ __global__ __launch_bounds__(kDThreads) void k_local_aggregate(FastArgs a, int a
     if (__any(!ok)) { LocalGiveUp(sh, wg_flags); break; }
   }
   __syncthreads();
-  if (*stop) {
+  if (stopped()) {
     ReportHotCandidates(sh, hot, tid);
     return;
   }
@@ -2233,12 +2491,14 @@ __global__ __launch_bounds__(kDThreads) void k_local_aggregate(FastArgs a, int a
 // Zero the first-row bitmap, the status words and the per-workgroup flags in one launch.
 __global__ __launch_bounds__(kThreads) void k_prepare(unsigned long long* bitmap, int64_t nwords, unsigned int* status,
                                                       unsigned int* wg_flags, int nflags, unsigned int* hot_cand_n,
-                                                      uint32_t* spill_counts /* counts[p][stride - 1], or null */, int spill_stride) {
+                                                      uint32_t* spill_counts /* counts[p][stride - 1], or null */, int spill_stride,
+                                                      unsigned int* key_minmax /* bin scatter, or null */) {
   for (int64_t w = int64_t(blockIdx.x) * kThreads + threadIdx.x; w < nwords; w += int64_t(gridDim.x) * kThreads) bitmap[w] = 0;
   if (blockIdx.x == 1 % gridDim.x && spill_counts)
     for (int p = threadIdx.x; p < kP; p += kThreads) spill_counts[int64_t(p) * spill_stride + spill_stride - 1] = 0;
   if (blockIdx.x == 0) {
     if (threadIdx.x < 8) status[threadIdx.x] = threadIdx.x == 4 ? kNoRow : 0u;
+    if (key_minmax && threadIdx.x < 2) key_minmax[threadIdx.x] = threadIdx.x == 0 ? 0xFFFFFFFFu : 0u;
     for (int i = threadIdx.x; i < nflags; i += kThreads) { wg_flags[i] = 0; if (hot_cand_n) hot_cand_n[i] = 0; }
   }
 }
@@ -2877,7 +3137,8 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
     hipLaunchKernelGGL(k_prepare, dim3(GridFor(r.nwords, kThreads, ctx->num_cus * 4)), dim3(kThreads), 0, ctx->stream, r.bitmap,
                        r.nwords, misc, wg_flags, nblocks_local > nblocks ? nblocks_local : nblocks,
                        path == 3 ? hot.cand_n : static_cast<unsigned int*>(nullptr),
-                       path >= 2 && use_bins ? reinterpret_cast<uint32_t*>(b + off_hist) : static_cast<uint32_t*>(nullptr), nseg);
+                       path >= 2 && use_bins ? reinterpret_cast<uint32_t*>(b + off_hist) : static_cast<uint32_t*>(nullptr), nseg,
+                       path >= 2 && use_bins ? misc + 8 : static_cast<unsigned int*>(nullptr));
     AA_HIP(hipGetLastError());
 
     if (fast) {
@@ -2888,6 +3149,8 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
       FastArgs fa{};
       fa.k_data = keys->values; fa.k_valid = keys->validity; fa.k_off = keys->offset; fa.k_bits = ks.total_bits;
       fa.k_load_bits = k_load_bits; fa.k_bias = k_bias;
+      fa.k_flip = keys->type_id == AMDARROW_INT32 ? 0x80000000u : 0u;
+      fa.key_minmax = misc + 8;  // (status words are misc[0..7]; the workgroup flags start at misc + 64)
       fa.v = v; fa.has_values = values ? 1 : 0;
       fa.m_data = m_data; fa.m_valid = m_valid; fa.m_off = m_off;
       fa.n = n; fa.nblocks = nblocks; fa.rows_per_block = rows_per_block;
@@ -2949,6 +3212,11 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
                                misc, use_hot, static_cast<const unsigned int*>(nullptr));
         }
         AA_HIP(hipGetLastError());
+        if (use_bins && !getenv("AMDARROW_GROUPBY_OLD_AGG"))
+          hipLaunchKernelGGL(k_part_aggregate_piped, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nseg,
+                             cap, ks.total_bits, acc_double, t, r.bitmap, misc, run_if, int64_t(sub) * kP * kSlots,
+                             sub == 0 ? static_cast<int64_t>(T) : int64_t(0), fa.key_minmax, fa.k_flip, use_hot);
+        else
         hipLaunchKernelGGL(k_part_aggregate_direct, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nseg,
                            cap, ks.total_bits, acc_double, t, r.bitmap, misc, run_if, int64_t(sub) * kP * kSlots,
                            sub == 0 ? static_cast<int64_t>(T) : int64_t(0));
