@@ -1843,6 +1843,11 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
 // one compare-and-swap per record on the first free entry of the buckets already fetched, all issued
 // together; only a lost race enters the probe loop.
 struct AggIter { int k; uint32_t i0, cnt; };
+// Directly indexed table: offset o = (key >> 9) - base lives in slot bitreverse12(o), so that a slice filled to
+// a fraction holds its groups spread over all of its slots (the kernels that walk the finished table split
+// it by slot ranges: with the groups packed at the front a few workgroups did all the work, 29 -> 44 us).
+static_assert(kSlots == 4096, "DirectSlot reverses 12 bits");
+__device__ __forceinline__ uint32_t DirectSlot(uint32_t o) { return __brev(o) >> 20; }
 // The probe loop as a real call: inlined, the twelve copies of it (four records x three register sets) made
 // the streaming loop several times the size of the instruction cache's share of one CU.
 __device__ __attribute__((noinline)) int ProbeInsertCold(unsigned int* s_tag, unsigned int* s_groups, uint32_t h) {
@@ -1992,7 +1997,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_piped(const uin
 #pragma unroll
         for (int u = 0; u < kPaUnroll; ++u) {
           if (!live[u]) continue;
-          const uint32_t slot = ((r[u].x ^ k_flip) >> kPBits) - dbase;
+          const uint32_t slot = DirectSlot(((r[u].x ^ k_flip) >> kPBits) - dbase);
           atomicMin(&s_first[slot], r[u].y & kRecRowMask);
           if (r[u].y & kRecValValid) {
             const unsigned long long bits = (static_cast<unsigned long long>(r[u].w) << 32) | r[u].z;
@@ -2033,7 +2038,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_piped(const uin
     // the shared numbering / emit kernels speak fmix64 of the packed key word
     if (direct) {
       // the key of (partition p, slot s): high part s + base, low part p XOR the high part's hashed bits (BinPartOf)
-      const uint32_t high = static_cast<uint32_t>(s) + dbase;
+      const uint32_t high = DirectSlot(static_cast<uint32_t>(s)) + dbase;  // (the bit reversal is its own inverse)
       const uint32_t kk = (high << kPBits) | (static_cast<uint32_t>(p) ^ ((high * 0x9E3779B1u) >> (32 - kPBits)));
       t.hkeys[g0 + s] = fr == kNoRow ? kEmpty : Fmix64(uint64_t(kk ^ k_flip));
     } else {
