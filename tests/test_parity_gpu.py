@@ -1210,3 +1210,87 @@ def test_grouper_key_rows_wider_than_64_bits(gpu, oracle):
                 v = np.asarray(wb[:want_ng], bool)
                 ga, wa = np.asarray(gv)[:got_ng][v], np.asarray(wv)[:want_ng][v]
                 assert np.array_equal(ga.view(np.uint8) if ga.dtype != bool else ga, wa.view(np.uint8) if wa.dtype != bool else wa), (types, k)
+
+
+# ---- round 2: bin scatter, pipelined aggregate, directly indexed partition tables ---------------------------
+def _check_groupby(oracle, gpu, v, k, m, what):
+    for x, y in zip(oracle.filter_groupby_sum(v, k, m), gpu.filter_groupby_sum(v, k, m)):
+        if x.dtype == np.float64:
+            assert x.shape == y.shape and np.allclose(x, y, rtol=F64_RTOL), what
+        else:
+            assert np.array_equal(x, y), what
+
+
+@pytest.mark.parametrize("shape", ["int32-negative", "uint32-high", "range-2M-direct", "range-over-2M-hashed",
+                                   "multiples-of-512", "float32-bits"])
+def test_filter_groupby_bin_scatter_direct_and_hashed_tables(gpu, oracle, shape, monkeypatch):
+    """The headline shape on the one-pass partition path (forced: no local attempt in front).  Keys whose
+    key >> 9 spans at most 4096 values index the partition tables directly -- signed keys by value order,
+    unsigned ones as they are -- wider ranges and float bit patterns take the hashed tables; keys that
+    share their low nine bits must still spread over the partitions."""
+    monkeypatch.setenv("AMDARROW_GROUPBY_PATH", "2")
+    rng = np.random.default_rng(0x0ff1ce + 31)
+    n = 1_200_000
+    if shape == "int32-negative":
+        k = Arr(INT32, rng.integers(-40_000, 40_000, n).astype(np.int32))
+    elif shape == "uint32-high":
+        k = Arr(UINT32, (rng.integers(0, 90_000, n) + 0xFFF00000).astype(np.uint32))
+    elif shape == "range-2M-direct":
+        k = Arr(INT32, (rng.integers(0, 4096 * 512, n) - 1_000_000).astype(np.int32))
+    elif shape == "range-over-2M-hashed":
+        k = Arr(INT32, rng.integers(0, 4097 * 512 + 5, n).astype(np.int32))
+    elif shape == "multiples-of-512":
+        k = Arr(INT32, (rng.integers(0, 60_000, n) * 512).astype(np.int32))
+    else:
+        k = Arr(FLOAT, rng.integers(0, 5000, n).astype(np.float32) * np.float32(0.25))
+    for vt in (INT64, DOUBLE):
+        v = R(rng, vt, n, .02, 2)
+        m = R(rng, BOOL, n, 0.0, 3)
+        _check_groupby(oracle, gpu, v, k, m, (shape, vt))
+
+
+@pytest.mark.parametrize("density", [0.05, 0.5, 0.7, 0.95, 1.0])
+def test_filter_groupby_bin_scatter_tile_size_follows_the_mask(gpu, oracle, density, monkeypatch):
+    """Every workgroup picks 4096- or 2048-row tiles from the density of its own mask range; a mask that is
+    sparse in the sampled rows and dense behind them fills the bins faster than they drain (spill list)."""
+    monkeypatch.setenv("AMDARROW_GROUPBY_PATH", "2")
+    rng = np.random.default_rng(0x0ff1ce + 32)
+    n = 2_500_000
+    k = Arr(INT32, rng.integers(0, 300_000, n).astype(np.int32))
+    v = R(rng, INT64, n, 0.0, 0)
+    mask = rng.random(n) < density
+    _check_groupby(oracle, gpu, v, k, Arr(BOOL, mask), density)
+    # the sampled head of every workgroup's rows says "sparse", the rest is dense
+    blocked = np.ones(n, bool)
+    per_block = 12288
+    for b in range(0, n, per_block):
+        blocked[b:b + 2048] = rng.random(min(2048, n - b)) < 0.1
+    _check_groupby(oracle, gpu, v, k, Arr(BOOL, blocked), "sparse head")
+
+
+def test_filter_groupby_bin_scatter_spill_list(gpu, oracle, monkeypatch):
+    """Few distinct keys on the forced partition path: every tile brings more rows of a partition than its
+    bin holds, the excess goes through the partition's spill list (an extra segment of the aggregate)."""
+    monkeypatch.setenv("AMDARROW_GROUPBY_PATH", "2")
+    rng = np.random.default_rng(0x0ff1ce + 33)
+    n = 16_000_000
+    for distinct in (400, 3000):
+        k = Arr(INT32, rng.integers(0, distinct, n).astype(np.int32))
+        v = R(rng, INT64, n, 0.01, 0)
+        m = R(rng, BOOL, n, 0.0, 3)
+        _check_groupby(oracle, gpu, v, k, m, distinct)
+
+
+def test_filter_groupby_unaligned_slices_leave_the_bin_scatter(gpu, oracle):
+    """Key / value slices that do not start on a 16-byte boundary cannot take the vector loads of the bin
+    scatter: the staged scatter runs instead, same rows."""
+    rng = np.random.default_rng(0x0ff1ce + 34)
+    n = 700_003
+    for koff, voff, moff in ((1, 0, 0), (0, 1, 3), (3, 5, 7)):
+        def cut(a, off):
+            return Arr(a.type_id, a.data, a.valid, offset=off, length=n - 8)
+        k = cut(R(rng, INT32, n, 0.0, 1, lo=0, hi=90_000), koff)
+        v = cut(R(rng, INT64, n, 0.01, 2), voff)
+        m = cut(R(rng, BOOL, n, 0.0, 3), moff)
+        for _ in range(2):  # the second call of a shape is the hinted one
+            _check_groupby(oracle, gpu, v, k, m, (koff, voff, moff))
