@@ -1330,15 +1330,49 @@ using BinU64x2 = __attribute__((ext_vector_type(2))) unsigned long long;
 // 2 M, to index the partition's LDS table directly (k_part_aggregate_piped) instead of hashing into it --
 // while keys that share their low bits (multiples of 512, say) are still spread by the hashed part.
 __device__ __forceinline__ uint32_t BinPartOf(uint32_t kk) { return (kk & (kP - 1)) ^ (((kk >> kPBits) * 0x9E3779B1u) >> (32 - kPBits)); }
-template <int R> struct BinTile;
-template <> struct BinTile<4> {
-  BinU32x4 kv; BinU64x2 va, vb; uint32_t m0, m1, v0, v1;
-  __device__ __forceinline__ uint32_t k(int j) const { return kv[j]; }
+// The keys of a tile as they were loaded: 32-bit keys, or 64-bit keys of a range-compressed column
+// (x = key - bias fits 32 bits; the subtraction happens when the tile is staged).
+template <int R, bool K64> struct BinKeys;
+template <> struct BinKeys<4, false> {
+  BinU32x4 kv;
+  __device__ __forceinline__ uint32_t k(int j, uint64_t) const { return kv[j]; }
+  __device__ __forceinline__ void load(const void* base, int64_t r0) { kv = __builtin_nontemporal_load(reinterpret_cast<const BinU32x4*>(static_cast<const uint32_t*>(base) + r0)); }
+  __device__ __forceinline__ void set(int j, const void* base, int64_t r) { kv[j] = static_cast<const uint32_t*>(base)[r]; }
+  __device__ __forceinline__ void touch() const { asm volatile("" :: "v"(kv)); }
+};
+template <> struct BinKeys<2, false> {
+  BinU32x2 kv;
+  __device__ __forceinline__ uint32_t k(int j, uint64_t) const { return kv[j]; }
+  __device__ __forceinline__ void load(const void* base, int64_t r0) { kv = __builtin_nontemporal_load(reinterpret_cast<const BinU32x2*>(static_cast<const uint32_t*>(base) + r0)); }
+  __device__ __forceinline__ void set(int j, const void* base, int64_t r) { kv[j] = static_cast<const uint32_t*>(base)[r]; }
+  __device__ __forceinline__ void touch() const { asm volatile("" :: "v"(kv)); }
+};
+template <> struct BinKeys<4, true> {
+  BinU64x2 ka, kb;
+  __device__ __forceinline__ uint32_t k(int j, uint64_t bias) const { return static_cast<uint32_t>((j < 2 ? ka[j] : kb[j - 2]) - bias); }
+  __device__ __forceinline__ void load(const void* base, int64_t r0) {
+    ka = __builtin_nontemporal_load(reinterpret_cast<const BinU64x2*>(static_cast<const uint64_t*>(base) + r0));
+    kb = __builtin_nontemporal_load(reinterpret_cast<const BinU64x2*>(static_cast<const uint64_t*>(base) + r0 + 2));
+  }
+  __device__ __forceinline__ void set(int j, const void* base, int64_t r) {
+    if (j < 2) ka[j] = static_cast<const uint64_t*>(base)[r]; else kb[j - 2] = static_cast<const uint64_t*>(base)[r];
+  }
+  __device__ __forceinline__ void touch() const { asm volatile("" :: "v"(ka), "v"(kb)); }
+};
+template <> struct BinKeys<2, true> {
+  BinU64x2 ka;
+  __device__ __forceinline__ uint32_t k(int j, uint64_t bias) const { return static_cast<uint32_t>(ka[j] - bias); }
+  __device__ __forceinline__ void load(const void* base, int64_t r0) { ka = __builtin_nontemporal_load(reinterpret_cast<const BinU64x2*>(static_cast<const uint64_t*>(base) + r0)); }
+  __device__ __forceinline__ void set(int j, const void* base, int64_t r) { ka[j] = static_cast<const uint64_t*>(base)[r]; }
+  __device__ __forceinline__ void touch() const { asm volatile("" :: "v"(ka)); }
+};
+template <int R, bool K64> struct BinTile;
+template <bool K64> struct BinTile<4, K64> {
+  BinKeys<4, K64> key; BinU64x2 va, vb; uint32_t m0, m1, v0, v1;
   __device__ __forceinline__ uint64_t v(int j) const { return j < 2 ? va[j] : vb[j - 2]; }
 };
-template <> struct BinTile<2> {
-  BinU32x2 kv; BinU64x2 va; uint32_t m0, m1, v0, v1;
-  __device__ __forceinline__ uint32_t k(int j) const { return kv[j]; }
+template <bool K64> struct BinTile<2, K64> {
+  BinKeys<2, K64> key; BinU64x2 va; uint32_t m0, m1, v0, v1;
   __device__ __forceinline__ uint64_t v(int j) const { return va[j]; }
 };
 
@@ -1357,31 +1391,26 @@ __device__ __forceinline__ uint32_t FewBits(uint32_t b0, uint32_t b1, int64_t po
 }
 
 // A whole tile (every row below hi): 16-byte loads, unconditional.
-template <bool MASK, bool VVALID, int R>
-__device__ __forceinline__ void BinLoadTile(const FastArgs& a, const uint32_t* __restrict__ keys,
-                                            const uint64_t* __restrict__ vals, int64_t tile0, int tid, BinTile<R>& t) {
+template <bool MASK, bool VVALID, int R, bool K64>
+__device__ __forceinline__ void BinLoadTile(const FastArgs& a, const void* __restrict__ keys,
+                                            const uint64_t* __restrict__ vals, int64_t tile0, int tid, BinTile<R, K64>& t) {
   const int64_t r0 = tile0 + int64_t(tid) * R;
-  if constexpr (R == 4) {
-    t.kv = __builtin_nontemporal_load(reinterpret_cast<const BinU32x4*>(keys + r0));
-    t.va = __builtin_nontemporal_load(reinterpret_cast<const BinU64x2*>(vals + r0));
-    t.vb = __builtin_nontemporal_load(reinterpret_cast<const BinU64x2*>(vals + r0 + 2));
-  } else {
-    t.kv = __builtin_nontemporal_load(reinterpret_cast<const BinU32x2*>(keys + r0));
-    t.va = __builtin_nontemporal_load(reinterpret_cast<const BinU64x2*>(vals + r0));
-  }
+  t.key.load(keys, r0);
+  t.va = __builtin_nontemporal_load(reinterpret_cast<const BinU64x2*>(vals + r0));
+  if constexpr (R == 4) t.vb = __builtin_nontemporal_load(reinterpret_cast<const BinU64x2*>(vals + r0 + 2));
   if (MASK) LoadBitBytes(a.m_data, a.m_off + r0, (a.m_off + a.n - 1) >> 3, &t.m0, &t.m1);
   if (VVALID) LoadBitBytes(a.v.valid, a.v.off + r0, (a.v.off + a.n - 1) >> 3, &t.v0, &t.v1);
 }
 // The last, partial tile of the last block: one row at a time, addresses kept inside the buffers.
-template <bool MASK, bool VVALID, int R>
-__device__ __forceinline__ void BinLoadTail(const FastArgs& a, const uint32_t* __restrict__ keys,
+template <bool MASK, bool VVALID, int R, bool K64>
+__device__ __forceinline__ void BinLoadTail(const FastArgs& a, const void* __restrict__ keys,
                                             const uint64_t* __restrict__ vals, int64_t tile0, int64_t hi, int tid,
-                                            BinTile<R>& t) {
+                                            BinTile<R, K64>& t) {
   const int64_t r0 = tile0 + int64_t(tid) * R;
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     const int64_t rc = r0 + j < hi ? r0 + j : hi - 1;
-    t.kv[j] = keys[rc];
+    t.key.set(j, keys, rc);
     if (j < 2) t.va[j] = vals[rc];
     if constexpr (R == 4) { if (j >= 2) t.vb[j - 2] = vals[rc]; }
   }
@@ -1391,8 +1420,8 @@ __device__ __forceinline__ void BinLoadTail(const FastArgs& a, const uint32_t* _
 }
 
 // Rank + stage: the slot of a selected row is what the LDS atomic on its bin's counter returns.
-template <bool MASK, bool VVALID, int R>
-__device__ __forceinline__ void BinStageTile(BinShared& sh, const FastArgs& a, const BinTile<R>& t, int64_t tile0, int64_t hi,
+template <bool MASK, bool VVALID, int R, bool K64>
+__device__ __forceinline__ void BinStageTile(BinShared& sh, const FastArgs& a, const BinTile<R, K64>& t, int64_t tile0, int64_t hi,
                                              int tid, int64_t cap, uint4* __restrict__ regions,
                                              uint32_t* __restrict__ counts, unsigned int* overflow, uint32_t& kmin,
                                              uint32_t& kmax) {
@@ -1406,9 +1435,10 @@ __device__ __forceinline__ void BinStageTile(BinShared& sh, const FastArgs& a, c
   bool sel[R];
 #pragma unroll
   for (int j = 0; j < R; ++j) {
-    const uint32_t kk = t.k(j) ^ a.k_flip;
+    const uint32_t x = t.key.k(j, a.k_bias);
+    const uint32_t kk = x ^ a.k_flip;
     sel[j] = (mbits >> j) & 1u;
-    if (a.sub_bits) sel[j] = sel[j] && InSub(Fmix32(t.k(j)), a.sub_bits, a.sub_id);  // (uniform branch: sub-problems only)
+    if (a.sub_bits) sel[j] = sel[j] && InSub(Fmix32(x), a.sub_bits, a.sub_id);  // (uniform branch: sub-problems only)
     part[j] = BinPartOf(kk);
     slot[j] = 0;
     if (sel[j]) {
@@ -1423,7 +1453,7 @@ __device__ __forceinline__ void BinStageTile(BinShared& sh, const FastArgs& a, c
     const bool vvalid = (vbits >> j) & 1u;
     const uint64_t v = vvalid ? t.v(j) : 0;
     uint4 q;
-    q.x = t.k(j);
+    q.x = t.key.k(j, a.k_bias);
     q.y = static_cast<uint32_t>(r0 + j) | (vvalid ? kRecValValid : 0u);
     q.z = static_cast<uint32_t>(v); q.w = static_cast<uint32_t>(v >> 32);
     if (slot[j] < static_cast<uint32_t>(kBinSlots)) {
@@ -1474,39 +1504,39 @@ __device__ __forceinline__ void BinFlush(BinShared& sh, int tid, int64_t cap, ui
 }
 
 // The tile loop of one workgroup over its row range, R rows per thread and tile.
-template <bool MASK, bool VVALID, int R>
+template <bool MASK, bool VVALID, int R, bool K64>
 __device__ __forceinline__ void BinRun(BinShared& sh, const FastArgs& a, int64_t lo, int64_t hi, int64_t cap,
                                        uint4* __restrict__ regions, uint4* __restrict__ my_regions,
                                        uint32_t* __restrict__ counts, unsigned int* overflow, uint32_t& kmin, uint32_t& kmax) {
   constexpr int kRows = kBThreads * R;
   const int tid = threadIdx.x;
-  const uint32_t* keys = reinterpret_cast<const uint32_t*>(a.k_data) + a.k_off;
+  const void* keys = static_cast<const char*>(a.k_data) + a.k_off * (K64 ? 8 : 4);
   const uint64_t* vals = reinterpret_cast<const uint64_t*>(a.v.data) + a.v.off;
   // Three register sets: tile X is staged while the loads of X+1 and X+2 are in flight.  Per tile:
   //   stage(X) | barrier | wait for X+1 | flush(X) | issue X+3 | barrier
   // The wait sits BEFORE the flush stores, where the only younger memory operations are the loads of
   // X+2 (an exact vmcnt): behind the flush it would also wait for the flush's own stores.
-  BinTile<R> t0{}, t1{}, t2{};
-#define AA_TOUCH(T) do { asm volatile("" :: "v"(T.kv), "v"(T.va)); if constexpr (R == 4) asm volatile("" :: "v"(T.vb)); \
+  BinTile<R, K64> t0{}, t1{}, t2{};
+#define AA_TOUCH(T) do { T.key.touch(); asm volatile("" :: "v"(T.va)); if constexpr (R == 4) asm volatile("" :: "v"(T.vb)); \
                          if (MASK) asm volatile("" :: "v"(T.m0), "v"(T.m1)); if (VVALID) asm volatile("" :: "v"(T.v0), "v"(T.v1)); } while (0)
   // Every prefetch is issued unconditionally -- past the last whole tile it fetches that tile again
   // and the result is dropped -- so that the number of loads in flight at each wait is a constant
   // the compiler can count (a conditional load makes it wait for everything).
 #define AA_BIN_STEP(CUR, NEXT, TILE0)                                                                  \
   do {                                                                                                   \
-    BinStageTile<MASK, VVALID, R>(sh, a, CUR, (TILE0), hi, tid, cap, regions, counts, overflow, kmin, kmax); \
+    BinStageTile<MASK, VVALID, R, K64>(sh, a, CUR, (TILE0), hi, tid, cap, regions, counts, overflow, kmin, kmax); \
     LdsBarrier();                                                                                        \
     AA_TOUCH(NEXT);                                                                                      \
     BinFlush(sh, tid, cap, my_regions, overflow);                                                        \
-    BinLoadTile<MASK, VVALID, R>(a, keys, vals, (TILE0) + 3 * kRows <= last_whole ? (TILE0) + 3 * kRows : last_whole, tid, CUR); \
+    BinLoadTile<MASK, VVALID, R, K64>(a, keys, vals, (TILE0) + 3 * kRows <= last_whole ? (TILE0) + 3 * kRows : last_whole, tid, CUR); \
     LdsBarrier();                                                                                        \
   } while (0)
   int64_t tile0 = lo;
   if (lo + kRows <= hi) {
     const int64_t last_whole = lo + ((hi - lo) / kRows - 1) * kRows;
-    BinLoadTile<MASK, VVALID, R>(a, keys, vals, lo, tid, t0);
-    BinLoadTile<MASK, VVALID, R>(a, keys, vals, lo + kRows <= last_whole ? lo + kRows : last_whole, tid, t1);
-    BinLoadTile<MASK, VVALID, R>(a, keys, vals, lo + 2 * kRows <= last_whole ? lo + 2 * kRows : last_whole, tid, t2);
+    BinLoadTile<MASK, VVALID, R, K64>(a, keys, vals, lo, tid, t0);
+    BinLoadTile<MASK, VVALID, R, K64>(a, keys, vals, lo + kRows <= last_whole ? lo + kRows : last_whole, tid, t1);
+    BinLoadTile<MASK, VVALID, R, K64>(a, keys, vals, lo + 2 * kRows <= last_whole ? lo + 2 * kRows : last_whole, tid, t2);
     AA_TOUCH(t0);  // (the loop body starts with its first tile complete on every path into it)
     // whole tiles, three per trip (a trip ends with the register sets back in phase); no exit from
     // inside a trip: with one the compiler sees paths into the loop head on which t0 was just reloaded
@@ -1525,8 +1555,8 @@ __device__ __forceinline__ void BinRun(BinShared& sh, const FastArgs& a, int64_t
     }
   }
   if (tile0 < hi) {  // the partial tile at the end of the input
-    BinLoadTail<MASK, VVALID, R>(a, keys, vals, tile0, hi, tid, t0);
-    BinStageTile<MASK, VVALID, R>(sh, a, t0, tile0, hi, tid, cap, regions, counts, overflow, kmin, kmax);
+    BinLoadTail<MASK, VVALID, R, K64>(a, keys, vals, tile0, hi, tid, t0);
+    BinStageTile<MASK, VVALID, R, K64>(sh, a, t0, tile0, hi, tid, cap, regions, counts, overflow, kmin, kmax);
     LdsBarrier();
     BinFlush(sh, tid, cap, my_regions, overflow);
   }
@@ -1539,7 +1569,7 @@ __device__ __forceinline__ void BinRun(BinShared& sh, const FastArgs& a, int64_t
 // 0.6 % at 75 % (mean 6); denser input runs on 2048-row tiles (mean <= 4).  Every workgroup decides for
 // itself from the mask bits of its first rows.
 constexpr int kBinSampleWords = 256;  // 64-bit words of the workgroup's mask range that are counted
-template <bool MASK, bool VVALID>
+template <bool MASK, bool VVALID, bool K64>
 __global__ __launch_bounds__(kBThreads) void k_part_scatter_bins(FastArgs a, int64_t cap, uint4* regions, uint32_t* counts,
                                                                  unsigned int* overflow, const unsigned int* run_if,
                                                                  const unsigned int* skip_if) {
@@ -1569,8 +1599,8 @@ __global__ __launch_bounds__(kBThreads) void k_part_scatter_bins(FastArgs a, int
     dense = 3 * int64_t(s_sample) > 2 * sample_rows;  // more than two thirds of the rows selected
   }
   uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
-  if (dense) BinRun<MASK, VVALID, 2>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow, kmin, kmax);
-  else BinRun<MASK, VVALID, 4>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow, kmin, kmax);
+  if (dense) BinRun<MASK, VVALID, 2, K64>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow, kmin, kmax);
+  else BinRun<MASK, VVALID, 4, K64>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow, kmin, kmax);
   {  // the range of the selected keys: wave, workgroup (LDS), device -- two device atomics per workgroup
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -3062,8 +3092,11 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
   const bool headline_shape = ks.total_bits == 32 && k_load_bits == 32 && !keys->validity && values &&
                               BitWidth(values->type_id) == 64 && !m_valid;
   // the bin scatter loads 16-byte vectors: keys and values must start on a 16-byte boundary
-  const bool use_bins = headline_shape && !getenv("AMDARROW_GROUPBY_NO_BINS") &&
-                        (reinterpret_cast<uintptr_t>(keys->values) + 4 * static_cast<uintptr_t>(keys->offset)) % 16 == 0 &&
+  // (also for a 64-bit key column that range-compressed onto 32 bits: the kernel loads the 64-bit keys and subtracts the bias)
+  const bool bins_shape = ks.total_bits == 32 && (k_load_bits == 32 || k_load_bits == 64) && !keys->validity && values &&
+                          BitWidth(values->type_id) == 64 && !m_valid;
+  const bool use_bins = bins_shape && !getenv("AMDARROW_GROUPBY_NO_BINS") &&
+                        (reinterpret_cast<uintptr_t>(keys->values) + (k_load_bits / 8) * static_cast<uintptr_t>(keys->offset)) % 16 == 0 &&
                         (reinterpret_cast<uintptr_t>(values->values) + 8 * static_cast<uintptr_t>(values->offset)) % 16 == 0;
   GroupTable t{};
   RankMem r{};
@@ -3154,7 +3187,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
       FastArgs fa{};
       fa.k_data = keys->values; fa.k_valid = keys->validity; fa.k_off = keys->offset; fa.k_bits = ks.total_bits;
       fa.k_load_bits = k_load_bits; fa.k_bias = k_bias;
-      fa.k_flip = keys->type_id == AMDARROW_INT32 ? 0x80000000u : 0u;
+      fa.k_flip = keys->type_id == AMDARROW_INT32 ? 0x80000000u : 0u;  // (a range-compressed column: x = key - min >= 0 as it is)
       fa.key_minmax = misc + 8;  // (status words are misc[0..7]; the workgroup flags start at misc + 64)
       fa.v = v; fa.has_values = values ? 1 : 0;
       fa.m_data = m_data; fa.m_valid = m_valid; fa.m_off = m_off;
@@ -3198,7 +3231,8 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
         FastArgs fh = fa;  // the same scatter on the mask k_hot_aggregate wrote
         fh.m_data = hot.alt_mask; fh.m_valid = nullptr; fh.m_off = 0;
         if (use_bins) {
-#define AA_BINS(MM, VV, ARGS, RUN, SKIP) hipLaunchKernelGGL((k_part_scatter_bins<MM, VV>), dim3(nblocks), dim3(kBThreads), 0, ctx->stream, ARGS, cap, records, hist, misc, RUN, SKIP)
+#define AA_BINS(MM, VV, ARGS, RUN, SKIP) do { if (k_load_bits == 64) hipLaunchKernelGGL((k_part_scatter_bins<MM, VV, true>), dim3(nblocks), dim3(kBThreads), 0, ctx->stream, ARGS, cap, records, hist, misc, RUN, SKIP); \
+          else hipLaunchKernelGGL((k_part_scatter_bins<MM, VV, false>), dim3(nblocks), dim3(kBThreads), 0, ctx->stream, ARGS, cap, records, hist, misc, RUN, SKIP); } while (0)
           if (M && V) AA_BINS(true, true, fa, run_if, use_hot); else if (M) AA_BINS(true, false, fa, run_if, use_hot);
           else if (V) AA_BINS(false, true, fa, run_if, use_hot); else AA_BINS(false, false, fa, run_if, use_hot);
           if (use_hot) { if (V) AA_BINS(true, true, fh, use_hot, nullptr); else AA_BINS(true, false, fh, use_hot, nullptr); }
