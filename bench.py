@@ -317,9 +317,11 @@ def pmc_traffic(workload):
     there): sum over the kernels of one step.  None when no summary is committed for the workload."""
     if workload != "filter_groupby_sum_i64":
         return None, None
-    path = os.path.join(ROOT, "profiles", "r01_headline_hbm_pmc.txt")
-    if not os.path.exists(path):
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_headline_hbm_pmc.txt")))
+    if not found:
         return None, None
+    path = found[-1]  # the latest round's collection
     total_kb = 0.0
     for line in open(path):
         parts = line.split()
