@@ -1735,6 +1735,65 @@ __device__ __forceinline__ bool AggFold(const uint4 (&rec)[N], const bool (&live
   return ok;
 }
 
+// The local pre-aggregation's table for the headline shape: tags are the RAW keys, the slot of a key is
+// (key ^ key >> 12) & 4095 -- dense small keys (ids, codes, dates: what few-groups-per-range input mostly
+// is) sit at their own value without a collision -- and a miss probes linearly, at most kRawProbes slots.
+// ~15 vector instructions per record where the hashed, bucketised fold above needs ~100 (two multiplies of
+// the finaliser, eight tag compares), which is what bounds that fold.  A chain longer than kRawProbes, or
+// the one key that equals the free marker, fails the attempt: the caller gives up and the partition path,
+// which takes any key, runs instead.
+constexpr int kRawProbes = 8;
+__device__ __forceinline__ uint32_t RawSlot(uint32_t x) { return (x ^ (x >> 12)) & (kSlots - 1); }
+__device__ __attribute__((noinline)) int ProbeRaw(unsigned int* s_tag, unsigned int* s_groups, uint32_t x, uint32_t slot,
+                                                  unsigned int limit) {
+  for (int probes = 0; probes < kRawProbes; ++probes) {
+    for (;;) {
+      const unsigned int t = s_tag[slot];
+      if (t == x) return static_cast<int>(slot);
+      if (t != kTagFree) break;  // another key lives here: next slot
+      if (*s_groups >= limit) return -1;
+      const unsigned int old = atomicCAS(&s_tag[slot], kTagFree, x);
+      if (old == kTagFree) { atomicAdd(s_groups, 1u); return static_cast<int>(slot); }
+      if (old == x) return static_cast<int>(slot);
+      // another key took it: look again (and move on)
+    }
+    slot = (slot + 1) & (kSlots - 1);
+  }
+  return -1;
+}
+template <int N>
+__device__ __forceinline__ bool AggFoldRaw(const uint4 (&rec)[N], const bool (&live)[N], int acc_double,
+                                           unsigned int* s_tag, unsigned long long* s_sum, uint32_t* s_first,
+                                           unsigned int* s_cnt, unsigned int* s_groups, unsigned int limit) {
+  bool ok = true;
+  uint32_t home[N];
+  unsigned int t0[N];
+  int slot[N];
+#pragma unroll
+  for (int u = 0; u < N; ++u) { home[u] = RawSlot(rec[u].x); t0[u] = s_tag[home[u]]; }
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    if (!live[u]) { slot[u] = -2; continue; }
+    if (t0[u] == rec[u].x && rec[u].x != kTagFree) slot[u] = static_cast<int>(home[u]);
+    else if (rec[u].x == kTagFree) slot[u] = -1;
+    else slot[u] = ProbeRaw(s_tag, s_groups, rec[u].x, home[u], limit);
+  }
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    if (slot[u] == -2) continue;
+    if (slot[u] < 0) { ok = false; continue; }
+    const uint4 r = rec[u];
+    atomicMin(&s_first[slot[u]], r.y & kRecRowMask);
+    if (r.y & kRecValValid) {
+      const unsigned long long bits = (static_cast<unsigned long long>(r.w) << 32) | r.z;
+      if (acc_double) atomicAdd(reinterpret_cast<double*>(&s_sum[slot[u]]), __longlong_as_double(bits));
+      else atomicAdd(&s_sum[slot[u]], bits);
+      atomicAdd(&s_cnt[slot[u]], 1u);
+    }
+  }
+  return ok;
+}
+
 template <int N>
 __device__ __forceinline__ bool AggFoldStep(const uint4 (&rec)[N], uint32_t i0, uint32_t cnt, int lane,
                                             int acc_double, unsigned int* s_tag, unsigned long long* s_sum,
@@ -2140,10 +2199,14 @@ __device__ __forceinline__ void LocalInit(LocalShared& sh, int tid) {
 __device__ __forceinline__ void LocalGiveUp(LocalShared& sh, unsigned int* wg_flags) {
   if ((threadIdx.x & 63) == 0) { __hip_atomic_store(&sh.stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); wg_flags[blockIdx.x] = 1; }
 }
-__device__ __forceinline__ void LocalWriteOut(const LocalShared& sh, const LocalStage& st, int tid) {
+// raw_tags: the table holds raw keys (AggFoldRaw); the staging table, like everything behind it, speaks
+// fmix32 tags.  (k_local_merge tells a free slot by its first row, not by its tag, and recovers the key as
+// Fmix32Inv(tag): the one key whose tag equals the free marker comes through like any other.)
+__device__ __forceinline__ void LocalWriteOut(const LocalShared& sh, const LocalStage& st, int tid, bool raw_tags = false) {
   const int64_t base = int64_t(blockIdx.x) * kStageSlots;
   for (int s = tid; s < kStageSlots; s += kDThreads) {
-    st.tag[base + s] = s < kSlots ? sh.tag[s] : 0u;
+    const unsigned int tag = s < kSlots ? sh.tag[s] : 0u;
+    st.tag[base + s] = raw_tags && s < kSlots && tag != kTagFree ? Fmix32(tag) : tag;
     st.first[base + s] = sh.first[s];
     st.sum[base + s] = sh.sum[s];
     st.cnt[base + s] = sh.cnt[s];
@@ -2176,7 +2239,7 @@ constexpr int kHotMapSlots = 4096;  // LDS open-addressing map tag -> hot index 
 // keys of the sample (power-of-two count classes, from the top until kHotPerWg would be exceeded):
 // slot order is the same in every workgroup, so "the first kHotPerWg found" would drop the same
 // keys everywhere, however hot.
-__device__ __forceinline__ void ReportHotCandidates(LocalShared& sh, const HotMem& hot, int tid) {
+__device__ __forceinline__ void ReportHotCandidates(LocalShared& sh, const HotMem& hot, int tid, bool raw_tags = false) {
   __shared__ unsigned int s_n, s_class[33], s_min_class;
   if (tid == 0) s_n = 0;
   if (tid < 33) s_class[tid] = 0;
@@ -2198,7 +2261,7 @@ __device__ __forceinline__ void ReportHotCandidates(LocalShared& sh, const HotMe
   for (int s = tid; s < kSlots; s += kDThreads) {
     if (sh.tag[s] != kTagFree && sh.cnt[s] >= kHotMin && 32u - __clz(sh.cnt[s]) >= min_class) {
       const unsigned int i = atomicAdd(&s_n, 1u);
-      if (i < static_cast<unsigned int>(kHotPerWg)) hot.cand[int64_t(blockIdx.x) * kHotPerWg + i] = sh.tag[s];
+      if (i < static_cast<unsigned int>(kHotPerWg)) hot.cand[int64_t(blockIdx.x) * kHotPerWg + i] = raw_tags ? Fmix32(sh.tag[s]) : sh.tag[s];
     }
   }
   __syncthreads();
@@ -2431,7 +2494,7 @@ __device__ __forceinline__ bool LocalFoldFast(LocalShared& sh, int64_t tile0, in
                             static_cast<uint32_t>(kv[j] >> 32));
       }
     }
-    ok &= AggFold(rec, live, acc_double, sh.tag, sh.sum, sh.first, sh.cnt, &sh.groups, kLocalLimit);
+    ok &= AggFoldRaw(rec, live, acc_double, sh.tag, sh.sum, sh.first, sh.cnt, &sh.groups, kLocalLimit);
   }
   return ok;
 }
@@ -2476,10 +2539,81 @@ __global__ __launch_bounds__(kDThreads) void k_local_aggregate_fast(FastArgs a, 
   }
   __syncthreads();
   if (stopped()) {  // a stale staging table is never read: the merge is gated on the flags
-    ReportHotCandidates(sh, hot, tid);
+    ReportHotCandidates(sh, hot, tid, /*raw_tags=*/true);
     return;
   }
-  LocalWriteOut(sh, st, tid);
+  LocalWriteOut(sh, st, tid, /*raw_tags=*/true);
+}
+
+// The same attempt with the bin scatter's loader: a thread owns four consecutive rows (one 16-byte key load,
+// two 16-byte value loads, a nibble of the mask), three tiles in flight, nothing but LDS work between the
+// loads (k_local_aggregate_fast reads one element per lane and step: 4.9 TB/s; the row range of a workgroup
+// and its staged table are the same).  Needs keys and values on a 16-byte boundary, like the bin scatter.
+template <bool MASK, bool VVALID>
+__global__ __launch_bounds__(kBThreads) void k_local_aggregate_vec(FastArgs a, int acc_double, LocalStage st,
+                                                                  unsigned int* wg_flags, HotMem hot) {
+  __shared__ LocalShared sh;
+  constexpr int R = 4, kRows = kBThreads * R;
+  const int tid = threadIdx.x;
+  LocalInit(sh, tid);
+  const int64_t lo = int64_t(blockIdx.x) * a.rows_per_block;
+  const int64_t hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
+  const void* keys = static_cast<const char*>(a.k_data) + a.k_off * 4;
+  const uint64_t* vals = reinterpret_cast<const uint64_t*>(a.v.data) + a.v.off;
+  auto stopped = [&]() { return __hip_atomic_load(&sh.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; };
+  auto fold = [&](const BinTile<R, false>& t, int64_t tile0) -> bool {
+    const int64_t r0 = tile0 + int64_t(tid) * R;
+    const int64_t left = hi - r0;
+    const uint32_t live_bits = left >= R ? (1u << R) - 1u : (left > 0 ? (1u << left) - 1u : 0u);
+    const int64_t rb = left > 0 ? r0 : hi - 1;
+    const uint32_t mbits = MASK ? (FewBits<R>(t.m0, t.m1, a.m_off + rb) & live_bits) : live_bits;
+    const uint32_t vbits = VVALID ? FewBits<R>(t.v0, t.v1, a.v.off + rb) : live_bits;
+    uint4 rec[R];
+    bool live[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      live[j] = (mbits >> j) & 1u;
+      const bool vv = (vbits >> j) & 1u;
+      const uint64_t v = t.v(j);
+      rec[j] = make_uint4(t.key.k(j, 0), static_cast<uint32_t>(r0 + j) | (vv ? kRecValValid : 0u), static_cast<uint32_t>(v),
+                          static_cast<uint32_t>(v >> 32));
+    }
+    return AggFoldRaw(rec, live, acc_double, sh.tag, sh.sum, sh.first, sh.cnt, &sh.groups, kLocalLimit);
+  };
+  BinTile<R, false> t0{}, t1{}, t2{};
+  int64_t tile0 = lo;
+  bool gave_up = false;
+  if (lo + kRows <= hi) {
+    const int64_t last_whole = lo + ((hi - lo) / kRows - 1) * kRows;
+    auto at = [&](int64_t t) { return t <= last_whole ? t : last_whole; };  // (past the end: the last whole tile again, dropped)
+    BinLoadTile<MASK, VVALID, R, false>(a, keys, vals, lo, tid, t0);
+    BinLoadTile<MASK, VVALID, R, false>(a, keys, vals, at(lo + kRows), tid, t1);
+    BinLoadTile<MASK, VVALID, R, false>(a, keys, vals, at(lo + 2 * kRows), tid, t2);
+#define AA_LOCAL_STEP(CUR, TILE0)                                                            \
+    do {                                                                                       \
+      if ((TILE0) <= last_whole && !gave_up && __any(!fold(CUR, (TILE0)))) gave_up = true;     \
+      BinLoadTile<MASK, VVALID, R, false>(a, keys, vals, at((TILE0) + 3 * kRows), tid, CUR);   \
+    } while (0)
+    for (; tile0 <= last_whole; tile0 += 3 * kRows) {
+      AA_LOCAL_STEP(t0, tile0);
+      AA_LOCAL_STEP(t1, tile0 + kRows);
+      AA_LOCAL_STEP(t2, tile0 + 2 * kRows);
+      if (gave_up) LocalGiveUp(sh, wg_flags);
+      if (gave_up || stopped()) break;
+    }
+#undef AA_LOCAL_STEP
+    if (tile0 > last_whole) tile0 = last_whole + kRows;
+  }
+  if (tile0 < hi && !gave_up && !stopped()) {  // the partial tile at the end of the input
+    BinLoadTail<MASK, VVALID, R, false>(a, keys, vals, tile0, hi, tid, t0);
+    if (__any(!fold(t0, tile0))) LocalGiveUp(sh, wg_flags);
+  }
+  __syncthreads();
+  if (stopped()) {  // a stale staging table is never read: the merge is gated on the flags
+    ReportHotCandidates(sh, hot, tid, /*raw_tags=*/true);
+    return;
+  }
+  LocalWriteOut(sh, st, tid, /*raw_tags=*/true);
 }
 
 // Any key width <= 32 bits, key / value / mask validity, every value type (LoadTile).
@@ -2557,6 +2691,62 @@ __global__ __launch_bounds__(kThreads) void k_clear_table_unless(GroupTable t, i
 }
 
 // Merge the staged workgroup tables into the global table (global atomics, few entries).
+// The merge for the raw-key local tables (k_local_aggregate_fast): every workgroup's table puts a key at the
+// same home slot (probing only displaces it when keys collide), so the entries of one slot across all staged
+// tables are almost always ONE group.  A workgroup here takes kMergeSlots slots, folds each slot's entries over
+// the staged tables in LDS (the first tag met owns the slot; an entry with another tag goes to the global table on
+// its own) and inserts one reduced group per slot: G global-table updates instead of G x 256 (64 -> ~10 us at
+// 1000 groups).
+constexpr int kMergeSlots = 64;
+constexpr int kMergeThreads = 1024;
+__global__ __launch_bounds__(kMergeThreads) void k_local_merge_slots(LocalStage st, int nwg, int k_bits, int acc_double,
+                                                                     GroupTable t, const unsigned int* skip_if,
+                                                                     unsigned int* overflow) {
+  if (*skip_if) return;
+  __shared__ unsigned long long s_owner[kMergeSlots];  // 0 = nobody yet, else (1 << 32) | tag of the slot's group
+  __shared__ uint32_t s_first[kMergeSlots];
+  __shared__ unsigned long long s_sum[kMergeSlots], s_cnt[kMergeSlots];
+  const int tid = threadIdx.x;
+  const int sl = tid & (kMergeSlots - 1);
+  const int slot = blockIdx.x * kMergeSlots + sl;  // (slots kSlots, kSlots + 1: the two side slots, never filled by the raw fold)
+  if (tid < kMergeSlots) { s_owner[tid] = 0; s_first[tid] = kNoRow; s_sum[tid] = 0; s_cnt[tid] = 0; }
+  __syncthreads();
+  auto to_global = [&](unsigned int tag, uint32_t fr, unsigned long long sum, unsigned long long cnt) {
+    const int64_t idx = FindOrInsert(t, Fmix64(uint64_t(Fmix32Inv(tag))), true);
+    if (idx < 0) { *overflow = 1; return; }
+    atomicMin(&t.first[idx], fr);
+    if (cnt) {
+      Accumulate(&t.sums[idx], sum, acc_double != 0);
+      atomicAdd(&t.counts[idx], cnt);
+    }
+  };
+  if (slot < kSlots) {
+    for (int w = tid / kMergeSlots; w < nwg; w += kMergeThreads / kMergeSlots) {
+      const int64_t i = int64_t(w) * kStageSlots + slot;
+      const uint32_t fr = st.first[i];
+      if (fr == kNoRow) continue;
+      const unsigned int tag = st.tag[i];
+      // the first entry to arrive owns the slot: one 64-bit compare-and-swap publishes (taken | tag), nobody waits
+      const unsigned long long mine = (1ull << 32) | tag;
+      const unsigned long long prev = atomicCAS(&s_owner[sl], 0ull, mine);
+      const unsigned int owner_tag = prev == 0ull ? tag : static_cast<unsigned int>(prev);
+      if (tag == owner_tag) {
+        atomicMin(&s_first[sl], fr);
+        const unsigned int c = st.cnt[i];
+        if (c) {
+          if (acc_double) atomicAdd(reinterpret_cast<double*>(&s_sum[sl]), __longlong_as_double(st.sum[i]));
+          else atomicAdd(&s_sum[sl], st.sum[i]);
+          atomicAdd(&s_cnt[sl], static_cast<unsigned long long>(c));
+        }
+      } else {
+        to_global(tag, fr, st.sum[i], st.cnt[i]);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < kMergeSlots && s_first[tid] != kNoRow) to_global(static_cast<unsigned int>(s_owner[tid]), s_first[tid], s_sum[tid], s_cnt[tid]);
+}
+
 __global__ __launch_bounds__(kThreads) void k_local_merge(LocalStage st, int64_t nentries, int k_bits, int acc_double,
                                                           GroupTable t, const unsigned int* skip_if, unsigned int* overflow) {
   if (*skip_if) return;
@@ -3209,13 +3399,22 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
           st.cnt = reinterpret_cast<unsigned int*>(sb + 16 * ne);
           unsigned int* abort_flag = misc + 1;  // written by k_clear_table_unless (OR of the workgroup flags)
 #define AA_LOCAL(MM, VV) hipLaunchKernelGGL((k_local_aggregate_fast<MM, VV>), dim3(nblocks_local), dim3(kDThreads), 0, ctx->stream, fl, acc_double, st, wg_flags, hot)
+#define AA_LVEC(MM, VV) hipLaunchKernelGGL((k_local_aggregate_vec<MM, VV>), dim3(nblocks_local), dim3(kBThreads), 0, ctx->stream, fl, acc_double, st, wg_flags, hot)
           if (!headline_shape) hipLaunchKernelGGL(k_local_aggregate, dim3(nblocks_local), dim3(kDThreads), 0, ctx->stream, fl, acc_double, st, wg_flags, hot);
+          else if (use_bins && k_load_bits == 32 && !getenv("AMDARROW_GROUPBY_OLD_LOCAL")) {
+            if (M && V) AA_LVEC(true, true); else if (M) AA_LVEC(true, false); else if (V) AA_LVEC(false, true); else AA_LVEC(false, false);
+          }
           else if (M && V) AA_LOCAL(true, true); else if (M) AA_LOCAL(true, false); else if (V) AA_LOCAL(false, true); else AA_LOCAL(false, false);
 #undef AA_LOCAL
+#undef AA_LVEC
           AA_HIP(hipGetLastError());
           const int64_t nslots = static_cast<int64_t>(T) + 2;
           hipLaunchKernelGGL(k_clear_table_unless, dim3(GridFor(nslots, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0,
                              ctx->stream, t, nslots, wg_flags, nblocks_local, abort_flag, hot, misc + 5);
+          if (headline_shape && !getenv("AMDARROW_GROUPBY_OLD_MERGE"))
+            hipLaunchKernelGGL(k_local_merge_slots, dim3(kSlots / kMergeSlots), dim3(kMergeThreads), 0, ctx->stream, st,
+                               nblocks_local, ks.total_bits, acc_double, t, abort_flag, misc);
+          else
           hipLaunchKernelGGL(k_local_merge, dim3(GridFor(static_cast<int64_t>(ne), kThreads, ctx->num_cus * 8)), dim3(kThreads),
                              0, ctx->stream, st, static_cast<int64_t>(ne), ks.total_bits, acc_double, t, abort_flag, misc);
           AA_HIP(hipGetLastError());
