@@ -3552,6 +3552,37 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
 
 // The packed key column: one uint32 per row (PackedKey).  Four rows per thread and step; the raw values of every
 // column are requested before any is used (the width switch is uniform: one branch per column, four loads inside).
+// Every column 32 bits wide, no validity, every slice on a 16-byte boundary: four rows per thread as one 16-byte
+// load per column and one 16-byte store (the general kernel below moves 1.2 GB for two int32 columns at 3.75 TB/s).
+__global__ __launch_bounds__(256) void k_pack_keys_vec32(KeyPack p, int64_t n, uint32_t* out) {
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+  const int64_t nvec = n / 4;
+  for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < nvec; i += int64_t(gridDim.x) * 256) {
+    u32x4 c[kMaxPackedKeys];
+#pragma unroll
+    for (int k = 0; k < kMaxPackedKeys; ++k) {
+      if (k >= p.ncols) break;
+      c[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const uint32_t*>(p.data[k]) + p.off[k]) + i);
+    }
+    u32x4 x = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < kMaxPackedKeys; ++k) {
+      if (k >= p.ncols) break;
+      // (value - bias in 32 bits: the signed / unsigned reading of the column is in the bias; the code fits its field)
+      const uint32_t b = static_cast<uint32_t>(p.bias[k]);
+      x |= (c[k] - b) << static_cast<unsigned int>(p.shift[k]);
+    }
+    __builtin_nontemporal_store(x, reinterpret_cast<u32x4*>(out) + i);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < n - nvec * 4) {  // the rows behind the last whole vector
+    const int64_t r = nvec * 4 + threadIdx.x;
+    uint32_t x = 0;
+    for (int k = 0; k < p.ncols; ++k)
+      x |= (reinterpret_cast<const uint32_t*>(p.data[k])[p.off[k] + r] - static_cast<uint32_t>(p.bias[k])) << p.shift[k];
+    out[r] = x;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_pack_keys(KeyPack p, int64_t n, uint32_t* out) {
   constexpr int kU = 4;
   for (int64_t base = (int64_t(blockIdx.x) * 256) * kU; base < n; base += int64_t(gridDim.x) * 256 * kU) {
@@ -3702,6 +3733,12 @@ int amdarrow_filter_groupby_multi(amdarrow_ctx* ctx, const amdarrow_array* value
   auto* codes = static_cast<uint32_t*>(ctx->pack_buf);
   uint32_t* packed = codes + ((n + 63) / 64) * 64;
   uint8_t* dummy_validity = reinterpret_cast<uint8_t*>(packed + ((bound + 63) / 64) * 64);
+  bool vec32 = n >= 1024 && reinterpret_cast<uintptr_t>(codes) % 16 == 0;
+  for (int k = 0; k < p.ncols; ++k)
+    vec32 = vec32 && p.load_bits[k] == 32 && !p.valid[k] &&
+            (reinterpret_cast<uintptr_t>(p.data[k]) + 4 * static_cast<uintptr_t>(p.off[k])) % 16 == 0;
+  if (vec32) hipLaunchKernelGGL(k_pack_keys_vec32, dim3(GridFor(n / 4, 256, ctx->num_cus * 16)), dim3(256), 0, ctx->stream, p, n, codes);
+  else
   hipLaunchKernelGGL(k_pack_keys, dim3(GridFor(n, 1024, ctx->num_cus * 8)), dim3(256), 0, ctx->stream, p, n, codes);
   AA_HIP(hipGetLastError());
   amdarrow_array stand_in{};
