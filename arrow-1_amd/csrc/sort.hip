@@ -420,7 +420,20 @@ __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_i
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < kOWaves * 256; i += kOThreads) (&s_whist[0][0])[i] = 0;
   __syncthreads();
-  const uint32_t tile = blockIdx.x;
+  // Tile of this workgroup.  Workgroups go to the eight XCDs round robin, each XCD with its own L2, and the
+  // runs two neighbouring tiles write for a digit share the cache line where they meet: with tile = blockIdx
+  // both halves of that line leave as partial writes from two different L2s.  kXcdRun consecutive tiles are
+  // therefore handed to the SAME XCD (inside every group of 8 * kXcdRun workgroups), so that the halves meet in
+  // one L2.  A tile's predecessors are dispatched at most one such group later, which the look-back tolerates
+  // (the blocks of a group never wait for a later group).
+  uint32_t tile = blockIdx.x;
+#ifndef SORT_NO_XCD_RUNS
+  {
+    constexpr uint32_t kXcdRun = 16, kGroup = 8 * kXcdRun;
+    const uint32_t g0 = tile / kGroup * kGroup, in = tile - g0;
+    if (g0 + kGroup <= gridDim.x) tile = g0 + (in % 8) * kXcdRun + in / 8;  // (the ragged last group keeps tile = blockIdx)
+  }
+#endif
   const int64_t base = int64_t(tile) * kRTile;
   const int64_t left = n - base;
   const uint32_t count = left >= kRTile ? kRTile : static_cast<uint32_t>(left);
