@@ -1294,3 +1294,22 @@ def test_filter_groupby_unaligned_slices_leave_the_bin_scatter(gpu, oracle):
         m = cut(R(rng, BOOL, n, 0.0, 3), moff)
         for _ in range(2):  # the second call of a shape is the hinted one
             _check_groupby(oracle, gpu, v, k, m, (koff, voff, moff))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_filter_groupby_bin_path_random_shapes(gpu, oracle, seed):
+    """Random shapes through the default strategy (first call: local attempt + partition path behind it; second
+    call: the hinted partition path): ragged lengths, with / without mask and value validity, int64 / float64 /
+    uint64 values, int32 / uint32 / int64 keys of small and wide ranges."""
+    rng = np.random.default_rng(0x0ff1ce + 100 + seed)
+    n = int(rng.integers(262_144, 1_500_000)) + int(rng.integers(0, 7))
+    kt = [INT32, UINT32, INT64, INT32][seed % 4]
+    span = [40_000, 3_000_000, 700_000, 2**31 - 2][(seed // 2) % 4]
+    lo = -(span // 2) if kt in (INT32, INT64) and span < 2**31 - 2 else 0
+    keys = rng.integers(lo, lo + span, n)
+    k = Arr(kt, keys.astype({INT32: np.int32, UINT32: np.uint32, INT64: np.int64}[kt]))
+    vt = [INT64, DOUBLE, UINT64][seed % 3]
+    v = R(rng, vt, n, 0.03 if seed % 2 else 0.0, 2)
+    m = Arr(BOOL, np.ones(n, bool)) if seed % 5 == 0 else Arr(BOOL, rng.random(n) < [0.5, 0.08, 0.93][seed % 3])
+    for _ in range(2):
+        _check_groupby(oracle, gpu, v, k, m, (seed, n, kt, vt))
