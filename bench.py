@@ -82,6 +82,9 @@ def make_inputs(workload, n, dev, rank, sel):
         if KEY_BITS == 64 and WIDE_KEYS:  # ids / hashes: NUM_GROUPS distinct values spread over the whole 64-bit range
             pool = torch.randint(-2**63, 2**63 - 1, (NUM_GROUPS,), dtype=torch.int64, device=dev, generator=gen)
             keys = pool[keys]
+        elif KEY_BITS == 32 and WIDE_KEYS:  # sparse ids: NUM_GROUPS distinct values spread over the int32 range (hashed tables)
+            pool = torch.randint(-2**31, 2**31 - 1, (NUM_GROUPS,), dtype=torch.int32, device=dev, generator=gen)
+            keys = pool[keys.long()]
         elif KEY_BITS == 64:
             keys += 1_700_000_000_000  # e.g. millisecond timestamps / large ids: wide values, narrow range
         d["values"] = device.DeviceArray(_abi.INT64, vals.view(torch.uint8), None, n)
@@ -343,7 +346,7 @@ def main():
     ap.add_argument("--groups", type=int, default=1_000_000, help="distinct group keys (tuning aid; the headline is 1M)")
     ap.add_argument("--hot-frac", type=float, default=0.0, help="headline workload: share of rows that carry one hot key")
     ap.add_argument("--key-bits", type=int, default=32, choices=[32, 64], help="headline workload: width of the key column")
-    ap.add_argument("--wide-keys", action="store_true", help="with --key-bits 64: distinct keys spread over the whole int64 range")
+    ap.add_argument("--wide-keys", action="store_true", help="distinct keys spread over the whole range of the key type (64-bit: the wide-key path; 32-bit: hashed partition tables)")
     ap.add_argument("--chunks", type=int, default=1, help="sort workloads: present the rows as this many equal chunks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
