@@ -191,6 +191,65 @@ __global__ __launch_bounds__(kAggThreads) void k_aggregate_vec(const T* values, 
   if (threadIdx.x == 0) partials[blockIdx.x] = AggPartial{valid, Bits(sum), Bits(mn), Bits(mx)};
 }
 
+// The same with a validity bitmap: the 16 / sizeof(T) rows of a lane's vector take their validity bits from one
+// or two bytes of the bitmap (any bit offset), fetched next to the vector.
+template <typename T, int KIND>
+__global__ __launch_bounds__(kAggThreads) void k_aggregate_vec_valid(const T* values, const uint8_t* __restrict__ valid_bits,
+                                                                     int64_t bit_off, int64_t n, unsigned long long min_identity,
+                                                                     unsigned long long max_identity, AggPartial* partials) {
+  using Ops = AggOps<KIND>;
+  using A = typename Ops::A;
+  constexpr int kPer = 16 / sizeof(T);  // elements per 16-byte load: 2 or 4
+  constexpr int kU = 4;
+  using Vec = __attribute__((ext_vector_type(kPer))) T;
+  long long valid = 0;
+  A sum = Ops::Zero(), mn = FromBits<A>(min_identity), mx = FromBits<A>(max_identity);
+  const int64_t nvec = n / kPer;
+  const int64_t last_byte = (bit_off + n - 1) >> 3;
+  const Vec* vp = reinterpret_cast<const Vec*>(values);
+  const int64_t tid = int64_t(blockIdx.x) * kAggThreads + threadIdx.x, nthreads = int64_t(gridDim.x) * kAggThreads;
+  for (int64_t i0 = tid; i0 < nvec; i0 += nthreads * kU) {
+    Vec v[kU];
+    uint32_t b0[kU], b1[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {  // every load of the round first
+      const int64_t i = i0 + u * nthreads < nvec ? i0 + u * nthreads : nvec - 1;
+      v[u] = __builtin_nontemporal_load(vp + i);
+      const int64_t byte = (bit_off + i * kPer) >> 3;
+      b0[u] = valid_bits[byte];
+      b1[u] = valid_bits[byte + 1 <= last_byte ? byte + 1 : last_byte];
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t i = i0 + u * nthreads;
+      if (i >= nvec) continue;
+      const uint32_t bits = ((b0[u] | (b1[u] << 8)) >> ((bit_off + i * kPer) & 7)) & ((1u << kPer) - 1u);
+#pragma unroll
+      for (int e = 0; e < kPer; ++e) {
+        if ((bits >> e) & 1u) {
+          const A x = static_cast<A>(v[u][e]);
+          ++valid;
+          sum = Ops::Add(sum, x);
+          mn = Ops::Min(mn, x);
+          mx = Ops::Max(mx, x);
+        }
+      }
+    }
+  }
+  if (tid == 0) {  // the elements behind the last whole vector
+    for (int64_t r = nvec * kPer; r < n; ++r) {
+      if (!((valid_bits[(bit_off + r) >> 3] >> ((bit_off + r) & 7)) & 1)) continue;
+      const A x = static_cast<A>(values[r]);
+      ++valid;
+      sum = Ops::Add(sum, x);
+      mn = Ops::Min(mn, x);
+      mx = Ops::Max(mx, x);
+    }
+  }
+  BlockFold<KIND>(valid, sum, mn, mx);
+  if (threadIdx.x == 0) partials[blockIdx.x] = AggPartial{valid, Bits(sum), Bits(mn), Bits(mx)};
+}
+
 // booleans: one 64-bit word per lane (BooleanArray::true_count, BooleanMinMaxImpl :317-343)
 __global__ __launch_bounds__(kAggThreads) void k_aggregate_bool(const uint8_t* data, const uint8_t* valid_bits, int64_t off,
                                                                 int64_t n, AggPartial* partials) {
@@ -266,13 +325,16 @@ int AggregateLocked(amdarrow_ctx* ctx, const amdarrow_array* a, amdarrow_agg* ou
   auto* partials = static_cast<AggPartial*>(base);
   AggPartial* result = partials + nblocks;
   const uint8_t* valid = MayHaveNulls(a) ? a->validity : nullptr;
-  const bool vec_ok = !valid && a->length >= (int64_t(1) << 16) && bw >= 32;
+  const bool vec_ok = a->length >= (int64_t(1) << 16) && bw >= 32;
 #define AA_AGG(T, K)                                                                                                              \
   do {                                                                                                                             \
     const T* first = static_cast<const T*>(a->values) + a->offset;                                                                 \
-    if (vec_ok && reinterpret_cast<uintptr_t>(first) % 16 == 0)                                                                    \
+    if (vec_ok && !valid && reinterpret_cast<uintptr_t>(first) % 16 == 0)                                                          \
       hipLaunchKernelGGL((k_aggregate_vec<T, K>), dim3(nblocks), dim3(kAggThreads), 0, ctx->stream, first, a->length, min_id,    \
                          max_id, partials);                                                                                        \
+    else if (vec_ok && valid && reinterpret_cast<uintptr_t>(first) % 16 == 0)                                                      \
+      hipLaunchKernelGGL((k_aggregate_vec_valid<T, K>), dim3(nblocks), dim3(kAggThreads), 0, ctx->stream, first, valid,           \
+                         a->offset, a->length, min_id, max_id, partials);                                                          \
     else                                                                                                                           \
       hipLaunchKernelGGL((k_aggregate<T, K>), dim3(nblocks), dim3(kAggThreads), 0, ctx->stream, static_cast<const T*>(a->values), \
                          valid, a->offset, a->length, min_id, max_id, partials);                                                   \
