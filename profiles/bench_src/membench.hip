@@ -81,6 +81,105 @@ __global__ __launch_bounds__(kThreads) void k_mem(Args a) {
   if (acc == 0x123456789abcull) *a.sink = acc;
 }
 
+// the filter kernel's geometry: 256-thread workgroups, grid-stride over 4096-row tiles (8 x 16-byte value loads
+// per thread and tile, next tile prefetched), a barrier pair per tile; optional contiguous 8-byte stores of half the rows
+template <bool STORE, bool BARRIER>
+__global__ __launch_bounds__(256) void k_tiles(const uint64_t* vals, uint64_t* out, int64_t ntiles, unsigned long long* sink) {
+  const int tid = threadIdx.x;
+  u64x2 cur[8], nxt[8];
+  unsigned long long acc = 0;
+  int64_t tile = blockIdx.x;
+  auto issue = [&](int64_t t, u64x2 (&r)[8]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const uint64_t* src = vals + t * 4096 + (g * 256 + tid) * 4;
+      r[2 * g] = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(src));
+      r[2 * g + 1] = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(src + 2));
+    }
+  };
+  if (tile < ntiles) issue(tile, cur);
+  for (; tile < ntiles; tile += gridDim.x) {
+    if (tile + gridDim.x < ntiles) issue(tile + gridDim.x, nxt);
+    if (BARRIER) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += cur[i].x + cur[i].y;
+    if (STORE) {
+      for (int i = tid; i < 2048; i += 256) out[tile * 2048 + i] = acc + i;
+    }
+    if (BARRIER) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+  }
+  if (acc == 0x123456789abcull) *sink = acc;
+}
+
+// the filter compaction, rebuilt feature by feature on top of k_tiles (FEAT bits):
+//   1 = the tile's 64 filter words loaded by the first wave, popcount + wave scan -> LDS, barrier (stores then write `count` values)
+//   2 = row-per-lane ranks: every lane reads its word / base from LDS, ranks with mbcnt, stores its value at out[base + rank]
+//   4 = output validity: LDS byte flag per rank, ballot-packed and stored after a barrier
+template <int FEAT>
+__global__ __launch_bounds__(256) void k_filt(const uint64_t* vals, const uint64_t* fwords, uint64_t* out, uint64_t* out_valid,
+                                              int64_t ntiles, unsigned long long* sink, const int64_t* tile_off) {
+  __shared__ uint64_t s_sel[64];
+  __shared__ uint32_t s_base[64];
+  __shared__ uint32_t s_count;
+  __shared__ uint8_t s_vflag[4096];
+  __shared__ uint64_t s_packed[65];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long acc = 0;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * 4096;
+    uint32_t count = 2048;
+    if (FEAT & 1) {
+      if (tid < 64) {
+        const uint64_t w = fwords[tile * 64 + tid];
+        s_sel[tid] = w;
+        const uint32_t pc = __popcll(w);
+        uint32_t incl = pc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        s_base[tid] = incl - pc;
+        if (tid == 63) s_count = incl;
+      }
+      __syncthreads();
+      count = s_count;
+    }
+    const int64_t out_base = tile_off ? tile_off[tile] : tile * 2048;
+    uint64_t v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = vals[row0 + (j * 4 + wave) * 64 + lane];
+    if (FEAT & 2) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int word = j * 4 + wave;
+        const uint64_t sel = s_sel[word];
+        if ((sel >> lane) & 1) {
+          const uint32_t rank = s_base[word] + __builtin_amdgcn_mbcnt_hi(uint32_t(sel >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(sel), 0));
+          out[out_base + rank] = v[j];
+          if (FEAT & 4) s_vflag[rank & 4095] = uint8_t(v[j] & 1);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc += v[j];
+      for (int i = tid; i < int(count) && i < 2048; i += 256) out[out_base + i] = acc + i;
+    }
+    __syncthreads();
+    if (FEAT & 4) {
+      const uint32_t nlw = (count + 63) >> 6;
+      for (uint32_t lw = wave; lw < nlw; lw += 4) {
+        const uint32_t i = lw * 64 + lane;
+        const uint64_t b = __ballot(i < count && s_vflag[i & 4095] != 0);
+        if (lane == 0) s_packed[lw] = b;
+      }
+      __syncthreads();
+      for (uint32_t i = tid; i < nlw && i < 32; i += 256) out_valid[tile * 32 + i] = s_packed[i];
+      __syncthreads();
+    }
+  }
+  if (acc == 0x123456789abcull) *sink = acc;
+}
+
 // consumer: workgroup p streams partition p's segment of every block's region (fill records each)
 __global__ __launch_bounds__(kThreads) void k_consume(const uint4* regions, int64_t cap, int nblocks, int fill, unsigned long long* sink) {
   const int p = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -131,6 +230,47 @@ int main() {
     const double bytes = ((MODE & 1) ? rd : 0) + ((MODE & 2) ? wr : 0);                                                \
     printf("%-44s %8.1f us  %6.2f TB/s\n", NAME, us, bytes / us / 1e6);                                                \
   } while (0)
+  {
+    uint64_t* fout; CK(hipMalloc(&fout, 8 * (n / 2 + 4096)));
+    const int64_t ntiles = n / 4096;
+    for (int grid : {512, 1024, 2048, 4096, 24576}) {
+      float t0 = TimeIt([&] { hipLaunchKernelGGL((k_tiles<false, false>), dim3(grid), dim3(256), 0, 0, vals, fout, ntiles, sink); }, 5);
+      float t1 = TimeIt([&] { hipLaunchKernelGGL((k_tiles<false, true>), dim3(grid), dim3(256), 0, 0, vals, fout, ntiles, sink); }, 5);
+      float t2 = TimeIt([&] { hipLaunchKernelGGL((k_tiles<true, true>), dim3(grid), dim3(256), 0, 0, vals, fout, ntiles, sink); }, 5);
+      printf("tiles grid %5d: read %.1f us (%.2f TB/s), + barriers %.1f us, + stores of half the rows %.1f us (%.2f TB/s)\n", grid, t0,
+             8.0 * n / t0 / 1e6, t1, t2, 12.0 * n / t2 / 1e6);
+    }
+  }
+  {
+    uint64_t* fout; CK(hipMalloc(&fout, 8 * (n / 2 + (1 << 20))));
+    uint64_t* fvalid; CK(hipMalloc(&fvalid, n / 8 + 4096));
+    uint64_t* fwords; CK(hipMalloc(&fwords, n / 8 + 4096));
+    {  // every 64-bit word with exactly 32 set bits (so every tile selects exactly 2048 rows), in a few patterns
+      std::vector<uint64_t> h(n / 64);
+      const uint64_t pats[4] = {0x5555555555555555ull, 0x33CC33CC33CC33CCull, 0x0F0FF0F00F0FF0F0ull, 0xA5A55A5AC3C33C3Cull};
+      for (size_t i = 0; i < h.size(); ++i) h[i] = pats[(i * 2654435761u >> 7) & 3];
+      CK(hipMemcpy(fwords, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    }
+    const int64_t ntiles = n / 4096;
+    const int64_t* toff = nullptr;
+#define RUNF(FEAT) do { float t = TimeIt([&] { hipLaunchKernelGGL((k_filt<FEAT>), dim3(2048), dim3(256), 0, 0, vals, fwords, fout, fvalid, ntiles, sink, toff); }, 5); \
+      printf("filter features %d%s: %.1f us (%.2f TB/s)\n", FEAT, toff ? " random mask" : "", t, 12.1 * n / t / 1e6); } while (0)
+    RUNF(0); RUNF(1); RUNF(3); RUNF(7);
+    {  // Bernoulli(0.5) mask words, tile offsets from their popcounts
+      std::vector<uint64_t> h(n / 64);
+      uint64_t x = 88172645463325252ull;
+      for (auto& w : h) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; w = x; }
+      std::vector<int64_t> off(ntiles + 1);
+      int64_t run = 0;
+      for (int64_t t = 0; t < ntiles; ++t) { off[t] = run; for (int k = 0; k < 64; ++k) run += __builtin_popcountll(h[t * 64 + k]); }
+      off[ntiles] = run;
+      CK(hipMemcpy(fwords, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+      int64_t* d_off; CK(hipMalloc(&d_off, 8 * (ntiles + 1)));
+      CK(hipMemcpy(d_off, off.data(), 8 * (ntiles + 1), hipMemcpyHostToDevice));
+      toff = d_off;
+      RUNF(3); RUNF(7);
+    }
+  }
   RUN("read  blocked nt depth3", 1, false, 64, true, true, 3);
   RUN("read  cyclic  nt depth3", 1, true, 64, true, true, 3);
   RUN("read  cyclic  plain depth3", 1, true, 64, false, true, 3);
