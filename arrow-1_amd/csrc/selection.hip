@@ -24,6 +24,10 @@ constexpr int kThreads = 256;   // 4 waves
 constexpr int kCThreads = 256;  // compaction workgroup
 constexpr int kCWaves = kCThreads / 64;
 
+// A tile's two edge words sit in a 128-byte line of their own: neighbouring tiles run on different XCDs, and a line
+// shared by several of them would leave each L2 as a partial write.
+constexpr int kEdgeStride = 16;
+
 struct FilterArgs {
   // filter
   const uint8_t* f_data; const uint8_t* f_valid; int64_t f_off; int emit_null;
@@ -33,6 +37,7 @@ struct FilterArgs {
   // outputs
   void* out_values; uint8_t* out_validity; int64_t out_capacity; int has_validity;
   const int64_t* tile_offsets;  // exclusive scan, ntiles + 1 entries
+  unsigned long long* edge_words;  // [ntiles][kEdgeStride], two used: what a tile of >= 64 output rows adds to the validity words it shares with its neighbours
 };
 
 // emit = rows that produce an output slot; sel = rows whose value is copied.
@@ -121,8 +126,12 @@ int LaunchScanU32(amdarrow_ctx* ctx, const uint32_t* counts, int64_t n, int64_t*
 // Pack `count` LDS byte flags into the global bitmap `bm` at bit position `bit_base`.
 // `bm` has been zeroed; interior words are plain stores, the (at most two) words shared
 // with neighbouring tiles are merged with atomicOr.  Called by the whole workgroup.
+// `edge` (optional, two words): a tile of at least 64 bits shares its first and / or last word with exactly one
+// neighbour each; instead of merging them with memory-side atomics (an atomic drops its line from the L2: every
+// tile's first and last bitmap line then leaves early and partial, 33 us per 100 M rows) it hands its share of
+// them over in edge[0] / edge[1] and k_filter_merge_edges stores the words whole.
 __device__ __forceinline__ void DepositFlags(const uint8_t* s_flags, uint64_t* s_packed, uint32_t count,
-                                             uint8_t* bm, int64_t bit_base) {
+                                             uint8_t* bm, int64_t bit_base, unsigned long long* edge = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t nlw = (count + 63) >> 6;
   for (uint32_t lw = wave; lw < nlw; lw += blockDim.x / 64) {
@@ -140,8 +149,38 @@ __device__ __forceinline__ void DepositFlags(const uint8_t* s_flags, uint64_t* s
     if (s > 0 && i > 0) w |= s_packed[i - 1] >> (64 - s);
     const bool owned = (i > 0 || s == 0) && (uint64_t(i + 1) * 64 <= uint64_t(s) + count);
     if (owned) words[g0 + i] = w;
+    else if (edge && count >= 64) edge[i == 0 ? 0 : 1] = w;
     else if (w) atomicOr(&words[g0 + i], static_cast<unsigned long long>(w));
   }
+  if (edge && tid < 2) {  // a side without a shared word adds nothing
+    const bool has_head = s > 0, has_tail = ((s + count) & 63) != 0 && ngw > 1;
+    if (count < 64 || (tid == 0 ? !has_head : !has_tail)) edge[tid] = 0;
+  }
+}
+
+// One thread per tile boundary: the validity word in which tile t ends and tile t + 1 begins.  Two tiles of >= 64
+// output rows: nobody else touches the word, it is stored whole.  A smaller tile ORs its own bits in with an
+// atomic (k_filter_compact), so the big neighbour's share is ORed in as well.
+__global__ __launch_bounds__(256) void k_filter_merge_edges(const int64_t* tile_offsets, int64_t ntiles,
+                                                            const unsigned long long* edge_words, uint8_t* out_validity,
+                                                            int64_t out_capacity) {
+  const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (t >= ntiles) return;
+  const int64_t b = tile_offsets[t], e = tile_offsets[t + 1];
+  if ((e & 63) == 0 || e > out_capacity) return;
+  const int64_t e2 = t + 1 < ntiles ? tile_offsets[t + 2] : e;
+  const bool big = e - b >= 64, big_next = e2 - e >= 64 && e2 <= out_capacity;
+  unsigned long long w = 0;
+  if (big) w |= edge_words[kEdgeStride * t + 1];
+  if (big_next) w |= edge_words[kEdgeStride * (t + 1)];
+  unsigned long long* words = reinterpret_cast<unsigned long long*>(out_validity);
+  if (big && (big_next || t + 1 == ntiles || e2 == e)) {
+    // (the last tile with output: nothing follows in the word)
+    bool alone = big_next || t + 1 == ntiles;
+    if (!alone) { alone = true; for (int64_t u = t + 1; u < ntiles; ++u) if (tile_offsets[u + 1] != e) { alone = false; break; } }
+    if (alone) { words[e >> 6] = w; return; }
+  }
+  if (w) atomicOr(&words[e >> 6], w);
 }
 
 template <int W> struct UIntOf;
@@ -235,13 +274,14 @@ __global__ __launch_bounds__(kCThreads) void k_filter_compact(FilterArgs a) {
       }
     }
     __syncthreads();
+    if (!fits && a.edge_words && tid < 2) a.edge_words[kEdgeStride * tile + tid] = 0;
     if (fits) {
       if (kBits) {
         DepositFlags(reinterpret_cast<const uint8_t*>(s_stage), s_packed, count,
                      reinterpret_cast<uint8_t*>(a.out_values), out_base);
         __syncthreads();
       }
-      if (a.has_validity) DepositFlags(s_vflag, s_packed, count, a.out_validity, out_base);
+      if (a.has_validity) DepositFlags(s_vflag, s_packed, count, a.out_validity, out_base, a.edge_words ? a.edge_words + kEdgeStride * tile : nullptr);
     }
     __syncthreads();
   }
@@ -446,11 +486,14 @@ static int RunCompaction(amdarrow_ctx* ctx, FilterArgs a, int width_bytes /*0 = 
   Carver c;
   const size_t off_counts = c.Take(sizeof(uint32_t) * a.ntiles);
   const size_t off_offsets = c.Take(sizeof(int64_t) * (a.ntiles + 1));
+  const bool merge_edges = a.has_validity && !getenv("AMDARROW_FILTER_EDGE_ATOMICS");
+  const size_t off_edges = c.Take(merge_edges ? 8 * kEdgeStride * static_cast<size_t>(a.ntiles) : 0);
   void* base;
   AA_TRY(Scratch(ctx, c.off, &base));
   auto* counts = reinterpret_cast<uint32_t*>(static_cast<char*>(base) + off_counts);
   auto* offsets = reinterpret_cast<int64_t*>(static_cast<char*>(base) + off_offsets);
   a.tile_offsets = offsets;
+  a.edge_words = merge_edges ? reinterpret_cast<unsigned long long*>(static_cast<char*>(base) + off_edges) : nullptr;
 
   hipLaunchKernelGGL(k_filter_tile_counts, dim3(GridFor(a.ntiles, 4, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream,
                      a.f_data, a.f_valid, a.f_off, a.emit_null, a.length, a.ntiles, counts);
@@ -478,6 +521,11 @@ static int RunCompaction(amdarrow_ctx* ctx, FilterArgs a, int width_bytes /*0 = 
     }
   }
   AA_TRY(rc);
+  if (merge_edges) {
+    hipLaunchKernelGGL(k_filter_merge_edges, dim3(static_cast<unsigned>((a.ntiles + 255) / 256)), dim3(256), 0, ctx->stream, offsets,
+                       a.ntiles, a.edge_words, a.out_validity, a.out_capacity);
+    AA_HIP(hipGetLastError());
+  }
   AA_HIP(hipEventSynchronize(ctx->status_event));
   memcpy(total, static_cast<const char*>(ctx->pinned) + kStatusOffset, 8);
   if (*total > a.out_capacity)
