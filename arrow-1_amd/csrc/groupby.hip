@@ -1306,7 +1306,9 @@ __global__ __launch_bounds__(kFThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
 // The aggregate kernel reads it as one more segment.
 constexpr int kBinSlots = 16;
 constexpr int kBThreads = 1024;
-constexpr unsigned int kOverflowRegionWord = 1;  // == kOverflowRegion (status[0])
+// status[0]: why a partitioned attempt failed
+constexpr unsigned int kOverflowRegion = 1;  // a (workgroup, partition) region was too small: the exact two-pass variant helps
+constexpr unsigned int kOverflowTable = 2;   // a partition holds more groups than LDS slots: only the generic table helps
 struct BinShared {
   unsigned int cnt[kP];  // records in the bin (runs past kBinSlots while a tile is ranked: the excess was spilled)
   uint32_t cur[kP];      // records of this workgroup's region already written (a multiple of 4)
@@ -1461,7 +1463,7 @@ __device__ __forceinline__ void BinStageTile(BinShared& sh, const FastArgs& a, c
     } else {  // the bin is full until the next flush: the partition's spill list takes the record
       const uint32_t at = atomicAdd(&counts[int64_t(part[j]) * (a.nblocks + 1) + a.nblocks], 1u);
       if (at < cap) regions[(int64_t(a.nblocks) * kP + part[j]) * cap + at] = q;
-      else __hip_atomic_store(overflow, kOverflowRegionWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else __hip_atomic_store(overflow, kOverflowRegion, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -1498,7 +1500,7 @@ __device__ __forceinline__ void BinFlush(BinShared& sh, int tid, int64_t cap, ui
     if (ll == 0 && nfull > 0) {
       sh.cnt[p] = left;
       if (ok) sh.cur[p] = cur + nfull;
-      else __hip_atomic_store(overflow, kOverflowRegionWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else __hip_atomic_store(overflow, kOverflowRegion, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -1620,7 +1622,7 @@ __global__ __launch_bounds__(kBThreads) void k_part_scatter_bins(FastArgs a, int
       uint4* dst = my_regions + int64_t(tid) * cap + cur;
       for (uint32_t k = 0; k < left; ++k) dst[k] = sh.bin[BinIndex(tid, k)];
     } else {
-      __hip_atomic_store(overflow, kOverflowRegionWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(overflow, kOverflowRegion, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     counts[int64_t(tid) * (a.nblocks + 1) + blockIdx.x] = ok ? cur + left : 0;
   }
@@ -1632,9 +1634,6 @@ __global__ __launch_bounds__(kBThreads) void k_part_scatter_bins(FastArgs a, int
 // two side slots.  Per step a lane takes 4 records: 4 unconditional 16-byte loads, then the
 // 4 first probes are issued together; only mismatches enter the probe loop.
 constexpr uint32_t kTagFree = 0xFFFFFFFFu;
-// status[0]: why a partitioned attempt failed
-constexpr unsigned int kOverflowRegion = 1;  // a (workgroup, partition) region was too small: the exact two-pass variant helps
-constexpr unsigned int kOverflowTable = 2;   // a partition holds more groups than LDS slots: only the generic table helps
 constexpr int kSideNull = kSlots, kSideFree = kSlots + 1;
 
 // The LDS table is bucketised: 1024 buckets of 4 tags (one ds_read_b128 fetches a bucket).  At
@@ -1881,9 +1880,6 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
   __syncthreads();
   if (*abort_lds || __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // nothing reads the table
   const int64_t g0 = slice0 + int64_t(p) * kSlots;
-#ifdef AGG_DEBUG_NOWRITE
-  if (s_tag[tid] != 12345) return;
-#endif
   for (int s = tid; s < kSlots; s += kPartThreads) {
     const unsigned int tag = s_tag[s];
     // the shared numbering / emit kernels speak fmix64 of the packed key word
@@ -1893,9 +1889,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
     t.sums[g0 + s] = s_sum[s];
     t.counts[g0 + s] = s_cnt[s];
     // mark the group's first row for the first-appearance numbering (was a separate kernel)
-#ifndef AGG_DEBUG_NOMARK
     if (fr != kNoRow) atomicOr(&first_bitmap[fr >> 6], 1ull << (fr & 63));
-#endif
   }
   // side slots -> two spare regular slots of the global table: partition p's slice is only
   // kSlotLimit full, so the (at most two) extra groups go to free slots of the slice.
@@ -1923,98 +1917,19 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_direct(const ui
 
 
 // ---- the partition aggregate, pipelined three steps deep -------------------------------------------------------
-// Same table, same output as k_part_aggregate_direct (which it replaces behind the bin scatter).  Measured on
-// that kernel: 127 us to stream the 0.8 GB of records without folding them, 100 us more for the fold -- the two
-// did not overlap, with two steps in flight per wave the stream ran at the speed of one dependent round trip
-// per step -- and 55 us of the fold were the first ~2 k records of every partition, all inserts, each going
-// through the serial probe loop.  Here a wave keeps three steps in flight (the loads are unconditional, so
-// the compiler counts them: vmcnt(8) before a fold), and the first insertion attempt of a step's records is
-// one compare-and-swap per record on the first free entry of the buckets already fetched, all issued
-// together; only a lost race enters the probe loop.
+// Same table, same output as k_part_aggregate_direct (which it replaces behind the bin scatter).  A wave keeps
+// three 256-record steps in flight -- the loads are unconditional, so the compiler counts them: vmcnt(11..8)
+// before a fold -- and the LDS abort flag is read with relaxed atomic loads: a `volatile` read made the compiler
+// drain every counter, i.e. the prefetched steps, once per step (k_part_aggregate_direct has it).  Keys of a small
+// range index the table directly (see `direct` below); the others go through the hashed fold (AggFold).
+// Measured and NOT kept: a parallel first-attempt insert (compare-and-swap on the first free entry of the
+// fetched buckets, probe loop as a cold call) was 20 % slower than the serial probe loop.
 struct AggIter { int k; uint32_t i0, cnt; };
 // Directly indexed table: offset o = (key >> 9) - base lives in slot bitreverse12(o), so that a slice filled to
 // a fraction holds its groups spread over all of its slots (the kernels that walk the finished table split
 // it by slot ranges: with the groups packed at the front a few workgroups did all the work, 29 -> 44 us).
 static_assert(kSlots == 4096, "DirectSlot reverses 12 bits");
 __device__ __forceinline__ uint32_t DirectSlot(uint32_t o) { return __brev(o) >> 20; }
-// The probe loop as a real call: inlined, the twelve copies of it (four records x three register sets) made
-// the streaming loop several times the size of the instruction cache's share of one CU.
-__device__ __attribute__((noinline)) int ProbeInsertCold(unsigned int* s_tag, unsigned int* s_groups, uint32_t h) {
-  return ProbeInsert(s_tag, s_groups, h, h & (kBuckets - 1), (h >> kBucketBits) & (kBuckets - 1), kSlotLimit);
-}
-template <int N>
-__device__ __forceinline__ bool AggFoldFast(const uint4 (&rec)[N], const bool (&live)[N], int acc_double,
-                                            unsigned int* s_tag, unsigned long long* s_sum, uint32_t* s_first,
-                                            unsigned int* s_cnt, unsigned int* s_groups) {
-  bool ok = true;
-  uint32_t h[N];
-  int slot[N], target[N];
-  uint4 home1[N], home2[N];
-#pragma unroll
-  for (int u = 0; u < N; ++u) {
-    h[u] = Fmix32(rec[u].x);
-    home1[u] = *reinterpret_cast<const uint4*>(&s_tag[(h[u] & (kBuckets - 1)) * kBucket]);
-    home2[u] = *reinterpret_cast<const uint4*>(&s_tag[((h[u] >> kBucketBits) & (kBuckets - 1)) * kBucket]);
-  }
-#pragma unroll
-  for (int u = 0; u < N; ++u) {
-    target[u] = -1;
-    if (!live[u]) { slot[u] = -2; continue; }
-    if (rec[u].y & kRecKeyNull) slot[u] = kSideNull;
-    else if (h[u] == kTagFree) slot[u] = kSideFree;
-    else {
-      const uint32_t b1 = h[u] & (kBuckets - 1), b2 = (h[u] >> kBucketBits) & (kBuckets - 1);
-      const int j1 = MatchBucket(home1[u], h[u]), j2 = MatchBucket(home2[u], h[u]);
-      if (j1 >= 0) slot[u] = static_cast<int>(b1 * kBucket) + j1;
-      else if (j2 >= 0) slot[u] = static_cast<int>(b2 * kBucket) + j2;
-      else {
-        // a new key (or one inserted since the buckets were read): aim at the first free entry in probe order
-        slot[u] = -3;
-        const int f1 = MatchBucket(home1[u], kTagFree), f2 = MatchBucket(home2[u], kTagFree);
-        if (f1 >= 0) target[u] = static_cast<int>(b1 * kBucket) + f1;
-        else if (f2 >= 0) target[u] = static_cast<int>(b2 * kBucket) + f2;
-      }
-    }
-  }
-  unsigned int old[N];
-#pragma unroll
-  for (int u = 0; u < N; ++u) {
-    old[u] = 0;
-    if (target[u] >= 0) old[u] = atomicCAS(&s_tag[target[u]], kTagFree, h[u]);
-  }
-  unsigned int added = 0;  // (wave-uniform: counted with ballots, no cross-lane data movement)
-#pragma unroll
-  for (int u = 0; u < N; ++u) {
-    const bool won = slot[u] == -3 && target[u] >= 0 && old[u] == kTagFree;
-    added += static_cast<unsigned int>(__popcll(__ballot(won)));
-    if (slot[u] != -3) continue;
-    if (target[u] >= 0 && (old[u] == kTagFree || old[u] == h[u])) {
-      slot[u] = target[u];
-    } else {  // both buckets full, or another key took the entry meanwhile
-      slot[u] = ProbeInsertCold(s_tag, s_groups, h[u]);
-    }
-  }
-  // one counter update per wave (the count only decides when the table is called full)
-  if (added && LaneId() == 0) atomicAdd(s_groups, added);
-#ifdef AGG_DEBUG_NOACC
-  return ok;
-#endif
-#pragma unroll
-  for (int u = 0; u < N; ++u) {
-    if (slot[u] == -2) continue;
-    if (slot[u] < 0) { ok = false; continue; }
-    const uint4 r = rec[u];
-    atomicMin(&s_first[slot[u]], r.y & kRecRowMask);
-    if (r.y & kRecValValid) {
-      const unsigned long long bits = (static_cast<unsigned long long>(r.w) << 32) | r.z;
-      if (acc_double) atomicAdd(reinterpret_cast<double*>(&s_sum[slot[u]]), __longlong_as_double(bits));
-      else atomicAdd(&s_sum[slot[u]], bits);
-      atomicAdd(&s_cnt[slot[u]], 1u);
-    }
-  }
-  return ok;
-}
-
 __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_piped(const uint4* regions, const uint32_t* counts,
                                                                        int nblocks, int64_t cap, int k_bits,
                                                                        int acc_double, GroupTable t,
@@ -2078,10 +1993,6 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_piped(const uin
       bool live[kPaUnroll];
 #pragma unroll
       for (int u = 0; u < kPaUnroll; ++u) live[u] = it.k < nseg && it.i0 + lane + 64 * u < it.cnt;
-#ifdef AGG_DEBUG_NOFOLD
-#pragma unroll
-      for (int u = 0; u < kPaUnroll; ++u) asm volatile("" :: "v"(r[u].x), "v"(r[u].y), "v"(r[u].z), "v"(r[u].w));
-#else
       if (direct) {
 #pragma unroll
         for (int u = 0; u < kPaUnroll; ++u) {
@@ -2098,7 +2009,6 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_piped(const uin
       } else {
         failed |= !AggFold(r, live, acc_double, s_tag, s_sum, s_first, s_cnt, &s_groups);
       }
-#endif
     };
     AggIter i0{-1, 0, 0};
     i0 = advance(i0);  // the first step of the first non-empty segment
