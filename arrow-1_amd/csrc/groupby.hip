@@ -2906,6 +2906,165 @@ int amdarrow_grouper_num_groups(amdarrow_grouper* g, uint32_t* out) {
   return AMDARROW_OK;
 }
 
+static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, const amdarrow_array* keys,
+                             const amdarrow_array* mask, int64_t group_capacity, void* out_sums, int64_t* out_counts,
+                             void* out_keys, uint8_t* out_key_validity, uint32_t* out_first_rows,
+                             int64_t* out_num_groups, bool locked, ulonglong4** packed_out);
+
+__global__ __launch_bounds__(kThreads) void k_gx_from_packed(const ulonglong4* packed, uint32_t G, unsigned long long* gx) {
+  for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < G; i += gridDim.x * kThreads) gx[i] = packed[i].x;
+}
+
+// Ids of the rows of a batch whose distinct keys span a small range: a table id_of[key - min] (4 bytes per
+// possible key, L2 / Infinity-Cache resident) filled from the G key words, then one gather per row -- the hashed
+// look-up (k_lookup_ids) fetches two sectors of a table several times that size per row: 3 ms per 100 M rows.
+__global__ __launch_bounds__(kThreads) void k_gx_minmax(const unsigned long long* gx, uint32_t G, int null_bit, unsigned long long flip,
+                                                        unsigned long long* out /* [0] min, [1] max; preset ~0, 0 */) {
+  unsigned long long mn = ~0ull, mx = 0;
+  for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < G; i += gridDim.x * kThreads) {
+    const unsigned long long raw = gx[i];
+    if ((raw >> null_bit) & 1) continue;  // the null key has no value
+    const unsigned long long x = raw ^ flip;  // (signed keys: value order)
+    mn = x < mn ? x : mn;
+    mx = x > mx ? x : mx;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned long long a = __shfl_xor(mn, d, 64), b = __shfl_xor(mx, d, 64);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  if ((threadIdx.x & 63) == 0 && mn <= mx) { atomicMin(&out[0], mn); atomicMax(&out[1], mx); }
+}
+__global__ __launch_bounds__(kThreads) void k_dense_fill(uint32_t* dense, int64_t range, unsigned long long* minmax, uint32_t* null_id,
+                                                         int init_minmax) {
+  if (init_minmax) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { minmax[0] = ~0ull; minmax[1] = 0; *null_id = kNoRow; }
+    return;
+  }
+  for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < range; i += int64_t(gridDim.x) * kThreads) dense[i] = kNoRow;
+}
+__global__ __launch_bounds__(kThreads) void k_dense_scatter(const unsigned long long* gx, uint32_t G, int null_bit, unsigned long long flip,
+                                                            unsigned long long kmin, uint32_t* dense, uint32_t* null_id) {
+  for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < G; i += gridDim.x * kThreads) {
+    const unsigned long long x = gx[i];
+    if ((x >> null_bit) & 1) *null_id = i;
+    else dense[(x ^ flip) - kmin] = i;
+  }
+}
+__global__ __launch_bounds__(kThreads) void k_lookup_dense(KeyCol c, int64_t n, unsigned long long flip, unsigned long long kmin, const uint32_t* __restrict__ dense,
+                                                           const uint32_t* null_id, uint32_t* __restrict__ out_ids, int vec32) {
+  if (vec32) {  // 32-bit keys without validity on a 16-byte boundary: four rows per thread
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+    const uint32_t* keys = reinterpret_cast<const uint32_t*>(c.data) + c.off;
+    const int64_t nvec = n / 4;
+    const uint32_t k0 = static_cast<uint32_t>(kmin), f = static_cast<uint32_t>(flip);
+    for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < nvec; i += int64_t(gridDim.x) * kThreads) {
+      const u32x4 k = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(keys) + i);
+      u32x4 r;
+      r.x = dense[(k.x ^ f) - k0]; r.y = dense[(k.y ^ f) - k0]; r.z = dense[(k.z ^ f) - k0]; r.w = dense[(k.w ^ f) - k0];
+      __builtin_nontemporal_store(r, reinterpret_cast<u32x4*>(out_ids) + i);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - nvec * 4) {
+      const int64_t r = nvec * 4 + threadIdx.x;
+      out_ids[r] = dense[(keys[r] ^ f) - k0];
+    }
+    return;
+  }
+  const uint32_t nid = *null_id;
+  for (int64_t row = int64_t(blockIdx.x) * kThreads + threadIdx.x; row < n; row += int64_t(gridDim.x) * kThreads) {
+    const bool valid = c.valid ? GetBit(c.valid, c.off + row) : true;
+    out_ids[row] = valid ? dense[(LoadBitsOfWidth(c.data, c.off + row, c.bits) ^ flip) - kmin] : nid;
+  }
+}
+constexpr int64_t kDenseLookupMax = int64_t(1) << 23;  // keys of a range up to 8 M: a 32 MB table
+
+// The FIRST batch of a grouper over one key column of at most 32 bits: the groups and their first-appearance
+// order come from the partitioned group-by (no values, no mask: the local / bin / partition kernels of
+// amdarrow_filter_groupby), the grouper's own table is then filled from the G key words (k_reinsert) and every row
+// looks its id up -- no insert pass of n rows with global atomics (7.4 ms per 100 M rows).  Returns 1 when the
+// batch has to take the general path after all (more groups than the attempt was sized for).
+static int GrouperFirstBatch(amdarrow_grouper* g, const amdarrow_array* keys, const KeySpec& ks, uint32_t* out_ids) {
+  amdarrow_ctx* ctx = g->ctx;
+  const int64_t n = keys[0].length;
+  const int64_t cap = std::min<int64_t>(n, int64_t(1) << 22);
+  int64_t G = 0;
+  ulonglong4* packed = nullptr;
+  const int rc = FilterGroupByImpl(ctx, nullptr, &keys[0], nullptr, cap, nullptr, nullptr, nullptr, nullptr, nullptr, &G,
+                                   /*locked=*/true, &packed);
+  if (rc == AMDARROW_CAPACITY_ERROR) return 1;
+  if (rc != AMDARROW_OK) return rc;
+  const uint64_t need = NextPow2(2 * std::max<uint64_t>(static_cast<uint64_t>(G), 2048));
+  if (need > g->T) {
+    char* mem; TableMem tm;
+    AA_TRY(GrouperAllocTable(g, need, &mem, &tm));
+    AA_HIP(hipStreamSynchronize(ctx->stream));
+    AA_HIP(hipFree(g->table_mem));
+    g->table_mem = mem; g->tm = tm; g->T = need;
+  }
+  if (static_cast<uint64_t>(G) > g->gx_cap) {
+    const uint64_t gcap = NextPow2(2 * static_cast<uint64_t>(G));
+    unsigned long long* ngx;
+    AA_HIP(hipMalloc(reinterpret_cast<void**>(&ngx), 8 * gcap));
+    if (g->gx) { AA_HIP(hipStreamSynchronize(ctx->stream)); AA_HIP(hipFree(g->gx)); }
+    g->gx = ngx; g->gx_cap = gcap;
+  }
+  GroupTable t = BindTable(g->table_mem, g->tm, g->T, true);
+  if (G > 0) {
+    hipLaunchKernelGGL(k_gx_from_packed, dim3(GridFor(G, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, packed,
+                       static_cast<uint32_t>(G), g->gx);
+    hipLaunchKernelGGL(k_reinsert, dim3(GridFor(G, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, g->gx,
+                       static_cast<uint32_t>(G), kNoRow, t);
+    AA_HIP(hipGetLastError());
+  }
+  g->num_groups = static_cast<uint32_t>(G);
+  // ids of the batch's rows: through a directly indexed table when the distinct keys span a small range
+  bool dense_done = false;
+  if (G > 0 && !getenv("AMDARROW_GROUPER_HASHED_LOOKUP")) {
+    void* base;
+    AA_TRY(Scratch(ctx, 256, &base));
+    auto* minmax = static_cast<unsigned long long*>(base);
+    auto* null_id = reinterpret_cast<uint32_t*>(static_cast<char*>(base) + 64);
+    // signed keys in value order (as unsigned: x ^ sign bit), so that a range around zero is a small range
+    const unsigned long long flip = IsSignedInt(keys[0].type_id) && ks.col[0].bits > 1 ? 1ull << (ks.col[0].bits - 1) : 0ull;
+    hipLaunchKernelGGL(k_dense_fill, dim3(1), dim3(kThreads), 0, ctx->stream, static_cast<uint32_t*>(nullptr), int64_t(0), minmax, null_id, 1);
+    hipLaunchKernelGGL(k_gx_minmax, dim3(GridFor(G, kThreads, ctx->num_cus * 4)), dim3(kThreads), 0, ctx->stream, g->gx,
+                       static_cast<uint32_t>(G), ks.total_bits, flip, minmax);
+    AA_HIP(hipGetLastError());
+    unsigned long long mm[2];
+    AA_TRY(ReadBack(ctx, minmax, 16, mm));
+    const bool any = mm[0] <= mm[1];
+    const int64_t range = any ? static_cast<int64_t>(mm[1] - mm[0]) + 1 : 1;
+    if (range <= kDenseLookupMax) {
+      AA_TRY(Scratch(ctx, 256 + 4 * static_cast<size_t>(range), &base));
+      minmax = static_cast<unsigned long long*>(base);
+      null_id = reinterpret_cast<uint32_t*>(static_cast<char*>(base) + 64);
+      auto* dense = reinterpret_cast<uint32_t*>(static_cast<char*>(base) + 256);
+      const unsigned long long kmin = any ? mm[0] : 0;
+      hipLaunchKernelGGL(k_dense_fill, dim3(1), dim3(kThreads), 0, ctx->stream, dense, range, minmax, null_id, 1);  // (a grown arena: the null id again)
+      hipLaunchKernelGGL(k_dense_fill, dim3(GridFor(range, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, dense, range,
+                         minmax, null_id, 0);
+      hipLaunchKernelGGL(k_dense_scatter, dim3(GridFor(G, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, g->gx,
+                         static_cast<uint32_t>(G), ks.total_bits, flip, kmin, dense, null_id);
+      const KeyCol c0{keys[0].values, MayHaveNulls(&keys[0]) ? keys[0].validity : nullptr, keys[0].offset, ks.col[0].bits, 0};
+      const int vec32 = c0.bits == 32 && !c0.valid &&
+                        (reinterpret_cast<uintptr_t>(c0.data) + 4 * static_cast<uintptr_t>(c0.off)) % 16 == 0 &&
+                        reinterpret_cast<uintptr_t>(out_ids) % 16 == 0;
+      hipLaunchKernelGGL(k_lookup_dense, dim3(GridFor(vec32 ? n / 4 + 1 : n, kThreads, ctx->num_cus * 16)), dim3(kThreads), 0, ctx->stream, c0,
+                         n, flip, kmin, dense, null_id, out_ids, vec32);
+      AA_HIP(hipGetLastError());
+      dense_done = true;
+    }
+  }
+  if (!dense_done) {
+    hipLaunchKernelGGL(k_lookup_ids, dim3(GridFor(n, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, ks, n, t, out_ids,
+                       static_cast<unsigned long long*>(nullptr));
+    AA_HIP(hipGetLastError());
+  }
+  AA_HIP(hipStreamSynchronize(ctx->stream));
+  return AMDARROW_OK;
+}
+
 int amdarrow_grouper_consume(amdarrow_grouper* g, const amdarrow_array* keys, uint32_t* out_ids) {
   if (g->wide) return WideIds(g, keys, out_ids, /*insert=*/true);
   amdarrow_ctx* ctx = g->ctx;
@@ -2919,6 +3078,11 @@ int amdarrow_grouper_consume(amdarrow_grouper* g, const amdarrow_array* keys, ui
   KeySpec ks;
   AA_TRY(MakeKeySpec(g->nkeys, keys, nullptr, &ks));
   std::lock_guard<std::mutex> lock(ctx->mu);
+  if (g->num_groups == 0 && g->nkeys == 1 && ks.total_bits <= 32 && n >= (int64_t(1) << 18) && n < (int64_t(1) << 30) &&
+      !getenv("AMDARROW_GROUPER_GENERAL")) {
+    const int rc = GrouperFirstBatch(g, keys, ks, out_ids);
+    if (rc != 1) return rc;
+  }
   // Grow the table so that (known + possible new) groups stay under 50 % load.  Every row of the batch COULD be a
   // new group, but sizing for that costs gigabytes per 50 M-row batch (allocation, clearing, re-insertion) when
   // the batch usually brings few: start with room for 1 M (or as many as are known) new groups and come back
@@ -3125,7 +3289,7 @@ int amdarrow_hash_aggregate(amdarrow_ctx* ctx, int func, const amdarrow_array* v
 static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, const amdarrow_array* keys,
                              const amdarrow_array* mask, int64_t group_capacity, void* out_sums, int64_t* out_counts,
                              void* out_keys, uint8_t* out_key_validity, uint32_t* out_first_rows,
-                             int64_t* out_num_groups, bool locked) {
+                             int64_t* out_num_groups, bool locked, ulonglong4** packed_out) {
   const int64_t n = keys->length;
   *out_num_groups = 0;
   if (values && values->length != n) return SetError(AMDARROW_INVALID, "Array arguments must all be the same length");
@@ -3407,6 +3571,8 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
     AA_HIP(hipGetLastError());
     const int64_t bound = group_capacity < n ? group_capacity : n;
     const KeySpec& ku = fast ? ks : ks_generic;  // how x was built on this path
+    if (packed_out) *packed_out = e.packed;  // {key word, sum, count, first row} per group id, in the context's scratch
+    if (out_keys)
     hipLaunchKernelGGL(k_unpack_groups, dim3(GridFor(bound, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream,
                        e.packed, bound, ku.col[0].bits, ks_generic.col[0].bits, fast ? k_bias : 0ull,
                        ku.wide_null_slot ? -1 : ku.total_bits, static_cast<unsigned long long*>(out_sums), reinterpret_cast<long long*>(out_counts), out_first_rows,
@@ -3458,6 +3624,14 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
   }
   // no trailing synchronise: *out_num_groups is final, the output arrays are stream-ordered
   return AMDARROW_OK;
+}
+
+static int FilterGroupByImplCall(amdarrow_ctx* ctx, const amdarrow_array* values, const amdarrow_array* keys,
+                                 const amdarrow_array* mask, int64_t group_capacity, void* out_sums, int64_t* out_counts,
+                                 void* out_keys, uint8_t* out_key_validity, uint32_t* out_first_rows,
+                                 int64_t* out_num_groups, bool locked) {
+  return FilterGroupByImpl(ctx, values, keys, mask, group_capacity, out_sums, out_counts, out_keys, out_key_validity,
+                           out_first_rows, out_num_groups, locked, nullptr);
 }
 
 // The packed key column: one uint32 per row (PackedKey).  Four rows per thread and step; the raw values of every
@@ -3584,7 +3758,7 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values, con
                             const amdarrow_array* mask, int64_t group_capacity, void* out_sums, int64_t* out_counts,
                             void* out_keys, uint8_t* out_key_validity, uint32_t* out_first_rows,
                             int64_t* out_num_groups) {
-  return FilterGroupByImpl(ctx, values, keys, mask, group_capacity, out_sums, out_counts, out_keys, out_key_validity, out_first_rows,
+  return FilterGroupByImplCall(ctx, values, keys, mask, group_capacity, out_sums, out_counts, out_keys, out_key_validity, out_first_rows,
                            out_num_groups, /*locked=*/false);
 }
 
@@ -3655,7 +3829,7 @@ int amdarrow_filter_groupby_multi(amdarrow_ctx* ctx, const amdarrow_array* value
   stand_in.values = codes; stand_in.validity = nullptr; stand_in.length = n; stand_in.offset = 0;
   stand_in.type_id = AMDARROW_UINT32; stand_in.null_count = 0;
   int64_t G = 0;
-  int rc = FilterGroupByImpl(ctx, values, &stand_in, mask, group_capacity, out_sums, out_counts, packed, dummy_validity, out_first_rows,
+  int rc = FilterGroupByImplCall(ctx, values, &stand_in, mask, group_capacity, out_sums, out_counts, packed, dummy_validity, out_first_rows,
                              &G, /*locked=*/true);
   if (rc == AMDARROW_OK && G > 0) {
     void* base;

@@ -1313,3 +1313,30 @@ def test_filter_groupby_bin_path_random_shapes(gpu, oracle, seed):
     m = Arr(BOOL, np.ones(n, bool)) if seed % 5 == 0 else Arr(BOOL, rng.random(n) < [0.5, 0.08, 0.93][seed % 3])
     for _ in range(2):
         _check_groupby(oracle, gpu, v, k, m, (seed, n, kt, vt))
+
+
+@pytest.mark.parametrize("kt", [BOOL, INT8, UINT16, INT32, UINT32, FLOAT])
+def test_grouper_first_batch_through_the_partitioned_groupby(gpu, oracle, kt):
+    """A first batch of >= 2^18 rows over one key column of at most 32 bits takes the partitioned group-by for its
+    groups and a directly indexed id table (small key range) or the hashed table (wide range) for the rows' ids;
+    later batches continue on the general path with the same table.  Nulls, negative keys, sliced input."""
+    rng = np.random.default_rng(0x0ff1ce + 200 + kt)
+    n1, n2 = 400_003, 30_000
+    for knp, (lo, hi) in ((0.0, (-3000, 3000)), (0.05, (-3000, 3000)), (0.0, (-2**30, 2**30))):
+        if kt in (BOOL, INT8, UINT16) and hi > 3000:
+            continue
+        if kt in (BOOL, UINT16, UINT32):
+            lo, hi = 0, hi
+        if kt == INT8:
+            lo, hi = -100, 100
+        b1 = [R(rng, kt, n1, knp, 4, lo=lo, hi=hi)]
+        b2 = [R(rng, kt, n2, knp, 0, lo=lo * 2 if kt != INT8 else -128, hi=hi * 2 if kt != INT8 else 127)]
+        io, ngo, uo = oracle.group_ids([b1, b2])
+        ig, ngg, ug = gpu.group_ids([b1, b2])
+        assert ngo == ngg, (kt, knp, hi)
+        for x, y in zip(io, ig):
+            assert np.array_equal(x, y), (kt, knp, hi)
+        (va, vb, nca), (vc, vd, ncb) = uo[0], ug[0]
+        assert np.array_equal(vb, vd) and nca == ncb
+        sel = vb if vb is not None and len(vb) else slice(None)
+        assert np.array_equal(np.asarray(va)[sel], np.asarray(vc)[sel])
