@@ -1398,8 +1398,11 @@ __device__ __forceinline__ void BinLoadTile(const FastArgs& a, const void* __res
                                             const uint64_t* __restrict__ vals, int64_t tile0, int tid, BinTile<R, K64>& t) {
   const int64_t r0 = tile0 + int64_t(tid) * R;
   t.key.load(keys, r0);
-  t.va = __builtin_nontemporal_load(reinterpret_cast<const BinU64x2*>(vals + r0));
-  if constexpr (R == 4) t.vb = __builtin_nontemporal_load(reinterpret_cast<const BinU64x2*>(vals + r0 + 2));
+  // (a call without a value column: `vals` is any readable buffer and every lane loads its first bytes -- the
+  // load stays unconditional, which keeps the count of loads in flight a constant; see BinRun)
+  const int64_t rv = r0 * a.has_values;
+  t.va = __builtin_nontemporal_load(reinterpret_cast<const BinU64x2*>(vals + rv));
+  if constexpr (R == 4) t.vb = __builtin_nontemporal_load(reinterpret_cast<const BinU64x2*>(vals + rv + 2));
   if (MASK) LoadBitBytes(a.m_data, a.m_off + r0, (a.m_off + a.n - 1) >> 3, &t.m0, &t.m1);
   if (VVALID) LoadBitBytes(a.v.valid, a.v.off + r0, (a.v.off + a.n - 1) >> 3, &t.v0, &t.v1);
 }
@@ -1413,8 +1416,8 @@ __device__ __forceinline__ void BinLoadTail(const FastArgs& a, const void* __res
   for (int j = 0; j < R; ++j) {
     const int64_t rc = r0 + j < hi ? r0 + j : hi - 1;
     t.key.set(j, keys, rc);
-    if (j < 2) t.va[j] = vals[rc];
-    if constexpr (R == 4) { if (j >= 2) t.vb[j - 2] = vals[rc]; }
+    if (j < 2) t.va[j] = vals[rc * a.has_values];
+    if constexpr (R == 4) { if (j >= 2) t.vb[j - 2] = vals[rc * a.has_values]; }
   }
   const int64_t rb = r0 < hi ? r0 : hi - 1;
   if (MASK) LoadBitBytes(a.m_data, a.m_off + rb, (a.m_off + a.n - 1) >> 3, &t.m0, &t.m1);
@@ -1452,7 +1455,7 @@ __device__ __forceinline__ void BinStageTile(BinShared& sh, const FastArgs& a, c
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     if (!sel[j]) continue;
-    const bool vvalid = (vbits >> j) & 1u;
+    const bool vvalid = a.has_values && ((vbits >> j) & 1u);
     const uint64_t v = vvalid ? t.v(j) : 0;
     uint4 q;
     q.x = t.key.k(j, a.k_bias);
@@ -3357,11 +3360,14 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
                               BitWidth(values->type_id) == 64 && !m_valid;
   // the bin scatter loads 16-byte vectors: keys and values must start on a 16-byte boundary
   // (also for a 64-bit key column that range-compressed onto 32 bits: the kernel loads the 64-bit keys and subtracts the bias)
-  const bool bins_shape = ks.total_bits == 32 && (k_load_bits == 32 || k_load_bits == 64) && !keys->validity && values &&
-                          BitWidth(values->type_id) == 64 && !m_valid;
+  // (and for a call without values -- the Grouper's first batch -- as long as there is no mask either: the kernel
+  // then reads the first bytes of the key buffer where it would read values, and marks no record as carrying one)
+  const bool bins_shape = ks.total_bits == 32 && (k_load_bits == 32 || k_load_bits == 64) && !keys->validity && !m_valid &&
+                          (values ? BitWidth(values->type_id) == 64 : (!mask && n >= 64));
   const bool use_bins = bins_shape && !getenv("AMDARROW_GROUPBY_NO_BINS") &&
                         (reinterpret_cast<uintptr_t>(keys->values) + (k_load_bits / 8) * static_cast<uintptr_t>(keys->offset)) % 16 == 0 &&
-                        (reinterpret_cast<uintptr_t>(values->values) + 8 * static_cast<uintptr_t>(values->offset)) % 16 == 0;
+                        (values ? (reinterpret_cast<uintptr_t>(values->values) + 8 * static_cast<uintptr_t>(values->offset)) % 16 == 0
+                                : reinterpret_cast<uintptr_t>(keys->values) % 16 == 0);
   GroupTable t{};
   RankMem r{};
   unsigned long long* gx = nullptr;
@@ -3454,6 +3460,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
       fa.k_flip = keys->type_id == AMDARROW_INT32 ? 0x80000000u : 0u;  // (a range-compressed column: x = key - min >= 0 as it is)
       fa.key_minmax = misc + 8;  // (status words are misc[0..7]; the workgroup flags start at misc + 64)
       fa.v = v; fa.has_values = values ? 1 : 0;
+      if (!values && use_bins) fa.v = ValueCol{keys->values, nullptr, 0, AMDARROW_INT64};  // (never used as values: see BinLoadTile)
       fa.m_data = m_data; fa.m_valid = m_valid; fa.m_off = m_off;
       fa.n = n; fa.nblocks = nblocks; fa.rows_per_block = rows_per_block;
       const int acc_double = values && IsFloat(values->type_id) ? 1 : 0;
