@@ -3626,6 +3626,8 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
       if (status[1] != 0 && status[5] == 0 && sub_bits == 0) { shape.uses = hint.n == shape.n ? hint.uses : 0; hint = shape; }
       else hint.n = -1;
     }
+    // a hinted call that found few groups: the local attempt it skipped would have held them all -- next call, try it again
+    if (hinted && G <= static_cast<int64_t>(kLocalLimit)) hint.n = -1;
     *out_num_groups = G;
     break;
   }
