@@ -48,6 +48,8 @@ struct amdarrow_ctx {
   struct GroupByHint { int64_t n = -1; int key_type = 0, value_type = 0, has_mask = 0, has_value_validity = 0, uses = 0; } gb_hint;
   void* pack_buf = nullptr;  // groupby.hip amdarrow_filter_groupby_multi: packed key codes (grow-only)
   size_t pack_cap = 0;
+  void* side_buf = nullptr;  // groupby.hip amdarrow_hash_accumulate: the inner group-by's per-group outputs (grow-only)
+  size_t side_cap = 0;
   int lds_rank_ordered = -1;  // sort.hip LdsAtomicsLaneOrdered(): -1 not probed yet, 0 no, 1 yes
   int64_t bytes_allocated = 0;
   int64_t max_memory = 0;

@@ -3227,6 +3227,60 @@ int amdarrow_grouper_uniques(amdarrow_grouper* g, int k, void* out_values, uint8
   return AMDARROW_OK;
 }
 
+// acc[id] += the batch's per-group result; every id occurs once in (gkeys, gsums, gcounts): plain read-modify-write
+__global__ __launch_bounds__(kThreads) void k_add_by_id(const uint32_t* gkeys, const unsigned long long* gsums, const int64_t* gcounts,
+                                                        int64_t G, int is_double, int with_sums, unsigned long long* sums,
+                                                        unsigned long long* counts) {
+  for (int64_t g = int64_t(blockIdx.x) * kThreads + threadIdx.x; g < G; g += int64_t(gridDim.x) * kThreads) {
+    const uint32_t id = gkeys[g];
+    if (with_sums) {
+      if (is_double) sums[id] = static_cast<unsigned long long>(__double_as_longlong(__longlong_as_double(sums[id]) + __longlong_as_double(gsums[g])));
+      else sums[id] += gsums[g];
+    }
+    counts[id] += static_cast<unsigned long long>(gcounts[g]);
+  }
+}
+
+// hash_sum / hash_count / hash_mean of a batch of >= 256 K rows: the ids ARE a key column of the partitioned
+// group-by (dense, 32 bits: bin scatter + directly indexed tables, or the local tables when a row range holds few
+// of them), whose per-group sums and valid counts are then added to the accumulators -- one plain update per
+// group instead of two memory-side atomics per ROW (k_hash_agg: 8.7 ms per 100 M rows with 1 M groups, 14 ms with
+// 1000, where every row fights for the same few words).  Returns 1 when the batch has to take the atomics
+// after all (more distinct ids than the attempt was sized for).
+static int HashAccumulateGrouped(amdarrow_ctx* ctx, int func, const amdarrow_array* values, const uint32_t* ids,
+                                 unsigned long long* sums, unsigned long long* counts) {
+  const int64_t n = values->length;
+  const int64_t cap = std::min<int64_t>(n, int64_t(1) << 22);
+  const size_t off_valid = (static_cast<size_t>(cap) * 20 + 255) & ~size_t(255);
+  const size_t need = off_valid + static_cast<size_t>((cap + 63) / 64) * 8 + 256;
+  if (ctx->side_cap < need) {
+    AA_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->side_buf) (void)hipFree(ctx->side_buf);
+    ctx->side_buf = nullptr;
+    ctx->side_cap = 0;
+    AA_HIP(hipMalloc(&ctx->side_buf, need));
+    ctx->side_cap = need;
+  }
+  char* sb = static_cast<char*>(ctx->side_buf);
+  auto* gsums = reinterpret_cast<unsigned long long*>(sb);
+  auto* gcounts = reinterpret_cast<int64_t*>(sb + 8 * cap);
+  auto* gkeys = reinterpret_cast<uint32_t*>(sb + 16 * cap);
+  auto* gvalid = reinterpret_cast<uint8_t*>(sb + off_valid);
+  amdarrow_array key{};
+  key.values = const_cast<uint32_t*>(ids); key.validity = nullptr; key.length = n; key.offset = 0; key.type_id = AMDARROW_UINT32;
+  key.null_count = 0;
+  int64_t G = 0;
+  const int rc = FilterGroupByImpl(ctx, values, &key, nullptr, cap, gsums, gcounts, gkeys, gvalid, nullptr, &G, /*locked=*/true, nullptr);
+  if (rc == AMDARROW_CAPACITY_ERROR) return 1;
+  if (rc != AMDARROW_OK) return rc;
+  if (G > 0) {
+    hipLaunchKernelGGL(k_add_by_id, dim3(GridFor(G, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, gkeys, gsums, gcounts, G,
+                       IsFloat(values->type_id) ? 1 : 0, func != AMDARROW_HASH_COUNT ? 1 : 0, sums, counts);
+    AA_HIP(hipGetLastError());
+  }
+  return AMDARROW_OK;
+}
+
 int amdarrow_hash_accumulate(amdarrow_ctx* ctx, int func, const amdarrow_array* values, const uint32_t* ids,
                              int count_mode, void* sums, int64_t* counts) {
   if (func < AMDARROW_HASH_SUM || func > AMDARROW_HASH_MEAN) return SetError(AMDARROW_KEY_ERROR, "No such hash aggregate");
@@ -3234,6 +3288,12 @@ int amdarrow_hash_accumulate(amdarrow_ctx* ctx, int func, const amdarrow_array* 
   if (BitWidth(t) < 0) return SetError(AMDARROW_NOT_IMPLEMENTED, "Summing data of this type");  // :556-562
   if (values->length == 0) return AMDARROW_OK;
   std::lock_guard<std::mutex> lock(ctx->mu);
+  if (values->length >= (int64_t(1) << 18) && values->length < (int64_t(1) << 30) &&
+      !(func == AMDARROW_HASH_COUNT && count_mode == AMDARROW_COUNT_NULL) && !getenv("AMDARROW_HASH_ATOMICS")) {
+    const int rc = HashAccumulateGrouped(ctx, func, values, ids, static_cast<unsigned long long*>(sums),
+                                         reinterpret_cast<unsigned long long*>(counts));
+    if (rc != 1) return rc;
+  }
   ValueCol v{values->values, values->validity, values->offset, t};
   hipLaunchKernelGGL(k_hash_agg, dim3(GridFor(values->length, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, v,
                      ids, values->length, func, count_mode, static_cast<unsigned long long*>(sums),

@@ -102,6 +102,7 @@ int amdarrow_ctx_destroy(amdarrow_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->pack_buf) (void)hipFree(ctx->pack_buf);
+  if (ctx->side_buf) (void)hipFree(ctx->side_buf);
   if (ctx->status_event) (void)hipEventDestroy(ctx->status_event);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   for (auto& kv : ctx->allocs) (void)hipFree(kv.first);

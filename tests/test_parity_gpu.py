@@ -1340,3 +1340,28 @@ def test_grouper_first_batch_through_the_partitioned_groupby(gpu, oracle, kt):
         assert np.array_equal(vb, vd) and nca == ncb
         sel = vb if vb is not None and len(vb) else slice(None)
         assert np.array_equal(np.asarray(va)[sel], np.asarray(vc)[sel])
+
+
+@pytest.mark.parametrize("t", [INT8, UINT16, INT32, INT64, UINT64, FLOAT, DOUBLE, BOOL])
+def test_hash_aggregates_large_batches_through_the_partitioned_groupby(gpu, oracle, t):
+    """Batches of >= 2^18 rows: hash_sum / hash_count / hash_mean group by the ids with the partitioned group-by and
+    add one result per group to the accumulators (counting NULLS keeps the per-row atomics).  Many ids, few ids,
+    ids that never occur, null values, sliced values."""
+    rng = np.random.default_rng(0x0ff1ce + 300 + t)
+    n = 300_011
+    for ng, used in ((200_000, 200_000), (700, 690), (5, 5)):
+        for vnp, off in ((0.0, 0), (0.2, 3)):
+            v = R(rng, t, n, vnp, off)
+            ids = rng.integers(0, used, n).astype(np.uint32)
+            for fn in ("sum", "count", "mean"):
+                for mode in ((0, 1) if fn == "count" else (0,)):
+                    if off and fn == "count":
+                        continue  # (hash_count on a sliced input: a reference defect, see test_hash_aggregates_random)
+                    a = oracle.hash_aggregate(fn, v, ids, ng, mode)
+                    b = gpu.hash_aggregate(fn, v, ids, ng, mode)
+                    if a.values.dtype == np.float64:
+                        assert (a.length, a.null_count, a.has_validity) == (b.length, b.null_count, b.has_validity)
+                        assert np.array_equal(a.validity_bits, b.validity_bits)
+                        assert np.allclose(a.values, b.values, rtol=1e-9, atol=1e-6), (fn, t, ng, vnp)
+                    else:
+                        assert a.same(b), (fn, t, ng, vnp, mode)
