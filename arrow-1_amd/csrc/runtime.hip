@@ -106,6 +106,7 @@ int amdarrow_ctx_destroy(amdarrow_ctx* ctx) {
   if (ctx->status_event) (void)hipEventDestroy(ctx->status_event);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   for (auto& kv : ctx->allocs) (void)hipFree(kv.first);
+  for (auto& kv : ctx->free_blocks) for (void* p : kv.second) (void)hipFree(p);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return AMDARROW_OK;
@@ -118,19 +119,54 @@ int amdarrow_ctx_synchronize(amdarrow_ctx* ctx) {
 
 void* amdarrow_ctx_stream(amdarrow_ctx* ctx) { return ctx->stream; }
 
+// Size class of a block: capacities up to 4 KB as they are (64-byte multiples), above that rounded up to the next
+// multiple of an eighth of their leading power of two (<= 12.5 % over).
+static int64_t SizeClass(int64_t cap) {
+  if (cap <= 4096) return cap;
+  int lg = 63 - __builtin_clzll(static_cast<unsigned long long>(cap));
+  const int64_t step = int64_t(1) << (lg - 3);
+  return (cap + step - 1) / step * step;
+}
+constexpr int64_t kPoolCacheLimit = int64_t(16) << 30;  // cached (free) bytes beyond which blocks go back to the device
+
 int amdarrow_malloc(amdarrow_ctx* ctx, int64_t nbytes, void** out_ptr) {
   if (nbytes < 0) return SetError(AMDARROW_INVALID, "amdarrow_malloc: negative size");
   // capacity rounded up to 64 bytes like arrow::MemoryPool (memory_pool.cc:101, buffer.cc:196-216)
   const int64_t cap = ((nbytes + 63) / 64) * 64 + (nbytes == 0 ? 64 : 0);
+  const int64_t klass = SizeClass(cap);
   AA_HIP(hipSetDevice(ctx->device));
   void* p = nullptr;
-  AA_HIP(hipMalloc(&p, static_cast<size_t>(cap)));
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    auto it = ctx->free_blocks.find(klass);
+    if (it != ctx->free_blocks.end() && !it->second.empty()) {
+      p = it->second.back();
+      it->second.pop_back();
+      ctx->cached_bytes -= klass;
+    }
+  }
+  if (!p) {
+    hipError_t e = hipMalloc(&p, static_cast<size_t>(klass));
+    if (e != hipSuccess) {  // out of memory: give the cache back and try once more
+      (void)hipGetLastError();
+      std::vector<void*> drop;
+      {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        for (auto& kv : ctx->free_blocks) { for (void* q : kv.second) drop.push_back(q); kv.second.clear(); }
+        ctx->cached_bytes = 0;
+      }
+      AA_HIP(hipStreamSynchronize(ctx->stream));
+      for (void* q : drop) (void)hipFree(q);
+      AA_HIP(hipMalloc(&p, static_cast<size_t>(klass)));
+    }
+  }
   if (cap > nbytes) {
     // zero the padding so word-at-a-time bitmap readers see defined bytes
     AA_HIP(hipMemsetAsync(static_cast<char*>(p) + nbytes, 0, static_cast<size_t>(cap - nbytes), ctx->stream));
   }
   std::lock_guard<std::mutex> lock(ctx->mu);
   ctx->allocs[p] = cap;
+  ctx->alloc_class[p] = klass;
   ctx->bytes_allocated += cap;
   if (ctx->bytes_allocated > ctx->max_memory) ctx->max_memory = ctx->bytes_allocated;
   *out_ptr = p;
@@ -139,15 +175,23 @@ int amdarrow_malloc(amdarrow_ctx* ctx, int64_t nbytes, void** out_ptr) {
 
 int amdarrow_free(amdarrow_ctx* ctx, void* ptr) {
   if (!ptr) return AMDARROW_OK;
+  int64_t klass = 0;
+  bool keep = false;
   {
     std::lock_guard<std::mutex> lock(ctx->mu);
     auto it = ctx->allocs.find(ptr);
     if (it == ctx->allocs.end()) return SetError(AMDARROW_INVALID, "amdarrow_free: pointer not from this pool");
     ctx->bytes_allocated -= it->second;
     ctx->allocs.erase(it);
+    klass = ctx->alloc_class[ptr];
+    ctx->alloc_class.erase(ptr);
+    keep = ctx->cached_bytes + klass <= kPoolCacheLimit;
+    if (keep) { ctx->free_blocks[klass].push_back(ptr); ctx->cached_bytes += klass; }
   }
-  AA_HIP(hipStreamSynchronize(ctx->stream));
-  AA_HIP(hipFree(ptr));
+  if (!keep) {
+    AA_HIP(hipStreamSynchronize(ctx->stream));
+    AA_HIP(hipFree(ptr));
+  }
   return AMDARROW_OK;
 }
 
