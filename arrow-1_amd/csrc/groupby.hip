@@ -2982,12 +2982,34 @@ __global__ __launch_bounds__(kThreads) void k_lookup_dense(KeyCol c, int64_t n, 
 }
 constexpr int64_t kDenseLookupMax = int64_t(1) << 23;  // keys of a range up to 8 M: a 32 MB table
 
-// The FIRST batch of a grouper over one key column of at most 32 bits: the groups and their first-appearance
-// order come from the partitioned group-by (no values, no mask: the local / bin / partition kernels of
-// amdarrow_filter_groupby), the grouper's own table is then filled from the G key words (k_reinsert) and every row
-// looks its id up -- no insert pass of n rows with global atomics (7.4 ms per 100 M rows).  Returns 1 when the
-// batch has to take the general path after all (more groups than the attempt was sized for).
-static int GrouperFirstBatch(amdarrow_grouper* g, const amdarrow_array* keys, const KeySpec& ks, uint32_t* out_ids) {
+// Known keys keep their ids, new keys are flagged (in the batch's first-appearance order, which is the order of `packed`).
+__global__ __launch_bounds__(kThreads) void k_grouper_probe(const ulonglong4* packed, uint32_t G, GroupTable t, uint32_t* slot_of,
+                                                            uint32_t* is_new, unsigned int* full) {
+  for (uint32_t j = blockIdx.x * kThreads + threadIdx.x; j < G; j += gridDim.x * kThreads) {
+    const int64_t idx = FindOrInsert(t, Fmix64(packed[j].x), true);  // (distinct keys: no two threads meet on a slot)
+    if (idx < 0) { *full = 1; slot_of[j] = 0; is_new[j] = 0; continue; }
+    slot_of[j] = static_cast<uint32_t>(idx);
+    is_new[j] = t.ids[idx] == kNoRow ? 1u : 0u;
+  }
+}
+__global__ __launch_bounds__(kThreads) void k_grouper_commit(const ulonglong4* packed, uint32_t G, GroupTable t, const uint32_t* slot_of,
+                                                             const uint32_t* is_new, const int64_t* new_before, uint32_t id_base,
+                                                             unsigned long long* gx) {
+  for (uint32_t j = blockIdx.x * kThreads + threadIdx.x; j < G; j += gridDim.x * kThreads) {
+    if (!is_new[j]) continue;
+    const uint32_t id = id_base + static_cast<uint32_t>(new_before[j]);
+    t.ids[slot_of[j]] = id;
+    gx[id] = packed[j].x;
+  }
+}
+
+// A batch of >= 256 K rows of a grouper over one key column of at most 32 bits: the batch's distinct keys and their
+// first-appearance order come from the partitioned group-by (no values, no mask: the local / bin / partition
+// kernels of amdarrow_filter_groupby); only those G keys meet the grouper's table -- known ones keep their ids,
+// new ones are numbered in that order behind the known groups -- and every row then looks its id up.  No insert
+// pass of n rows with global atomics (7.4 ms per 100 M rows).  Returns 1 when the batch has to take the general
+// path after all (more distinct keys than the attempt was sized for).
+static int GrouperBatchGrouped(amdarrow_grouper* g, const amdarrow_array* keys, const KeySpec& ks, uint32_t* out_ids) {
   amdarrow_ctx* ctx = g->ctx;
   const int64_t n = keys[0].length;
   const int64_t cap = std::min<int64_t>(n, int64_t(1) << 22);
@@ -2997,33 +3019,78 @@ static int GrouperFirstBatch(amdarrow_grouper* g, const amdarrow_array* keys, co
                                    /*locked=*/true, &packed);
   if (rc == AMDARROW_CAPACITY_ERROR) return 1;
   if (rc != AMDARROW_OK) return rc;
-  const uint64_t need = NextPow2(2 * std::max<uint64_t>(static_cast<uint64_t>(G), 2048));
+  // room for every distinct key of the batch being new (the table stays under 50 % load)
+  const uint64_t known = g->num_groups;
+  const uint64_t need = NextPow2(2 * std::max<uint64_t>(known + static_cast<uint64_t>(G), 2048));
   if (need > g->T) {
     char* mem; TableMem tm;
     AA_TRY(GrouperAllocTable(g, need, &mem, &tm));
+    GroupTable nt = BindTable(mem, tm, need, true);
+    if (known) {
+      hipLaunchKernelGGL(k_reinsert, dim3(GridFor(static_cast<int64_t>(known), kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream,
+                         g->gx, static_cast<uint32_t>(known), kNoRow, nt);
+      AA_HIP(hipGetLastError());
+    }
     AA_HIP(hipStreamSynchronize(ctx->stream));
     AA_HIP(hipFree(g->table_mem));
     g->table_mem = mem; g->tm = tm; g->T = need;
   }
-  if (static_cast<uint64_t>(G) > g->gx_cap) {
-    const uint64_t gcap = NextPow2(2 * static_cast<uint64_t>(G));
+  if (known + static_cast<uint64_t>(G) > g->gx_cap) {
+    const uint64_t gcap = NextPow2(2 * (known + static_cast<uint64_t>(G)));
     unsigned long long* ngx;
     AA_HIP(hipMalloc(reinterpret_cast<void**>(&ngx), 8 * gcap));
-    if (g->gx) { AA_HIP(hipStreamSynchronize(ctx->stream)); AA_HIP(hipFree(g->gx)); }
+    if (known) AA_HIP(hipMemcpyAsync(ngx, g->gx, 8 * known, hipMemcpyDeviceToDevice, ctx->stream));
+    AA_HIP(hipStreamSynchronize(ctx->stream));
+    if (g->gx) AA_HIP(hipFree(g->gx));
     g->gx = ngx; g->gx_cap = gcap;
   }
   GroupTable t = BindTable(g->table_mem, g->tm, g->T, true);
-  if (G > 0) {
+  if (G > 0 && known == 0) {
+    // an empty grouper: every key is new, ids in the order of `packed`
     hipLaunchKernelGGL(k_gx_from_packed, dim3(GridFor(G, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, packed,
                        static_cast<uint32_t>(G), g->gx);
     hipLaunchKernelGGL(k_reinsert, dim3(GridFor(G, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, g->gx,
                        static_cast<uint32_t>(G), kNoRow, t);
     AA_HIP(hipGetLastError());
+    g->num_groups = static_cast<uint32_t>(G);
+  } else if (G > 0) {
+    // side buffer (not the scratch arena: `packed` lives there): slot and new-flag per distinct key, their scan
+    const size_t off_new = (static_cast<size_t>(G) * 4 + 255) & ~size_t(255);
+    const size_t off_scan = off_new + ((static_cast<size_t>(G) * 4 + 255) & ~size_t(255));
+    const size_t off_full = off_scan + ((static_cast<size_t>(G + 1) * 8 + 255) & ~size_t(255));
+    const size_t need_side = off_full + 256;
+    if (ctx->side_cap < need_side) {
+      AA_HIP(hipStreamSynchronize(ctx->stream));
+      if (ctx->side_buf) (void)hipFree(ctx->side_buf);
+      ctx->side_buf = nullptr;
+      ctx->side_cap = 0;
+      AA_HIP(hipMalloc(&ctx->side_buf, need_side));
+      ctx->side_cap = need_side;
+    }
+    char* sb = static_cast<char*>(ctx->side_buf);
+    auto* slot_of = reinterpret_cast<uint32_t*>(sb);
+    auto* is_new = reinterpret_cast<uint32_t*>(sb + off_new);
+    auto* new_before = reinterpret_cast<int64_t*>(sb + off_scan);
+    auto* full = reinterpret_cast<unsigned int*>(sb + off_full);
+    AA_HIP(hipMemsetAsync(full, 0, 4, ctx->stream));
+    const int grid = GridFor(G, kThreads, ctx->num_cus * 8);
+    hipLaunchKernelGGL(k_grouper_probe, dim3(grid), dim3(kThreads), 0, ctx->stream, packed, static_cast<uint32_t>(G), t, slot_of, is_new, full);
+    AA_HIP(hipGetLastError());
+    AA_TRY(LaunchScanU32(ctx, is_new, G, new_before));
+    hipLaunchKernelGGL(k_grouper_commit, dim3(grid), dim3(kThreads), 0, ctx->stream, packed, static_cast<uint32_t>(G), t, slot_of, is_new,
+                       new_before, static_cast<uint32_t>(known), g->gx);
+    AA_HIP(hipGetLastError());
+    long long added = 0;
+    AA_TRY(ReadBack(ctx, new_before + G, 8, &added));
+    unsigned int was_full = 0;
+    AA_TRY(ReadBack(ctx, full, 4, &was_full));
+    if (was_full) return SetError(AMDARROW_CAPACITY_ERROR, "grouper: table full");  // (sized for every key being new: cannot happen)
+    g->num_groups = static_cast<uint32_t>(known + static_cast<uint64_t>(added));
   }
-  g->num_groups = static_cast<uint32_t>(G);
-  // ids of the batch's rows: through a directly indexed table when the distinct keys span a small range
+  const uint32_t total = g->num_groups;
+  // ids of the batch's rows: through a directly indexed table when ALL known keys span a small range
   bool dense_done = false;
-  if (G > 0 && !getenv("AMDARROW_GROUPER_HASHED_LOOKUP")) {
+  if (total > 0 && !getenv("AMDARROW_GROUPER_HASHED_LOOKUP")) {
     void* base;
     AA_TRY(Scratch(ctx, 256, &base));
     auto* minmax = static_cast<unsigned long long*>(base);
@@ -3031,8 +3098,8 @@ static int GrouperFirstBatch(amdarrow_grouper* g, const amdarrow_array* keys, co
     // signed keys in value order (as unsigned: x ^ sign bit), so that a range around zero is a small range
     const unsigned long long flip = IsSignedInt(keys[0].type_id) && ks.col[0].bits > 1 ? 1ull << (ks.col[0].bits - 1) : 0ull;
     hipLaunchKernelGGL(k_dense_fill, dim3(1), dim3(kThreads), 0, ctx->stream, static_cast<uint32_t*>(nullptr), int64_t(0), minmax, null_id, 1);
-    hipLaunchKernelGGL(k_gx_minmax, dim3(GridFor(G, kThreads, ctx->num_cus * 4)), dim3(kThreads), 0, ctx->stream, g->gx,
-                       static_cast<uint32_t>(G), ks.total_bits, flip, minmax);
+    hipLaunchKernelGGL(k_gx_minmax, dim3(GridFor(total, kThreads, ctx->num_cus * 4)), dim3(kThreads), 0, ctx->stream, g->gx, total,
+                       ks.total_bits, flip, minmax);
     AA_HIP(hipGetLastError());
     unsigned long long mm[2];
     AA_TRY(ReadBack(ctx, minmax, 16, mm));
@@ -3047,8 +3114,8 @@ static int GrouperFirstBatch(amdarrow_grouper* g, const amdarrow_array* keys, co
       hipLaunchKernelGGL(k_dense_fill, dim3(1), dim3(kThreads), 0, ctx->stream, dense, range, minmax, null_id, 1);  // (a grown arena: the null id again)
       hipLaunchKernelGGL(k_dense_fill, dim3(GridFor(range, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, dense, range,
                          minmax, null_id, 0);
-      hipLaunchKernelGGL(k_dense_scatter, dim3(GridFor(G, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, g->gx,
-                         static_cast<uint32_t>(G), ks.total_bits, flip, kmin, dense, null_id);
+      hipLaunchKernelGGL(k_dense_scatter, dim3(GridFor(total, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, g->gx, total,
+                         ks.total_bits, flip, kmin, dense, null_id);
       const KeyCol c0{keys[0].values, MayHaveNulls(&keys[0]) ? keys[0].validity : nullptr, keys[0].offset, ks.col[0].bits, 0};
       const int vec32 = c0.bits == 32 && !c0.valid &&
                         (reinterpret_cast<uintptr_t>(c0.data) + 4 * static_cast<uintptr_t>(c0.off)) % 16 == 0 &&
@@ -3081,9 +3148,8 @@ int amdarrow_grouper_consume(amdarrow_grouper* g, const amdarrow_array* keys, ui
   KeySpec ks;
   AA_TRY(MakeKeySpec(g->nkeys, keys, nullptr, &ks));
   std::lock_guard<std::mutex> lock(ctx->mu);
-  if (g->num_groups == 0 && g->nkeys == 1 && ks.total_bits <= 32 && n >= (int64_t(1) << 18) && n < (int64_t(1) << 30) &&
-      !getenv("AMDARROW_GROUPER_GENERAL")) {
-    const int rc = GrouperFirstBatch(g, keys, ks, out_ids);
+  if (g->nkeys == 1 && ks.total_bits <= 32 && n >= (int64_t(1) << 18) && n < (int64_t(1) << 30) && !getenv("AMDARROW_GROUPER_GENERAL")) {
+    const int rc = GrouperBatchGrouped(g, keys, ks, out_ids);
     if (rc != 1) return rc;
   }
   // Grow the table so that (known + possible new) groups stay under 50 % load.  Every row of the batch COULD be a

@@ -1317,9 +1317,9 @@ def test_filter_groupby_bin_path_random_shapes(gpu, oracle, seed):
 
 @pytest.mark.parametrize("kt", [BOOL, INT8, UINT16, INT32, UINT32, FLOAT])
 def test_grouper_first_batch_through_the_partitioned_groupby(gpu, oracle, kt):
-    """A first batch of >= 2^18 rows over one key column of at most 32 bits takes the partitioned group-by for its
-    groups and a directly indexed id table (small key range) or the hashed table (wide range) for the rows' ids;
-    later batches continue on the general path with the same table.  Nulls, negative keys, sliced input."""
+    """A batch of >= 2^18 rows over one key column of at most 32 bits takes the partitioned group-by for its distinct
+    keys and a directly indexed id table (small key range) or the hashed table (wide range) for the rows' ids;
+    small batches in between take the general path on the same table.  Nulls, negative keys, sliced input."""
     rng = np.random.default_rng(0x0ff1ce + 200 + kt)
     n1, n2 = 400_003, 30_000
     for knp, (lo, hi) in ((0.0, (-3000, 3000)), (0.05, (-3000, 3000)), (0.0, (-2**30, 2**30))):
@@ -1331,8 +1331,10 @@ def test_grouper_first_batch_through_the_partitioned_groupby(gpu, oracle, kt):
             lo, hi = -100, 100
         b1 = [R(rng, kt, n1, knp, 4, lo=lo, hi=hi)]
         b2 = [R(rng, kt, n2, knp, 0, lo=lo * 2 if kt != INT8 else -128, hi=hi * 2 if kt != INT8 else 127)]
-        io, ngo, uo = oracle.group_ids([b1, b2])
-        ig, ngg, ug = gpu.group_ids([b1, b2])
+        # a third, large batch that mixes known keys with new ones (the grouped route again: known keys keep their ids)
+        b3 = [R(rng, kt, 300_007, knp, 2, lo=lo * 3 if kt != INT8 else -128, hi=hi * 3 if kt != INT8 else 127)]
+        io, ngo, uo = oracle.group_ids([b1, b2, b3])
+        ig, ngg, ug = gpu.group_ids([b1, b2, b3])
         assert ngo == ngg, (kt, knp, hi)
         for x, y in zip(io, ig):
             assert np.array_equal(x, y), (kt, knp, hi)
@@ -1365,3 +1367,35 @@ def test_hash_aggregates_large_batches_through_the_partitioned_groupby(gpu, orac
                         assert np.allclose(a.values, b.values, rtol=1e-9, atol=1e-6), (fn, t, ng, vnp)
                     else:
                         assert a.same(b), (fn, t, ng, vnp, mode)
+
+
+@pytest.mark.parametrize("knob", ["AMDARROW_GROUPBY_NO_BINS", "AMDARROW_GROUPBY_OLD_AGG", "AMDARROW_GROUPBY_OLD_LOCAL",
+                                  "AMDARROW_GROUPBY_OLD_MERGE", "AMDARROW_GROUPER_HASHED_LOOKUP", "AMDARROW_GROUPER_GENERAL",
+                                  "AMDARROW_HASH_ATOMICS", "AMDARROW_FILTER_EDGE_ATOMICS"])
+def test_round1_kernels_behind_the_knobs_still_agree(gpu, oracle, knob, monkeypatch):
+    """The kernels the round-2 ones replaced stay in the library (unaligned slices, other shapes, fallbacks); each
+    knob forces one of them onto an input the new kernel would take."""
+    monkeypatch.setenv(knob, "1")
+    rng = np.random.default_rng(0x0ff1ce + 400)
+    n = 500_000
+    if "FILTER" in knob:
+        v, m = R(rng, INT64, n, 0.05, 0), R(rng, BOOL, n, 0.02, 0)
+        for ns in (DROP, EMIT_NULL):
+            assert oracle.filter(v, m, ns).same(gpu.filter(v, m, ns))
+        return
+    if "GROUPER" in knob:
+        b = [[R(rng, INT32, n, 0.01, 0, lo=-5000, hi=5000)], [R(rng, INT32, 10_000, 0.0, 0, lo=-9000, hi=9000)]]
+        io, ngo, _ = oracle.group_ids(b)
+        ig, ngg, _ = gpu.group_ids(b)
+        assert ngo == ngg and all(np.array_equal(x, y) for x, y in zip(io, ig))
+        return
+    if "HASH" in knob:
+        v, ids = R(rng, INT64, n, 0.1, 0), rng.integers(0, 3000, n).astype(np.uint32)
+        for fn in ("sum", "count", "mean"):
+            a, b = oracle.hash_aggregate(fn, v, ids, 3000, 0), gpu.hash_aggregate(fn, v, ids, 3000, 0)
+            assert (np.allclose(a.values, b.values, rtol=1e-9) if a.values.dtype == np.float64 else a.same(b)), fn
+        return
+    for hi in (400, 200_000):  # few groups per row range (local path), many (partition path); two calls: the second is hinted
+        v, k, m = R(rng, INT64, n, 0.02, 0), R(rng, INT32, n, 0.0, 0, lo=0, hi=hi), R(rng, BOOL, n, 0.0, 0)
+        for _ in range(2):
+            _check_groupby(oracle, gpu, v, k, m, (knob, hi))
