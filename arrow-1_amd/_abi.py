@@ -101,6 +101,7 @@ SYMBOLS = {
     "amdarrow_filter_groupby_multi": (C.c_int, [_P, _A, _P, C.c_int, _A, C.c_int64, _P, _P, _P, _P, C.POINTER(C.c_int64), _P,
                                                 C.POINTER(C.c_int64)]),
     "amdarrow_filter_groupby": (C.c_int, [_P, _A, _A, _A, C.c_int64, _P, _P, _P, _P, _P, C.POINTER(C.c_int64)]),
+    "amdarrow_groupby_last_path": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
 
 

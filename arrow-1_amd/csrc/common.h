@@ -46,7 +46,14 @@ struct amdarrow_ctx {
   int num_cus = 256;
   // groupby.hip: the shape of the last fused group-by call whose optimistic local pre-aggregation gave
   // up without finding heavy hitters -- the next call of that shape starts at the partition path
-  struct GroupByHint { int64_t n = -1; int key_type = 0, value_type = 0, has_mask = 0, has_value_validity = 0, uses = 0; } gb_hint;
+  struct GroupByHint {
+    int64_t n = -1; int key_type = 0, value_type = 0, has_mask = 0, has_value_validity = 0, uses = 0;
+    // what the call that set the hint saw (bin scatter only; `stats` = the three below are meaningful): smallest /
+    // largest selected key in the scatter's unsigned key order plus the call's key bias, and whether every
+    // selected valid value of an integer column was an int32 -- what a compact-record call assumes and checks
+    int stats = 0, values_narrow = 0; uint64_t key_lo = 1, key_hi = 0;
+  } gb_hint;
+  int gb_last_path = -1, gb_last_words = 0;  // amdarrow_groupby_last_path
   void* pack_buf = nullptr;  // groupby.hip amdarrow_filter_groupby_multi: packed key codes (grow-only)
   size_t pack_cap = 0;
   void* side_buf = nullptr;  // groupby.hip amdarrow_hash_accumulate: the inner group-by's per-group outputs (grow-only)

@@ -230,12 +230,54 @@ __global__ __launch_bounds__(kThreads) void k_word_prefix(const unsigned long lo
       for (int i = 0; i < 6; ++i) host_status[i] = status[i];
       host_status[6] = static_cast<unsigned int>(total);
       host_status[7] = static_cast<unsigned int>(static_cast<unsigned long long>(total) >> 32);
+      for (int i = 8; i < 12; ++i) host_status[i] = status[i];
     }
   }
   __shared__ uint32_t s_wave[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t base = int64_t(blockIdx.x) * 1024;
   uint32_t carry = static_cast<uint32_t>(block_offsets[blockIdx.x]);
+  for (int k = 0; k < 4; ++k) {
+    const int64_t w = base + k * kThreads + threadIdx.x;
+    const uint32_t pc = w < nwords ? __popcll(bitmap[w]) : 0;
+    const uint32_t incl = WaveInclusiveScan(pc);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+    for (int j = 0; j < 4; ++j) { if (j < wave) woff += s_wave[j]; total += s_wave[j]; }
+    if (w < nwords) prefix[w] = carry + woff + incl - pc;
+    carry += total;
+    __syncthreads();
+  }
+}
+
+// k_word_prefix without the scan launch in front: a block adds up the counts of the blocks before it itself (at
+// most kFusedScanBlocks of them, 16 KB out of the L2 -- cheaper than one more dependent launch); the last block
+// knows the total and mirrors the status words.
+constexpr int64_t kFusedScanBlocks = 4096;
+__global__ __launch_bounds__(kThreads) void k_word_prefix_scan(const unsigned long long* bitmap, int64_t nwords,
+                                                               const uint32_t* block_counts, uint32_t* prefix,
+                                                               unsigned int* status, unsigned int* host_status) {
+  __shared__ uint32_t s_wave[4];
+  __shared__ uint32_t s_before[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t mine = 0;
+  for (int b = threadIdx.x; b < static_cast<int>(blockIdx.x); b += kThreads) mine += block_counts[b];
+  mine = static_cast<uint32_t>(WaveReduceSum64(mine));
+  if (lane == 0) s_before[wave] = mine;
+  __syncthreads();
+  uint32_t carry = s_before[0] + s_before[1] + s_before[2] + s_before[3];
+  if (status && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    const long long total = static_cast<long long>(carry) + block_counts[blockIdx.x];
+    *reinterpret_cast<long long*>(status + 6) = total;
+    if (host_status) {
+      for (int i = 0; i < 6; ++i) host_status[i] = status[i];
+      host_status[6] = static_cast<unsigned int>(total);
+      host_status[7] = static_cast<unsigned int>(static_cast<unsigned long long>(total) >> 32);
+      for (int i = 8; i < 12; ++i) host_status[i] = status[i];
+    }
+  }
+  const int64_t base = int64_t(blockIdx.x) * 1024;
   for (int k = 0; k < 4; ++k) {
     const int64_t w = base + k * kThreads + threadIdx.x;
     const uint32_t pc = w < nwords ? __popcll(bitmap[w]) : 0;
@@ -264,27 +306,52 @@ struct EmitArgs {
 };
 __global__ __launch_bounds__(kThreads) void k_emit_groups(EmitArgs a) {
   if (a.skip_if && *a.skip_if) return;
-  for (int64_t s = int64_t(blockIdx.x) * kThreads + threadIdx.x; s < a.nslots; s += int64_t(gridDim.x) * kThreads) {
-    const uint32_t fr = a.t.first[s];
-    if (fr == kNoRow) continue;
-    if (a.only_unassigned && a.t.ids[s] != kNoRow) continue;
-    const uint64_t word = a.bitmap[fr >> 6];
-    const uint32_t id = a.id_base + a.prefix[fr >> 6] + __popcll(word & ((1ull << (fr & 63)) - 1));
-    if (a.t.ids) { a.t.ids[s] = id; a.t.first[s] = kNoRow; }
-    if (static_cast<int64_t>(id) >= a.capacity) continue;
-    const uint64_t T = a.t.mask + 1;
-    uint64_t x;
-    if (static_cast<uint64_t>(s) == T) { x = 0; *a.wide_null_id = id; }
-    else if (static_cast<uint64_t>(s) == T + 1) x = Fmix64Inv(kEmpty);
-    else x = Fmix64Inv(a.t.hkeys[s]);
-    if (a.packed) {
-      a.packed[id] = make_ulonglong4(x, a.t.sums[s], a.t.counts[s], fr);
-      continue;
+  // Four slots per thread and trip, every stage's loads issued together: one slot at a time is a chain of three
+  // dependent memory round trips per trip (first row -> bitmap word / prefix -> store), 29 us for 2 M slots.
+  constexpr int U = 4;
+  const int64_t stride = int64_t(gridDim.x) * kThreads;
+  const uint64_t T = a.t.mask + 1;
+  for (int64_t s0 = int64_t(blockIdx.x) * kThreads + threadIdx.x; s0 < a.nslots; s0 += U * stride) {
+    uint32_t fr[U], pre[U];
+    uint64_t hk[U], sum[U], cnt[U], word[U];
+    bool live[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t s = s0 + u * stride;
+      const int64_t sc = s < a.nslots ? s : a.nslots - 1;
+      fr[u] = a.t.first[sc];
+      hk[u] = a.t.hkeys[sc];
+      sum[u] = 0; cnt[u] = 0;
+      if (a.packed || a.sums || a.counts) { sum[u] = a.t.sums[sc]; cnt[u] = a.t.counts[sc]; }  // (uniform)
+      live[u] = s < a.nslots && fr[u] != kNoRow;
+      if (live[u] && a.only_unassigned && a.t.ids[sc] != kNoRow) live[u] = false;
     }
-    a.gx[id] = x;
-    if (a.sums) a.sums[id] = a.t.sums[s];
-    if (a.counts) a.counts[id] = static_cast<long long>(a.t.counts[s]);
-    if (a.first_rows) a.first_rows[id] = fr;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t w = live[u] ? fr[u] >> 6 : 0u;
+      word[u] = a.bitmap[w];
+      pre[u] = a.prefix[w];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!live[u]) continue;
+      const int64_t s = s0 + u * stride;
+      const uint32_t id = a.id_base + pre[u] + __popcll(word[u] & ((1ull << (fr[u] & 63)) - 1));
+      if (a.t.ids) { a.t.ids[s] = id; a.t.first[s] = kNoRow; }
+      if (static_cast<int64_t>(id) >= a.capacity) continue;
+      uint64_t x;
+      if (static_cast<uint64_t>(s) == T) { x = 0; *a.wide_null_id = id; }
+      else if (static_cast<uint64_t>(s) == T + 1) x = Fmix64Inv(kEmpty);
+      else x = Fmix64Inv(hk[u]);
+      if (a.packed) {
+        a.packed[id] = make_ulonglong4(x, sum[u], cnt[u], fr[u]);
+        continue;
+      }
+      a.gx[id] = x;
+      if (a.sums) a.sums[id] = sum[u];
+      if (a.counts) a.counts[id] = static_cast<long long>(cnt[u]);
+      if (a.first_rows) a.first_rows[id] = fr[u];
+    }
   }
 }
 
@@ -532,7 +599,7 @@ static RankMem BindRank(char* base, const size_t off[4], int64_t n_rows) {
   return r;
 }
 // Wait for the status words queued by RankFirstRows(status_dev != nullptr).
-static int AwaitStatus(amdarrow_ctx* ctx, unsigned int (&status)[8]) {
+static int AwaitStatus(amdarrow_ctx* ctx, unsigned int (&status)[12]) {
   AA_HIP(hipEventSynchronize(ctx->status_event));
   memcpy(status, static_cast<const char*>(ctx->pinned) + kStatusOffset, sizeof(status));
   return AMDARROW_OK;
@@ -542,9 +609,9 @@ static int AwaitStatus(amdarrow_ctx* ctx, unsigned int (&status)[8]) {
 // the kernel that built the table; 2 = bitmap already cleared, mark here unless status[1] is
 // set on the device (then the partition path built the table and marked on the way); 3 = bitmap
 // already cleared, mark here.
-// `status_dev` (optional): 8 device words {overflow, local-abort, null count x2, wide-null id, -,
-// total lo, total hi}; k_word_prefix stores the total there and mirrors the words into mapped
-// host memory.  With status_dev the caller collects them with AwaitStatus (after queueing
+// `status_dev` (optional): 12 device words {overflow, local-abort, null count x2, wide-null id, -,
+// total lo, total hi, smallest / largest selected key (bin scatter), a value wider than 32 bits was seen, -};
+// k_word_prefix stores the total there and mirrors the words into mapped host memory.  With status_dev the caller collects them with AwaitStatus (after queueing
 // whatever else does not need them on the host).
 struct HotInject { HotMem hot; int nwg, k_bits, acc_double; };  // heavy hitters to add while marking (mode 2)
 static int RankFirstRows(amdarrow_ctx* ctx, const GroupTable& t, int only_unassigned, const RankMem& r, int64_t* total,
@@ -560,6 +627,14 @@ static int RankFirstRows(amdarrow_ctx* ctx, const GroupTable& t, int only_unassi
   hipLaunchKernelGGL(k_popc_blocks, dim3(static_cast<unsigned>(r.nblocks)), dim3(kThreads), 0, ctx->stream, r.bitmap,
                      r.nwords, r.block_counts);
   AA_HIP(hipGetLastError());
+  if (status_dev && r.nblocks <= kFusedScanBlocks && !getenv("AMDARROW_GROUPBY_SCAN_LAUNCH")) {
+    hipLaunchKernelGGL(k_word_prefix_scan, dim3(static_cast<unsigned>(r.nblocks)), dim3(kThreads), 0, ctx->stream, r.bitmap,
+                       r.nwords, r.block_counts, r.prefix, status_dev,
+                       reinterpret_cast<unsigned int*>(static_cast<char*>(ctx->pinned_dev) + kStatusOffset));
+    AA_HIP(hipGetLastError());
+    AA_HIP(hipEventRecord(ctx->status_event, ctx->stream));
+    return AMDARROW_OK;
+  }
   AA_TRY(LaunchScanU32(ctx, r.block_counts, r.nblocks, r.block_offsets));
   hipLaunchKernelGGL(k_word_prefix, dim3(static_cast<unsigned>(r.nblocks)), dim3(kThreads), 0, ctx->stream, r.bitmap,
                      r.nwords, r.block_offsets, r.prefix, status_dev,
@@ -615,6 +690,11 @@ struct FastArgs {
   // bin scatter only: keys are compared / partitioned as k ^ k_flip (0x80000000 for signed keys: value order as
   // unsigned order); the smallest / largest selected key lands in key_minmax[0 / 1] (atomicMin / atomicMax)
   uint32_t k_flip; unsigned int* key_minmax;
+  // bin scatter: optional device word set when a selected, valid INTEGER value does not fit 32 bits (what a later
+  // call of the same shape needs to know before it may carry the values as 32-bit words, see the compact records)
+  unsigned int* val_wide;
+  // compact records only: (key ^ k_flip) >> kPBits - c_base is the record's 12-bit slot offset
+  uint32_t c_base;
 };
 __device__ __forceinline__ uint32_t PartOf(uint32_t h, int sub_bits) { return (h << sub_bits) >> (32 - kPBits); }
 __device__ __forceinline__ bool InSub(uint32_t h, int sub_bits, uint32_t sub_id) {
@@ -1429,7 +1509,7 @@ template <bool MASK, bool VVALID, int R, bool K64>
 __device__ __forceinline__ void BinStageTile(BinShared& sh, const FastArgs& a, const BinTile<R, K64>& t, int64_t tile0, int64_t hi,
                                              int tid, int64_t cap, uint4* __restrict__ regions,
                                              uint32_t* __restrict__ counts, unsigned int* overflow, uint32_t& kmin,
-                                             uint32_t& kmax) {
+                                             uint32_t& kmax, uint32_t& vwide) {
   const int64_t r0 = tile0 + int64_t(tid) * R;
   const int64_t left = hi - r0;
   const uint32_t live = left >= R ? (1u << R) - 1u : (left > 0 ? (1u << left) - 1u : 0u);
@@ -1457,6 +1537,7 @@ __device__ __forceinline__ void BinStageTile(BinShared& sh, const FastArgs& a, c
     if (!sel[j]) continue;
     const bool vvalid = a.has_values && ((vbits >> j) & 1u);
     const uint64_t v = vvalid ? t.v(j) : 0;
+    if (a.val_wide) vwide |= static_cast<uint32_t>((v + 0x80000000ull) >> 32);  // (uniform branch; non-zero: not an int32)
     uint4 q;
     q.x = t.key.k(j, a.k_bias);
     q.y = static_cast<uint32_t>(r0 + j) | (vvalid ? kRecValValid : 0u);
@@ -1508,11 +1589,130 @@ __device__ __forceinline__ void BinFlush(BinShared& sh, int tid, int64_t cap, ui
   }
 }
 
-// The tile loop of one workgroup over its row range, R rows per thread and tile.
-template <bool MASK, bool VVALID, int R, bool K64>
-__device__ __forceinline__ void BinRun(BinShared& sh, const FastArgs& a, int64_t lo, int64_t hi, int64_t cap,
+// ---- compact records ------------------------------------------------------------------------------------
+// The 16-byte record {key, row, value} is what bounds the partitioned group-by: every selected row's record is
+// written once and read once (0.8 GB each way next to the 1.2 GB input at 50 % selectivity).  When the selected
+// keys span a small range -- the case in which the aggregate indexes its LDS table directly -- a record needs
+// only 12 key bits (its slot offset (key >> 9) - c_base; the partition supplies the low 9 bits), and with every
+// workgroup writing its own regions only the row's offset inside the workgroup's row range (19 bits):
+//     word 0 = row offset << 13 | value valid << 12 | slot offset,  then the value: 64 bits (RW = 3 words per
+//     record) or, when every selected value of an integer column is an int32, 32 bits (RW = 2).
+// Whether a call qualifies is known only after a pass over its keys and values, so the context's hint (the
+// last call of this shape went the partition way without heavy hitters) also carries that call's key range
+// and whether its values were narrow; a hinted call scatters compact records and CHECKS every selected row
+// against both assumptions -- a row that breaks one raises kOverflowCompact, and the call starts over on the
+// 16-byte path like any hinted call whose assumption failed.
+// A partition's records form a stream of 32-bit words: the bin holds up to 64 of them, whole 128-byte lines
+// (32 words, records may straddle them) leave at a flush and the words behind them move to the bin's front.
+// A record that does not fit the bin goes to the spill list as a 16-byte record, as in the 16-byte scatter.
+constexpr unsigned int kOverflowCompact = 4;  // a selected row did not fit the compact record of a hinted call
+constexpr int kCBinWords = 64;
+constexpr int kCBinStride = kCBinWords + 4;  // consecutive bins start four banks apart
+constexpr int kCRowBits = 19, kCSlotBits = 12;
+constexpr uint32_t kCValid = 1u << kCSlotBits;
+struct CBinShared {
+  unsigned int cnt[kP];  // low half: words in the bin (runs past kCBinWords while a tile is ranked: the excess was spilled); high half: words at the tile's start
+  uint32_t cur[kP];      // 16-byte units of this workgroup's region already written (a multiple of 8)
+  __attribute__((aligned(16))) uint32_t bin[kP * kCBinStride];
+};
+template <bool MASK, bool VVALID, int R, bool K64, int RW>
+__device__ __forceinline__ void CBinStageTile(CBinShared& sh, const FastArgs& a, const BinTile<R, K64>& t, int64_t lo, int64_t tile0,
+                                              int64_t hi, int tid, int64_t cap, uint4* __restrict__ regions,
+                                              uint32_t* __restrict__ counts, unsigned int* overflow, uint32_t& kmin,
+                                              uint32_t& kmax, uint32_t& vwide, uint32_t& bad) {
+  const int64_t r0 = tile0 + int64_t(tid) * R;
+  const int64_t left = hi - r0;
+  const uint32_t live = left >= R ? (1u << R) - 1u : (left > 0 ? (1u << left) - 1u : 0u);
+  const int64_t rb = left > 0 ? r0 : hi - 1;
+  const uint32_t mbits = MASK ? (FewBits<R>(t.m0, t.m1, a.m_off + rb) & live) : live;
+  const uint32_t vbits = VVALID ? FewBits<R>(t.v0, t.v1, a.v.off + rb) : live;
+  uint32_t part[R], at[R], off[R];
+  bool sel[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const uint32_t kk = t.key.k(j, a.k_bias) ^ a.k_flip;
+    sel[j] = (mbits >> j) & 1u;
+    part[j] = BinPartOf(kk);
+    off[j] = (kk >> kPBits) - a.c_base;
+    at[j] = 0;
+    if (sel[j]) {
+      at[j] = atomicAdd(&sh.cnt[part[j]], static_cast<unsigned int>(RW)) & 0xFFFFu;
+      kmin = kk < kmin ? kk : kmin;
+      kmax = kk > kmax ? kk : kmax;
+      bad |= off[j] >> kCSlotBits;  // (a key below c_base wraps around to a large offset)
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    if (!sel[j]) continue;
+    const bool vvalid = a.has_values && ((vbits >> j) & 1u);
+    const uint64_t v = vvalid ? t.v(j) : 0;
+    if (RW == 2) bad |= static_cast<uint32_t>((v + 0x80000000ull) >> 32);
+    else if (a.val_wide) vwide |= static_cast<uint32_t>((v + 0x80000000ull) >> 32);  // (could the next call carry 32-bit values?)
+    if (at[j] + RW <= static_cast<uint32_t>(kCBinWords)) {
+      uint32_t* w = &sh.bin[part[j] * kCBinStride + at[j]];
+      w[0] = static_cast<uint32_t>(r0 + j - lo) << (kCSlotBits + 1) | (vvalid ? kCValid : 0u) | (off[j] & (kCValid - 1u));
+      w[1] = static_cast<uint32_t>(v);
+      if (RW == 3) w[2] = static_cast<uint32_t>(v >> 32);
+    } else {  // the bin is full until the next flush: the spill list takes the row as a 16-byte record
+      uint4 q;
+      q.x = t.key.k(j, a.k_bias);
+      q.y = static_cast<uint32_t>(r0 + j) | (vvalid ? kRecValValid : 0u);
+      q.z = static_cast<uint32_t>(v); q.w = static_cast<uint32_t>(v >> 32);
+      const uint32_t s = atomicAdd(&counts[int64_t(part[j]) * (a.nblocks + 1) + a.nblocks], 1u);
+      if (s < cap) regions[(int64_t(a.nblocks) * kP + part[j]) * cap + s] = q;
+      else __hip_atomic_store(overflow, kOverflowRegion, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+// Eight lanes per partition: the stream's whole 128-byte lines leave, the words behind them move to the front.
+template <int RW>
+__device__ __forceinline__ void CBinFlush(CBinShared& sh, int tid, int64_t cap, uint4* __restrict__ my_regions,
+                                          unsigned int* overflow) {
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+  const uint32_t ll = tid & 7;
+#pragma unroll
+  for (int round = 0; round < kP / (kBThreads / 8); ++round) {
+    const uint32_t p = (tid / 8) + round * (kBThreads / 8);
+    const uint32_t raw = sh.cnt[p];
+    const uint32_t start = raw >> 16, fill = raw & 0xFFFFu;
+    // (arrivals were accepted while their last word still fitted)
+    const uint32_t end = fill <= static_cast<uint32_t>(kCBinWords) ? fill : start + ((kCBinWords - start) / RW) * RW;
+    const uint32_t nl = end >> 5, left = end & 31u;
+    const uint32_t cur = sh.cur[p];
+    const bool ok = cur + 8 * nl <= cap;
+    uint4* dst = my_regions + int64_t(p) * cap + cur + ll;
+    const uint32_t* bin = &sh.bin[p * kCBinStride];
+#pragma unroll
+    for (uint32_t l = 0; l < 2; ++l) {
+      if (l < nl && ok) {
+        const uint4 q = *reinterpret_cast<const uint4*>(&bin[32 * l + 4 * ll]);
+        const u32x4 v = {q.x, q.y, q.z, q.w};
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + 8 * l));
+      }
+    }
+    const bool move = nl > 0 && 4 * ll < left;  // (nl == 1 here: two whole lines leave nothing behind)
+    uint4 keep;
+    if (move) keep = *reinterpret_cast<const uint4*>(&bin[32 + 4 * ll]);
+    if (move) *reinterpret_cast<uint4*>(&sh.bin[p * kCBinStride + 4 * ll]) = keep;  // (LDS operations of one wave execute in order)
+    if (ll == 0) {
+      const uint32_t rest = nl > 0 ? left : end;
+      sh.cnt[p] = rest << 16 | rest;
+      if (nl > 0) {
+        if (ok) sh.cur[p] = cur + 8 * nl;
+        else __hip_atomic_store(overflow, kOverflowRegion, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
+// The tile loop of one workgroup over its row range, R rows per thread and tile.  RW = 0: 16-byte records
+// (BinShared); RW = 2 / 3: compact records of RW words (CBinShared).
+template <bool MASK, bool VVALID, int R, bool K64, int RW = 0, class SH = BinShared>
+__device__ __forceinline__ void BinRun(SH& sh, const FastArgs& a, int64_t lo, int64_t hi, int64_t cap,
                                        uint4* __restrict__ regions, uint4* __restrict__ my_regions,
-                                       uint32_t* __restrict__ counts, unsigned int* overflow, uint32_t& kmin, uint32_t& kmax) {
+                                       uint32_t* __restrict__ counts, unsigned int* overflow, uint32_t& kmin, uint32_t& kmax,
+                                       uint32_t& vwide, uint32_t& bad) {
   constexpr int kRows = kBThreads * R;
   const int tid = threadIdx.x;
   const void* keys = static_cast<const char*>(a.k_data) + a.k_off * (K64 ? 8 : 4);
@@ -1529,10 +1729,12 @@ __device__ __forceinline__ void BinRun(BinShared& sh, const FastArgs& a, int64_t
   // the compiler can count (a conditional load makes it wait for everything).
 #define AA_BIN_STEP(CUR, NEXT, TILE0)                                                                  \
   do {                                                                                                   \
-    BinStageTile<MASK, VVALID, R, K64>(sh, a, CUR, (TILE0), hi, tid, cap, regions, counts, overflow, kmin, kmax); \
+    if constexpr (RW == 0) BinStageTile<MASK, VVALID, R, K64>(sh, a, CUR, (TILE0), hi, tid, cap, regions, counts, overflow, kmin, kmax, vwide); \
+    else CBinStageTile<MASK, VVALID, R, K64, RW>(sh, a, CUR, lo, (TILE0), hi, tid, cap, regions, counts, overflow, kmin, kmax, vwide, bad); \
     LdsBarrier();                                                                                        \
     AA_TOUCH(NEXT);                                                                                      \
-    BinFlush(sh, tid, cap, my_regions, overflow);                                                        \
+    if constexpr (RW == 0) BinFlush(sh, tid, cap, my_regions, overflow);                                 \
+    else CBinFlush<RW>(sh, tid, cap, my_regions, overflow);                                              \
     BinLoadTile<MASK, VVALID, R, K64>(a, keys, vals, (TILE0) + 3 * kRows <= last_whole ? (TILE0) + 3 * kRows : last_whole, tid, CUR); \
     LdsBarrier();                                                                                        \
   } while (0)
@@ -1561,9 +1763,11 @@ __device__ __forceinline__ void BinRun(BinShared& sh, const FastArgs& a, int64_t
   }
   if (tile0 < hi) {  // the partial tile at the end of the input
     BinLoadTail<MASK, VVALID, R, K64>(a, keys, vals, tile0, hi, tid, t0);
-    BinStageTile<MASK, VVALID, R, K64>(sh, a, t0, tile0, hi, tid, cap, regions, counts, overflow, kmin, kmax);
+    if constexpr (RW == 0) BinStageTile<MASK, VVALID, R, K64>(sh, a, t0, tile0, hi, tid, cap, regions, counts, overflow, kmin, kmax, vwide);
+    else CBinStageTile<MASK, VVALID, R, K64, RW>(sh, a, t0, lo, tile0, hi, tid, cap, regions, counts, overflow, kmin, kmax, vwide, bad);
     LdsBarrier();
-    BinFlush(sh, tid, cap, my_regions, overflow);
+    if constexpr (RW == 0) BinFlush(sh, tid, cap, my_regions, overflow);
+    else CBinFlush<RW>(sh, tid, cap, my_regions, overflow);
   }
 #undef AA_BIN_STEP
 #undef AA_TOUCH
@@ -1603,9 +1807,10 @@ __global__ __launch_bounds__(kBThreads) void k_part_scatter_bins(FastArgs a, int
     __syncthreads();
     dense = 3 * int64_t(s_sample) > 2 * sample_rows;  // more than two thirds of the rows selected
   }
-  uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
-  if (dense) BinRun<MASK, VVALID, 2, K64>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow, kmin, kmax);
-  else BinRun<MASK, VVALID, 4, K64>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow, kmin, kmax);
+  uint32_t kmin = 0xFFFFFFFFu, kmax = 0, vwide = 0, bad = 0;
+  if (dense) BinRun<MASK, VVALID, 2, K64>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow, kmin, kmax, vwide, bad);
+  else BinRun<MASK, VVALID, 4, K64>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow, kmin, kmax, vwide, bad);
+  if (a.val_wide && __syncthreads_or(vwide != 0) && tid == 0) __hip_atomic_store(a.val_wide, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   {  // the range of the selected keys: wave, workgroup (LDS), device -- two device atomics per workgroup
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -1628,6 +1833,65 @@ __global__ __launch_bounds__(kBThreads) void k_part_scatter_bins(FastArgs a, int
       __hip_atomic_store(overflow, kOverflowRegion, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     counts[int64_t(tid) * (a.nblocks + 1) + blockIdx.x] = ok ? cur + left : 0;
+  }
+}
+
+// The bin scatter with compact records of RW words (see above).  counts[p][b] = RECORDS in the region of
+// workgroup b for partition p (RW words each, packed); the spill list (segment nblocks) holds 16-byte records.
+template <bool MASK, bool VVALID, bool K64, int RW>
+__global__ __launch_bounds__(kBThreads) void k_part_scatter_compact(FastArgs a, int64_t cap, uint4* regions, uint32_t* counts,
+                                                                    unsigned int* overflow) {
+  __shared__ CBinShared sh;
+  __shared__ unsigned int s_sample, s_kmin, s_kmax;
+  const int tid = threadIdx.x;
+  if (tid < kP) { sh.cnt[tid] = 0; sh.cur[tid] = 0; }
+  if (tid == 0) { s_sample = 0; s_kmin = 0xFFFFFFFFu; s_kmax = 0; }
+  __syncthreads();
+  const int64_t lo = int64_t(blockIdx.x) * a.rows_per_block;
+  const int64_t hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
+  uint4* const my_regions = regions + int64_t(blockIdx.x) * kP * cap;
+  bool dense = true;  // no mask: every row is selected
+  if (MASK) {
+    const int64_t sample_rows = hi - lo < 64 * kBinSampleWords ? hi - lo : 64 * kBinSampleWords;
+    if (tid < kBinSampleWords) {
+      const int64_t r = lo + 64 * int64_t(tid);
+      const int64_t left = lo + sample_rows - r;
+      if (left > 0) {
+        const uint64_t w = LoadBits64(a.m_data, a.m_off + r, left >= 64 ? 64 : static_cast<int>(left));
+        atomicAdd(&s_sample, static_cast<unsigned int>(__popcll(w)));
+      }
+    }
+    __syncthreads();
+    dense = 3 * int64_t(s_sample) > 2 * sample_rows;  // more than two thirds of the rows selected
+  }
+  uint32_t kmin = 0xFFFFFFFFu, kmax = 0, vwide = 0, bad = 0;
+  if (dense) BinRun<MASK, VVALID, 2, K64, RW, CBinShared>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow, kmin, kmax, vwide, bad);
+  else BinRun<MASK, VVALID, 4, K64, RW, CBinShared>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow, kmin, kmax, vwide, bad);
+  if (RW == 3 && a.val_wide && __syncthreads_or(vwide != 0) && tid == 0) __hip_atomic_store(a.val_wide, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // a selected row outside the hinted key range, or (RW == 2) a value that is not an int32: the call starts over
+  if (__syncthreads_or(bad != 0) && tid == 0) __hip_atomic_store(overflow, kOverflowCompact, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const uint32_t omin = __shfl_xor(kmin, d, 64), omax = __shfl_xor(kmax, d, 64);
+      kmin = omin < kmin ? omin : kmin;
+      kmax = omax > kmax ? omax : kmax;
+    }
+    if ((tid & 63) == 0 && kmin <= kmax) { atomicMin(&s_kmin, kmin); atomicMax(&s_kmax, kmax); }
+  }
+  __syncthreads();
+  if (tid == 0 && s_kmin <= s_kmax) { atomicMin(&a.key_minmax[0], s_kmin); atomicMax(&a.key_minmax[1], s_kmax); }
+  if (tid < kP) {
+    // what is left of every partition's stream (< 32 words after a flush), and the region fills
+    const uint32_t left = sh.cnt[tid] & 0xFFFFu, cur = sh.cur[tid];
+    const bool ok = 4 * cur + left <= 4 * cap;
+    if (ok) {
+      uint32_t* dst = reinterpret_cast<uint32_t*>(my_regions + int64_t(tid) * cap + cur);
+      for (uint32_t k = 0; k < left; ++k) dst[k] = sh.bin[tid * kCBinStride + k];
+    } else {
+      __hip_atomic_store(overflow, kOverflowRegion, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    counts[int64_t(tid) * (a.nblocks + 1) + blockIdx.x] = ok ? (4 * cur + left) / RW : 0;
   }
 }
 
@@ -2071,6 +2335,138 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_piped(const uin
     }
   }
   if (p == 0 && tid < 2 && total_slots > 0) {  // the two special slots behind the last slice stay empty on this path
+    const int64_t T = total_slots;
+    t.hkeys[T + tid] = kEmpty; t.first[T + tid] = kNoRow; t.sums[T + tid] = 0; t.counts[T + tid] = 0;
+  }
+}
+
+// ---- the partition aggregate over compact records (k_part_scatter_compact) ----------------------------------
+// Always the directly indexed table (the compact record IS a slot offset): no tags, 68 KB of LDS.  A wave walks
+// the regions of workgroups wave, wave + kWaves, ...; region b's rows start at b * rows_per_block.  RW = 2: a lane
+// loads 16 bytes = two records; RW = 3: one 12-byte record.  Three steps in flight as in k_part_aggregate_piped;
+// the spill list (16-byte records, a fraction of a per cent) is folded by all threads at the end.
+template <int RW> struct CUnit;
+template <> struct CUnit<2> { BinU32x4 w; };
+template <> struct CUnit<3> { __attribute__((ext_vector_type(3), aligned(4))) unsigned int w; };
+template <int RW>
+__global__ __launch_bounds__(kPartThreads) void k_part_aggregate_compact(const uint4* regions, const uint32_t* counts,
+                                                                         int nblocks, int64_t cap, int acc_double, GroupTable t,
+                                                                         unsigned long long* first_bitmap,
+                                                                         unsigned int* overflow, int64_t total_slots,
+                                                                         uint32_t c_base, uint32_t k_flip, uint32_t rows_per_block) {
+  __shared__ unsigned long long s_sum[kSlots];
+  __shared__ uint32_t s_first[kSlots];
+  __shared__ unsigned int s_cnt[kSlots];
+  __shared__ uint32_t s_fill[kMaxSegments];
+  if (__hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // the scatter gave up
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = blockIdx.x;
+  constexpr int kWaves = kPartThreads / 64;
+  constexpr int kUnitRecs = RW == 2 ? 2 : 1;                     // records per loaded unit
+  constexpr uint32_t kStepUnits = 64 * kPaUnroll;                // units per wave and step
+  const int nseg_all = nblocks + 1;
+  for (int b = tid; b < nseg_all; b += kPartThreads) {
+    const uint32_t c = counts[int64_t(p) * nseg_all + b];
+    const uint32_t most = static_cast<uint32_t>(b < nblocks ? (4 * cap) / RW : cap);
+    s_fill[b] = c > most ? most : c;  // (a region that overflowed; the attempt is abandoned anyway)
+  }
+  for (int s = tid; s < kSlots; s += kPartThreads) { s_sum[s] = 0; s_first[s] = kNoRow; s_cnt[s] = 0; }
+  __syncthreads();
+  auto fold_one = [&](uint32_t meta, uint32_t lo32, uint32_t hi32, uint32_t seg_lo) {
+    const uint32_t slot = DirectSlot(meta & (kCValid - 1u));
+    atomicMin(&s_first[slot], seg_lo + (meta >> (kCSlotBits + 1)));
+    if (meta & kCValid) {
+      const unsigned long long bits = RW == 2 ? static_cast<unsigned long long>(static_cast<long long>(static_cast<int>(lo32)))
+                                              : (static_cast<unsigned long long>(hi32) << 32) | lo32;
+      if (RW == 3 && acc_double) atomicAdd(reinterpret_cast<double*>(&s_sum[slot]), __longlong_as_double(bits));
+      else atomicAdd(&s_sum[slot], bits);
+      atomicAdd(&s_cnt[slot], 1u);
+    }
+  };
+  const int nseg = wave < nblocks ? (nblocks - wave + kWaves - 1) / kWaves : 0;  // this wave's regions: wave, wave + kWaves, ...
+  if (nseg > 0) {
+    const int64_t seg_stride = int64_t(kWaves) * kP * cap;
+    const uint4* seg0 = regions + (int64_t(wave) * kP + p) * cap;
+    struct It { int k; uint32_t i0, units, recs; };
+    auto advance = [&](It it) -> It {
+      it.i0 += kStepUnits;
+      if (it.i0 >= it.units) {
+        it.i0 = 0;
+        do {
+          ++it.k;
+          it.recs = it.k < nseg ? __builtin_amdgcn_readfirstlane(s_fill[wave + kWaves * it.k]) : 0u;
+          it.units = (it.recs + kUnitRecs - 1) / kUnitRecs;
+        } while (it.k < nseg && it.recs == 0);
+      }
+      return it;
+    };
+    auto load = [&](CUnit<RW> (&r)[kPaUnroll], const It& it) {
+      const bool in = it.k < nseg;
+      const uint32_t* base = reinterpret_cast<const uint32_t*>(seg0 + (in ? it.k : 0) * seg_stride);
+      const uint32_t units = in ? it.units : 0u, i0 = in ? it.i0 : 0u;
+      const uint32_t last = units ? units - 1 : 0;
+#pragma unroll
+      for (int u = 0; u < kPaUnroll; ++u) {
+        const uint32_t i = i0 + lane + 64 * u;
+        const uint32_t ii = i < units ? i : last;
+        r[u].w = __builtin_nontemporal_load(reinterpret_cast<const decltype(r[u].w)*>(base + (RW == 2 ? 4 : 3) * ii));
+      }
+    };
+    auto fold = [&](const CUnit<RW> (&r)[kPaUnroll], const It& it) {
+      if (it.k >= nseg) return;  // (wave-uniform)
+      const uint32_t seg_lo = static_cast<uint32_t>(wave + kWaves * it.k) * rows_per_block;
+#pragma unroll
+      for (int u = 0; u < kPaUnroll; ++u) {
+        const uint32_t i = it.i0 + lane + 64 * u;
+        if constexpr (RW == 2) {
+          if (2 * i < it.recs) fold_one(r[u].w.x, r[u].w.y, 0u, seg_lo);
+          if (2 * i + 1 < it.recs) fold_one(r[u].w.z, r[u].w.w, 0u, seg_lo);
+        } else {
+          if (i < it.recs) fold_one(r[u].w.x, r[u].w.y, r[u].w.z, seg_lo);
+        }
+      }
+    };
+    It i0{-1, 0, 0, 0};
+    i0 = advance(i0);
+    It i1 = advance(i0), i2 = advance(i1);
+    CUnit<RW> r0[kPaUnroll], r1[kPaUnroll], r2[kPaUnroll];
+    load(r0, i0); load(r1, i1); load(r2, i2);
+    while (i0.k < nseg) {  // three steps per trip, no exit inside (steps past the end fold nothing)
+      fold(r0, i0); i0 = advance(i2); load(r0, i0);
+      fold(r1, i1); i1 = advance(i0); load(r1, i1);
+      fold(r2, i2); i2 = advance(i1); load(r2, i2);
+    }
+  }
+  {  // the spill list: 16-byte records {key word, row | flags, value}
+    const uint4* sp = regions + (int64_t(nblocks) * kP + p) * cap;
+    const uint32_t n = s_fill[nblocks];
+    for (uint32_t i = tid; i < n; i += kPartThreads) {
+      const uint4 q = sp[i];
+      const uint32_t slot = DirectSlot((((q.x ^ k_flip) >> kPBits) - c_base) & (kCValid - 1u));
+      atomicMin(&s_first[slot], q.y & kRecRowMask);
+      if (q.y & kRecValValid) {
+        const unsigned long long bits = (static_cast<unsigned long long>(q.w) << 32) | q.z;
+        if (acc_double) atomicAdd(reinterpret_cast<double*>(&s_sum[slot]), __longlong_as_double(bits));
+        else atomicAdd(&s_sum[slot], bits);
+        atomicAdd(&s_cnt[slot], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  const int64_t g0 = int64_t(p) * kSlots;
+  for (int s = tid; s < kSlots; s += kPartThreads) {
+    const uint32_t fr = s_first[s];
+    // the key of (partition p, slot s): high part = slot offset + base, low part p XOR the high part's hashed bits (BinPartOf)
+    const uint32_t high = DirectSlot(static_cast<uint32_t>(s)) + c_base;
+    const uint32_t kk = (high << kPBits) | (static_cast<uint32_t>(p) ^ ((high * 0x9E3779B1u) >> (32 - kPBits)));
+    t.hkeys[g0 + s] = fr == kNoRow ? kEmpty : Fmix64(uint64_t(kk ^ k_flip));
+    t.first[g0 + s] = fr;
+    t.sums[g0 + s] = s_sum[s];
+    t.counts[g0 + s] = s_cnt[s];
+    if (fr != kNoRow) atomicOr(&first_bitmap[fr >> 6], 1ull << (fr & 63));
+  }
+  if (p == 0 && tid < 2) {  // the two special slots behind the table stay empty on this path
     const int64_t T = total_slots;
     t.hkeys[T + tid] = kEmpty; t.first[T + tid] = kNoRow; t.sums[T + tid] = 0; t.counts[T + tid] = 0;
   }
@@ -2580,6 +2976,7 @@ __global__ __launch_bounds__(kThreads) void k_prepare(unsigned long long* bitmap
     for (int p = threadIdx.x; p < kP; p += kThreads) spill_counts[int64_t(p) * spill_stride + spill_stride - 1] = 0;
   if (blockIdx.x == 0) {
     if (threadIdx.x < 8) status[threadIdx.x] = threadIdx.x == 4 ? kNoRow : 0u;
+    if (threadIdx.x >= 8 && threadIdx.x < 12 && !(key_minmax && threadIdx.x < 10)) status[threadIdx.x] = 0u;
     if (key_minmax && threadIdx.x < 2) key_minmax[threadIdx.x] = threadIdx.x == 0 ? 0xFFFFFFFFu : 0u;
     for (int i = threadIdx.x; i < nflags; i += kThreads) { wg_flags[i] = 0; if (hot_cand_n) hot_cand_n[i] = 0; }
   }
@@ -2912,10 +3309,10 @@ int amdarrow_grouper_num_groups(amdarrow_grouper* g, uint32_t* out) {
 static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, const amdarrow_array* keys,
                              const amdarrow_array* mask, int64_t group_capacity, void* out_sums, int64_t* out_counts,
                              void* out_keys, uint8_t* out_key_validity, uint32_t* out_first_rows,
-                             int64_t* out_num_groups, bool locked, ulonglong4** packed_out);
+                             int64_t* out_num_groups, bool locked, ulonglong4** packed_out, uint64_t* bias_out = nullptr);
 
-__global__ __launch_bounds__(kThreads) void k_gx_from_packed(const ulonglong4* packed, uint32_t G, unsigned long long* gx) {
-  for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < G; i += gridDim.x * kThreads) gx[i] = packed[i].x;
+__global__ __launch_bounds__(kThreads) void k_gx_from_packed(const ulonglong4* packed, uint32_t G, unsigned long long bias, unsigned long long* gx) {
+  for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < G; i += gridDim.x * kThreads) gx[i] = packed[i].x + bias;
 }
 
 // Ids of the rows of a batch whose distinct keys span a small range: a table id_of[key - min] (4 bytes per
@@ -2926,7 +3323,7 @@ __global__ __launch_bounds__(kThreads) void k_gx_minmax(const unsigned long long
   unsigned long long mn = ~0ull, mx = 0;
   for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < G; i += gridDim.x * kThreads) {
     const unsigned long long raw = gx[i];
-    if ((raw >> null_bit) & 1) continue;  // the null key has no value
+    if (null_bit < 64 && ((raw >> null_bit) & 1)) continue;  // the null key has no value
     const unsigned long long x = raw ^ flip;  // (signed keys: value order)
     mn = x < mn ? x : mn;
     mx = x > mx ? x : mx;
@@ -2951,7 +3348,7 @@ __global__ __launch_bounds__(kThreads) void k_dense_scatter(const unsigned long 
                                                             unsigned long long kmin, uint32_t* dense, uint32_t* null_id) {
   for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < G; i += gridDim.x * kThreads) {
     const unsigned long long x = gx[i];
-    if ((x >> null_bit) & 1) *null_id = i;
+    if (null_bit < 64 && ((x >> null_bit) & 1)) *null_id = i;
     else dense[(x ^ flip) - kmin] = i;
   }
 }
@@ -2983,10 +3380,10 @@ __global__ __launch_bounds__(kThreads) void k_lookup_dense(KeyCol c, int64_t n, 
 constexpr int64_t kDenseLookupMax = int64_t(1) << 23;  // keys of a range up to 8 M: a 32 MB table
 
 // Known keys keep their ids, new keys are flagged (in the batch's first-appearance order, which is the order of `packed`).
-__global__ __launch_bounds__(kThreads) void k_grouper_probe(const ulonglong4* packed, uint32_t G, GroupTable t, uint32_t* slot_of,
-                                                            uint32_t* is_new, unsigned int* full) {
+__global__ __launch_bounds__(kThreads) void k_grouper_probe(const ulonglong4* packed, uint32_t G, unsigned long long bias, GroupTable t,
+                                                            uint32_t* slot_of, uint32_t* is_new, unsigned int* full) {
   for (uint32_t j = blockIdx.x * kThreads + threadIdx.x; j < G; j += gridDim.x * kThreads) {
-    const int64_t idx = FindOrInsert(t, Fmix64(packed[j].x), true);  // (distinct keys: no two threads meet on a slot)
+    const int64_t idx = FindOrInsert(t, Fmix64(packed[j].x + bias), true);  // (distinct keys: no two threads meet on a slot)
     if (idx < 0) { *full = 1; slot_of[j] = 0; is_new[j] = 0; continue; }
     slot_of[j] = static_cast<uint32_t>(idx);
     is_new[j] = t.ids[idx] == kNoRow ? 1u : 0u;
@@ -2994,12 +3391,12 @@ __global__ __launch_bounds__(kThreads) void k_grouper_probe(const ulonglong4* pa
 }
 __global__ __launch_bounds__(kThreads) void k_grouper_commit(const ulonglong4* packed, uint32_t G, GroupTable t, const uint32_t* slot_of,
                                                              const uint32_t* is_new, const int64_t* new_before, uint32_t id_base,
-                                                             unsigned long long* gx) {
+                                                             unsigned long long bias, unsigned long long* gx) {
   for (uint32_t j = blockIdx.x * kThreads + threadIdx.x; j < G; j += gridDim.x * kThreads) {
     if (!is_new[j]) continue;
     const uint32_t id = id_base + static_cast<uint32_t>(new_before[j]);
     t.ids[slot_of[j]] = id;
-    gx[id] = packed[j].x;
+    gx[id] = packed[j].x + bias;
   }
 }
 
@@ -3015,8 +3412,9 @@ static int GrouperBatchGrouped(amdarrow_grouper* g, const amdarrow_array* keys, 
   const int64_t cap = std::min<int64_t>(n, int64_t(1) << 22);
   int64_t G = 0;
   ulonglong4* packed = nullptr;
+  uint64_t bias = 0;  // a 64-bit key column comes back range-compressed (key word + bias) or whole (bias 0)
   const int rc = FilterGroupByImpl(ctx, nullptr, &keys[0], nullptr, cap, nullptr, nullptr, nullptr, nullptr, nullptr, &G,
-                                   /*locked=*/true, &packed);
+                                   /*locked=*/true, &packed, &bias);
   if (rc == AMDARROW_CAPACITY_ERROR) return 1;
   if (rc != AMDARROW_OK) return rc;
   // room for every distinct key of the batch being new (the table stays under 50 % load)
@@ -3048,7 +3446,7 @@ static int GrouperBatchGrouped(amdarrow_grouper* g, const amdarrow_array* keys, 
   if (G > 0 && known == 0) {
     // an empty grouper: every key is new, ids in the order of `packed`
     hipLaunchKernelGGL(k_gx_from_packed, dim3(GridFor(G, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, packed,
-                       static_cast<uint32_t>(G), g->gx);
+                       static_cast<uint32_t>(G), bias, g->gx);
     hipLaunchKernelGGL(k_reinsert, dim3(GridFor(G, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, g->gx,
                        static_cast<uint32_t>(G), kNoRow, t);
     AA_HIP(hipGetLastError());
@@ -3074,11 +3472,11 @@ static int GrouperBatchGrouped(amdarrow_grouper* g, const amdarrow_array* keys, 
     auto* full = reinterpret_cast<unsigned int*>(sb + off_full);
     AA_HIP(hipMemsetAsync(full, 0, 4, ctx->stream));
     const int grid = GridFor(G, kThreads, ctx->num_cus * 8);
-    hipLaunchKernelGGL(k_grouper_probe, dim3(grid), dim3(kThreads), 0, ctx->stream, packed, static_cast<uint32_t>(G), t, slot_of, is_new, full);
+    hipLaunchKernelGGL(k_grouper_probe, dim3(grid), dim3(kThreads), 0, ctx->stream, packed, static_cast<uint32_t>(G), bias, t, slot_of, is_new, full);
     AA_HIP(hipGetLastError());
     AA_TRY(LaunchScanU32(ctx, is_new, G, new_before));
     hipLaunchKernelGGL(k_grouper_commit, dim3(grid), dim3(kThreads), 0, ctx->stream, packed, static_cast<uint32_t>(G), t, slot_of, is_new,
-                       new_before, static_cast<uint32_t>(known), g->gx);
+                       new_before, static_cast<uint32_t>(known), bias, g->gx);
     AA_HIP(hipGetLastError());
     long long added = 0;
     AA_TRY(ReadBack(ctx, new_before + G, 8, &added));
@@ -3104,7 +3502,8 @@ static int GrouperBatchGrouped(amdarrow_grouper* g, const amdarrow_array* keys, 
     unsigned long long mm[2];
     AA_TRY(ReadBack(ctx, minmax, 16, mm));
     const bool any = mm[0] <= mm[1];
-    const int64_t range = any ? static_cast<int64_t>(mm[1] - mm[0]) + 1 : 1;
+    const unsigned long long span = any ? mm[1] - mm[0] : 0;  // (unsigned: 64-bit keys may span more than 2^63)
+    const int64_t range = span < static_cast<unsigned long long>(kDenseLookupMax) ? static_cast<int64_t>(span) + 1 : kDenseLookupMax + 1;
     if (range <= kDenseLookupMax) {
       AA_TRY(Scratch(ctx, 256 + 4 * static_cast<size_t>(range), &base));
       minmax = static_cast<unsigned long long*>(base);
@@ -3148,7 +3547,9 @@ int amdarrow_grouper_consume(amdarrow_grouper* g, const amdarrow_array* keys, ui
   KeySpec ks;
   AA_TRY(MakeKeySpec(g->nkeys, keys, nullptr, &ks));
   std::lock_guard<std::mutex> lock(ctx->mu);
-  if (g->nkeys == 1 && ks.total_bits <= 32 && n >= (int64_t(1) << 18) && n < (int64_t(1) << 30) && !getenv("AMDARROW_GROUPER_GENERAL")) {
+  // (one key column of at most 32 bits, or of 64 bits without nulls: a null 64-bit key lives in the table's special slot)
+  if (g->nkeys == 1 && (ks.total_bits <= 32 || (ks.total_bits == 64 && !MayHaveNulls(&keys[0]))) && n >= (int64_t(1) << 18) &&
+      n < (int64_t(1) << 30) && !getenv("AMDARROW_GROUPER_GENERAL")) {
     const int rc = GrouperBatchGrouped(g, keys, ks, out_ids);
     if (rc != 1) return rc;
   }
@@ -3418,7 +3819,7 @@ int amdarrow_hash_aggregate(amdarrow_ctx* ctx, int func, const amdarrow_array* v
 static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, const amdarrow_array* keys,
                              const amdarrow_array* mask, int64_t group_capacity, void* out_sums, int64_t* out_counts,
                              void* out_keys, uint8_t* out_key_validity, uint32_t* out_first_rows,
-                             int64_t* out_num_groups, bool locked, ulonglong4** packed_out) {
+                             int64_t* out_num_groups, bool locked, ulonglong4** packed_out, uint64_t* bias_out) {
   const int64_t n = keys->length;
   *out_num_groups = 0;
   if (values && values->length != n) return SetError(AMDARROW_INVALID, "Array arguments must all be the same length");
@@ -3482,6 +3883,11 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
       !getenv("AMDARROW_GROUPBY_PATH") && !getenv("AMDARROW_GROUPBY_NO_HINT")) {
     if (++hint.uses % 16 != 0) { path = 2; hinted = true; }
   }
+  // Compact records (k_part_scatter_compact): a hinted call whose predecessor's selected keys spanned few enough
+  // values carries 12-byte records, 8-byte ones if that call's (integer) values were all int32; the kernel checks
+  // both for every selected row and a miss starts the call over without the hint.
+  int compact_rw = 0;
+  uint32_t c_base = 0;
   const bool headline_shape = ks.total_bits == 32 && k_load_bits == 32 && !keys->validity && values &&
                               BitWidth(values->type_id) == 64 && !m_valid;
   // the bin scatter loads 16-byte vectors: keys and values must start on a 16-byte boundary
@@ -3494,13 +3900,26 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
                         (reinterpret_cast<uintptr_t>(keys->values) + (k_load_bits / 8) * static_cast<uintptr_t>(keys->offset)) % 16 == 0 &&
                         (values ? (reinterpret_cast<uintptr_t>(values->values) + 8 * static_cast<uintptr_t>(values->offset)) % 16 == 0
                                 : reinterpret_cast<uintptr_t>(keys->values) % 16 == 0);
+  if (hinted && use_bins && hint.stats && hint.key_lo <= hint.key_hi && hint.key_lo >= k_bias &&
+      hint.key_hi - k_bias <= 0xFFFFFFFFull && !getenv("AMDARROW_GROUPBY_NO_COMPACT")) {
+    const uint32_t first = static_cast<uint32_t>(hint.key_lo - k_bias) >> kPBits;
+    const uint32_t span = (static_cast<uint32_t>(hint.key_hi - k_bias) >> kPBits) - first + 1;
+    if (span <= (1u << kCSlotBits)) {
+      const uint32_t slack = ((1u << kCSlotBits) - span) / 2;  // the window is centred on the range seen last time
+      c_base = first > slack ? first - slack : 0;
+      compact_rw = values && !IsFloat(values->type_id) && hint.values_narrow ? 2 : 3;
+      if (const char* env = getenv("AMDARROW_GROUPBY_COMPACT_WORDS")) compact_rw = atoi(env) == 2 && compact_rw == 2 ? 2 : 3;
+    }
+  }
   GroupTable t{};
   RankMem r{};
   unsigned long long* gx = nullptr;
   unsigned int* misc = nullptr;  // status words, see RankFirstRows; [64..] one flag per workgroup of the local path
   constexpr int kMaxFlags = 1024;
   int sub_bits = 0;  // 2 after a partition's LDS table overflowed: four sub-problems, up to ~7 M groups
+  bool fa_val_wide = false;  // the last attempt's scatter reported whether the values were all int32 (status[10])
   for (;; --path) {
+    fa_val_wide = false;
     const bool fast = path > 0;
     const int nsub = (fast && path == 2) ? 1 << sub_bits : 1;
     const uint64_t T = fast ? uint64_t(nsub) * kP * kSlots
@@ -3515,6 +3934,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
     // partition scratch
     int nblocks = 0, nblocks_local = 0;
     int64_t rows_per_block = 0, rows_per_block_local = 0, cap = 0, hist_n = 0;
+    bool compact = false;
     if (path >= 2) {
       // the specialised scatter runs two 512-thread workgroups per CU on 3584-row tiles
       const int64_t tile = use_bins ? kBThreads * 4 : headline_shape ? kFRows : kDRows;
@@ -3525,6 +3945,8 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
       const double mean = static_cast<double>(rows_per_block) / kP / nsub;
       // room for a key of up to ~0.25 % of the rows next to the uniform share (hotter keys are taken out before the scatter)
       cap = (static_cast<int64_t>(mean * 2.0 + 8.0 * std::sqrt(mean) + 32.0) + 7) & ~int64_t(7);  // whole 128-byte lines
+      compact = compact_rw != 0 && hinted && path == 2 && nsub == 1 && rows_per_block <= (int64_t(1) << kCRowBits);
+      if (compact) cap = ((cap * compact_rw + 3) / 4 + 7) & ~int64_t(7);  // the same number of records, in 16-byte units
       hist_n = int64_t(kP) * (nblocks + (use_bins ? 1 : 0));  // bins: one more segment per partition, the spill list
     } else if (path == 1) {
       nblocks = static_cast<int>(std::min<int64_t>(ctx->num_cus, (n + kPartRows - 1) / kPartRows));
@@ -3584,7 +4006,10 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
       fa.k_data = keys->values; fa.k_valid = keys->validity; fa.k_off = keys->offset; fa.k_bits = ks.total_bits;
       fa.k_load_bits = k_load_bits; fa.k_bias = k_bias;
       fa.k_flip = keys->type_id == AMDARROW_INT32 ? 0x80000000u : 0u;  // (a range-compressed column: x = key - min >= 0 as it is)
-      fa.key_minmax = misc + 8;  // (status words are misc[0..7]; the workgroup flags start at misc + 64)
+      fa.key_minmax = misc + 8;  // (status words are misc[0..11]; the workgroup flags start at misc + 64)
+      fa.val_wide = path >= 2 && use_bins && values && !IsFloat(values->type_id) ? misc + 10 : nullptr;
+      fa.c_base = c_base;
+      fa_val_wide = fa.val_wide != nullptr;
       fa.v = v; fa.has_values = values ? 1 : 0;
       if (!values && use_bins) fa.v = ValueCol{keys->values, nullptr, 0, AMDARROW_INT64};  // (never used as values: see BinLoadTile)
       fa.m_data = m_data; fa.m_valid = m_valid; fa.m_off = m_off;
@@ -3636,7 +4061,14 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
         fa.sub_bits = nsub > 1 ? sub_bits : 0; fa.sub_id = static_cast<uint32_t>(sub);
         FastArgs fh = fa;  // the same scatter on the mask k_hot_aggregate wrote
         fh.m_data = hot.alt_mask; fh.m_valid = nullptr; fh.m_off = 0;
-        if (use_bins) {
+        if (compact) {
+#define AA_CBINS3(MM, VV, KK) do { if (compact_rw == 2) hipLaunchKernelGGL((k_part_scatter_compact<MM, VV, KK, 2>), dim3(nblocks), dim3(kBThreads), 0, ctx->stream, fa, cap, records, hist, misc); \
+          else hipLaunchKernelGGL((k_part_scatter_compact<MM, VV, KK, 3>), dim3(nblocks), dim3(kBThreads), 0, ctx->stream, fa, cap, records, hist, misc); } while (0)
+#define AA_CBINS(MM, VV) do { if (k_load_bits == 64) AA_CBINS3(MM, VV, true); else AA_CBINS3(MM, VV, false); } while (0)
+          if (M && V) AA_CBINS(true, true); else if (M) AA_CBINS(true, false); else if (V) AA_CBINS(false, true); else AA_CBINS(false, false);
+#undef AA_CBINS
+#undef AA_CBINS3
+        } else if (use_bins) {
 #define AA_BINS(MM, VV, ARGS, RUN, SKIP) do { if (k_load_bits == 64) hipLaunchKernelGGL((k_part_scatter_bins<MM, VV, true>), dim3(nblocks), dim3(kBThreads), 0, ctx->stream, ARGS, cap, records, hist, misc, RUN, SKIP); \
           else hipLaunchKernelGGL((k_part_scatter_bins<MM, VV, false>), dim3(nblocks), dim3(kBThreads), 0, ctx->stream, ARGS, cap, records, hist, misc, RUN, SKIP); } while (0)
           if (M && V) AA_BINS(true, true, fa, run_if, use_hot); else if (M) AA_BINS(true, false, fa, run_if, use_hot);
@@ -3657,7 +4089,14 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
                                misc, use_hot, static_cast<const unsigned int*>(nullptr));
         }
         AA_HIP(hipGetLastError());
-        if (use_bins && !getenv("AMDARROW_GROUPBY_OLD_AGG"))
+        if (compact) {
+          if (compact_rw == 2)
+            hipLaunchKernelGGL(k_part_aggregate_compact<2>, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nblocks, cap,
+                               acc_double, t, r.bitmap, misc, static_cast<int64_t>(T), c_base, fa.k_flip, static_cast<uint32_t>(rows_per_block));
+          else
+            hipLaunchKernelGGL(k_part_aggregate_compact<3>, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nblocks, cap,
+                               acc_double, t, r.bitmap, misc, static_cast<int64_t>(T), c_base, fa.k_flip, static_cast<uint32_t>(rows_per_block));
+        } else if (use_bins && !getenv("AMDARROW_GROUPBY_OLD_AGG"))
           hipLaunchKernelGGL(k_part_aggregate_piped, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nseg,
                              cap, ks.total_bits, acc_double, t, r.bitmap, misc, run_if, int64_t(sub) * kP * kSlots,
                              sub == 0 ? static_cast<int64_t>(T) : int64_t(0), fa.key_minmax, fa.k_flip, use_hot);
@@ -3705,13 +4144,14 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
     const int64_t bound = group_capacity < n ? group_capacity : n;
     const KeySpec& ku = fast ? ks : ks_generic;  // how x was built on this path
     if (packed_out) *packed_out = e.packed;  // {key word, sum, count, first row} per group id, in the context's scratch
+    if (bias_out) *bias_out = fast ? k_bias : 0;  // (a range-compressed 64-bit key column: key = key word + bias)
     if (out_keys)
     hipLaunchKernelGGL(k_unpack_groups, dim3(GridFor(bound, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream,
                        e.packed, bound, ku.col[0].bits, ks_generic.col[0].bits, fast ? k_bias : 0ull,
                        ku.wide_null_slot ? -1 : ku.total_bits, static_cast<unsigned long long*>(out_sums), reinterpret_cast<long long*>(out_counts), out_first_rows,
                        out_keys, reinterpret_cast<uint64_t*>(out_key_validity), misc);
     AA_HIP(hipGetLastError());
-    unsigned int status[8] = {0};
+    unsigned int status[12] = {0};
     AA_TRY(AwaitStatus(ctx, status));
 #ifdef SC_PHASES
     if (getenv("AMDARROW_PHASES")) {
@@ -3749,15 +4189,37 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
                       "group-by: more than group_capacity = " + std::to_string(group_capacity) + " groups");
     if (path == 3 && !hinted) {
       // status[1]: the local pre-aggregation gave up; status[5]: heavy hitters were taken out
-      if (status[1] != 0 && status[5] == 0 && sub_bits == 0) { shape.uses = hint.n == shape.n ? hint.uses : 0; hint = shape; }
+      if (status[1] != 0 && status[5] == 0 && sub_bits == 0) {
+        shape.uses = hint.n == shape.n ? hint.uses : 0;
+        // what the bin scatter saw: the range of the selected keys, and whether the values were all int32
+        shape.stats = use_bins && status[8] <= status[9] ? 1 : 0;
+        shape.key_lo = status[8] + k_bias; shape.key_hi = status[9] + k_bias;
+        shape.values_narrow = values && !IsFloat(values->type_id) && status[10] == 0 ? 1 : 0;
+        hint = shape;
+      }
       else hint.n = -1;
     }
     // a hinted call that found few groups: the local attempt it skipped would have held them all -- next call, try it again
     if (hinted && G <= static_cast<int64_t>(kLocalLimit)) hint.n = -1;
+    // a hinted call's scatter measured the same things: the next call's records follow the data
+    if (hinted && use_bins && hint.n == shape.n && status[8] <= status[9]) {
+      if (!compact) { hint.stats = 1; hint.key_lo = status[8] + k_bias; hint.key_hi = status[9] + k_bias; }
+      if (fa_val_wide && !(compact && compact_rw == 2)) hint.values_narrow = status[10] == 0 ? 1 : 0;
+    }
     *out_num_groups = G;
+    ctx->gb_last_path = path == 3 && status[1] != 0 ? 2 : path;
+    ctx->gb_last_words = ctx->gb_last_path == 0 || ctx->gb_last_path == 3 ? 0 : compact ? compact_rw : 4;
     break;
   }
   // no trailing synchronise: *out_num_groups is final, the output arrays are stream-ordered
+  return AMDARROW_OK;
+}
+
+int amdarrow_groupby_last_path(amdarrow_ctx* ctx, int* path, int* record_words) {
+  if (!ctx) return SetError(AMDARROW_INVALID, "null context");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (path) *path = ctx->gb_last_path;
+  if (record_words) *record_words = ctx->gb_last_words;
   return AMDARROW_OK;
 }
 

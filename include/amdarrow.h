@@ -402,6 +402,13 @@ int amdarrow_filter_groupby(amdarrow_ctx* ctx, const amdarrow_array* values,
                             void* out_keys, uint8_t* out_key_validity,
                             uint32_t* out_first_rows, int64_t* out_num_groups);
 
+/* Diagnostics (tests, bench): how the context's last amdarrow_filter_groupby / _multi / grouped Grouper batch was
+ * computed.  *path: 3 = per-workgroup LDS pre-aggregation, 2 = one-pass partition, 1 = exact two-pass partition,
+ * 0 = global-atomic table; *record_words: 32-bit words per partitioned record (4 = {key, row, value}; 3 / 2 = the
+ * compact records of a call whose predecessor of the same shape had a small key range / int32 values); 0 when no
+ * records were written.  No reference counterpart. */
+int amdarrow_groupby_last_path(amdarrow_ctx* ctx, int* path, int* record_words);
+
 #ifdef __cplusplus
 }
 #endif

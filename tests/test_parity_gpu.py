@@ -1315,7 +1315,7 @@ def test_filter_groupby_bin_path_random_shapes(gpu, oracle, seed):
         _check_groupby(oracle, gpu, v, k, m, (seed, n, kt, vt))
 
 
-@pytest.mark.parametrize("kt", [BOOL, INT8, UINT16, INT32, UINT32, FLOAT])
+@pytest.mark.parametrize("kt", [BOOL, INT8, UINT16, INT32, UINT32, FLOAT, INT64, UINT64, DOUBLE])
 def test_grouper_first_batch_through_the_partitioned_groupby(gpu, oracle, kt):
     """A batch of >= 2^18 rows over one key column of at most 32 bits takes the partitioned group-by for its distinct
     keys and a directly indexed id table (small key range) or the hashed table (wide range) for the rows' ids;
@@ -1325,7 +1325,11 @@ def test_grouper_first_batch_through_the_partitioned_groupby(gpu, oracle, kt):
     for knp, (lo, hi) in ((0.0, (-3000, 3000)), (0.05, (-3000, 3000)), (0.0, (-2**30, 2**30))):
         if kt in (BOOL, INT8, UINT16) and hi > 3000:
             continue
-        if kt in (BOOL, UINT16, UINT32):
+        if kt in (INT64, UINT64, DOUBLE) and knp > 0:
+            continue  # (a null 64-bit key lives in the table's special slot: the general path)
+        if kt in (INT64, UINT64) and hi > 3000:
+            lo, hi = -2**61, 2**61  # (does not range-compress: the wide-key path)
+        if kt in (BOOL, UINT16, UINT32, UINT64):
             lo, hi = 0, hi
         if kt == INT8:
             lo, hi = -100, 100
@@ -1399,3 +1403,82 @@ def test_round1_kernels_behind_the_knobs_still_agree(gpu, oracle, knob, monkeypa
         v, k, m = R(rng, INT64, n, 0.02, 0), R(rng, INT32, n, 0.0, 0, lo=0, hi=hi), R(rng, BOOL, n, 0.0, 0)
         for _ in range(2):
             _check_groupby(oracle, gpu, v, k, m, (knob, hi))
+
+
+def _last_groupby_path(gpu):
+    import ctypes as C
+    path, words = C.c_int(-9), C.c_int(-9)
+    assert gpu.ctx.lib.amdarrow_groupby_last_path(gpu.ctx.handle, C.byref(path), C.byref(words)) == 0
+    return path.value, words.value
+
+
+@pytest.mark.parametrize("shape", ["int32-narrow-values", "int32-negative-wide-values", "uint32-high-double", "int64-keys",
+                                   "no-mask", "dense-mask", "value-nulls", "sliced-16"])
+def test_filter_groupby_compact_records(gpu, oracle, shape, monkeypatch):
+    """A call whose predecessor of the same shape went the partition way with a small key range carries compact
+    records: 8 bytes (int32-valued integer column) or 12 bytes per selected row instead of 16.  First call: 16-byte
+    records, the hint is learnt; second call (other data, same shape): compact; then data that breaks the call's
+    assumption (keys outside the window / an int64 value that is not an int32): the kernel notices, the call
+    starts over on the general path; and the compact path comes back.  Every call returns the reference's rows."""
+    rng = np.random.default_rng(0x0ff1ce + 77)
+    n = 1_500_000
+    off = 16 if shape == "sliced-16" else 0
+
+    def data(kind):
+        lo = {"int32-negative-wide-values": -200_000, "uint32-high-double": 0xFFF00000}.get(shape, 1000)
+        kt = {"uint32-high-double": UINT32, "int64-keys": INT64}.get(shape, INT32)
+        base = rng.integers(0, 300_000, n + off) + lo
+        if shape == "int64-keys":
+            base = base + 7_000_000_000_000
+        if kind == "far-keys":
+            base[rng.integers(off, n + off, 16)] += 3_000_000 if shape != "uint32-high-double" else -3_000_000
+        k = Arr(kt, base.astype(orc.NP_OF[kt]), offset=off, length=n)
+        wide = shape in ("int32-negative-wide-values", "int64-keys")
+        if shape == "uint32-high-double":
+            v = R(rng, DOUBLE, n, 0.02, off)
+        else:
+            v = R(rng, INT64, n, 0.05 if shape == "value-nulls" else 0.0, off, lo=-2**62 if wide else -2**31,
+                  hi=2**62 if wide else 2**31 - 1)
+            if kind == "wide-value":
+                d = v.data.copy()
+                d[rng.integers(off, n + off, 16)] = 2**31
+                v = Arr(INT64, d, v.valid, offset=off, length=n)  # (an Arr copies its buffers at construction)
+        p = {"dense-mask": 0.9}.get(shape, 0.5)
+        m = None if shape == "no-mask" else R(rng, BOOL, n, 0.0, off, hi=p)
+        return v, k, m
+    narrow = shape in ("int32-narrow-values", "no-mask", "dense-mask", "value-nulls", "sliced-16")
+    W = 2 if narrow else 3
+    import gpu_api
+    gpu = gpu_api.GpuApi()  # a context of its own: the hint (and its use count) starts fresh
+    # (kind, words per record): the first call learns the hint on 16-byte records; a call that breaks the hinted
+    # assumption starts over on them, and the call behind it re-measures (key range: one 16-byte call; value width:
+    # one 12-byte call) before the compact records are back
+    plan = [("plain", 4), ("plain", W), ("plain", W), ("far-keys", 4), ("plain", 4), ("plain", W),
+            ("wide-value", 4 if narrow else 3), ("plain", 3), ("plain", W)]
+    for step, (kind, want_words) in enumerate(plan):
+        v, k, m = data(kind)
+        all_true = Arr(BOOL, np.ones(n + off, bool), offset=off, length=n)  # (the oracle's group-by wants a mask)
+        for x, y in zip(oracle.filter_groupby_sum(v, k, m if m is not None else all_true), gpu.filter_groupby_sum(v, k, m)):
+            if x.dtype == np.float64:
+                assert x.shape == y.shape and np.allclose(x, y, rtol=F64_RTOL), (shape, step, kind)
+            else:
+                assert np.array_equal(x, y), (shape, step, kind)
+        assert _last_groupby_path(gpu) == (2, want_words), (shape, step, kind)
+
+
+def test_filter_groupby_compact_records_knob(gpu, oracle, monkeypatch):
+    """AMDARROW_GROUPBY_NO_COMPACT keeps hinted calls on 16-byte records; AMDARROW_GROUPBY_COMPACT_WORDS=3 keeps a
+    narrow-valued call on 12-byte records."""
+    rng = np.random.default_rng(5)
+    n = 1_000_000
+    import gpu_api
+    gpu = gpu_api.GpuApi()
+    mk = lambda: (R(rng, INT64, n, 0.0, 0), Arr(INT32, rng.integers(0, 400_000, n).astype(np.int32)), R(rng, BOOL, n, 0.0, 0))
+    for env, want in ((("AMDARROW_GROUPBY_NO_COMPACT", "1"), 4), (("AMDARROW_GROUPBY_COMPACT_WORDS", "3"), 3), (None, 2)):
+        if env:
+            monkeypatch.setenv(*env)
+        for step in range(3):
+            _check_groupby(oracle, gpu, *mk(), (env, step))
+        assert _last_groupby_path(gpu) == (2, want), env
+        if env:
+            monkeypatch.delenv(env[0])
