@@ -1613,12 +1613,20 @@ constexpr uint32_t kCValid = 1u << kCSlotBits;
 struct CBinShared {
   unsigned int cnt[kP];  // low half: words in the bin (runs past kCBinWords while a tile is ranked: the excess was spilled); high half: words at the tile's start
   uint32_t cur[kP];      // 16-byte units of this workgroup's region already written (a multiple of 8)
+  uint32_t list[kP];     // per wave (32 entries each): the partitions with a line to flush, see CBinFlush
+  unsigned int spill[kP];  // records of this workgroup that found their bin full (they sit at the top of the region)
   __attribute__((aligned(16))) uint32_t bin[kP * kCBinStride];
 };
+// A record that finds its bin full goes straight to the TOP of the workgroup's region for its partition, as a
+// 16-byte record {key word, row | flags, value}, growing downwards: its place comes from an LDS counter.  (The
+// 16-byte scatter hands such records to a per-partition list filled through a device atomic: the returning
+// atomic makes the wave wait for every load it has in flight -- two tiles -- and the workgroup waits for that
+// wave at the next barrier, ~1-2 us each time.)  kCSpillUnits records per region; more raise kOverflowRegion.
+constexpr int kCSpillUnits = 32;
 template <bool MASK, bool VVALID, int R, bool K64, int RW>
 __device__ __forceinline__ void CBinStageTile(CBinShared& sh, const FastArgs& a, const BinTile<R, K64>& t, int64_t lo, int64_t tile0,
-                                              int64_t hi, int tid, int64_t cap, uint4* __restrict__ regions,
-                                              uint32_t* __restrict__ counts, unsigned int* overflow, uint32_t& kmin,
+                                              int64_t hi, int tid, int64_t cap, uint4* __restrict__ my_regions,
+                                              unsigned int* overflow, uint32_t& kmin,
                                               uint32_t& kmax, uint32_t& vwide, uint32_t& bad) {
   const int64_t r0 = tile0 + int64_t(tid) * R;
   const int64_t left = hi - r0;
@@ -1659,56 +1667,96 @@ __device__ __forceinline__ void CBinStageTile(CBinShared& sh, const FastArgs& a,
       q.x = t.key.k(j, a.k_bias);
       q.y = static_cast<uint32_t>(r0 + j) | (vvalid ? kRecValValid : 0u);
       q.z = static_cast<uint32_t>(v); q.w = static_cast<uint32_t>(v >> 32);
-      const uint32_t s = atomicAdd(&counts[int64_t(part[j]) * (a.nblocks + 1) + a.nblocks], 1u);
-      if (s < cap) regions[(int64_t(a.nblocks) * kP + part[j]) * cap + s] = q;
+      const uint32_t s = atomicAdd(&sh.spill[part[j]], 1u);
+      if (s < static_cast<uint32_t>(kCSpillUnits)) my_regions[int64_t(part[j]) * cap + (cap - 1 - s)] = q;
       else __hip_atomic_store(overflow, kOverflowRegion, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
-// Eight lanes per partition: the stream's whole 128-byte lines leave, the words behind them move to the front.
+// Flush: the stream's whole 128-byte lines leave, the words behind them move to the front.  A wave owns 32
+// partitions.  ONE lane per partition decides (counter read, clamp, lines to go, new counter) -- with eight lanes
+// per partition doing that in four rounds the flush logic was a third of the kernel (116 of 372 us; the global
+// stores it feeds: 10 us) -- and the partitions with a line to go (a quarter to a third of them per tile) are
+// compacted into a wave-private list; eight lanes per listed partition then copy its line (16 bytes each) and
+// move the rest to the front, eight partitions per trip.  Everything stays inside the wave: LDS operations of
+// one wave execute in order, no barrier between the steps.
 template <int RW>
 __device__ __forceinline__ void CBinFlush(CBinShared& sh, int tid, int64_t cap, uint4* __restrict__ my_regions,
                                           unsigned int* overflow) {
   using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
-  const uint32_t ll = tid & 7;
-#pragma unroll
-  for (int round = 0; round < kP / (kBThreads / 8); ++round) {
-    const uint32_t p = (tid / 8) + round * (kBThreads / 8);
-    const uint32_t raw = sh.cnt[p];
+  constexpr int kPerWave = kP / (kBThreads / 64);
+  static_assert(kPerWave == 32, "one lane of the low half per partition");
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint32_t nl = 0, entry = 0;
+  if (lane < kPerWave) {
+    const uint32_t p = wave * kPerWave + lane;
+    const uint32_t raw = sh.cnt[p], cur = sh.cur[p];
     const uint32_t start = raw >> 16, fill = raw & 0xFFFFu;
     // (arrivals were accepted while their last word still fitted)
     const uint32_t end = fill <= static_cast<uint32_t>(kCBinWords) ? fill : start + ((kCBinWords - start) / RW) * RW;
-    const uint32_t nl = end >> 5, left = end & 31u;
-    const uint32_t cur = sh.cur[p];
-    const bool ok = cur + 8 * nl <= cap;
-    uint4* dst = my_regions + int64_t(p) * cap + cur + ll;
-    const uint32_t* bin = &sh.bin[p * kCBinStride];
-#pragma unroll
-    for (uint32_t l = 0; l < 2; ++l) {
-      if (l < nl && ok) {
-        const uint4 q = *reinterpret_cast<const uint4*>(&bin[32 * l + 4 * ll]);
-        const u32x4 v = {q.x, q.y, q.z, q.w};
-        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + 8 * l));
+    nl = end >> 5;
+    const uint32_t rest = nl > 0 ? (end & 31u) : end;
+    sh.cnt[p] = rest << 16 | rest;  // words now in the bin, in both halves (the next tile's arrivals start there)
+    if (nl > 0) {
+      if (cur + 8 * nl <= cap - kCSpillUnits) {
+        sh.cur[p] = cur + 8 * nl;
+        entry = p | nl << 9 | rest << 11 | (cur >> 3) << 16;
+      } else {
+        nl = 0;
+        __hip_atomic_store(overflow, kOverflowRegion, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    const bool move = nl > 0 && 4 * ll < left;  // (nl == 1 here: two whole lines leave nothing behind)
-    uint4 keep;
-    if (move) keep = *reinterpret_cast<const uint4*>(&bin[32 + 4 * ll]);
-    if (move) *reinterpret_cast<uint4*>(&sh.bin[p * kCBinStride + 4 * ll]) = keep;  // (LDS operations of one wave execute in order)
-    if (ll == 0) {
-      const uint32_t rest = nl > 0 ? left : end;
-      sh.cnt[p] = rest << 16 | rest;
-      if (nl > 0) {
-        if (ok) sh.cur[p] = cur + 8 * nl;
-        else __hip_atomic_store(overflow, kOverflowRegion, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const uint64_t going = __ballot(nl > 0);
+  const int count = __popcll(going);
+  if (nl > 0) sh.list[wave * kPerWave + __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(going), 0u)] = entry;
+  // up to four trips of eight partitions; every step's LDS reads are issued for all trips before any is used
+  // (trip by trip the chain list entry -> line -> store is paid once per trip: with most bins flushing -- every
+  // row selected, 12-byte records -- that was 10 % of the kernel)
+  const uint32_t ll = lane & 7;
+  const int trips = (count + 7) >> 3;  // (wave-uniform, <= kPerWave / 8)
+  constexpr int kTrips = kPerWave / 8;
+  uint32_t e[kTrips];
+#pragma unroll
+  for (int t = 0; t < kTrips; ++t) {
+    e[t] = 0;  // (no lines: skipped below)
+    if (t < trips) {
+      const int k = 8 * t + (lane >> 3);
+      if (k < count) e[t] = sh.list[wave * kPerWave + k];
+    }
+  }
+  uint4 lo[kTrips], hi[kTrips];
+#pragma unroll
+  for (int t = 0; t < kTrips; ++t) {
+    if (t < trips && ((e[t] >> 9) & 3u) != 0) {
+      const uint32_t* bin = &sh.bin[(e[t] & (kP - 1)) * kCBinStride];
+      lo[t] = *reinterpret_cast<const uint4*>(&bin[4 * ll]);
+      hi[t] = *reinterpret_cast<const uint4*>(&bin[32 + 4 * ll]);  // the second line, or the words that move to the front
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < kTrips; ++t) {
+    const uint32_t lines = (e[t] >> 9) & 3u;
+    if (t < trips && lines != 0) {
+      const uint32_t p = e[t] & (kP - 1), rest = (e[t] >> 11) & 31u, cur = (e[t] >> 16) << 3;
+      uint4* dst = my_regions + int64_t(p) * cap + cur + ll;
+      const u32x4 v = {lo[t].x, lo[t].y, lo[t].z, lo[t].w};
+      __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst));
+      if (lines > 1) {
+        const u32x4 w = {hi[t].x, hi[t].y, hi[t].z, hi[t].w};
+        __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(dst + 8));
       }
+      if (lines == 1 && 4 * ll < rest) *reinterpret_cast<uint4*>(&sh.bin[p * kCBinStride + 4 * ll]) = hi[t];
     }
   }
 }
 
 // The tile loop of one workgroup over its row range, R rows per thread and tile.  RW = 0: 16-byte records
 // (BinShared); RW = 2 / 3: compact records of RW words (CBinShared).
-template <bool MASK, bool VVALID, int R, bool K64, int RW = 0, class SH = BinShared>
+// FE: the bins are flushed after every FE-th tile (2 for the 8-byte records: a tile brings a bin eight words on
+// average, two tiles fit behind what a flush leaves, and the flush with its two barriers is paid half as often).
+template <bool MASK, bool VVALID, int R, bool K64, int RW = 0, class SH = BinShared, int FE = 1>
 __device__ __forceinline__ void BinRun(SH& sh, const FastArgs& a, int64_t lo, int64_t hi, int64_t cap,
                                        uint4* __restrict__ regions, uint4* __restrict__ my_regions,
                                        uint32_t* __restrict__ counts, unsigned int* overflow, uint32_t& kmin, uint32_t& kmax,
@@ -1730,14 +1778,18 @@ __device__ __forceinline__ void BinRun(SH& sh, const FastArgs& a, int64_t lo, in
 #define AA_BIN_STEP(CUR, NEXT, TILE0)                                                                  \
   do {                                                                                                   \
     if constexpr (RW == 0) BinStageTile<MASK, VVALID, R, K64>(sh, a, CUR, (TILE0), hi, tid, cap, regions, counts, overflow, kmin, kmax, vwide); \
-    else CBinStageTile<MASK, VVALID, R, K64, RW>(sh, a, CUR, lo, (TILE0), hi, tid, cap, regions, counts, overflow, kmin, kmax, vwide, bad); \
-    LdsBarrier();                                                                                        \
+    else CBinStageTile<MASK, VVALID, R, K64, RW>(sh, a, CUR, lo, (TILE0), hi, tid, cap, my_regions, overflow, kmin, kmax, vwide, bad); \
+    const bool flush_now = FE == 1 || (++step_no % FE) == 0;  /* (uniform) */                            \
+    if (flush_now) LdsBarrier();                                                                         \
     AA_TOUCH(NEXT);                                                                                      \
-    if constexpr (RW == 0) BinFlush(sh, tid, cap, my_regions, overflow);                                 \
-    else CBinFlush<RW>(sh, tid, cap, my_regions, overflow);                                              \
+    if (flush_now) {                                                                                     \
+      if constexpr (RW == 0) BinFlush(sh, tid, cap, my_regions, overflow);                               \
+      else CBinFlush<RW>(sh, tid, cap, my_regions, overflow);                                            \
+    }                                                                                                    \
     BinLoadTile<MASK, VVALID, R, K64>(a, keys, vals, (TILE0) + 3 * kRows <= last_whole ? (TILE0) + 3 * kRows : last_whole, tid, CUR); \
-    LdsBarrier();                                                                                        \
+    if (flush_now) LdsBarrier();                                                                         \
   } while (0)
+  uint32_t step_no = 0;
   int64_t tile0 = lo;
   if (lo + kRows <= hi) {
     const int64_t last_whole = lo + ((hi - lo) / kRows - 1) * kRows;
@@ -1764,7 +1816,11 @@ __device__ __forceinline__ void BinRun(SH& sh, const FastArgs& a, int64_t lo, in
   if (tile0 < hi) {  // the partial tile at the end of the input
     BinLoadTail<MASK, VVALID, R, K64>(a, keys, vals, tile0, hi, tid, t0);
     if constexpr (RW == 0) BinStageTile<MASK, VVALID, R, K64>(sh, a, t0, tile0, hi, tid, cap, regions, counts, overflow, kmin, kmax, vwide);
-    else CBinStageTile<MASK, VVALID, R, K64, RW>(sh, a, t0, lo, tile0, hi, tid, cap, regions, counts, overflow, kmin, kmax, vwide, bad);
+    else CBinStageTile<MASK, VVALID, R, K64, RW>(sh, a, t0, lo, tile0, hi, tid, cap, my_regions, overflow, kmin, kmax, vwide, bad);
+    LdsBarrier();
+    if constexpr (RW == 0) BinFlush(sh, tid, cap, my_regions, overflow);
+    else CBinFlush<RW>(sh, tid, cap, my_regions, overflow);
+  } else if (FE > 1) {  // (the last whole tile may have gone without a flush: the write-out behind expects less than a line per bin)
     LdsBarrier();
     if constexpr (RW == 0) BinFlush(sh, tid, cap, my_regions, overflow);
     else CBinFlush<RW>(sh, tid, cap, my_regions, overflow);
@@ -1837,14 +1893,14 @@ __global__ __launch_bounds__(kBThreads) void k_part_scatter_bins(FastArgs a, int
 }
 
 // The bin scatter with compact records of RW words (see above).  counts[p][b] = RECORDS in the region of
-// workgroup b for partition p (RW words each, packed); the spill list (segment nblocks) holds 16-byte records.
+// workgroup b for partition p (RW words each, packed from the region's start) | 16-byte records at its top << 24.
 template <bool MASK, bool VVALID, bool K64, int RW>
 __global__ __launch_bounds__(kBThreads) void k_part_scatter_compact(FastArgs a, int64_t cap, uint4* regions, uint32_t* counts,
                                                                     unsigned int* overflow) {
   __shared__ CBinShared sh;
   __shared__ unsigned int s_sample, s_kmin, s_kmax;
   const int tid = threadIdx.x;
-  if (tid < kP) { sh.cnt[tid] = 0; sh.cur[tid] = 0; }
+  if (tid < kP) { sh.cnt[tid] = 0; sh.cur[tid] = 0; sh.spill[tid] = 0; }
   if (tid == 0) { s_sample = 0; s_kmin = 0xFFFFFFFFu; s_kmax = 0; }
   __syncthreads();
   const int64_t lo = int64_t(blockIdx.x) * a.rows_per_block;
@@ -1862,11 +1918,13 @@ __global__ __launch_bounds__(kBThreads) void k_part_scatter_compact(FastArgs a, 
       }
     }
     __syncthreads();
-    dense = 3 * int64_t(s_sample) > 2 * sample_rows;  // more than two thirds of the rows selected
+    dense = RW == 2 ? 20 * int64_t(s_sample) > 11 * sample_rows  // (two tiles per flush: the half-size tiles from 55 % on)
+                    : 3 * int64_t(s_sample) > 2 * sample_rows;   // more than two thirds of the rows selected
   }
   uint32_t kmin = 0xFFFFFFFFu, kmax = 0, vwide = 0, bad = 0;
-  if (dense) BinRun<MASK, VVALID, 2, K64, RW, CBinShared>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow, kmin, kmax, vwide, bad);
-  else BinRun<MASK, VVALID, 4, K64, RW, CBinShared>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow, kmin, kmax, vwide, bad);
+  constexpr int FE = RW == 2 ? 2 : 1;
+  if (dense) BinRun<MASK, VVALID, 2, K64, RW, CBinShared, FE>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow, kmin, kmax, vwide, bad);
+  else BinRun<MASK, VVALID, 4, K64, RW, CBinShared, FE>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow, kmin, kmax, vwide, bad);
   if (RW == 3 && a.val_wide && __syncthreads_or(vwide != 0) && tid == 0) __hip_atomic_store(a.val_wide, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // a selected row outside the hinted key range, or (RW == 2) a value that is not an int32: the call starts over
   if (__syncthreads_or(bad != 0) && tid == 0) __hip_atomic_store(overflow, kOverflowCompact, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1883,15 +1941,15 @@ __global__ __launch_bounds__(kBThreads) void k_part_scatter_compact(FastArgs a, 
   if (tid == 0 && s_kmin <= s_kmax) { atomicMin(&a.key_minmax[0], s_kmin); atomicMax(&a.key_minmax[1], s_kmax); }
   if (tid < kP) {
     // what is left of every partition's stream (< 32 words after a flush), and the region fills
-    const uint32_t left = sh.cnt[tid] & 0xFFFFu, cur = sh.cur[tid];
-    const bool ok = 4 * cur + left <= 4 * cap;
+    const uint32_t left = sh.cnt[tid] & 0xFFFFu, cur = sh.cur[tid], spilled = sh.spill[tid];
+    const bool ok = 4 * cur + left <= 4 * (cap - kCSpillUnits) && spilled <= static_cast<uint32_t>(kCSpillUnits);
     if (ok) {
       uint32_t* dst = reinterpret_cast<uint32_t*>(my_regions + int64_t(tid) * cap + cur);
       for (uint32_t k = 0; k < left; ++k) dst[k] = sh.bin[tid * kCBinStride + k];
     } else {
       __hip_atomic_store(overflow, kOverflowRegion, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    counts[int64_t(tid) * (a.nblocks + 1) + blockIdx.x] = ok ? (4 * cur + left) / RW : 0;
+    counts[int64_t(tid) * (a.nblocks + 1) + blockIdx.x] = ok ? (4 * cur + left) / RW | spilled << 24 : 0;  // (records | spilled << 24)
   }
 }
 
@@ -2366,11 +2424,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_compact(const u
   constexpr int kUnitRecs = RW == 2 ? 2 : 1;                     // records per loaded unit
   constexpr uint32_t kStepUnits = 64 * kPaUnroll;                // units per wave and step
   const int nseg_all = nblocks + 1;
-  for (int b = tid; b < nseg_all; b += kPartThreads) {
-    const uint32_t c = counts[int64_t(p) * nseg_all + b];
-    const uint32_t most = static_cast<uint32_t>(b < nblocks ? (4 * cap) / RW : cap);
-    s_fill[b] = c > most ? most : c;  // (a region that overflowed; the attempt is abandoned anyway)
-  }
+  for (int b = tid; b < nblocks; b += kPartThreads) s_fill[b] = counts[int64_t(p) * nseg_all + b];  // records | spilled << 24
   for (int s = tid; s < kSlots; s += kPartThreads) { s_sum[s] = 0; s_first[s] = kNoRow; s_cnt[s] = 0; }
   __syncthreads();
   auto fold_one = [&](uint32_t meta, uint32_t lo32, uint32_t hi32, uint32_t seg_lo) {
@@ -2395,7 +2449,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_compact(const u
         it.i0 = 0;
         do {
           ++it.k;
-          it.recs = it.k < nseg ? __builtin_amdgcn_readfirstlane(s_fill[wave + kWaves * it.k]) : 0u;
+          it.recs = it.k < nseg ? __builtin_amdgcn_readfirstlane(s_fill[wave + kWaves * it.k]) & 0xFFFFFFu : 0u;
           it.units = (it.recs + kUnitRecs - 1) / kUnitRecs;
         } while (it.k < nseg && it.recs == 0);
       }
@@ -2438,11 +2492,13 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_compact(const u
       fold(r2, i2); i2 = advance(i1); load(r2, i2);
     }
   }
-  {  // the spill list: 16-byte records {key word, row | flags, value}
-    const uint4* sp = regions + (int64_t(nblocks) * kP + p) * cap;
-    const uint32_t n = s_fill[nblocks];
-    for (uint32_t i = tid; i < n; i += kPartThreads) {
-      const uint4 q = sp[i];
+  // the records that found their bin full: 16-byte records {key word, row | flags, value} at the top of each region
+  for (int b = wave; b < nblocks; b += kWaves) {
+    const uint32_t ns = __builtin_amdgcn_readfirstlane(s_fill[b]) >> 24;
+    if (ns == 0) continue;
+    const uint4* top = regions + (int64_t(b) * kP + p) * cap + (cap - 1);
+    if (static_cast<uint32_t>(lane) < ns) {
+      const uint4 q = *(top - lane);
       const uint32_t slot = DirectSlot((((q.x ^ k_flip) >> kPBits) - c_base) & (kCValid - 1u));
       atomicMin(&s_first[slot], q.y & kRecRowMask);
       if (q.y & kRecValValid) {
@@ -3816,6 +3872,7 @@ int amdarrow_hash_aggregate(amdarrow_ctx* ctx, int func, const amdarrow_array* v
 
 // The fused Filter -> GroupBy.  `locked`: the caller already holds ctx->mu (the multi-key entry point, which runs
 // this on its column of packed key codes).
+constexpr int kHintProbeEvery = 64;  // hinted group-by calls between two calls that try the per-workgroup pre-aggregation again
 static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, const amdarrow_array* keys,
                              const amdarrow_array* mask, int64_t group_capacity, void* out_sums, int64_t* out_counts,
                              void* out_keys, uint8_t* out_key_validity, uint32_t* out_first_rows,
@@ -3872,7 +3929,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
   // evenly spread groups both give up (~60 us of kernels and launches for nothing).  A call of the
   // same shape as the last one that went that way starts at the partition path directly; if its
   // capacity assumption then fails (the data changed character) the call starts over at path 3, and
-  // every 16th hinted call takes path 3 anyway so that a change for the better is noticed too.
+  // every kHintProbeEvery-th hinted call takes path 3 anyway so that a change for the better is noticed too.
   amdarrow_ctx::GroupByHint shape;
   shape.n = n; shape.key_type = keys->type_id; shape.value_type = values ? values->type_id : 0;
   shape.has_mask = mask != nullptr; shape.has_value_validity = values && values->validity != nullptr;
@@ -3881,7 +3938,9 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
   if (path == 3 && hint.n == shape.n && hint.key_type == shape.key_type && hint.value_type == shape.value_type &&
       hint.has_mask == shape.has_mask && hint.has_value_validity == shape.has_value_validity &&
       !getenv("AMDARROW_GROUPBY_PATH") && !getenv("AMDARROW_GROUPBY_NO_HINT")) {
-    if (++hint.uses % 16 != 0) { path = 2; hinted = true; }
+    int every = kHintProbeEvery;
+    if (const char* env = getenv("AMDARROW_GROUPBY_PROBE_EVERY")) every = std::max(2, atoi(env));
+    if (++hint.uses % every != 0) { path = 2; hinted = true; }
   }
   // Compact records (k_part_scatter_compact): a hinted call whose predecessor's selected keys spanned few enough
   // values carries 12-byte records, 8-byte ones if that call's (integer) values were all int32; the kernel checks
@@ -3946,7 +4005,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
       // room for a key of up to ~0.25 % of the rows next to the uniform share (hotter keys are taken out before the scatter)
       cap = (static_cast<int64_t>(mean * 2.0 + 8.0 * std::sqrt(mean) + 32.0) + 7) & ~int64_t(7);  // whole 128-byte lines
       compact = compact_rw != 0 && hinted && path == 2 && nsub == 1 && rows_per_block <= (int64_t(1) << kCRowBits);
-      if (compact) cap = ((cap * compact_rw + 3) / 4 + 7) & ~int64_t(7);  // the same number of records, in 16-byte units
+      if (compact) cap = (((cap * compact_rw + 3) / 4 + 7) & ~int64_t(7)) + kCSpillUnits;  // the same number of records in 16-byte units, + room at the top for the records that found their bin full
       hist_n = int64_t(kP) * (nblocks + (use_bins ? 1 : 0));  // bins: one more segment per partition, the spill list
     } else if (path == 1) {
       nblocks = static_cast<int>(std::min<int64_t>(ctx->num_cus, (n + kPartRows - 1) / kPartRows));

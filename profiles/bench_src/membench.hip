@@ -23,7 +23,7 @@ struct Args {
 
 // MODE bits: 1 = loads, 2 = stores; CYCLIC: tile t of workgroup w is global tile t * nblocks + w;
 // SECT: bytes per partition write (64 or 128); NT: nontemporal loads / stores
-template <int MODE, bool CYCLIC, int SECT, bool NTL, bool NTS, int DEPTH>
+template <int MODE, bool CYCLIC, int SECT, bool NTL, bool NTS, int DEPTH, int PMUL = 1>
 __global__ __launch_bounds__(kThreads) void k_mem(Args a) {
   const int tid = threadIdx.x;
   const int64_t ntiles_total = a.n / kRows;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kThreads) void k_mem(Args a) {
         // partition gets SECT bytes each `period` tiles so that the bytes per tile stay 32 KB
         constexpr int L = SECT / 16;
         constexpr int rounds = kP / (kThreads / L);      // rounds to cover all partitions once
-        constexpr int period = SECT / 64;                // tiles between two writes of a partition
+        constexpr int period = SECT / 64 * PMUL;         // tiles between two writes of a partition (PMUL = 2: half the bytes, the 8-byte records)
         if ((tt % period) == 0) {
 #pragma unroll
           for (int h = 0; h < rounds; ++h) {
@@ -272,6 +272,18 @@ int main() {
     }
   }
   RUN("read  blocked nt depth3", 1, false, 64, true, true, 3);
+#define RUNH(NAME, CYC, NTS, PMUL)                                                                                     \
+  do {                                                                                                                 \
+    float us = TimeIt([&] { hipLaunchKernelGGL((k_mem<3, CYC, 128, true, NTS, 3, PMUL>), dim3(nblocks), dim3(kThreads), 0, 0, a); }, 5); \
+    printf("%-44s %8.1f us  %6.2f TB/s\n", NAME, us, (rd + wr / PMUL) / us / 1e6);                                   \
+  } while (0)
+  // the compact records: the same input next to half (8-byte records) / a quarter of the region bytes
+  RUNH("copy  blocked nt / 128B nt, write x 1", false, true, 1);
+  RUNH("copy  blocked nt / 128B nt, write x 1/2", false, true, 2);
+  RUNH("copy  blocked nt / 128B plain, write x 1/2", false, false, 2);
+  RUNH("copy  cyclic nt / 128B nt, write x 1/2", true, true, 2);
+  RUNH("copy  blocked nt / 128B nt, write x 1/4", false, true, 4);
+  if (getenv("MEMBENCH_SHORT")) return 0;
   RUN("read  cyclic  nt depth3", 1, true, 64, true, true, 3);
   RUN("read  cyclic  plain depth3", 1, true, 64, false, true, 3);
   RUN("read  blocked plain depth3", 1, false, 64, false, true, 3);

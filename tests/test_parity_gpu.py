@@ -898,11 +898,12 @@ def test_sort_hybrid_windows_match_oracle(gpu, oracle, t, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_filter_groupby_path_hint_follows_the_data(gpu, oracle):
+def test_filter_groupby_path_hint_follows_the_data(gpu, oracle, monkeypatch):
     """Calls of one shape in a row: many spread-out groups (the hint is learnt and the next calls start
     at the partition path), then the same shape with a heavy hitter (the hinted path overflows its
     regions and the call starts over), then few groups (local path), then spread-out again.  Every
     call returns the reference's rows; 20 calls in a row cross the periodic re-probe."""
+    monkeypatch.setenv("AMDARROW_GROUPBY_PROBE_EVERY", "16")  # (default: every 64th hinted call)
     rng = np.random.default_rng(77)
     n = 2_000_000
 
