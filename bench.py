@@ -33,6 +33,7 @@ from arrow1_amd import _abi, compute, device  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 SEED = 0x0ff1ce         # kRandomSeed, compute/kernels/test_util.h:123
 
+VALUE_RANGE = "small"
 NUM_GROUPS = 1_000_000  # --groups
 NUM_CHUNKS = 1  # --chunks (sort workloads)
 HOT_FRAC = 0.0  # --hot-frac (headline workload: this share of the rows carries ONE key)
@@ -74,7 +75,10 @@ def make_inputs(workload, n, dev, rank, sel):
     gen.manual_seed(SEED + rank)
     d = {}
     if workload in ("filter_groupby_sum_i64",):
-        vals = torch.randint(-100, 101, (n,), dtype=torch.int64, device=dev, generator=gen)
+        if VALUE_RANGE == "full":  # int64 values over the whole 64-bit range (12-byte compact records instead of 8-byte ones)
+            vals = torch.randint(-2**63, 2**63 - 1, (n,), dtype=torch.int64, device=dev, generator=gen)
+        else:  # int64 uniform in [-100, 100]
+            vals = torch.randint(-100, 101, (n,), dtype=torch.int64, device=dev, generator=gen)
         kdt, kid = (torch.int64, _abi.INT64) if KEY_BITS == 64 else (torch.int32, _abi.INT32)
         keys = torch.randint(0, NUM_GROUPS, (n,), dtype=kdt, device=dev, generator=gen)
         if HOT_FRAC > 0:  # a heavy hitter among many distinct keys (skew)
@@ -328,11 +332,32 @@ def pmc_traffic(workload):
     total_kb = 0.0
     for line in open(path):
         parts = line.split()
-        if parts[:1] == ["PER_STEP_TOTAL"]:  # FETCH_SIZE and WRITE_SIZE, all kernels of one step
+        if parts[:1] == ["PER_STEP_STEADY"]:  # FETCH_SIZE and WRITE_SIZE, the kernels of a steady-state step
             total_kb += float(parts[2])
     if total_kb == 0.0:
         return None, None
     return total_kb * 1024.0, os.path.relpath(path, ROOT)
+
+
+def dominant_kernel(workload, algorithmic_bytes):
+    """The op's longest kernel in the committed `rocprofv3 --kernel-trace --stats` summary of this command
+    (profiles/rNN_<workload>_kernel_stats.csv): name, average duration, and the algorithmic bytes of a step over that
+    duration alone (the op's other kernels not counted -- `frac` above counts the whole step)."""
+    import csv
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s_kernel_stats.csv" % workload)))
+    if not found:
+        return None
+    best = None
+    for r in csv.DictReader(open(found[-1])):
+        if "amdarrow::" in r["Name"] and int(r["Calls"]) >= 5 and (best is None or float(r["AverageNs"]) > float(best["AverageNs"])):
+            best = r
+    if best is None:
+        return None
+    us = float(best["AverageNs"]) / 1e3
+    gbps = algorithmic_bytes / (us * 1e-6) / 1e9
+    return {"name": best["Name"].split("(")[0].replace("void ", ""), "avg_us": us, "achieved": gbps, "frac": gbps / HBM_PEAK_GBPS,
+            "source": os.path.relpath(found[-1], ROOT)}
 
 
 def main():
@@ -348,9 +373,12 @@ def main():
     ap.add_argument("--key-bits", type=int, default=32, choices=[32, 64], help="headline workload: width of the key column")
     ap.add_argument("--wide-keys", action="store_true", help="distinct keys spread over the whole range of the key type (64-bit: the wide-key path; 32-bit: hashed partition tables)")
     ap.add_argument("--chunks", type=int, default=1, help="sort workloads: present the rows as this many equal chunks")
+    ap.add_argument("--value-range", default="small", choices=["small", "full"],
+                    help="headline workload: int64 values uniform in [-100, 100] (SURVEY 8d) or over the whole 64-bit range")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
-    global NUM_GROUPS, NUM_CHUNKS, KEY_BITS, HOT_FRAC, WIDE_KEYS
+    global NUM_GROUPS, NUM_CHUNKS, KEY_BITS, HOT_FRAC, WIDE_KEYS, VALUE_RANGE
+    VALUE_RANGE = args.value_range
     WIDE_KEYS = args.wide_keys
     HOT_FRAC = args.hot_frac
     KEY_BITS = args.key_bits
@@ -422,12 +450,24 @@ def main():
                          "note": "algorithmic %.3f B/row x %d rows / HIP-event time per step (%.3f ms) on the kernel stream; "
                                  "whole step (all kernels of the op), rank 0" % (bpr, n, step_s * 1e3)},
         }
+        headline_default = (args.workload == "filter_groupby_sum_i64" and n == 100_000_000 and NUM_GROUPS == 1_000_000 and sel == 0.5
+                            and VALUE_RANGE == "small" and KEY_BITS == 32 and not WIDE_KEYS and HOT_FRAC == 0.0)
         traffic, src = pmc_traffic(args.workload)
-        if traffic is not None and n == 100_000_000 and NUM_GROUPS == 1_000_000 and sel == 0.5:
+        if traffic is not None and headline_default:
             out["roofline"]["traffic"] = traffic
-            out["roofline"]["note"] += "; traffic = FETCH_SIZE + WRITE_SIZE bytes per step over all kernels of the op, from %s" % src
+            out["roofline"]["note"] += "; traffic = FETCH_SIZE + WRITE_SIZE bytes per steady-state step over all kernels of the op, from %s" % src
+        if headline_default:
+            dom = dominant_kernel(args.workload, bpr * n)
+            if dom:
+                out["roofline"]["dominant_kernel"] = dom
         if hasattr(res, "num_groups"):
             out["config"]["result_groups"] = int(res.num_groups)
+        if args.workload in ("filter_groupby_sum_i64", "hash_agg_f64", "groupby_2key_i64"):
+            import ctypes as C
+            gp, gw = C.c_int(-1), C.c_int(-1)
+            ctx.lib.amdarrow_groupby_last_path(ctx.handle, C.byref(gp), C.byref(gw))
+            out["config"]["groupby_path"] = {3: "per-workgroup LDS pre-aggregation", 2: "one-pass partition", 1: "two-pass partition",
+                                             0: "global table"}.get(gp.value, "?") + (", %d-byte records" % (4 * gw.value) if gw.value else "")
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.workload, sel)

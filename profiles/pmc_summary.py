@@ -26,3 +26,10 @@ for d in sys.argv[1:]:
         print("%-72s %-11s avg %12.1f KB (n=%d)%s" % (name, c, kb / len(v), len(v), "  [x2 applied]" if scale == 2.0 else ""))
     if counter and steps:
         print("PER_STEP_TOTAL %s %.1f KB over %d steps" % (counter, grand / steps, steps))
+        # a steady-state step: the kernels that run in at least half of the steps, each with its average bytes (the
+        # group-by's first call of a shape runs other kernels -- it learns the hint the later calls start from)
+        steady = 0.0
+        for (name, c), v in acc.items():
+            if 2 * len(v) >= steps:
+                steady += sum(v) * (2.0 if c == "FETCH_SIZE" else 1.0) / len(v) * max(1, round(len(v) / steps))
+        print("PER_STEP_STEADY %s %.1f KB (kernels present in >= half of the %d steps)" % (counter, steady, steps))
