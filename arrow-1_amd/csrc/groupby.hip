@@ -1389,9 +1389,12 @@ constexpr int kBThreads = 1024;
 // status[0]: why a partitioned attempt failed
 constexpr unsigned int kOverflowRegion = 1;  // a (workgroup, partition) region was too small: the exact two-pass variant helps
 constexpr unsigned int kOverflowTable = 2;   // a partition holds more groups than LDS slots: only the generic table helps
+constexpr int kCSpillUnits = 32;  // records per (workgroup, partition) region that may find their bin full, see below
 struct BinShared {
   unsigned int cnt[kP];  // records in the bin (runs past kBinSlots while a tile is ranked: the excess was spilled)
-  uint32_t cur[kP];      // records of this workgroup's region already written (a multiple of 4)
+  uint32_t cur[kP];      // records of this workgroup's region already written (a multiple of 8)
+  uint32_t list[kP];     // per wave (32 entries each): the partitions with a line to flush, see BinFlush
+  unsigned int spill[kP];  // records of this workgroup that found their bin full (they sit at the top of the region)
   uint4 bin[kP * kBinSlots];
 };
 // A bin is four 64-byte sectors; sector s of bin p lives at physical sector s ^ (p & 2 ? 3 : 0).  The flush
@@ -1544,47 +1547,82 @@ __device__ __forceinline__ void BinStageTile(BinShared& sh, const FastArgs& a, c
     q.z = static_cast<uint32_t>(v); q.w = static_cast<uint32_t>(v >> 32);
     if (slot[j] < static_cast<uint32_t>(kBinSlots)) {
       sh.bin[BinIndex(part[j], slot[j])] = q;
-    } else {  // the bin is full until the next flush: the partition's spill list takes the record
-      const uint32_t at = atomicAdd(&counts[int64_t(part[j]) * (a.nblocks + 1) + a.nblocks], 1u);
-      if (at < cap) regions[(int64_t(a.nblocks) * kP + part[j]) * cap + at] = q;
+    } else {  // the bin is full until the next flush: the record goes to the top of the region (LDS counter, no device atomic)
+      const uint32_t at = atomicAdd(&sh.spill[part[j]], 1u);
+      if (at < static_cast<uint32_t>(kCSpillUnits)) regions[(int64_t(blockIdx.x) * kP + part[j]) * cap + (cap - 1 - at)] = q;
       else __hip_atomic_store(overflow, kOverflowRegion, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
 
-// Flush: eight lanes per partition; whole 128-byte lines (kBinUnit records) leave, the rest moves to the
-// front of the bin.  Measured with the kernel's access pattern and no LDS work at all (exp/membench.hip): the
-// input stream next to 64-byte region writes runs at 4.7 TB/s, next to 128-byte writes at 6.0 TB/s.
+// Flush: whole 128-byte lines (kBinUnit records) leave, the rest moves to the front of the bin.  Measured with the
+// kernel's access pattern and no LDS work at all (exp/membench.hip): the input stream next to 64-byte region writes
+// runs at 4.7 TB/s, next to 128-byte writes at 6.0 TB/s.  A wave owns 32 partitions: one lane per partition decides,
+// the partitions with a line to go are compacted into a wave-private list, eight lanes per listed partition copy
+// (see CBinFlush, where this scheme was measured against eight lanes per partition deciding in four rounds).
 constexpr int kBinUnit = 8;
 __device__ __forceinline__ void BinFlush(BinShared& sh, int tid, int64_t cap, uint4* __restrict__ my_regions,
                                          unsigned int* overflow) {
   using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
-  const uint32_t ll = tid & (kBinUnit - 1);
-#pragma unroll
-  for (int round = 0; round < kP / (kBThreads / kBinUnit); ++round) {
-    const uint32_t p = (tid / kBinUnit) + round * (kBThreads / kBinUnit);
-    const uint32_t raw = sh.cnt[p];
+  constexpr int kPerWave = kP / (kBThreads / 64);
+  static_assert(kPerWave == 32 && kBinSlots == 2 * kBinUnit, "one lane of the low half per partition; two lines per bin");
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint32_t nl = 0, entry = 0;
+  if (lane < kPerWave) {
+    const uint32_t p = wave * kPerWave + lane;
+    const uint32_t raw = sh.cnt[p], cur = sh.cur[p];
     const uint32_t c = raw < static_cast<uint32_t>(kBinSlots) ? raw : static_cast<uint32_t>(kBinSlots);
-    const uint32_t nfull = c & ~uint32_t(kBinUnit - 1), left = c & uint32_t(kBinUnit - 1);
-    const uint32_t cur = sh.cur[p];
-    const bool ok = cur + nfull <= cap;
-    uint4* dst = my_regions + int64_t(p) * cap + cur + ll;
-#pragma unroll
-    for (uint32_t s = 0; s < kBinSlots / kBinUnit; ++s) {
-      if (kBinUnit * s < nfull && ok) {
-        const uint4 q = sh.bin[BinIndex(p, kBinUnit * s + ll)];
-        const u32x4 v = {q.x, q.y, q.z, q.w};
-        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + kBinUnit * s));
+    nl = c / kBinUnit;
+    const uint32_t left = c & uint32_t(kBinUnit - 1);
+    if (nl > 0) {
+      sh.cnt[p] = left;
+      if (cur + kBinUnit * nl <= cap - kCSpillUnits) {
+        sh.cur[p] = cur + kBinUnit * nl;
+        entry = p | nl << 9 | left << 11 | (cur >> 3) << 16;
+      } else {
+        nl = 0;
+        __hip_atomic_store(overflow, kOverflowRegion, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    uint4 keep;
-    const bool move = nfull > 0 && ll < left;  // (nfull == 8 here: a full bin leaves nothing behind)
-    if (move) keep = sh.bin[BinIndex(p, nfull + ll)];
-    if (move) sh.bin[BinIndex(p, ll)] = keep;  // (LDS operations of one wave execute in order: every read above is done)
-    if (ll == 0 && nfull > 0) {
-      sh.cnt[p] = left;
-      if (ok) sh.cur[p] = cur + nfull;
-      else __hip_atomic_store(overflow, kOverflowRegion, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const uint64_t going = __ballot(nl > 0);
+  const int count = __popcll(going);
+  if (nl > 0) sh.list[wave * kPerWave + __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(going), 0u)] = entry;
+  const uint32_t ll = lane & 7;
+  const int trips = (count + 7) >> 3;  // (wave-uniform)
+  constexpr int kTrips = kPerWave / 8;
+  uint32_t e[kTrips];
+#pragma unroll
+  for (int t = 0; t < kTrips; ++t) {
+    e[t] = 0;
+    if (t < trips) {
+      const int k = 8 * t + (lane >> 3);
+      if (k < count) e[t] = sh.list[wave * kPerWave + k];
+    }
+  }
+  uint4 lo[kTrips], hi[kTrips];
+#pragma unroll
+  for (int t = 0; t < kTrips; ++t) {
+    if (t < trips && ((e[t] >> 9) & 3u) != 0) {
+      const uint32_t p = e[t] & (kP - 1);
+      lo[t] = sh.bin[BinIndex(p, ll)];
+      hi[t] = sh.bin[BinIndex(p, kBinUnit + ll)];  // the second line, or the records that move to the front
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < kTrips; ++t) {
+    const uint32_t lines = (e[t] >> 9) & 3u;
+    if (t < trips && lines != 0) {
+      const uint32_t p = e[t] & (kP - 1), left = (e[t] >> 11) & 31u, cur = (e[t] >> 16) << 3;
+      uint4* dst = my_regions + int64_t(p) * cap + cur + ll;
+      const u32x4 v = {lo[t].x, lo[t].y, lo[t].z, lo[t].w};
+      __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst));
+      if (lines > 1) {
+        const u32x4 w = {hi[t].x, hi[t].y, hi[t].z, hi[t].w};
+        __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(dst + kBinUnit));
+      }
+      if (lines == 1 && ll < left) sh.bin[BinIndex(p, ll)] = hi[t];
     }
   }
 }
@@ -1611,18 +1649,17 @@ constexpr int kCBinStride = kCBinWords + 4;  // consecutive bins start four bank
 constexpr int kCRowBits = 19, kCSlotBits = 12;
 constexpr uint32_t kCValid = 1u << kCSlotBits;
 struct CBinShared {
-  unsigned int cnt[kP];  // low half: words in the bin (runs past kCBinWords while a tile is ranked: the excess was spilled); high half: words at the tile's start
+  unsigned int cnt[kP];  // low half: the stream's position in words, mod 2^16 (runs past what the bin holds while a tile is ranked: the excess was spilled); high half: the position at the tile's start
   uint32_t cur[kP];      // 16-byte units of this workgroup's region already written (a multiple of 8)
   uint32_t list[kP];     // per wave (32 entries each): the partitions with a line to flush, see CBinFlush
   unsigned int spill[kP];  // records of this workgroup that found their bin full (they sit at the top of the region)
   __attribute__((aligned(16))) uint32_t bin[kP * kCBinStride];
 };
 // A record that finds its bin full goes straight to the TOP of the workgroup's region for its partition, as a
-// 16-byte record {key word, row | flags, value}, growing downwards: its place comes from an LDS counter.  (The
-// 16-byte scatter hands such records to a per-partition list filled through a device atomic: the returning
-// atomic makes the wave wait for every load it has in flight -- two tiles -- and the workgroup waits for that
-// wave at the next barrier, ~1-2 us each time.)  kCSpillUnits records per region; more raise kOverflowRegion.
-constexpr int kCSpillUnits = 32;
+// 16-byte record {key word, row | flags, value}, growing downwards: its place comes from an LDS counter.  (Such
+// records used to go to a per-partition list filled through a device atomic: the returning atomic makes the wave
+// wait for every load it has in flight -- two tiles -- and the workgroup waits for that wave at the next barrier,
+// ~1-2 us each time.)  kCSpillUnits records per region; more raise kOverflowRegion.  Both bin scatters do this.
 template <bool MASK, bool VVALID, int R, bool K64, int RW>
 __device__ __forceinline__ void CBinStageTile(CBinShared& sh, const FastArgs& a, const BinTile<R, K64>& t, int64_t lo, int64_t tile0,
                                               int64_t hi, int tid, int64_t cap, uint4* __restrict__ my_regions,
@@ -1644,7 +1681,7 @@ __device__ __forceinline__ void CBinStageTile(CBinShared& sh, const FastArgs& a,
     off[j] = (kk >> kPBits) - a.c_base;
     at[j] = 0;
     if (sel[j]) {
-      at[j] = atomicAdd(&sh.cnt[part[j]], static_cast<unsigned int>(RW)) & 0xFFFFu;
+      at[j] = atomicAdd(&sh.cnt[part[j]], static_cast<unsigned int>(RW));  // (stream position | position at the tile's start << 16)
       kmin = kk < kmin ? kk : kmin;
       kmax = kk > kmax ? kk : kmax;
       bad |= off[j] >> kCSlotBits;  // (a key below c_base wraps around to a large offset)
@@ -1657,11 +1694,14 @@ __device__ __forceinline__ void CBinStageTile(CBinShared& sh, const FastArgs& a,
     const uint64_t v = vvalid ? t.v(j) : 0;
     if (RW == 2) bad |= static_cast<uint32_t>((v + 0x80000000ull) >> 32);
     else if (a.val_wide) vwide |= static_cast<uint32_t>((v + 0x80000000ull) >> 32);  // (could the next call carry 32-bit values?)
-    if (at[j] + RW <= static_cast<uint32_t>(kCBinWords)) {
-      uint32_t* w = &sh.bin[part[j] * kCBinStride + at[j]];
-      w[0] = static_cast<uint32_t>(r0 + j - lo) << (kCSlotBits + 1) | (vvalid ? kCValid : 0u) | (off[j] & (kCValid - 1u));
-      w[1] = static_cast<uint32_t>(v);
-      if (RW == 3) w[2] = static_cast<uint32_t>(v >> 32);
+    // the bin is a ring of kCBinWords words: the stream's words [flushed, flushed + 64) live at their position mod 64,
+    // `flushed` being the last whole line before the tile's start (a flush leaves less than a line behind)
+    const uint32_t pos = at[j] & 0xFFFFu, flushed = (at[j] >> 16) & ~31u;
+    if (((pos - flushed) & 0xFFFFu) + RW <= static_cast<uint32_t>(kCBinWords)) {
+      uint32_t* bin = &sh.bin[part[j] * kCBinStride];
+      bin[pos & (kCBinWords - 1)] = static_cast<uint32_t>(r0 + j - lo) << (kCSlotBits + 1) | (vvalid ? kCValid : 0u) | (off[j] & (kCValid - 1u));
+      bin[(pos + 1) & (kCBinWords - 1)] = static_cast<uint32_t>(v);
+      if (RW == 3) bin[(pos + 2) & (kCBinWords - 1)] = static_cast<uint32_t>(v >> 32);
     } else {  // the bin is full until the next flush: the spill list takes the row as a 16-byte record
       uint4 q;
       q.x = t.key.k(j, a.k_bias);
@@ -1673,13 +1713,15 @@ __device__ __forceinline__ void CBinStageTile(CBinShared& sh, const FastArgs& a,
     }
   }
 }
-// Flush: the stream's whole 128-byte lines leave, the words behind them move to the front.  A wave owns 32
-// partitions.  ONE lane per partition decides (counter read, clamp, lines to go, new counter) -- with eight lanes
-// per partition doing that in four rounds the flush logic was a third of the kernel (116 of 372 us; the global
-// stores it feeds: 10 us) -- and the partitions with a line to go (a quarter to a third of them per tile) are
-// compacted into a wave-private list; eight lanes per listed partition then copy its line (16 bytes each) and
-// move the rest to the front, eight partitions per trip.  Everything stays inside the wave: LDS operations of
-// one wave execute in order, no barrier between the steps.
+// Flush: the stream's whole 128-byte lines leave; what is behind them stays where it is (the bin is a ring).  A wave
+// owns 32 partitions.  ONE lane per partition decides (counter read, clamp, lines to go, new counter) -- with eight
+// lanes per partition doing that in four rounds the flush logic was a third of the kernel (116 of 372 us; the
+// global stores it feeds: 10 us) -- and the partitions with a line to go (a quarter to a third of them per tile)
+// are compacted into a wave-private list; eight lanes per listed partition then copy its line (16 bytes each),
+// eight partitions per trip.  Everything stays inside the wave: LDS operations of one wave execute in order, no
+// barrier between the steps.  (Bins that were refilled from the front after each flush paid a second 128-byte
+// LDS read and a write per flushed line to move the rest there: 163 us of LDS time per 100 M rows with 12-byte
+// records, the stores themselves 25.)
 template <int RW>
 __device__ __forceinline__ void CBinFlush(CBinShared& sh, int tid, int64_t cap, uint4* __restrict__ my_regions,
                                           unsigned int* overflow) {
@@ -1692,16 +1734,17 @@ __device__ __forceinline__ void CBinFlush(CBinShared& sh, int tid, int64_t cap, 
   if (lane < kPerWave) {
     const uint32_t p = wave * kPerWave + lane;
     const uint32_t raw = sh.cnt[p], cur = sh.cur[p];
-    const uint32_t start = raw >> 16, fill = raw & 0xFFFFu;
+    const uint32_t start = raw >> 16, flushed = start & ~31u, had = start - flushed;  // (had < 32)
+    const uint32_t came = (raw - start) & 0xFFFFu;  // words of the tile's arrivals, accepted or not
     // (arrivals were accepted while their last word still fitted)
-    const uint32_t end = fill <= static_cast<uint32_t>(kCBinWords) ? fill : start + ((kCBinWords - start) / RW) * RW;
-    nl = end >> 5;
-    const uint32_t rest = nl > 0 ? (end & 31u) : end;
-    sh.cnt[p] = rest << 16 | rest;  // words now in the bin, in both halves (the next tile's arrivals start there)
+    const uint32_t took = had + came <= static_cast<uint32_t>(kCBinWords) ? came : ((kCBinWords - had) / RW) * RW;
+    const uint32_t now = (start + took) & (kCBinWords - 1);  // (positions restart inside the ring: the counter's low half never carries into the high one)
+    nl = (had + took) >> 5;
+    sh.cnt[p] = now << 16 | now;  // the stream's position, in both halves (the next tile's arrivals start there)
     if (nl > 0) {
       if (cur + 8 * nl <= cap - kCSpillUnits) {
         sh.cur[p] = cur + 8 * nl;
-        entry = p | nl << 9 | rest << 11 | (cur >> 3) << 16;
+        entry = p | nl << 9 | ((flushed >> 5) & 1u) << 11 | (cur >> 3) << 16;
       } else {
         nl = 0;
         __hip_atomic_store(overflow, kOverflowRegion, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1729,17 +1772,19 @@ __device__ __forceinline__ void CBinFlush(CBinShared& sh, int tid, int64_t cap, 
   uint4 lo[kTrips], hi[kTrips];
 #pragma unroll
   for (int t = 0; t < kTrips; ++t) {
-    if (t < trips && ((e[t] >> 9) & 3u) != 0) {
+    const uint32_t lines = (e[t] >> 9) & 3u;
+    if (t < trips && lines != 0) {
       const uint32_t* bin = &sh.bin[(e[t] & (kP - 1)) * kCBinStride];
-      lo[t] = *reinterpret_cast<const uint4*>(&bin[4 * ll]);
-      hi[t] = *reinterpret_cast<const uint4*>(&bin[32 + 4 * ll]);  // the second line, or the words that move to the front
+      const uint32_t first = ((e[t] >> 11) & 1u) << 5;  // the ring's half that holds the oldest line
+      lo[t] = *reinterpret_cast<const uint4*>(&bin[first + 4 * ll]);
+      if (lines > 1) hi[t] = *reinterpret_cast<const uint4*>(&bin[(first ^ 32u) + 4 * ll]);
     }
   }
 #pragma unroll
   for (int t = 0; t < kTrips; ++t) {
     const uint32_t lines = (e[t] >> 9) & 3u;
     if (t < trips && lines != 0) {
-      const uint32_t p = e[t] & (kP - 1), rest = (e[t] >> 11) & 31u, cur = (e[t] >> 16) << 3;
+      const uint32_t p = e[t] & (kP - 1), cur = (e[t] >> 16) << 3;
       uint4* dst = my_regions + int64_t(p) * cap + cur + ll;
       const u32x4 v = {lo[t].x, lo[t].y, lo[t].z, lo[t].w};
       __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst));
@@ -1747,7 +1792,6 @@ __device__ __forceinline__ void CBinFlush(CBinShared& sh, int tid, int64_t cap, 
         const u32x4 w = {hi[t].x, hi[t].y, hi[t].z, hi[t].w};
         __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(dst + 8));
       }
-      if (lines == 1 && 4 * ll < rest) *reinterpret_cast<uint4*>(&sh.bin[p * kCBinStride + 4 * ll]) = hi[t];
     }
   }
 }
@@ -1843,7 +1887,7 @@ __global__ __launch_bounds__(kBThreads) void k_part_scatter_bins(FastArgs a, int
   __shared__ BinShared sh;
   __shared__ unsigned int s_sample, s_kmin, s_kmax;
   const int tid = threadIdx.x;
-  if (tid < kP) { sh.cnt[tid] = 0; sh.cur[tid] = 0; }
+  if (tid < kP) { sh.cnt[tid] = 0; sh.cur[tid] = 0; sh.spill[tid] = 0; }
   if (tid == 0) { s_sample = 0; s_kmin = 0xFFFFFFFFu; s_kmax = 0; }
   __syncthreads();
   const int64_t lo = int64_t(blockIdx.x) * a.rows_per_block;
@@ -1880,15 +1924,15 @@ __global__ __launch_bounds__(kBThreads) void k_part_scatter_bins(FastArgs a, int
   if (tid == 0 && s_kmin <= s_kmax) { atomicMin(&a.key_minmax[0], s_kmin); atomicMax(&a.key_minmax[1], s_kmax); }
   if (tid < kP) {
     // what is left of every partition's last line, and the region fills
-    const uint32_t left = sh.cnt[tid], cur = sh.cur[tid];  // left < kBinUnit after a flush
-    const bool ok = cur + left <= cap;
+    const uint32_t left = sh.cnt[tid], cur = sh.cur[tid], spilled = sh.spill[tid];  // left < kBinUnit after a flush
+    const bool ok = cur + left <= cap - kCSpillUnits && spilled <= static_cast<uint32_t>(kCSpillUnits);
     if (ok) {
       uint4* dst = my_regions + int64_t(tid) * cap + cur;
       for (uint32_t k = 0; k < left; ++k) dst[k] = sh.bin[BinIndex(tid, k)];
     } else {
       __hip_atomic_store(overflow, kOverflowRegion, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    counts[int64_t(tid) * (a.nblocks + 1) + blockIdx.x] = ok ? cur + left : 0;
+    counts[int64_t(tid) * (a.nblocks + 1) + blockIdx.x] = ok ? (cur + left) | spilled << 24 : 0;  // (records | records at the region's top << 24)
   }
 }
 
@@ -1940,12 +1984,13 @@ __global__ __launch_bounds__(kBThreads) void k_part_scatter_compact(FastArgs a, 
   __syncthreads();
   if (tid == 0 && s_kmin <= s_kmax) { atomicMin(&a.key_minmax[0], s_kmin); atomicMax(&a.key_minmax[1], s_kmax); }
   if (tid < kP) {
-    // what is left of every partition's stream (< 32 words after a flush), and the region fills
-    const uint32_t left = sh.cnt[tid] & 0xFFFFu, cur = sh.cur[tid], spilled = sh.spill[tid];
+    // what is left of every partition's stream (< 32 words after a flush, behind the last whole line), and the region fills
+    const uint32_t now = sh.cnt[tid] & 0xFFFFu, left = now & 31u, from = (now & ~31u) & (kCBinWords - 1);
+    const uint32_t cur = sh.cur[tid], spilled = sh.spill[tid];
     const bool ok = 4 * cur + left <= 4 * (cap - kCSpillUnits) && spilled <= static_cast<uint32_t>(kCSpillUnits);
     if (ok) {
       uint32_t* dst = reinterpret_cast<uint32_t*>(my_regions + int64_t(tid) * cap + cur);
-      for (uint32_t k = 0; k < left; ++k) dst[k] = sh.bin[tid * kCBinStride + k];
+      for (uint32_t k = 0; k < left; ++k) dst[k] = sh.bin[tid * kCBinStride + from + k];
     } else {
       __hip_atomic_store(overflow, kOverflowRegion, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -2276,10 +2321,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_piped(const uin
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform values stay in scalar registers: uniform loop control)
   const int p = blockIdx.x;
   constexpr int kWaves = kPartThreads / 64;
-  for (int b = tid; b < nblocks; b += kPartThreads) {
-    const uint32_t c = counts[int64_t(p) * nblocks + b];
-    s_fill[b] = c > cap ? static_cast<uint32_t>(cap) : c;  // (a spill list that overflowed; the attempt is abandoned anyway)
-  }
+  for (int b = tid; b < nblocks; b += kPartThreads) s_fill[b] = counts[int64_t(p) * nblocks + b];  // records | records at the region's top << 24
   for (int s = tid; s < kSlots + 2; s += kPartThreads) { s_tag[s] = kTagFree; s_sum[s] = 0; s_first[s] = kNoRow; s_cnt[s] = 0; }
   if (tid == 0) { s_groups = 0; s_abort = 0; }
   // Keys of a small range (key >> 9 spans at most kSlots values): the slot IS (key >> 9) - base, no tags, no
@@ -2305,7 +2347,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_piped(const uin
       it.i0 += kAggStep;
       if (it.i0 >= it.cnt) {
         it.i0 = 0;
-        do { ++it.k; it.cnt = it.k < nseg ? __builtin_amdgcn_readfirstlane(s_fill[wave + kWaves * it.k]) : 0u; } while (it.k < nseg && it.cnt == 0);
+        do { ++it.k; it.cnt = it.k < nseg ? __builtin_amdgcn_readfirstlane(s_fill[wave + kWaves * it.k]) & 0xFFFFFFu : 0u; } while (it.k < nseg && it.cnt == 0);
       }
       return it;
     };
@@ -2352,6 +2394,35 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_piped(const uin
         }
         break;
       }
+    }
+  }
+  // the records that found their bin full: at the top of each region, a few per region at most
+  for (int b = wave; b < nblocks && !aborted(); b += kWaves) {
+    const uint32_t ns = __builtin_amdgcn_readfirstlane(s_fill[b]) >> 24;
+    if (ns == 0) continue;
+    const uint4* top = regions + (int64_t(b) * kP + p) * cap + (cap - 1);
+    uint4 one[1];
+    bool live1[1];
+    live1[0] = static_cast<uint32_t>(lane) < ns;
+    one[0] = live1[0] ? *(top - lane) : make_uint4(0, 0, 0, 0);
+    bool ok1 = true;
+    if (direct) {
+      if (live1[0]) {
+        const uint32_t slot = DirectSlot(((one[0].x ^ k_flip) >> kPBits) - dbase);
+        atomicMin(&s_first[slot], one[0].y & kRecRowMask);
+        if (one[0].y & kRecValValid) {
+          const unsigned long long bits = (static_cast<unsigned long long>(one[0].w) << 32) | one[0].z;
+          if (acc_double) atomicAdd(reinterpret_cast<double*>(&s_sum[slot]), __longlong_as_double(bits));
+          else atomicAdd(&s_sum[slot], bits);
+          atomicAdd(&s_cnt[slot], 1u);
+        }
+      }
+    } else {
+      ok1 = AggFold(one, live1, acc_double, s_tag, s_sum, s_first, s_cnt, &s_groups);
+    }
+    if (__any(!ok1) && lane == 0) {
+      __hip_atomic_store(&s_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(overflow, kOverflowTable, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   __syncthreads();
@@ -4005,7 +4076,8 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
       // room for a key of up to ~0.25 % of the rows next to the uniform share (hotter keys are taken out before the scatter)
       cap = (static_cast<int64_t>(mean * 2.0 + 8.0 * std::sqrt(mean) + 32.0) + 7) & ~int64_t(7);  // whole 128-byte lines
       compact = compact_rw != 0 && hinted && path == 2 && nsub == 1 && rows_per_block <= (int64_t(1) << kCRowBits);
-      if (compact) cap = (((cap * compact_rw + 3) / 4 + 7) & ~int64_t(7)) + kCSpillUnits;  // the same number of records in 16-byte units, + room at the top for the records that found their bin full
+      if (compact) cap = ((cap * compact_rw + 3) / 4 + 7) & ~int64_t(7);  // the same number of records, in 16-byte units
+      if (use_bins) cap += kCSpillUnits;  // room at the top of every region for the records that found their bin full
       hist_n = int64_t(kP) * (nblocks + (use_bins ? 1 : 0));  // bins: one more segment per partition, the spill list
     } else if (path == 1) {
       nblocks = static_cast<int>(std::min<int64_t>(ctx->num_cus, (n + kPartRows - 1) / kPartRows));
@@ -4155,7 +4227,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
           else
             hipLaunchKernelGGL(k_part_aggregate_compact<3>, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nblocks, cap,
                                acc_double, t, r.bitmap, misc, static_cast<int64_t>(T), c_base, fa.k_flip, static_cast<uint32_t>(rows_per_block));
-        } else if (use_bins && !getenv("AMDARROW_GROUPBY_OLD_AGG"))
+        } else if (use_bins)
           hipLaunchKernelGGL(k_part_aggregate_piped, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nseg,
                              cap, ks.total_bits, acc_double, t, r.bitmap, misc, run_if, int64_t(sub) * kP * kSlots,
                              sub == 0 ? static_cast<int64_t>(T) : int64_t(0), fa.key_minmax, fa.k_flip, use_hot);

@@ -349,6 +349,48 @@ def test_full_size_groupby_conservation(gpu, full):
         assert int(sums[g]) == int(full["vals"][rows].sum()) and int(counts[g]) == int(rows.sum())
 
 
+@pytest.mark.parametrize("shape", ["narrow-values-mask-50", "wide-values-mask-65", "wide-values-no-mask"])
+def test_full_size_groupby_compact_records_exact(full, shape):
+    """100 M rows, 1 M groups through the compact records (8-byte records: int32-ranged values, flush every other tile;
+    12-byte records with a 65 % mask: the densest input the 4096-row tiles take, so bins fill up and records go to the
+    region tops; 12-byte records without a mask: the 2048-row tiles): every group's sum, count and first row against
+    torch's own scatter reductions -- exact in int64 -- on the first call (16-byte records) and the two behind it."""
+    import torch
+    import bench
+    import gpu_api
+    from arrow1_amd import compute, device
+    gpu = gpu_api.GpuApi()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x0ff1ce + 5)
+    keys, keys_arr = full["keys"], full["keys_arr"]
+    if shape == "narrow-values-mask-50":
+        vals, values, ok_valid, mask, mask_arr, words = full["vals"], full["values"], _bits(full["valid"], N_FULL), full["mask"], full["mask_arr"], 2
+    else:
+        vals = torch.randint(-2**63, 2**63 - 1, (N_FULL,), dtype=torch.int64, device="cuda", generator=g)
+        values = device.DeviceArray(orc.INT64, vals.view(torch.uint8), None, N_FULL)
+        ok_valid = torch.ones(N_FULL, dtype=torch.bool, device="cuda")
+        mask = bench.device_bitmap(N_FULL, 0.65, g, "cuda") if shape == "wide-values-mask-65" else None
+        mask_arr = device.DeviceArray(orc.BOOL, mask, None, N_FULL) if mask is not None else None
+        words = 3
+    sel = _bits(mask, N_FULL) if mask is not None else torch.ones(N_FULL, dtype=torch.bool, device="cuda")
+    ok = sel & ok_valid
+    rows = torch.arange(N_FULL, device="cuda")
+    exp_sum = torch.zeros(1_000_000, dtype=torch.int64, device="cuda").index_add_(0, keys[ok].long(), vals[ok])
+    exp_cnt = torch.zeros(1_000_000, dtype=torch.int64, device="cuda").index_add_(0, keys[ok].long(), torch.ones_like(vals[ok]))
+    exp_first = torch.full((1_000_000,), N_FULL, dtype=torch.int64, device="cuda").scatter_reduce_(0, keys[sel].long(), rows[sel], "amin")
+    present = exp_first < N_FULL
+    for step in range(3):
+        r = compute.filter_groupby(gpu.ctx, values, keys_arr, mask_arr, group_capacity=1 << 21)
+        G = r.num_groups
+        assert _last_groupby_path(gpu) == (2, 4 if step == 0 else words), (shape, step)
+        assert G == int(present.sum())
+        k = r.keys[:G * 4].view(torch.int32).long()
+        assert torch.equal(r.sums[:G * 8].view(torch.int64), exp_sum[k]), (shape, step)
+        assert torch.equal(r.counts[:G * 8].view(torch.int64), exp_cnt[k]), (shape, step)
+        first = r.first_rows[:G * 4].view(torch.int32).to(torch.int64)
+        assert torch.equal(first, exp_first[k]) and bool((first[1:] > first[:-1]).all()), (shape, step)
+
+
 def test_full_size_sort_is_sorted_stable_permutation(gpu, full):
     import torch
     from arrow1_amd import compute, device
@@ -1374,7 +1416,7 @@ def test_hash_aggregates_large_batches_through_the_partitioned_groupby(gpu, orac
                         assert a.same(b), (fn, t, ng, vnp, mode)
 
 
-@pytest.mark.parametrize("knob", ["AMDARROW_GROUPBY_NO_BINS", "AMDARROW_GROUPBY_OLD_AGG", "AMDARROW_GROUPBY_OLD_LOCAL",
+@pytest.mark.parametrize("knob", ["AMDARROW_GROUPBY_NO_BINS", "AMDARROW_GROUPBY_OLD_LOCAL",
                                   "AMDARROW_GROUPBY_OLD_MERGE", "AMDARROW_GROUPER_HASHED_LOOKUP", "AMDARROW_GROUPER_GENERAL",
                                   "AMDARROW_HASH_ATOMICS", "AMDARROW_FILTER_EDGE_ATOMICS"])
 def test_round1_kernels_behind_the_knobs_still_agree(gpu, oracle, knob, monkeypatch):
