@@ -1644,27 +1644,48 @@ __device__ __forceinline__ void BinFlush(BinShared& sh, int tid, int64_t cap, ui
 // (32 words, records may straddle them) leave at a flush and the words behind them move to the bin's front.
 // A record that does not fit the bin goes to the spill list as a 16-byte record, as in the 16-byte scatter.
 constexpr unsigned int kOverflowCompact = 4;  // a selected row did not fit the compact record of a hinted call
-constexpr int kCBinWords = 64;
-constexpr int kCBinStride = kCBinWords + 4;  // consecutive bins start four banks apart
-constexpr int kCRowBits = 19, kCSlotBits = 12;
-constexpr uint32_t kCValid = 1u << kCSlotBits;
-struct CBinShared {
-  unsigned int cnt[kP];  // low half: the stream's position in words, mod 2^16 (runs past what the bin holds while a tile is ranked: the excess was spilled); high half: the position at the tile's start
-  uint32_t cur[kP];      // 16-byte units of this workgroup's region already written (a multiple of 8)
-  uint32_t list[kP];     // per wave (32 entries each): the partitions with a line to flush, see CBinFlush
-  unsigned int spill[kP];  // records of this workgroup that found their bin full (they sit at the top of the region)
-  __attribute__((aligned(16))) uint32_t bin[kP * kCBinStride];
+// Two geometries, PB = log2(partitions): 512 partitions with bins of 64 words (12 slot bits, 19 row bits; the
+// 8-byte records) or 256 partitions with bins of 128 words (13 slot bits, 18 row bits -- twice the workgroups --;
+// the 12-byte records: a bin of 64 words takes one tile's twelve words on average behind what a flush leaves, a
+// bin of 128 takes two tiles' 48, so the flush and its two barriers run every other tile and decide half as many
+// bins).  Both keep 2 M table slots (partitions x slots) and the same number and size of regions.
+template <int PB> struct CGeo {
+  static constexpr int kParts = 1 << PB;
+  static constexpr int kBinWords = PB == 9 ? 64 : 128;
+  static constexpr int kStride = kBinWords + 4;     // consecutive bins start four banks apart
+  static constexpr int kSlotBits = 21 - PB;         // 12 / 13: the partition's directly indexed table
+  static constexpr int kSlots = 1 << kSlotBits;
+  static constexpr int kRowBits = 31 - kSlotBits;   // 19 / 18: a workgroup's row range
+  static constexpr uint32_t kValid = 1u << kSlotBits;
+  static constexpr int kPerWave = kParts / (kBThreads / 64);  // 32 / 16 partitions per wave of the flush
+  static constexpr int kMaxLines = kBinWords / 32;  // 2 / 4 lines of 128 bytes per bin
+  static constexpr int kListPerWave = kPerWave * kMaxLines;  // 64
+  __device__ static __forceinline__ uint32_t PartOf(uint32_t kk) {
+    return (kk & (kParts - 1)) ^ (((kk >> PB) * 0x9E3779B1u) >> (32 - PB));
+  }
+  // offset o lives in slot bitreverse(o): a slice filled to a fraction holds its groups spread over all its slots
+  __device__ static __forceinline__ uint32_t Slot(uint32_t o) { return __brev(o) >> (32 - kSlotBits); }
+};
+static_assert(CGeo<9>::kSlots == kSlots && CGeo<9>::kParts == kP, "the 512-partition geometry is the 16-byte path's");
+template <int PB> struct CBinShared {
+  using G = CGeo<PB>;
+  unsigned int cnt[G::kParts];  // low half: the stream's position in words (runs past what the bin holds while a tile is ranked: the excess was spilled); high half: the position at the last flush
+  uint32_t cur[G::kParts];      // 16-byte units of this workgroup's region already written (a multiple of 8)
+  unsigned int spill[G::kParts];  // records of this workgroup that found their bin full (they sit at the top of the region)
+  uint32_t list[(kBThreads / 64) * G::kListPerWave];  // per wave: the lines to flush, see CBinFlush
+  __attribute__((aligned(16))) uint32_t bin[G::kParts * G::kStride];
 };
 // A record that finds its bin full goes straight to the TOP of the workgroup's region for its partition, as a
 // 16-byte record {key word, row | flags, value}, growing downwards: its place comes from an LDS counter.  (Such
 // records used to go to a per-partition list filled through a device atomic: the returning atomic makes the wave
 // wait for every load it has in flight -- two tiles -- and the workgroup waits for that wave at the next barrier,
 // ~1-2 us each time.)  kCSpillUnits records per region; more raise kOverflowRegion.  Both bin scatters do this.
-template <bool MASK, bool VVALID, int R, bool K64, int RW>
-__device__ __forceinline__ void CBinStageTile(CBinShared& sh, const FastArgs& a, const BinTile<R, K64>& t, int64_t lo, int64_t tile0,
+template <bool MASK, bool VVALID, int R, bool K64, int RW, int PB>
+__device__ __forceinline__ void CBinStageTile(CBinShared<PB>& sh, const FastArgs& a, const BinTile<R, K64>& t, int64_t lo, int64_t tile0,
                                               int64_t hi, int tid, int64_t cap, uint4* __restrict__ my_regions,
                                               unsigned int* overflow, uint32_t& kmin,
                                               uint32_t& kmax, uint32_t& vwide, uint32_t& bad) {
+  using G = CGeo<PB>;
   const int64_t r0 = tile0 + int64_t(tid) * R;
   const int64_t left = hi - r0;
   const uint32_t live = left >= R ? (1u << R) - 1u : (left > 0 ? (1u << left) - 1u : 0u);
@@ -1677,14 +1698,14 @@ __device__ __forceinline__ void CBinStageTile(CBinShared& sh, const FastArgs& a,
   for (int j = 0; j < R; ++j) {
     const uint32_t kk = t.key.k(j, a.k_bias) ^ a.k_flip;
     sel[j] = (mbits >> j) & 1u;
-    part[j] = BinPartOf(kk);
-    off[j] = (kk >> kPBits) - a.c_base;
+    part[j] = G::PartOf(kk);
+    off[j] = (kk >> PB) - a.c_base;
     at[j] = 0;
     if (sel[j]) {
-      at[j] = atomicAdd(&sh.cnt[part[j]], static_cast<unsigned int>(RW));  // (stream position | position at the tile's start << 16)
+      at[j] = atomicAdd(&sh.cnt[part[j]], static_cast<unsigned int>(RW));  // (stream position | position at the last flush << 16)
       kmin = kk < kmin ? kk : kmin;
       kmax = kk > kmax ? kk : kmax;
-      bad |= off[j] >> kCSlotBits;  // (a key below c_base wraps around to a large offset)
+      bad |= off[j] >> G::kSlotBits;  // (a key below c_base wraps around to a large offset)
     }
   }
 #pragma unroll
@@ -1694,15 +1715,16 @@ __device__ __forceinline__ void CBinStageTile(CBinShared& sh, const FastArgs& a,
     const uint64_t v = vvalid ? t.v(j) : 0;
     if (RW == 2) bad |= static_cast<uint32_t>((v + 0x80000000ull) >> 32);
     else if (a.val_wide) vwide |= static_cast<uint32_t>((v + 0x80000000ull) >> 32);  // (could the next call carry 32-bit values?)
-    // the bin is a ring of kCBinWords words: the stream's words [flushed, flushed + 64) live at their position mod 64,
-    // `flushed` being the last whole line before the tile's start (a flush leaves less than a line behind)
+    // the bin is a ring of kBinWords words: the stream's words [flushed, flushed + kBinWords) live at their position
+    // mod kBinWords, `flushed` being the last whole line before the position at the last flush (a flush leaves
+    // less than a line behind)
     const uint32_t pos = at[j] & 0xFFFFu, flushed = (at[j] >> 16) & ~31u;
-    if (((pos - flushed) & 0xFFFFu) + RW <= static_cast<uint32_t>(kCBinWords)) {
-      uint32_t* bin = &sh.bin[part[j] * kCBinStride];
-      bin[pos & (kCBinWords - 1)] = static_cast<uint32_t>(r0 + j - lo) << (kCSlotBits + 1) | (vvalid ? kCValid : 0u) | (off[j] & (kCValid - 1u));
-      bin[(pos + 1) & (kCBinWords - 1)] = static_cast<uint32_t>(v);
-      if (RW == 3) bin[(pos + 2) & (kCBinWords - 1)] = static_cast<uint32_t>(v >> 32);
-    } else {  // the bin is full until the next flush: the spill list takes the row as a 16-byte record
+    if (pos - flushed + RW <= static_cast<uint32_t>(G::kBinWords)) {
+      uint32_t* bin = &sh.bin[part[j] * G::kStride];
+      bin[pos & (G::kBinWords - 1)] = static_cast<uint32_t>(r0 + j - lo) << (G::kSlotBits + 1) | (vvalid ? G::kValid : 0u) | (off[j] & (G::kValid - 1u));
+      bin[(pos + 1) & (G::kBinWords - 1)] = static_cast<uint32_t>(v);
+      if (RW == 3) bin[(pos + 2) & (G::kBinWords - 1)] = static_cast<uint32_t>(v >> 32);
+    } else {  // the bin is full until the next flush: the row goes to the top of the region as a 16-byte record
       uint4 q;
       q.x = t.key.k(j, a.k_bias);
       q.y = static_cast<uint32_t>(r0 + j) | (vvalid ? kRecValValid : 0u);
@@ -1714,83 +1736,75 @@ __device__ __forceinline__ void CBinStageTile(CBinShared& sh, const FastArgs& a,
   }
 }
 // Flush: the stream's whole 128-byte lines leave; what is behind them stays where it is (the bin is a ring).  A wave
-// owns 32 partitions.  ONE lane per partition decides (counter read, clamp, lines to go, new counter) -- with eight
-// lanes per partition doing that in four rounds the flush logic was a third of the kernel (116 of 372 us; the
-// global stores it feeds: 10 us) -- and the partitions with a line to go (a quarter to a third of them per tile)
-// are compacted into a wave-private list; eight lanes per listed partition then copy its line (16 bytes each),
-// eight partitions per trip.  Everything stays inside the wave: LDS operations of one wave execute in order, no
-// barrier between the steps.  (Bins that were refilled from the front after each flush paid a second 128-byte
-// LDS read and a write per flushed line to move the rest there: 163 us of LDS time per 100 M rows with 12-byte
-// records, the stores themselves 25.)
-template <int RW>
-__device__ __forceinline__ void CBinFlush(CBinShared& sh, int tid, int64_t cap, uint4* __restrict__ my_regions,
+// owns kPerWave partitions.  ONE lane per partition decides (counter read, clamp, lines to go, new counter) -- with
+// eight lanes per partition doing that in four rounds the flush logic was a third of the kernel (116 of 372 us; the
+// global stores it feeds: 10 us) -- and the lines to go are compacted into a wave-private list (a wave scan of the
+// line counts); eight lanes per listed line then copy it (16 bytes each), eight lines per trip, the LDS reads of
+// four trips issued before the first store.  Everything stays inside the wave: LDS operations of one wave execute
+// in order, no barrier between the steps.
+template <int RW, int PB>
+__device__ __forceinline__ void CBinFlush(CBinShared<PB>& sh, int tid, int64_t cap, uint4* __restrict__ my_regions,
                                           unsigned int* overflow) {
+  using G = CGeo<PB>;
   using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
-  constexpr int kPerWave = kP / (kBThreads / 64);
-  static_assert(kPerWave == 32, "one lane of the low half per partition");
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  uint32_t nl = 0, entry = 0;
-  if (lane < kPerWave) {
-    const uint32_t p = wave * kPerWave + lane;
-    const uint32_t raw = sh.cnt[p], cur = sh.cur[p];
+  uint32_t nl = 0, first_line = 0, cur = 0, p = 0;
+  if (lane < G::kPerWave) {
+    p = wave * G::kPerWave + lane;
+    const uint32_t raw = sh.cnt[p];
+    cur = sh.cur[p];
     const uint32_t start = raw >> 16, flushed = start & ~31u, had = start - flushed;  // (had < 32)
-    const uint32_t came = (raw - start) & 0xFFFFu;  // words of the tile's arrivals, accepted or not
+    const uint32_t came = (raw - start) & 0xFFFFu;  // words of the arrivals since the last flush, accepted or not
     // (arrivals were accepted while their last word still fitted)
-    const uint32_t took = had + came <= static_cast<uint32_t>(kCBinWords) ? came : ((kCBinWords - had) / RW) * RW;
-    const uint32_t now = (start + took) & (kCBinWords - 1);  // (positions restart inside the ring: the counter's low half never carries into the high one)
+    const uint32_t took = had + came <= static_cast<uint32_t>(G::kBinWords) ? came : ((G::kBinWords - had) / RW) * RW;
+    const uint32_t now = (start + took) & (G::kBinWords - 1);  // (positions restart inside the ring: the low half never carries into the high one)
     nl = (had + took) >> 5;
-    sh.cnt[p] = now << 16 | now;  // the stream's position, in both halves (the next tile's arrivals start there)
+    first_line = (flushed & (G::kBinWords - 1)) >> 5;
+    sh.cnt[p] = now << 16 | now;
     if (nl > 0) {
       if (cur + 8 * nl <= cap - kCSpillUnits) {
         sh.cur[p] = cur + 8 * nl;
-        entry = p | nl << 9 | ((flushed >> 5) & 1u) << 11 | (cur >> 3) << 16;
       } else {
         nl = 0;
         __hip_atomic_store(overflow, kOverflowRegion, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
-  const uint64_t going = __ballot(nl > 0);
-  const int count = __popcll(going);
-  if (nl > 0) sh.list[wave * kPerWave + __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(going), 0u)] = entry;
-  // up to four trips of eight partitions; every step's LDS reads are issued for all trips before any is used
-  // (trip by trip the chain list entry -> line -> store is paid once per trip: with most bins flushing -- every
-  // row selected, 12-byte records -- that was 10 % of the kernel)
+  // the lines' places in the wave's list: an inclusive scan of nl over the deciding lanes
+  uint32_t incl = nl;
+#pragma unroll
+  for (int d = 1; d < G::kPerWave; d <<= 1) {
+    const uint32_t up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  const int count = __builtin_amdgcn_readlane(incl, G::kPerWave - 1);  // lines of this wave (wave-uniform)
+  uint32_t* list = &sh.list[wave * G::kListPerWave];
+  for (uint32_t l = 0; l < nl; ++l)  // entry: partition | the line's quarter of the ring << 9 | its 128-byte unit of the region << 12
+    list[incl - nl + l] = p | ((first_line + l) & (G::kMaxLines - 1)) << 9 | ((cur >> 3) + l) << 12;
   const uint32_t ll = lane & 7;
-  const int trips = (count + 7) >> 3;  // (wave-uniform, <= kPerWave / 8)
-  constexpr int kTrips = kPerWave / 8;
-  uint32_t e[kTrips];
+  constexpr int kTrips = 4;  // lines of up to four trips in flight
+  for (int base = 0; base < count; base += 8 * kTrips) {  // (wave-uniform; one pass unless more than 32 lines go)
+    uint32_t e[kTrips];
+    bool on[kTrips];
 #pragma unroll
-  for (int t = 0; t < kTrips; ++t) {
-    e[t] = 0;  // (no lines: skipped below)
-    if (t < trips) {
-      const int k = 8 * t + (lane >> 3);
-      if (k < count) e[t] = sh.list[wave * kPerWave + k];
+    for (int t = 0; t < kTrips; ++t) {
+      const int k = base + 8 * t + (lane >> 3);
+      on[t] = k < count;
+      e[t] = 0;
+      if (base + 8 * t < count && on[t]) e[t] = list[k];
     }
-  }
-  uint4 lo[kTrips], hi[kTrips];
+    uint4 q[kTrips];
 #pragma unroll
-  for (int t = 0; t < kTrips; ++t) {
-    const uint32_t lines = (e[t] >> 9) & 3u;
-    if (t < trips && lines != 0) {
-      const uint32_t* bin = &sh.bin[(e[t] & (kP - 1)) * kCBinStride];
-      const uint32_t first = ((e[t] >> 11) & 1u) << 5;  // the ring's half that holds the oldest line
-      lo[t] = *reinterpret_cast<const uint4*>(&bin[first + 4 * ll]);
-      if (lines > 1) hi[t] = *reinterpret_cast<const uint4*>(&bin[(first ^ 32u) + 4 * ll]);
-    }
-  }
+    for (int t = 0; t < kTrips; ++t)
+      if (base + 8 * t < count && on[t])
+        q[t] = *reinterpret_cast<const uint4*>(&sh.bin[(e[t] & (G::kParts - 1)) * G::kStride + ((e[t] >> 9) & 7u) * 32 + 4 * ll]);
 #pragma unroll
-  for (int t = 0; t < kTrips; ++t) {
-    const uint32_t lines = (e[t] >> 9) & 3u;
-    if (t < trips && lines != 0) {
-      const uint32_t p = e[t] & (kP - 1), cur = (e[t] >> 16) << 3;
-      uint4* dst = my_regions + int64_t(p) * cap + cur + ll;
-      const u32x4 v = {lo[t].x, lo[t].y, lo[t].z, lo[t].w};
-      __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst));
-      if (lines > 1) {
-        const u32x4 w = {hi[t].x, hi[t].y, hi[t].z, hi[t].w};
-        __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(dst + 8));
+    for (int t = 0; t < kTrips; ++t) {
+      if (base + 8 * t < count && on[t]) {
+        uint4* dst = my_regions + int64_t(e[t] & (G::kParts - 1)) * cap + ((e[t] >> 12) << 3) + ll;
+        const u32x4 v = {q[t].x, q[t].y, q[t].z, q[t].w};
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst));
       }
     }
   }
@@ -1938,18 +1952,20 @@ __global__ __launch_bounds__(kBThreads) void k_part_scatter_bins(FastArgs a, int
 
 // The bin scatter with compact records of RW words (see above).  counts[p][b] = RECORDS in the region of
 // workgroup b for partition p (RW words each, packed from the region's start) | 16-byte records at its top << 24.
-template <bool MASK, bool VVALID, bool K64, int RW>
+// FE: tiles per flush.
+template <bool MASK, bool VVALID, bool K64, int RW, int PB>
 __global__ __launch_bounds__(kBThreads) void k_part_scatter_compact(FastArgs a, int64_t cap, uint4* regions, uint32_t* counts,
                                                                     unsigned int* overflow) {
-  __shared__ CBinShared sh;
+  using G = CGeo<PB>;
+  __shared__ CBinShared<PB> sh;
   __shared__ unsigned int s_sample, s_kmin, s_kmax;
   const int tid = threadIdx.x;
-  if (tid < kP) { sh.cnt[tid] = 0; sh.cur[tid] = 0; sh.spill[tid] = 0; }
+  if (tid < G::kParts) { sh.cnt[tid] = 0; sh.cur[tid] = 0; sh.spill[tid] = 0; }
   if (tid == 0) { s_sample = 0; s_kmin = 0xFFFFFFFFu; s_kmax = 0; }
   __syncthreads();
   const int64_t lo = int64_t(blockIdx.x) * a.rows_per_block;
   const int64_t hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
-  uint4* const my_regions = regions + int64_t(blockIdx.x) * kP * cap;
+  uint4* const my_regions = regions + int64_t(blockIdx.x) * G::kParts * cap;
   bool dense = true;  // no mask: every row is selected
   if (MASK) {
     const int64_t sample_rows = hi - lo < 64 * kBinSampleWords ? hi - lo : 64 * kBinSampleWords;
@@ -1962,13 +1978,14 @@ __global__ __launch_bounds__(kBThreads) void k_part_scatter_compact(FastArgs a, 
       }
     }
     __syncthreads();
-    dense = RW == 2 ? 20 * int64_t(s_sample) > 11 * sample_rows  // (two tiles per flush: the half-size tiles from 55 % on)
-                    : 3 * int64_t(s_sample) > 2 * sample_rows;   // more than two thirds of the rows selected
+    dense = RW == 2 && PB == 9 ? 20 * int64_t(s_sample) > 11 * sample_rows  // (two tiles per flush: the half-size tiles from 55 % on)
+                               : 3 * int64_t(s_sample) > 2 * sample_rows;   // more than two thirds of the rows selected
   }
   uint32_t kmin = 0xFFFFFFFFu, kmax = 0, vwide = 0, bad = 0;
-  constexpr int FE = RW == 2 ? 2 : 1;
-  if (dense) BinRun<MASK, VVALID, 2, K64, RW, CBinShared, FE>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow, kmin, kmax, vwide, bad);
-  else BinRun<MASK, VVALID, 4, K64, RW, CBinShared, FE>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow, kmin, kmax, vwide, bad);
+  // tiles per flush: what two (three) tiles bring on average fits behind what a flush leaves (< 32 words)
+  constexpr int FE = PB == 9 ? (RW == 2 ? 2 : 1) : (RW == 2 ? 3 : 2);
+  if (dense) BinRun<MASK, VVALID, 2, K64, RW, CBinShared<PB>, FE>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow, kmin, kmax, vwide, bad);
+  else BinRun<MASK, VVALID, 4, K64, RW, CBinShared<PB>, FE>(sh, a, lo, hi, cap, regions, my_regions, counts, overflow, kmin, kmax, vwide, bad);
   if (RW == 3 && a.val_wide && __syncthreads_or(vwide != 0) && tid == 0) __hip_atomic_store(a.val_wide, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // a selected row outside the hinted key range, or (RW == 2) a value that is not an int32: the call starts over
   if (__syncthreads_or(bad != 0) && tid == 0) __hip_atomic_store(overflow, kOverflowCompact, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1983,14 +2000,14 @@ __global__ __launch_bounds__(kBThreads) void k_part_scatter_compact(FastArgs a, 
   }
   __syncthreads();
   if (tid == 0 && s_kmin <= s_kmax) { atomicMin(&a.key_minmax[0], s_kmin); atomicMax(&a.key_minmax[1], s_kmax); }
-  if (tid < kP) {
+  if (tid < G::kParts) {
     // what is left of every partition's stream (< 32 words after a flush, behind the last whole line), and the region fills
-    const uint32_t now = sh.cnt[tid] & 0xFFFFu, left = now & 31u, from = (now & ~31u) & (kCBinWords - 1);
+    const uint32_t now = sh.cnt[tid] & 0xFFFFu, left = now & 31u, from = (now & ~31u) & (G::kBinWords - 1);
     const uint32_t cur = sh.cur[tid], spilled = sh.spill[tid];
     const bool ok = 4 * cur + left <= 4 * (cap - kCSpillUnits) && spilled <= static_cast<uint32_t>(kCSpillUnits);
     if (ok) {
       uint32_t* dst = reinterpret_cast<uint32_t*>(my_regions + int64_t(tid) * cap + cur);
-      for (uint32_t k = 0; k < left; ++k) dst[k] = sh.bin[tid * kCBinStride + from + k];
+      for (uint32_t k = 0; k < left; ++k) dst[k] = sh.bin[tid * G::kStride + from + k];
     } else {
       __hip_atomic_store(overflow, kOverflowRegion, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -2470,22 +2487,24 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_piped(const uin
 }
 
 // ---- the partition aggregate over compact records (k_part_scatter_compact) ----------------------------------
-// Always the directly indexed table (the compact record IS a slot offset): no tags, 68 KB of LDS.  A wave walks
-// the regions of workgroups wave, wave + kWaves, ...; region b's rows start at b * rows_per_block.  RW = 2: a lane
-// loads 16 bytes = two records; RW = 3: one 12-byte record.  Three steps in flight as in k_part_aggregate_piped;
-// the spill list (16-byte records, a fraction of a per cent) is folded by all threads at the end.
+// Always the directly indexed table (the compact record IS a slot offset): no tags, 68 KB (512 partitions) or
+// 132 KB (256 partitions) of LDS.  A wave walks the regions of workgroups wave, wave + kWaves, ...; region b's rows
+// start at b * rows_per_block.  RW = 2: a lane loads 16 bytes = two records; RW = 3: one 12-byte record.  Three
+// steps in flight as in k_part_aggregate_piped; the records at the tops of the regions (16-byte records of rows
+// that found their bin full, a fraction of a per cent) are folded at the end.
 template <int RW> struct CUnit;
 template <> struct CUnit<2> { BinU32x4 w; };
 template <> struct CUnit<3> { __attribute__((ext_vector_type(3), aligned(4))) unsigned int w; };
-template <int RW>
+template <int RW, int PB>
 __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_compact(const uint4* regions, const uint32_t* counts,
                                                                          int nblocks, int64_t cap, int acc_double, GroupTable t,
                                                                          unsigned long long* first_bitmap,
                                                                          unsigned int* overflow, int64_t total_slots,
                                                                          uint32_t c_base, uint32_t k_flip, uint32_t rows_per_block) {
-  __shared__ unsigned long long s_sum[kSlots];
-  __shared__ uint32_t s_first[kSlots];
-  __shared__ unsigned int s_cnt[kSlots];
+  using G = CGeo<PB>;
+  __shared__ unsigned long long s_sum[G::kSlots];
+  __shared__ uint32_t s_first[G::kSlots];
+  __shared__ unsigned int s_cnt[G::kSlots];
   __shared__ uint32_t s_fill[kMaxSegments];
   if (__hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // the scatter gave up
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2496,12 +2515,12 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_compact(const u
   constexpr uint32_t kStepUnits = 64 * kPaUnroll;                // units per wave and step
   const int nseg_all = nblocks + 1;
   for (int b = tid; b < nblocks; b += kPartThreads) s_fill[b] = counts[int64_t(p) * nseg_all + b];  // records | spilled << 24
-  for (int s = tid; s < kSlots; s += kPartThreads) { s_sum[s] = 0; s_first[s] = kNoRow; s_cnt[s] = 0; }
+  for (int s = tid; s < G::kSlots; s += kPartThreads) { s_sum[s] = 0; s_first[s] = kNoRow; s_cnt[s] = 0; }
   __syncthreads();
   auto fold_one = [&](uint32_t meta, uint32_t lo32, uint32_t hi32, uint32_t seg_lo) {
-    const uint32_t slot = DirectSlot(meta & (kCValid - 1u));
-    atomicMin(&s_first[slot], seg_lo + (meta >> (kCSlotBits + 1)));
-    if (meta & kCValid) {
+    const uint32_t slot = G::Slot(meta & (G::kValid - 1u));
+    atomicMin(&s_first[slot], seg_lo + (meta >> (G::kSlotBits + 1)));
+    if (meta & G::kValid) {
       const unsigned long long bits = RW == 2 ? static_cast<unsigned long long>(static_cast<long long>(static_cast<int>(lo32)))
                                               : (static_cast<unsigned long long>(hi32) << 32) | lo32;
       if (RW == 3 && acc_double) atomicAdd(reinterpret_cast<double*>(&s_sum[slot]), __longlong_as_double(bits));
@@ -2511,8 +2530,8 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_compact(const u
   };
   const int nseg = wave < nblocks ? (nblocks - wave + kWaves - 1) / kWaves : 0;  // this wave's regions: wave, wave + kWaves, ...
   if (nseg > 0) {
-    const int64_t seg_stride = int64_t(kWaves) * kP * cap;
-    const uint4* seg0 = regions + (int64_t(wave) * kP + p) * cap;
+    const int64_t seg_stride = int64_t(kWaves) * G::kParts * cap;
+    const uint4* seg0 = regions + (int64_t(wave) * G::kParts + p) * cap;
     struct It { int k; uint32_t i0, units, recs; };
     auto advance = [&](It it) -> It {
       it.i0 += kStepUnits;
@@ -2567,10 +2586,10 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_compact(const u
   for (int b = wave; b < nblocks; b += kWaves) {
     const uint32_t ns = __builtin_amdgcn_readfirstlane(s_fill[b]) >> 24;
     if (ns == 0) continue;
-    const uint4* top = regions + (int64_t(b) * kP + p) * cap + (cap - 1);
+    const uint4* top = regions + (int64_t(b) * G::kParts + p) * cap + (cap - 1);
     if (static_cast<uint32_t>(lane) < ns) {
       const uint4 q = *(top - lane);
-      const uint32_t slot = DirectSlot((((q.x ^ k_flip) >> kPBits) - c_base) & (kCValid - 1u));
+      const uint32_t slot = G::Slot((((q.x ^ k_flip) >> PB) - c_base) & (G::kValid - 1u));
       atomicMin(&s_first[slot], q.y & kRecRowMask);
       if (q.y & kRecValValid) {
         const unsigned long long bits = (static_cast<unsigned long long>(q.w) << 32) | q.z;
@@ -2581,12 +2600,12 @@ __global__ __launch_bounds__(kPartThreads) void k_part_aggregate_compact(const u
     }
   }
   __syncthreads();
-  const int64_t g0 = int64_t(p) * kSlots;
-  for (int s = tid; s < kSlots; s += kPartThreads) {
+  const int64_t g0 = int64_t(p) * G::kSlots;
+  for (int s = tid; s < G::kSlots; s += kPartThreads) {
     const uint32_t fr = s_first[s];
-    // the key of (partition p, slot s): high part = slot offset + base, low part p XOR the high part's hashed bits (BinPartOf)
-    const uint32_t high = DirectSlot(static_cast<uint32_t>(s)) + c_base;
-    const uint32_t kk = (high << kPBits) | (static_cast<uint32_t>(p) ^ ((high * 0x9E3779B1u) >> (32 - kPBits)));
+    // the key of (partition p, slot s): high part = slot offset + base, low part p XOR the high part's hashed bits (CGeo::PartOf)
+    const uint32_t high = G::Slot(static_cast<uint32_t>(s)) + c_base;  // (the bit reversal is its own inverse)
+    const uint32_t kk = (high << PB) | (static_cast<uint32_t>(p) ^ ((high * 0x9E3779B1u) >> (32 - PB)));
     t.hkeys[g0 + s] = fr == kNoRow ? kEmpty : Fmix64(uint64_t(kk ^ k_flip));
     t.first[g0 + s] = fr;
     t.sums[g0 + s] = s_sum[s];
@@ -4016,7 +4035,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
   // Compact records (k_part_scatter_compact): a hinted call whose predecessor's selected keys spanned few enough
   // values carries 12-byte records, 8-byte ones if that call's (integer) values were all int32; the kernel checks
   // both for every selected row and a miss starts the call over without the hint.
-  int compact_rw = 0;
+  int compact_rw = 0, compact_pb = 9;  // words per record; log2(partitions): see CGeo
   uint32_t c_base = 0;
   const bool headline_shape = ks.total_bits == 32 && k_load_bits == 32 && !keys->validity && values &&
                               BitWidth(values->type_id) == 64 && !m_valid;
@@ -4032,13 +4051,18 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
                                 : reinterpret_cast<uintptr_t>(keys->values) % 16 == 0);
   if (hinted && use_bins && hint.stats && hint.key_lo <= hint.key_hi && hint.key_lo >= k_bias &&
       hint.key_hi - k_bias <= 0xFFFFFFFFull && !getenv("AMDARROW_GROUPBY_NO_COMPACT")) {
-    const uint32_t first = static_cast<uint32_t>(hint.key_lo - k_bias) >> kPBits;
-    const uint32_t span = (static_cast<uint32_t>(hint.key_hi - k_bias) >> kPBits) - first + 1;
-    if (span <= (1u << kCSlotBits)) {
-      const uint32_t slack = ((1u << kCSlotBits) - span) / 2;  // the window is centred on the range seen last time
+    int rw = values && !IsFloat(values->type_id) && hint.values_narrow ? 2 : 3;
+    if (const char* env = getenv("AMDARROW_GROUPBY_COMPACT_WORDS")) rw = atoi(env) == 2 && rw == 2 ? 2 : 3;
+    int pb = rw == 2 ? 9 : 8;  // 8-byte records: 512 partitions, bins of 64 words; 12-byte records: 256 partitions, bins of 128
+    if (const char* env = getenv("AMDARROW_GROUPBY_COMPACT_PARTS")) pb = atoi(env) == 256 ? 8 : atoi(env) == 512 ? 9 : pb;
+    const int slot_bits = 21 - pb;
+    const uint32_t first = static_cast<uint32_t>(hint.key_lo - k_bias) >> pb;
+    const uint32_t span = (static_cast<uint32_t>(hint.key_hi - k_bias) >> pb) - first + 1;
+    if (span <= (1u << slot_bits)) {
+      const uint32_t slack = ((1u << slot_bits) - span) / 2;  // the window is centred on the range seen last time
       c_base = first > slack ? first - slack : 0;
-      compact_rw = values && !IsFloat(values->type_id) && hint.values_narrow ? 2 : 3;
-      if (const char* env = getenv("AMDARROW_GROUPBY_COMPACT_WORDS")) compact_rw = atoi(env) == 2 && compact_rw == 2 ? 2 : 3;
+      compact_rw = rw;
+      compact_pb = pb;
     }
   }
   GroupTable t{};
@@ -4075,8 +4099,22 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
       const double mean = static_cast<double>(rows_per_block) / kP / nsub;
       // room for a key of up to ~0.25 % of the rows next to the uniform share (hotter keys are taken out before the scatter)
       cap = (static_cast<int64_t>(mean * 2.0 + 8.0 * std::sqrt(mean) + 32.0) + 7) & ~int64_t(7);  // whole 128-byte lines
-      compact = compact_rw != 0 && hinted && path == 2 && nsub == 1 && rows_per_block <= (int64_t(1) << kCRowBits);
-      if (compact) cap = ((cap * compact_rw + 3) / 4 + 7) & ~int64_t(7);  // the same number of records, in 16-byte units
+      if (compact_rw != 0 && hinted && path == 2 && nsub == 1) {
+        // a compact record carries its row as an offset into the workgroup's row range (19 / 18 bits): more workgroups
+        // (whole multiples of the CUs) for large inputs
+        const int64_t limit = int64_t(1) << (10 + compact_pb);
+        const int64_t rounds = (n + ctx->num_cus * limit - 1) / (ctx->num_cus * limit);
+        const int64_t nb = std::min<int64_t>(ctx->num_cus * rounds, (n + tile - 1) / tile);
+        const int64_t rpb = (((n + nb - 1) / nb + tile - 1) / tile) * tile;
+        if (nb <= kMaxFlags && rpb <= limit) {
+          compact = true;
+          nblocks = static_cast<int>(nb);
+          rows_per_block = rpb;
+          const double cmean = static_cast<double>(rpb) / (1 << compact_pb);
+          cap = (static_cast<int64_t>(cmean * 2.0 + 8.0 * std::sqrt(cmean) + 32.0) + 7) & ~int64_t(7);
+          cap = ((cap * compact_rw + 3) / 4 + 7) & ~int64_t(7);  // that number of records, in 16-byte units
+        }
+      }
       if (use_bins) cap += kCSpillUnits;  // room at the top of every region for the records that found their bin full
       hist_n = int64_t(kP) * (nblocks + (use_bins ? 1 : 0));  // bins: one more segment per partition, the spill list
     } else if (path == 1) {
@@ -4089,7 +4127,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
     const size_t off_sums = c.Take(4 * scan_nb);
     const size_t off_sumoff = c.Take(8 * (scan_nb + 1));
     const int nseg = nblocks + (path >= 2 && use_bins ? 1 : 0);  // segments per partition the aggregate walks
-    const size_t rec_bytes = path >= 2 ? std::max(16 * static_cast<size_t>(cap) * kP * nseg, LocalStageBytes(nblocks_local))
+    const size_t rec_bytes = path >= 2 ? std::max(16 * static_cast<size_t>(cap) * (compact ? size_t(1) << compact_pb : size_t(kP)) * nseg, LocalStageBytes(nblocks_local))
                            : path == 1 ? 16 * static_cast<size_t>(n) : 0;
     const size_t off_rec = c.Take(rec_bytes);
     const size_t off_hi = c.Take(path == 1 && wide ? 4 * static_cast<size_t>(n) : 0);
@@ -4193,11 +4231,13 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
         FastArgs fh = fa;  // the same scatter on the mask k_hot_aggregate wrote
         fh.m_data = hot.alt_mask; fh.m_valid = nullptr; fh.m_off = 0;
         if (compact) {
-#define AA_CBINS3(MM, VV, KK) do { if (compact_rw == 2) hipLaunchKernelGGL((k_part_scatter_compact<MM, VV, KK, 2>), dim3(nblocks), dim3(kBThreads), 0, ctx->stream, fa, cap, records, hist, misc); \
-          else hipLaunchKernelGGL((k_part_scatter_compact<MM, VV, KK, 3>), dim3(nblocks), dim3(kBThreads), 0, ctx->stream, fa, cap, records, hist, misc); } while (0)
+#define AA_CBINS4(MM, VV, KK, RR, PP) hipLaunchKernelGGL((k_part_scatter_compact<MM, VV, KK, RR, PP>), dim3(nblocks), dim3(kBThreads), 0, ctx->stream, fa, cap, records, hist, misc)
+#define AA_CBINS3(MM, VV, KK) do { if (compact_rw == 2 && compact_pb == 9) AA_CBINS4(MM, VV, KK, 2, 9); else if (compact_rw == 2) AA_CBINS4(MM, VV, KK, 2, 8); \
+          else if (compact_pb == 9) AA_CBINS4(MM, VV, KK, 3, 9); else AA_CBINS4(MM, VV, KK, 3, 8); } while (0)
 #define AA_CBINS(MM, VV) do { if (k_load_bits == 64) AA_CBINS3(MM, VV, true); else AA_CBINS3(MM, VV, false); } while (0)
           if (M && V) AA_CBINS(true, true); else if (M) AA_CBINS(true, false); else if (V) AA_CBINS(false, true); else AA_CBINS(false, false);
 #undef AA_CBINS
+#undef AA_CBINS4
 #undef AA_CBINS3
         } else if (use_bins) {
 #define AA_BINS(MM, VV, ARGS, RUN, SKIP) do { if (k_load_bits == 64) hipLaunchKernelGGL((k_part_scatter_bins<MM, VV, true>), dim3(nblocks), dim3(kBThreads), 0, ctx->stream, ARGS, cap, records, hist, misc, RUN, SKIP); \
@@ -4221,12 +4261,11 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
         }
         AA_HIP(hipGetLastError());
         if (compact) {
-          if (compact_rw == 2)
-            hipLaunchKernelGGL(k_part_aggregate_compact<2>, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nblocks, cap,
-                               acc_double, t, r.bitmap, misc, static_cast<int64_t>(T), c_base, fa.k_flip, static_cast<uint32_t>(rows_per_block));
-          else
-            hipLaunchKernelGGL(k_part_aggregate_compact<3>, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nblocks, cap,
-                               acc_double, t, r.bitmap, misc, static_cast<int64_t>(T), c_base, fa.k_flip, static_cast<uint32_t>(rows_per_block));
+#define AA_CAGG(RR, PP) hipLaunchKernelGGL((k_part_aggregate_compact<RR, PP>), dim3(1 << PP), dim3(kPartThreads), 0, ctx->stream, records, hist, nblocks, cap, \
+                               acc_double, t, r.bitmap, misc, static_cast<int64_t>(T), c_base, fa.k_flip, static_cast<uint32_t>(rows_per_block))
+          if (compact_rw == 2 && compact_pb == 9) AA_CAGG(2, 9); else if (compact_rw == 2) AA_CAGG(2, 8);
+          else if (compact_pb == 9) AA_CAGG(3, 9); else AA_CAGG(3, 8);
+#undef AA_CAGG
         } else if (use_bins)
           hipLaunchKernelGGL(k_part_aggregate_piped, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nseg,
                              cap, ks.total_bits, acc_double, t, r.bitmap, misc, run_if, int64_t(sub) * kP * kSlots,
