@@ -52,7 +52,12 @@ struct amdarrow_ctx {
     // largest selected key in the scatter's unsigned key order plus the call's key bias, and whether every
     // selected valid value of an integer column was an int32 -- what a compact-record call assumes and checks
     int stats = 0, values_narrow = 0; uint64_t key_lo = 1, key_hi = 0;
-  } gb_hint;
+    uint64_t last_used = 0;
+  };
+  // one hint per call shape, the least recently used one gives way: queries that alternate keep their hints
+  static constexpr int kGroupByHints = 4;
+  GroupByHint gb_hints[kGroupByHints];
+  uint64_t gb_hint_clock = 0;
   int gb_last_path = -1, gb_last_words = 0;  // amdarrow_groupby_last_path
   void* pack_buf = nullptr;  // groupby.hip amdarrow_filter_groupby_multi: packed key codes (grow-only)
   size_t pack_cap = 0;

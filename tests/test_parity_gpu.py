@@ -1525,3 +1525,19 @@ def test_filter_groupby_compact_records_knob(gpu, oracle, monkeypatch):
         assert _last_groupby_path(gpu) == (2, want), env
         if env:
             monkeypatch.delenv(env[0])
+
+
+def test_filter_groupby_hints_per_shape(oracle):
+    """Two queries that alternate (different row counts, one with an int64 key column): each keeps its own hint, so
+    from the second round on both run on compact records instead of evicting each other's hint every call."""
+    import gpu_api
+    gpu = gpu_api.GpuApi()
+    rng = np.random.default_rng(11)
+
+    def mk(n, kt):
+        base = rng.integers(0, 350_000, n) + (5_000_000_000 if kt == INT64 else 0)
+        return R(rng, INT64, n, 0.0, 0), Arr(kt, base.astype(orc.NP_OF[kt])), R(rng, BOOL, n, 0.0, 0)
+    for rnd in range(3):
+        for n, kt in ((1_100_000, INT32), (1_300_000, INT64)):
+            _check_groupby(oracle, gpu, *mk(n, kt), (rnd, n))
+            assert _last_groupby_path(gpu) == (2, 4 if rnd == 0 else 2), (rnd, n)
