@@ -123,6 +123,25 @@ int LaunchScanU32(amdarrow_ctx* ctx, const uint32_t* counts, int64_t n, int64_t*
   return AMDARROW_OK;
 }
 
+__device__ __forceinline__ void DepositPacked(const uint64_t* s_packed, uint32_t count, uint8_t* bm, int64_t bit_base,
+                                              unsigned long long* edge);
+// The bits of `x` at the positions of the set bits of `m`, packed to the low end (a software PEXT).  Loops over the
+// MINORITY value among the selected bits -- a validity word is mostly ones -- clearing (or setting) the bit at the
+// rank of each: a handful of iterations per word for the usual few per cent of nulls, 32 at worst.
+__device__ __forceinline__ uint64_t CompressBits(uint64_t x, uint64_t m) {
+  const int n = __popcll(m);
+  const uint64_t ones = x & m, zeros = ~x & m;
+  const bool few_zeros = __popcll(zeros) <= __popcll(ones);
+  uint64_t rest = few_zeros ? zeros : ones, flip = 0;
+  while (rest) {
+    const uint64_t low = rest & (0 - rest);
+    flip |= uint64_t(1) << __popcll(m & (low - 1));
+    rest ^= low;
+  }
+  const uint64_t all = n >= 64 ? ~uint64_t(0) : (uint64_t(1) << n) - 1;
+  return few_zeros ? all & ~flip : flip;
+}
+
 // Pack `count` LDS byte flags into the global bitmap `bm` at bit position `bit_base`.
 // `bm` has been zeroed; interior words are plain stores, the (at most two) words shared
 // with neighbouring tiles are merged with atomicOr.  Called by the whole workgroup.
@@ -140,6 +159,15 @@ __device__ __forceinline__ void DepositFlags(const uint8_t* s_flags, uint64_t* s
     if (lane == 0) s_packed[lw] = b;
   }
   __syncthreads();
+  DepositPacked(s_packed, count, bm, bit_base, edge);
+}
+
+// The `count` bits packed in s_packed[0 .. (count + 63) / 64) -> the global bitmap at bit position `bit_base` (see
+// DepositFlags).  Called by the whole workgroup, the packed words complete (a barrier behind their last write).
+__device__ __forceinline__ void DepositPacked(const uint64_t* s_packed, uint32_t count, uint8_t* bm, int64_t bit_base,
+                                              unsigned long long* edge) {
+  const int tid = threadIdx.x;
+  const uint32_t nlw = (count + 63) >> 6;
   const int s = static_cast<int>(bit_base & 63);
   const int64_t g0 = bit_base >> 6;
   const uint32_t ngw = (s + count + 63) >> 6;
@@ -200,7 +228,7 @@ __global__ __launch_bounds__(kCThreads) void k_filter_compact(FilterArgs a) {
   __shared__ uint32_t s_count;
   __shared__ uint64_t s_packed[65];
   __shared__ __attribute__((aligned(16))) T s_stage[kBits ? kTile : 1];  // value-bit flags by rank
-  __shared__ uint8_t s_vflag[kTile];                          // validity flags by rank
+  __shared__ uint8_t s_vflag[kBits ? kTile : 1];                // validity flags by rank (bit-packed values only: fixed-width values pack their validity at word level)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const T* values = reinterpret_cast<const T*>(a.v_data);
 
@@ -221,6 +249,19 @@ __global__ __launch_bounds__(kCThreads) void k_filter_compact(FilterArgs a) {
       const uint32_t incl = WaveInclusiveScan(pc);
       s_base[tid] = incl - pc;
       if (tid == 63) s_count = incl;
+      if (!kBits && a.has_validity) {
+        // the output validity of this word's emitted rows (WriteNotNull / WriteMaybeNull / WriteNull, :646-657, :706-709),
+        // packed at word level and ORed into the tile's packed bits at the word's rank: no per-row flags, no ballot
+        // pass, two barriers per tile less
+        s_packed[tid] = 0;  // (LDS operations of one wave execute in order: cleared before any lane's OR below)
+        if (tid == 0) s_packed[64] = 0;
+        const uint64_t cv = CompressBits(sel & vv, emit);
+        const uint32_t at = incl - pc, sh = at & 63u;
+        if (pc) {
+          atomicOr(reinterpret_cast<unsigned long long*>(&s_packed[at >> 6]), static_cast<unsigned long long>(cv << sh));
+          if (sh + pc > 64) atomicOr(reinterpret_cast<unsigned long long*>(&s_packed[(at >> 6) + 1]), static_cast<unsigned long long>(cv >> (64 - sh)));
+        }
+      }
     }
     __syncthreads();
     const uint32_t count = s_count;
@@ -267,21 +308,23 @@ __global__ __launch_bounds__(kCThreads) void k_filter_compact(FilterArgs a) {
         // run, and without a value stage the workgroup needs 3 KB of LDS instead of 35.
         if (!kBits) { if (fits) reinterpret_cast<T*>(a.out_values)[out_base + rank] = vals[j]; }
         else s_stage[rank] = vals[j];
-        if (a.has_validity) {
+        if (kBits && a.has_validity) {
           // WriteNotNull / WriteMaybeNull / WriteNull (:646-657, :706-709)
           s_vflag[rank] = static_cast<uint8_t>(((s_sel[word] & s_vvalid[word]) >> lane) & 1);
         }
       }
     }
-    __syncthreads();
+    if (kBits) __syncthreads();
     if (!fits && a.edge_words && tid < 2) a.edge_words[kEdgeStride * tile + tid] = 0;
     if (fits) {
       if (kBits) {
         DepositFlags(reinterpret_cast<const uint8_t*>(s_stage), s_packed, count,
                      reinterpret_cast<uint8_t*>(a.out_values), out_base);
         __syncthreads();
+        if (a.has_validity) DepositFlags(s_vflag, s_packed, count, a.out_validity, out_base, a.edge_words ? a.edge_words + kEdgeStride * tile : nullptr);
+      } else if (a.has_validity) {
+        DepositPacked(s_packed, count, a.out_validity, out_base, a.edge_words ? a.edge_words + kEdgeStride * tile : nullptr);  // (packed by the first wave, before the barrier above)
       }
-      if (a.has_validity) DepositFlags(s_vflag, s_packed, count, a.out_validity, out_base, a.edge_words ? a.edge_words + kEdgeStride * tile : nullptr);
     }
     __syncthreads();
   }
