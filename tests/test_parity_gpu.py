@@ -1541,3 +1541,20 @@ def test_filter_groupby_hints_per_shape(oracle):
         for n, kt in ((1_100_000, INT32), (1_300_000, INT64)):
             _check_groupby(oracle, gpu, *mk(n, kt), (rnd, n))
             assert _last_groupby_path(gpu) == (2, 4 if rnd == 0 else 2), (rnd, n)
+
+
+def test_grouper_batches_of_one_shape_take_the_compact_records(oracle):
+    """Grouper::Consume over batches of one shape (no values, no mask): from the second batch on the distinct keys come
+    from the group-by's compact records; ids and uniques stay the reference's, known keys keep their ids."""
+    import gpu_api
+    gpu = gpu_api.GpuApi()
+    rng = np.random.default_rng(3)
+    n = 600_000
+    batches = [[Arr(INT32, (rng.integers(0, 200_000 + 50_000 * i, n) - 70_000).astype(np.int32))] for i in range(4)]
+    io, ngo, uo = oracle.group_ids(batches)
+    ig, ngg, ug = gpu.group_ids(batches)
+    assert ngo == ngg
+    assert all(np.array_equal(x, y) for x, y in zip(io, ig))
+    for (va, vb, _), (vc, vd, _) in zip(uo, ug):
+        assert np.array_equal(va, vc) and np.array_equal(vb, vd)
+    assert _last_groupby_path(gpu)[1] in (2, 3)  # (the last batch went through compact records)
