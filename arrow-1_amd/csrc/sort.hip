@@ -156,6 +156,44 @@ __global__ __launch_bounds__(kThreads) void k_sort_count_all_sortable(const Sort
   counts[2 * ntiles + tile] = 0;
 }
 
+// The digit histograms of a column without nulls or NaNs, straight from its values: what k_sort_partition builds on
+// the way, without its copy of the keys and indices -- the first radix pass then reads the column itself (RAW in
+// k_radix_onesweep) and numbers the rows as it goes.
+template <typename KeyT>
+__global__ __launch_bounds__(kThreads) void k_sort_hist(const void* values, int64_t off, int type_id, int64_t n, KeyT key_mask, KeyT flip,
+                                                        unsigned int* ghist) {
+  constexpr int kPasses = sizeof(KeyT);
+  __shared__ unsigned int s_h[kPasses * 256];
+  for (int i = threadIdx.x; i < kPasses * 256; i += kThreads) s_h[i] = 0;
+  __syncthreads();
+  constexpr int kIters = kCTile / kThreads;
+  const int64_t ntiles = (n + kCTile - 1) / kCTile;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    KeyT key[kIters];
+    bool in[kIters];
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      const int64_t r = tile * kCTile + j * kThreads + threadIdx.x;
+      in[j] = r < n;
+      key[j] = reinterpret_cast<const KeyT*>(values)[off + (in[j] ? r : n - 1)];  // (unconditional: all of the tile's loads in flight together)
+    }
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) key[j] = (key[j] ^ flip) & key_mask;  // (flip: sign bit and order, see the caller)
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      if (!in[j]) continue;
+#pragma unroll
+      for (int q = 0; q < kPasses; ++q) atomicAdd(&s_h[q * 256 + ((key[j] >> (8 * q)) & 255)], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kPasses * 256; i += kThreads)
+    if (s_h[i]) atomicAdd(&ghist[i], s_h[i]);
+}
+__global__ __launch_bounds__(kThreads) void k_iota_indices(int64_t n, uint64_t* out) {
+  for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < n; i += int64_t(gridDim.x) * kThreads) out[i] = static_cast<uint64_t>(i);
+}
+
 // Stable 3-way partition.  offsets = exclusive scan of counts laid out [class][tile]: it is
 // directly the global output position (sortable rows first, then NaNs, then nulls).
 template <typename KeyT, bool PERM>
@@ -420,12 +458,15 @@ constexpr int kOWaves = kOThreads / 64;
 // is the stable order.  That ordering is not an architectural promise: LdsAtomicsLaneOrdered()
 // checks it on the device once per context, and the ballot-based match-any ranking (!ARANK, ~10x
 // the instructions) stays as the variant for a device that fails the check.
-template <typename KeyT, bool LAST, bool ARANK>
+// RAW: the first pass over a column without nulls or NaNs -- keys_in is the column itself (the key transformation is
+// applied here: raw_type, raw_flip, raw_mask), the row numbers are the positions.
+template <typename KeyT, bool LAST, bool ARANK, bool RAW = false>
 __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_in, const uint32_t* idx_in, int64_t n, int shift,
                                                               const uint32_t* dbase /* [256] of this pass */,
                                                               uint32_t* lookback /* [nblocks][256], zeroed */,
                                                               unsigned int* error, KeyT* keys_out,
-                                                              uint32_t* idx_out, uint64_t* out64) {
+                                                              uint32_t* idx_out, uint64_t* out64, int raw_type = 0,
+                                                              KeyT raw_flip = 0, KeyT raw_mask = 0) {
   constexpr int kIters = kOTile / kOThreads;  // 16; wave w owns keys [w*1024, (w+1)*1024) of the tile, in order
   __shared__ uint32_t s_whist[kOWaves][256];  // per-wave digit counts, then per-wave running local positions
   __shared__ uint32_t s_dstart[256];          // first local position of each digit
@@ -462,8 +503,13 @@ __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_i
     key[j] = 0; idx[j] = 0;
     if (li < count) {
       key[j] = keys_in[base + li];
-      idx[j] = idx_in[base + li];
+      idx[j] = RAW ? static_cast<uint32_t>(base + li) : idx_in[base + li];
     }
+  }
+  if (RAW) {  // integers as wide as the key: the transformation is one XOR (sign bit and order) and the mask -- behind
+              // the loop, so that no load is waited for before the next one is issued
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) key[j] = (key[j] ^ raw_flip) & raw_mask;
   }
   uint32_t rk[ARANK ? kIters : 1];
 #pragma unroll
@@ -1055,16 +1101,34 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
                        ntiles, perm, n, counts);
   AA_HIP(hipGetLastError());
   AA_TRY(ScanU32InPlace(ctx, counts, 3 * ntiles, sums, sumoff));  // counts -> offsets (rows < 2^32)
-  if (perm)
-    hipLaunchKernelGGL((k_sort_partition<KeyT, true>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, d_chunks, nchunks,
-                       type_id, ntiles, perm, n, counts, key_mask, flip, keys_a, idx_a, out, ghist);
-  else
-    hipLaunchKernelGGL((k_sort_partition<KeyT, false>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, d_chunks, nchunks,
-                       type_id, ntiles, perm, n, counts, key_mask, flip, keys_a, idx_a, out, ghist);
-  AA_HIP(hipGetLastError());
-  uint32_t n0_32 = 0;
-  AA_TRY(ReadBack(ctx, counts + ntiles, 4, &n0_32));  // start of the NaN region = number of sortable rows
-  const int64_t n0 = n0_32;
+  // One chunk of integers without a validity buffer, as wide as the sort key: every row is sortable and the partition
+  // below would be a copy.  Only its histograms are built (k_sort_hist) and the FIRST radix pass reads the column
+  // itself; if the plan below leaves no pass that can (no pass at all, or a single last one), the partition runs
+  // after all.
+  const bool raw_try = all_sortable && nchunks == 1 && allow_onesweep && n < (int64_t(1) << 30) && BitWidth(type_id) == 8 * int(sizeof(KeyT)) &&
+                       !getenv("AMDARROW_SORT_THREE_KERNEL") && !getenv("AMDARROW_SORT_NO_RAW_FIRST_PASS");
+  auto run_partition = [&]() -> int {
+    if (perm)
+      hipLaunchKernelGGL((k_sort_partition<KeyT, true>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, d_chunks, nchunks,
+                         type_id, ntiles, perm, n, counts, key_mask, flip, keys_a, idx_a, out, ghist);
+    else
+      hipLaunchKernelGGL((k_sort_partition<KeyT, false>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, d_chunks, nchunks,
+                         type_id, ntiles, perm, n, counts, key_mask, flip, keys_a, idx_a, out, ghist);
+    AA_HIP(hipGetLastError());
+    return AMDARROW_OK;
+  };
+  int64_t n0 = n;
+  // MakeKey of a signed integer flips the sign bit; together with the order's `flip` one XOR constant
+  const KeyT raw_xor = flip ^ (IsSignedInt(type_id) ? KeyT(1) << (8 * sizeof(KeyT) - 1) : KeyT(0));
+  if (raw_try) {
+    hipLaunchKernelGGL((k_sort_hist<KeyT>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, hc[0].values, hc[0].off, type_id, n, key_mask, raw_xor, ghist);
+    AA_HIP(hipGetLastError());
+  } else {
+    AA_TRY(run_partition());
+    uint32_t n0_32 = 0;
+    AA_TRY(ReadBack(ctx, counts + ntiles, 4, &n0_32));  // start of the NaN region = number of sortable rows
+    n0 = n0_32;
+  }
   if (n0 == 0) return AMDARROW_OK;
 
   // 2. histograms of every digit (built by the partition kernel); skip digits on which all keys agree
@@ -1078,6 +1142,8 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
     if (!trivial) active.push_back(p);
   }
   if (active.empty()) {
+    if (raw_try) hipLaunchKernelGGL(k_iota_indices, dim3(GridFor(n0, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, n0, out);
+    else
     hipLaunchKernelGGL(k_widen_indices, dim3(GridFor(n0, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, idx_a, n0,
                        out);
     AA_HIP(hipGetLastError());
@@ -1098,7 +1164,9 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   bool heavy_values = false;
   if (onesweep && allow_hybrid && n0 >= hybrid_min && n0 >= kSampleKeys && static_cast<int>(active.size()) >= 4 &&
       !min_env /* the testing knob forces the attempt */ && !getenv("AMDARROW_SORT_NO_HYBRID")) {
-    hipLaunchKernelGGL((k_sample_has_duplicates<KeyT>), dim3(1), dim3(256), 0, ctx->stream, keys_a, n0, ctl + 13);
+    // (equal keys stay equal under the key transformation: the column itself serves where the partition did not run)
+    const KeyT* sample_from = raw_try ? reinterpret_cast<const KeyT*>(hc[0].values) + hc[0].off : keys_a;
+    hipLaunchKernelGGL((k_sample_has_duplicates<KeyT>), dim3(1), dim3(256), 0, ctx->stream, sample_from, n0, ctl + 13);
     AA_HIP(hipGetLastError());
     unsigned int dup = 0;
     AA_TRY(ReadBack(ctx, ctl + 13, 4, &dup));
@@ -1130,16 +1198,34 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
     AA_HIP(hipMemsetAsync(ctl, 0, 256, ctx->stream));
     AA_HIP(hipMemsetAsync(lookback, 0, 4 * static_cast<size_t>(hn0) * active.size(), ctx->stream));
   }
+  const bool raw_first = raw_try && onesweep && !(active.size() == 1 && !top);  // (the first pass is not the one that writes the result)
+  if (raw_try && !raw_first) {  // the partition after all (its histograms are the ones already read)
+    AA_HIP(hipMemsetAsync(ghist, 0, 4 * 256 * kPasses, ctx->stream));
+    AA_TRY(run_partition());
+    if (onesweep) { hipLaunchKernelGGL(k_digit_bases, dim3(kPasses), dim3(kThreads), 0, ctx->stream, ghist, dbase); AA_HIP(hipGetLastError()); }
+  }
   for (size_t a = 0; a < active.size(); ++a) {
     const int shift = 8 * active[a];
     const bool last = a + 1 == active.size() && !top;
+    if (onesweep && a == 0 && raw_first) {
+      const uint32_t* db = dbase + 256 * active[a];
+      auto* pass = arank ? k_radix_onesweep<KeyT, false, true, true> : k_radix_onesweep<KeyT, false, false, true>;
+      const KeyT* raw_src = reinterpret_cast<const KeyT*>(hc[0].values) + hc[0].off;
+      hipLaunchKernelGGL(pass, dim3(static_cast<unsigned>((n0 + kOTile - 1) / kOTile)), dim3(kOThreads), 0, ctx->stream,
+                         raw_src, static_cast<const uint32_t*>(nullptr), n0, shift, db, lookback,
+                         ctl + 15, keys_b, idx_b, out, type_id, raw_xor, key_mask);
+      AA_HIP(hipGetLastError());
+      std::swap(keys_a, keys_b);
+      std::swap(idx_a, idx_b);
+      continue;
+    }
     if (onesweep) {
       uint32_t* lb = lookback + static_cast<size_t>(hn0) * a;
       const uint32_t* db = dbase + 256 * active[a];
       auto* pass = last ? (arank ? k_radix_onesweep<KeyT, true, true> : k_radix_onesweep<KeyT, true, false>)
                         : (arank ? k_radix_onesweep<KeyT, false, true> : k_radix_onesweep<KeyT, false, false>);
       hipLaunchKernelGGL(pass, dim3(static_cast<unsigned>((n0 + kOTile - 1) / kOTile)), dim3(kOThreads), 0, ctx->stream, keys_a, idx_a, n0, shift, db, lb,
-                         ctl + 15, keys_b, idx_b, out);
+                         ctl + 15, keys_b, idx_b, out, 0, KeyT(0), KeyT(0));
       AA_HIP(hipGetLastError());
       std::swap(keys_a, keys_b);
       std::swap(idx_a, idx_b);
