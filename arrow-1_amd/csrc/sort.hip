@@ -93,6 +93,59 @@ __device__ __forceinline__ int FindChunkOfRow(const SortChunk* chunks, int nchun
   return lo;
 }
 
+// MakeKey in two halves, for loops that want all their loads in flight before the first use: N raw values (the
+// switch on the width sits outside the loop over the values -- inside, every load ends up behind a branch and a wait),
+// then the arithmetic.
+template <typename KeyT, int N>
+__device__ __forceinline__ void LoadRawKeys(int t, const void* d, const int64_t (&i)[N], KeyT (&raw)[N]) {
+  if constexpr (sizeof(KeyT) == 8) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) raw[j] = reinterpret_cast<const uint64_t*>(d)[i[j]];
+  } else {
+    if (t == AMDARROW_UINT8 || t == AMDARROW_INT8) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) raw[j] = reinterpret_cast<const uint8_t*>(d)[i[j]];
+    } else if (t == AMDARROW_UINT16 || t == AMDARROW_INT16) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) raw[j] = reinterpret_cast<const uint16_t*>(d)[i[j]];
+    } else {
+#pragma unroll
+      for (int j = 0; j < N; ++j) raw[j] = reinterpret_cast<const uint32_t*>(d)[i[j]];
+    }
+  }
+}
+template <typename KeyT> __device__ __forceinline__ KeyT KeyFromRaw(int t, KeyT raw, bool* is_nan);
+template <> __device__ __forceinline__ uint32_t KeyFromRaw<uint32_t>(int t, uint32_t raw, bool* is_nan) {
+  *is_nan = false;
+  switch (t) {
+    case AMDARROW_UINT8: case AMDARROW_UINT16: case AMDARROW_UINT32: return raw;
+    case AMDARROW_INT8: return raw ^ 0x80u;
+    case AMDARROW_INT16: return raw ^ 0x8000u;
+    case AMDARROW_INT32: return raw ^ 0x80000000u;
+    default: {  // FLOAT
+      float f = __uint_as_float(raw);
+      *is_nan = f != f;
+      if (f == 0.0f) f = 0.0f;  // -0.0 == +0.0 is a tie
+      const uint32_t u = __float_as_uint(f);
+      return (u >> 31) ? ~u : (u | 0x80000000u);
+    }
+  }
+}
+template <> __device__ __forceinline__ uint64_t KeyFromRaw<uint64_t>(int t, uint64_t raw, bool* is_nan) {
+  *is_nan = false;
+  switch (t) {
+    case AMDARROW_UINT64: return raw;
+    case AMDARROW_INT64: return raw ^ 0x8000000000000000ULL;
+    default: {  // DOUBLE
+      double f = __longlong_as_double(static_cast<long long>(raw));
+      *is_nan = f != f;
+      if (f == 0.0) f = 0.0;
+      const uint64_t u = static_cast<uint64_t>(__double_as_longlong(f));
+      return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
+    }
+  }
+}
+
 // class of a row: 0 sortable, 1 NaN, 2 null
 template <typename KeyT>
 __device__ __forceinline__ int Classify(const SortChunk& c, int type_id, int64_t r, KeyT key_mask, KeyT flip, KeyT* key) {
@@ -119,19 +172,45 @@ __global__ __launch_bounds__(kThreads) void k_sort_count(const SortChunk* chunks
     if (PERM) { r0 = tile * kCTile; c.length = n; }
     else { c = chunks[FindChunk(chunks, nchunks, tile)]; r0 = (tile - c.tile_start) * kCTile; }
     uint32_t n1 = 0, n2 = 0, n0 = 0;
-    for (int k = 0; k < kCTile / kThreads; ++k) {
-      const int64_t r = r0 + k * kThreads + threadIdx.x;
-      if (r < c.length) {
-        KeyT key;
-        int cls;
-        if (PERM) {
+    if (PERM) {
+      for (int k = 0; k < kCTile / kThreads; ++k) {
+        const int64_t r = r0 + k * kThreads + threadIdx.x;
+        if (r < c.length) {
+          KeyT key;
           const int64_t row = static_cast<int64_t>(perm[r]);
           const SortChunk rc = chunks[FindChunkOfRow(chunks, nchunks, row)];
-          cls = Classify<KeyT>(rc, type_id, row - rc.row_start, ~KeyT(0), 0, &key);
-        } else {
-          cls = Classify<KeyT>(c, type_id, r, ~KeyT(0), 0, &key);
+          const int cls = Classify<KeyT>(rc, type_id, row - rc.row_start, ~KeyT(0), 0, &key);
+          n0 += cls == 0; n1 += cls == 1; n2 += cls == 2;
         }
-        n0 += cls == 0; n1 += cls == 1; n2 += cls == 2;
+      }
+    } else if (c.length > 0) {
+      // the tile's loads (values where a NaN is possible, validity bytes) all issued before the first is looked at
+      constexpr int kI = kCTile / kThreads;
+      const bool floats = type_id == AMDARROW_FLOAT || type_id == AMDARROW_DOUBLE;
+      int64_t ri[kI];
+      bool in[kI];
+      KeyT raw[kI];
+      uint32_t vb[kI];
+#pragma unroll
+      for (int k = 0; k < kI; ++k) {
+        const int64_t r = r0 + k * kThreads + threadIdx.x;
+        in[k] = r < c.length;
+        ri[k] = c.off + (in[k] ? r : c.length - 1);
+        raw[k] = 0;
+        vb[k] = 0xFFu;
+      }
+      if (floats) LoadRawKeys<KeyT, kI>(type_id, c.values, ri, raw);
+      if (c.valid) {
+#pragma unroll
+        for (int k = 0; k < kI; ++k) vb[k] = c.valid[ri[k] >> 3];
+      }
+#pragma unroll
+      for (int k = 0; k < kI; ++k) {
+        if (!in[k]) continue;
+        bool is_nan = false;
+        if (!((vb[k] >> (ri[k] & 7)) & 1u)) { n2 += 1; continue; }
+        if (floats) KeyFromRaw<KeyT>(type_id, raw[k], &is_nan);
+        n0 += !is_nan; n1 += is_nan;
       }
     }
     n0 = static_cast<uint32_t>(WaveReduceSum64(n0));
@@ -224,19 +303,53 @@ __global__ __launch_bounds__(kThreads) void k_sort_partition(const SortChunk* ch
         rows[j] = perm[r < n ? r : n - 1];
       }
     }
+    if (!PERM && c.length > 0) {
+      // the tile's loads (values, validity bytes) all issued before the first is looked at: with the classification
+      // inside each row's bounds check every load was waited for before the next was issued
+      int64_t ri[kIters];
+      bool in[kIters];
+      uint32_t vb[kIters];
+#pragma unroll
+      for (int j = 0; j < kIters; ++j) {
+        const int64_t r = r0 + j * 64 + lane;
+        in[j] = r < c.length;
+        ri[j] = c.off + (in[j] ? r : c.length - 1);
+        vb[j] = 0xFFu;
+      }
+      LoadRawKeys<KeyT, kIters>(type_id, c.values, ri, key);
+      if (c.valid) {
+#pragma unroll
+        for (int j = 0; j < kIters; ++j) vb[j] = c.valid[ri[j] >> 3];
+      }
+#pragma unroll
+      for (int j = 0; j < kIters; ++j) {
+        cls[j] = 3;
+        if (in[j]) {
+          if (!((vb[j] >> (ri[j] & 7)) & 1u)) { cls[j] = 2; key[j] = 0; }
+          else {
+            bool is_nan;
+            key[j] = (KeyFromRaw<KeyT>(type_id, key[j], &is_nan) ^ flip) & key_mask;
+            cls[j] = is_nan ? 1 : 0;
+          }
+        } else {
+          key[j] = 0;
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < kIters; ++j) {
       const int64_t r = r0 + j * 64 + lane;
-      cls[j] = 3;
-      key[j] = 0;
       if (PERM) {
+        cls[j] = 3;
+        key[j] = 0;
         if (r < n) {
           const int64_t row = static_cast<int64_t>(rows[j]);
           const SortChunk rc = chunks[FindChunkOfRow(chunks, nchunks, row)];
           cls[j] = Classify<KeyT>(rc, type_id, row - rc.row_start, key_mask, flip, &key[j]);
         }
-      } else if (r < c.length) {
-        cls[j] = Classify<KeyT>(c, type_id, r, key_mask, flip, &key[j]);
+      } else if (c.length <= 0) {
+        cls[j] = 3;
+        key[j] = 0;
       }
       tot[0] += __popcll(__ballot(cls[j] == 0));
       tot[1] += __popcll(__ballot(cls[j] == 1));
