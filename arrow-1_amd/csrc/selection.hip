@@ -418,15 +418,28 @@ __global__ __launch_bounds__(kThreads) void k_take(TakeArgs a) {
   const int64_t nwaves = (int64_t(gridDim.x) * kThreads) >> 6;
   const bool have_values = a.v_len > 0;
   for (int64_t base = wave_id * (64 * kU); base < a.n; base += nwaves * (64 * kU)) {
+    // Every stage's loads are stored RAW for all four rows before one of them is looked at: a bit test or a bounds
+    // check right behind its load makes the compiler wait for that load (and, the counter being in order, for every
+    // load before it) ahead of the next row's -- the "four gathers in flight" were four dependent round trips.
     bool ok[kU];
     int64_t j[kU];
+    IdxT iraw[kU];
+    uint32_t ivb[kU];
 #pragma unroll
-    for (int u = 0; u < kU; ++u) {  // indices (coalesced)
+    for (int u = 0; u < kU; ++u) {  // indices (coalesced) and their validity bytes
       const int64_t i = base + 64 * u + lane;
-      const int64_t ic = i < a.n ? i : a.n - 1;
-      ok[u] = i < a.n;
-      if (a.i_valid) ok[u] = ok[u] && GetBit(a.i_valid, a.i_off + ic);
-      const bool inb = IndexLoad<IdxT>::Load(a.i_data, a.i_off + ic, a.v_len, &j[u]);
+      const int64_t ic = a.i_off + (i < a.n ? i : a.n - 1);
+      iraw[u] = reinterpret_cast<const IdxT*>(a.i_data)[ic];
+      ivb[u] = a.i_valid ? a.i_valid[ic >> 3] : 0xFFu;
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t i = base + 64 * u + lane;
+      const int64_t ic = a.i_off + (i < a.n ? i : a.n - 1);
+      ok[u] = i < a.n && ((ivb[u] >> (ic & 7)) & 1u);
+      j[u] = static_cast<int64_t>(iraw[u]);
+      // IsOutOfBounds, util/int_util.cc:548-551
+      const bool inb = (static_cast<IdxT>(-1) < 0 && iraw[u] < 0) ? false : static_cast<uint64_t>(iraw[u]) < static_cast<uint64_t>(a.v_len);
       if (ok[u] && !inb) {
         ok[u] = false;
         if (a.boundscheck) atomicMin(a.err_pos, static_cast<unsigned long long>(i));
@@ -435,13 +448,22 @@ __global__ __launch_bounds__(kThreads) void k_take(TakeArgs a) {
     }
     bool vbit[kU];
     T v[kU];
+    uint32_t vvb[kU], bvb[kU];
+    const bool need_vbits = a.v_may_null && have_values;
 #pragma unroll
     for (int u = 0; u < kU; ++u) {  // gathers, all in flight together
       // values' validity is consulted only when values.null_count != 0 (:306, :338)
-      vbit[u] = (a.v_may_null && have_values) ? GetBit(a.v_valid, a.v_off + j[u]) : true;
-      if (!have_values) v[u] = 0;
-      else if (kBits) v[u] = GetBit(reinterpret_cast<const uint8_t*>(a.v_data), a.v_off + j[u]);
-      else v[u] = reinterpret_cast<const T*>(a.v_data)[a.v_off + j[u]];
+      vvb[u] = need_vbits ? a.v_valid[(a.v_off + j[u]) >> 3] : 0xFFu;
+      v[u] = 0; bvb[u] = 0;
+      if (have_values) {
+        if (kBits) bvb[u] = reinterpret_cast<const uint8_t*>(a.v_data)[(a.v_off + j[u]) >> 3];
+        else v[u] = reinterpret_cast<const T*>(a.v_data)[a.v_off + j[u]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      vbit[u] = (vvb[u] >> ((a.v_off + j[u]) & 7)) & 1u;
+      if (kBits) v[u] = static_cast<T>((bvb[u] >> ((a.v_off + j[u]) & 7)) & 1u);
     }
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
