@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kThreads) void k_sort_count(const SortChunk* chunks
     if (PERM) { r0 = tile * kCTile; c.length = n; }
     else { c = chunks[FindChunk(chunks, nchunks, tile)]; r0 = (tile - c.tile_start) * kCTile; }
     uint32_t n1 = 0, n2 = 0, n0 = 0;
-    if (PERM) {
+    if (PERM && nchunks > 1) {
       for (int k = 0; k < kCTile / kThreads; ++k) {
         const int64_t r = r0 + k * kThreads + threadIdx.x;
         if (r < c.length) {
@@ -185,20 +185,25 @@ __global__ __launch_bounds__(kThreads) void k_sort_count(const SortChunk* chunks
       }
     } else if (c.length > 0) {
       // the tile's loads (values where a NaN is possible, validity bytes) all issued before the first is looked at
+      // (through a permutation over ONE chunk as well: the positions' rows first, then the same)
       constexpr int kI = kCTile / kThreads;
       const bool floats = type_id == AMDARROW_FLOAT || type_id == AMDARROW_DOUBLE;
       int64_t ri[kI];
       bool in[kI];
       KeyT raw[kI];
       uint32_t vb[kI];
+      if (PERM) { const int64_t len = c.length; c = chunks[0]; c.length = len; }
 #pragma unroll
       for (int k = 0; k < kI; ++k) {
         const int64_t r = r0 + k * kThreads + threadIdx.x;
         in[k] = r < c.length;
-        ri[k] = c.off + (in[k] ? r : c.length - 1);
+        ri[k] = in[k] ? r : c.length - 1;
+        if (PERM) ri[k] = static_cast<int64_t>(perm[ri[k]]) - c.row_start;
         raw[k] = 0;
         vb[k] = 0xFFu;
       }
+#pragma unroll
+      for (int k = 0; k < kI; ++k) ri[k] += c.off;
       if (floats) LoadRawKeys<KeyT, kI>(type_id, c.values, ri, raw);
       if (c.valid) {
 #pragma unroll
@@ -303,7 +308,11 @@ __global__ __launch_bounds__(kThreads) void k_sort_partition(const SortChunk* ch
         rows[j] = perm[r < n ? r : n - 1];
       }
     }
-    if (!PERM && c.length > 0) {
+    // (visiting the rows through a permutation: one chunk -- the usual case -- takes the batched loads too, the rows
+    // being its rows; several chunks look every row's chunk up, below)
+    const bool batched = PERM ? nchunks == 1 : c.length > 0;
+    if (PERM && batched) { const int64_t len = c.length; c = chunks[0]; c.length = len; }
+    if (batched) {
       // the tile's loads (values, validity bytes) all issued before the first is looked at: with the classification
       // inside each row's bounds check every load was waited for before the next was issued
       int64_t ri[kIters];
@@ -313,7 +322,8 @@ __global__ __launch_bounds__(kThreads) void k_sort_partition(const SortChunk* ch
       for (int j = 0; j < kIters; ++j) {
         const int64_t r = r0 + j * 64 + lane;
         in[j] = r < c.length;
-        ri[j] = c.off + (in[j] ? r : c.length - 1);
+        if (PERM) ri[j] = c.off + (static_cast<int64_t>(rows[PERM ? j : 0]) - c.row_start);  // (rows[] past the end repeat the last row)
+        else ri[j] = c.off + (in[j] ? r : c.length - 1);
         vb[j] = 0xFFu;
       }
       LoadRawKeys<KeyT, kIters>(type_id, c.values, ri, key);
@@ -339,7 +349,7 @@ __global__ __launch_bounds__(kThreads) void k_sort_partition(const SortChunk* ch
 #pragma unroll
     for (int j = 0; j < kIters; ++j) {
       const int64_t r = r0 + j * 64 + lane;
-      if (PERM) {
+      if (PERM && !batched) {
         cls[j] = 3;
         key[j] = 0;
         if (r < n) {
@@ -347,7 +357,7 @@ __global__ __launch_bounds__(kThreads) void k_sort_partition(const SortChunk* ch
           const SortChunk rc = chunks[FindChunkOfRow(chunks, nchunks, row)];
           cls[j] = Classify<KeyT>(rc, type_id, row - rc.row_start, key_mask, flip, &key[j]);
         }
-      } else if (c.length <= 0) {
+      } else if (!batched) {
         cls[j] = 3;
         key[j] = 0;
       }
