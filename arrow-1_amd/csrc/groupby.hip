@@ -315,16 +315,21 @@ __global__ __launch_bounds__(kThreads) void k_emit_groups(EmitArgs a) {
     uint32_t fr[U], pre[U];
     uint64_t hk[U], sum[U], cnt[U], word[U];
     bool live[U];
+    uint32_t had_id[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < U; ++u) {  // (raw loads only: a value looked at here would be waited for before the next slot's loads)
       const int64_t s = s0 + u * stride;
       const int64_t sc = s < a.nslots ? s : a.nslots - 1;
       fr[u] = a.t.first[sc];
       hk[u] = a.t.hkeys[sc];
-      sum[u] = 0; cnt[u] = 0;
+      sum[u] = 0; cnt[u] = 0; had_id[u] = kNoRow;
       if (a.packed || a.sums || a.counts) { sum[u] = a.t.sums[sc]; cnt[u] = a.t.counts[sc]; }  // (uniform)
-      live[u] = s < a.nslots && fr[u] != kNoRow;
-      if (live[u] && a.only_unassigned && a.t.ids[sc] != kNoRow) live[u] = false;
+      if (a.only_unassigned) had_id[u] = a.t.ids[sc];  // (uniform)
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t s = s0 + u * stride;
+      live[u] = s < a.nslots && fr[u] != kNoRow && had_id[u] == kNoRow;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
