@@ -59,6 +59,10 @@ struct amdarrow_ctx {
   GroupByHint gb_hints[kGroupByHints];
   uint64_t gb_hint_clock = 0;
   int gb_last_path = -1, gb_last_words = 0;  // amdarrow_groupby_last_path
+  // amdarrow_filter_groupby_multi: the key columns' ranges as the last call of this shape found them (32-bit columns
+  // without nulls): the next call packs with them -- the pack kernel checks every value -- instead of a min / max pass
+  // per column first
+  struct PackHint { int64_t n = -1; int ncols = 0; int types[4] = {0, 0, 0, 0}; uint64_t bias[4] = {0, 0, 0, 0}; uint32_t span[4] = {0, 0, 0, 0}; } pack_hint;
   void* pack_buf = nullptr;  // groupby.hip amdarrow_filter_groupby_multi: packed key codes (grow-only)
   size_t pack_cap = 0;
   void* side_buf = nullptr;  // groupby.hip amdarrow_hash_accumulate: the inner group-by's per-group outputs (grow-only)

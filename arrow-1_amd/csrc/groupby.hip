@@ -681,6 +681,8 @@ struct KeyPack {
   const void* data[kMaxPackedKeys]; const uint8_t* valid[kMaxPackedKeys]; int64_t off[kMaxPackedKeys];
   int load_bits[kMaxPackedKeys]; int is_signed[kMaxPackedKeys]; int shift[kMaxPackedKeys]; int bits[kMaxPackedKeys];
   uint32_t null_code[kMaxPackedKeys]; uint64_t bias[kMaxPackedKeys];
+  // hinted ranges (k_pack_keys_vec32): a value with value - bias > span[c] sets *out_of_range (null: not checked)
+  uint32_t span[kMaxPackedKeys]; unsigned int* out_of_range;
 };
 struct FastArgs {
   const void* k_data; const uint8_t* k_valid; int64_t k_off; int k_bits;
@@ -4426,6 +4428,7 @@ static int FilterGroupByImplCall(amdarrow_ctx* ctx, const amdarrow_array* values
 __global__ __launch_bounds__(256) void k_pack_keys_vec32(KeyPack p, int64_t n, uint32_t* out) {
   using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
   const int64_t nvec = n / 4;
+  int bad = 0;
   for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < nvec; i += int64_t(gridDim.x) * 256) {
     u32x4 c[kMaxPackedKeys];
 #pragma unroll
@@ -4439,15 +4442,21 @@ __global__ __launch_bounds__(256) void k_pack_keys_vec32(KeyPack p, int64_t n, u
       if (k >= p.ncols) break;
       // (value - bias in 32 bits: the signed / unsigned reading of the column is in the bias; the code fits its field)
       const uint32_t b = static_cast<uint32_t>(p.bias[k]);
-      x |= (c[k] - b) << static_cast<unsigned int>(p.shift[k]);
+      const u32x4 d = c[k] - b;
+      if (p.out_of_range) bad |= (d.x > p.span[k]) | (d.y > p.span[k]) | (d.z > p.span[k]) | (d.w > p.span[k]);  // (uniform branch)
+      x |= d << static_cast<unsigned int>(p.shift[k]);
     }
     __builtin_nontemporal_store(x, reinterpret_cast<u32x4*>(out) + i);
   }
+  if (p.out_of_range && __syncthreads_or(bad) && threadIdx.x == 0) __hip_atomic_store(p.out_of_range, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (blockIdx.x == 0 && threadIdx.x < n - nvec * 4) {  // the rows behind the last whole vector
     const int64_t r = nvec * 4 + threadIdx.x;
     uint32_t x = 0;
-    for (int k = 0; k < p.ncols; ++k)
-      x |= (reinterpret_cast<const uint32_t*>(p.data[k])[p.off[k] + r] - static_cast<uint32_t>(p.bias[k])) << p.shift[k];
+    for (int k = 0; k < p.ncols; ++k) {
+      const uint32_t d = reinterpret_cast<const uint32_t*>(p.data[k])[p.off[k] + r] - static_cast<uint32_t>(p.bias[k]);
+      if (p.out_of_range && d > p.span[k]) __hip_atomic_store(p.out_of_range, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      x |= d << p.shift[k];
+    }
     out[r] = x;
   }
 }
@@ -4564,6 +4573,16 @@ int amdarrow_filter_groupby_multi(amdarrow_ctx* ctx, const amdarrow_array* value
   if (n == 0) return AMDARROW_OK;
   if (n >= (int64_t(1) << 32) - 1) return SetError(AMDARROW_NOT_IMPLEMENTED, "group-by: 2^32 rows or more per call");
   std::lock_guard<std::mutex> lock(ctx->mu);
+  // the ranges of the last call of this shape (32-bit columns without a validity buffer, every slice on a 16-byte
+  // boundary): taken on trust, every value checked while packing, the call redone with measured ranges on a miss
+  auto& ph = ctx->pack_hint;
+  bool hintable = n >= 1024;
+  for (int c = 0; c < nkeys; ++c)
+    hintable = hintable && BitWidth(keys[c].type_id) == 32 && keys[c].validity == nullptr &&
+               (reinterpret_cast<uintptr_t>(keys[c].values) + 4 * static_cast<uintptr_t>(keys[c].offset)) % 16 == 0;
+  bool hinted = hintable && ph.n == n && ph.ncols == nkeys && !getenv("AMDARROW_GROUPBY_NO_HINT");
+  for (int c = 0; c < nkeys && hinted; ++c) hinted = ph.types[c] == keys[c].type_id;
+  for (;;) {  // (second trip: the hinted ranges did not hold)
   // plan: one pass per key column for its range (the aggregate kernel's min / max), bits = log2(range [+ a code for null])
   KeyPack p{};
   p.ncols = nkeys;
@@ -4571,6 +4590,8 @@ int amdarrow_filter_groupby_multi(amdarrow_ctx* ctx, const amdarrow_array* value
   for (int c = 0; c < nkeys; ++c) {
     const amdarrow_array& k = keys[c];
     amdarrow_agg r;
+    if (hinted) { r = amdarrow_agg{}; r.valid_count = n; r.min = ph.bias[c]; r.max = ph.bias[c] + ph.span[c]; }
+    else
     AA_TRY(AggregateLocked(ctx, &k, &r));
     const bool has_null = k.validity && k.null_count != 0 && r.valid_count < n;
     const uint64_t span = r.valid_count > 0 ? r.max - r.min : 0;  // wrap-around difference: exact for both signednesses
@@ -4585,13 +4606,15 @@ int amdarrow_filter_groupby_multi(amdarrow_ctx* ctx, const amdarrow_array* value
     p.null_code[c] = static_cast<uint32_t>(r.valid_count > 0 ? span + 1 : 0);
     p.bits[c] = bits;
     p.shift[c] = total;
+    p.span[c] = static_cast<uint32_t>(span);
+    if (!hinted && hintable) { ph.types[c] = k.type_id; ph.bias[c] = p.bias[c]; ph.span[c] = static_cast<uint32_t>(span); }
     total += bits;
     if (total > 32) return SetError(AMDARROW_NOT_IMPLEMENTED, "group-by: the key columns need more than 32 bits together");
   }
   // the single-key machinery on the column of packed codes (grow-only buffer of the context: codes of the rows, then of
   // the groups, then a validity bitmap nobody reads)
   const int64_t bound = group_capacity < n ? group_capacity : n;
-  const size_t need = 4 * static_cast<size_t>(n) + 4 * static_cast<size_t>(bound) + static_cast<size_t>(bound) / 8 + 512;
+  const size_t need = 4 * static_cast<size_t>(n) + 4 * static_cast<size_t>(bound) + static_cast<size_t>(bound) / 8 + 1024;
   if (ctx->pack_cap < need) {
     if (ctx->pack_buf) (void)hipFree(ctx->pack_buf);
     ctx->pack_buf = nullptr;
@@ -4602,10 +4625,14 @@ int amdarrow_filter_groupby_multi(amdarrow_ctx* ctx, const amdarrow_array* value
   auto* codes = static_cast<uint32_t*>(ctx->pack_buf);
   uint32_t* packed = codes + ((n + 63) / 64) * 64;
   uint8_t* dummy_validity = reinterpret_cast<uint8_t*>(packed + ((bound + 63) / 64) * 64);
+  unsigned int* range_flag = reinterpret_cast<unsigned int*>(static_cast<char*>(ctx->pack_buf) + ((need - 256) & ~size_t(255)));
+  p.out_of_range = nullptr;
+  if (hinted) { AA_HIP(hipMemsetAsync(range_flag, 0, 4, ctx->stream)); p.out_of_range = range_flag; }
   bool vec32 = n >= 1024 && reinterpret_cast<uintptr_t>(codes) % 16 == 0;
   for (int k = 0; k < p.ncols; ++k)
     vec32 = vec32 && p.load_bits[k] == 32 && !p.valid[k] &&
             (reinterpret_cast<uintptr_t>(p.data[k]) + 4 * static_cast<uintptr_t>(p.off[k])) % 16 == 0;
+  if (hinted && !vec32) { hinted = false; ph.n = -1; continue; }  // (only the vector kernel checks the hinted ranges)
   if (vec32) hipLaunchKernelGGL(k_pack_keys_vec32, dim3(GridFor(n / 4, 256, ctx->num_cus * 16)), dim3(256), 0, ctx->stream, p, n, codes);
   else
   hipLaunchKernelGGL(k_pack_keys, dim3(GridFor(n, 1024, ctx->num_cus * 8)), dim3(256), 0, ctx->stream, p, n, codes);
@@ -4616,6 +4643,13 @@ int amdarrow_filter_groupby_multi(amdarrow_ctx* ctx, const amdarrow_array* value
   int64_t G = 0;
   int rc = FilterGroupByImplCall(ctx, values, &stand_in, mask, group_capacity, out_sums, out_counts, packed, dummy_validity, out_first_rows,
                              &G, /*locked=*/true);
+  if (hinted) {  // (the group-by has synchronised: this read-back finds the stream idle)
+    unsigned int missed = 0;
+    AA_TRY(ReadBack(ctx, range_flag, 4, &missed));
+    if (missed) { hinted = false; ph.n = -1; continue; }
+  } else if (hintable && rc == AMDARROW_OK) {
+    ph.n = n; ph.ncols = nkeys;
+  }
   if (rc == AMDARROW_OK && G > 0) {
     void* base;
     rc = Scratch(ctx, kCounterBytes, &base);
@@ -4642,6 +4676,7 @@ int amdarrow_filter_groupby_multi(amdarrow_ctx* ctx, const amdarrow_array* value
   AA_HIP(e);
   *out_num_groups = G;
   return AMDARROW_OK;
+  }  // (trips)
 }
 
 }  // extern "C"

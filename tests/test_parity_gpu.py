@@ -1558,3 +1558,30 @@ def test_grouper_batches_of_one_shape_take_the_compact_records(oracle):
     for (va, vb, _), (vc, vd, _) in zip(uo, ug):
         assert np.array_equal(va, vc) and np.array_equal(vb, vd)
     assert _last_groupby_path(gpu)[1] in (2, 3)  # (the last batch went through compact records)
+
+
+def test_filter_groupby_multi_key_hinted_ranges(oracle):
+    """Two int32 key columns, calls of one shape: the second call packs with the first call's column ranges (no min /
+    max passes) and checks every value; a call whose keys leave those ranges is redone with measured ranges; results are
+    the oracle's every time."""
+    import gpu_api
+    from arrow1_amd import compute
+    from gpu_api import up
+    gpu = gpu_api.GpuApi()
+    rng = np.random.default_rng(501)
+    n = 600_000
+    for step, (lo1, hi1, lo2, hi2) in enumerate([(0, 300, 1000, 1400), (0, 300, 1000, 1400), (0, 300, 1000, 1400),
+                                                  (-50, 500, 900, 1500), (0, 300, 1000, 1400), (10, 20, 1100, 1200)]):
+        keys = [Arr(INT32, rng.integers(lo1, hi1, n).astype(np.int32)), Arr(INT32, rng.integers(lo2, hi2, n).astype(np.int32))]
+        v = R(rng, INT64, n, .02, 0)
+        m = rng.random(n) < .6
+        G, sums, counts, okeys, first = compute.filter_groupby_multi(gpu.ctx, up(v), [up(k) for k in keys], up(Arr(BOOL, m)), 1 << 21)
+        sel = np.nonzero(m)[0]
+        fk = [Arr(k.type_id, k.data[sel]) for k in keys]
+        fv = Arr(INT64, v.data[sel], None if v.valid is None else v.valid[sel])
+        ids, ng, uniq = oracle.group_ids([fk])
+        assert G == ng, step
+        assert np.array_equal(sums.values_numpy(), oracle.hash_aggregate("sum", fv, ids[0], ng).values.view(np.int64)), step
+        assert np.array_equal(counts.values_numpy(), oracle.hash_aggregate("count", fv, ids[0], ng).values), step
+        for c, (uv, uvalid, unull) in enumerate(uniq):
+            assert np.array_equal(np.asarray(okeys[c].values_numpy()), np.asarray(uv)), (step, c)
