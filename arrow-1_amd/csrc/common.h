@@ -52,8 +52,10 @@ struct amdarrow_ctx {
     // largest selected key in the scatter's unsigned key order plus the call's key bias, and whether every
     // selected valid value of an integer column was an int32 -- what a compact-record call assumes and checks
     int stats = 0, values_narrow = 0; uint64_t key_lo = 1, key_hi = 0;
+    uint64_t k_bias = 0;  // the bias of that call's range-compressed 64-bit key column (the next compact call skips the min / max pass)
     uint64_t last_used = 0;
   };
+  bool gb_no_bias_hint = false;  // set around the retry of a call whose hinted bias did not hold
   // one hint per call shape, the least recently used one gives way: queries that alternate keep their hints
   static constexpr int kGroupByHints = 4;
   GroupByHint gb_hints[kGroupByHints];

@@ -1427,6 +1427,7 @@ __device__ __forceinline__ uint32_t BinPartOf(uint32_t kk) { return (kk & (kP - 
 template <int R, bool K64> struct BinKeys;
 template <> struct BinKeys<4, false> {
   BinU32x4 kv;
+  __device__ __forceinline__ uint32_t hi(int, uint64_t) const { return 0u; }
   __device__ __forceinline__ uint32_t k(int j, uint64_t) const { return kv[j]; }
   __device__ __forceinline__ void load(const void* base, int64_t r0) { kv = __builtin_nontemporal_load(reinterpret_cast<const BinU32x4*>(static_cast<const uint32_t*>(base) + r0)); }
   __device__ __forceinline__ void set(int j, const void* base, int64_t r) { kv[j] = static_cast<const uint32_t*>(base)[r]; }
@@ -1434,6 +1435,7 @@ template <> struct BinKeys<4, false> {
 };
 template <> struct BinKeys<2, false> {
   BinU32x2 kv;
+  __device__ __forceinline__ uint32_t hi(int, uint64_t) const { return 0u; }
   __device__ __forceinline__ uint32_t k(int j, uint64_t) const { return kv[j]; }
   __device__ __forceinline__ void load(const void* base, int64_t r0) { kv = __builtin_nontemporal_load(reinterpret_cast<const BinU32x2*>(static_cast<const uint32_t*>(base) + r0)); }
   __device__ __forceinline__ void set(int j, const void* base, int64_t r) { kv[j] = static_cast<const uint32_t*>(base)[r]; }
@@ -1441,6 +1443,8 @@ template <> struct BinKeys<2, false> {
 };
 template <> struct BinKeys<4, true> {
   BinU64x2 ka, kb;
+  // (the upper half of key - bias: non-zero when a hinted bias does not hold for this key)
+  __device__ __forceinline__ uint32_t hi(int j, uint64_t bias) const { return static_cast<uint32_t>(((j < 2 ? ka[j] : kb[j - 2]) - bias) >> 32); }
   __device__ __forceinline__ uint32_t k(int j, uint64_t bias) const { return static_cast<uint32_t>((j < 2 ? ka[j] : kb[j - 2]) - bias); }
   __device__ __forceinline__ void load(const void* base, int64_t r0) {
     ka = __builtin_nontemporal_load(reinterpret_cast<const BinU64x2*>(static_cast<const uint64_t*>(base) + r0));
@@ -1453,6 +1457,7 @@ template <> struct BinKeys<4, true> {
 };
 template <> struct BinKeys<2, true> {
   BinU64x2 ka;
+  __device__ __forceinline__ uint32_t hi(int j, uint64_t bias) const { return static_cast<uint32_t>((ka[j] - bias) >> 32); }
   __device__ __forceinline__ uint32_t k(int j, uint64_t bias) const { return static_cast<uint32_t>(ka[j] - bias); }
   __device__ __forceinline__ void load(const void* base, int64_t r0) { ka = __builtin_nontemporal_load(reinterpret_cast<const BinU64x2*>(static_cast<const uint64_t*>(base) + r0)); }
   __device__ __forceinline__ void set(int j, const void* base, int64_t r) { ka[j] = static_cast<const uint64_t*>(base)[r]; }
@@ -1713,6 +1718,7 @@ __device__ __forceinline__ void CBinStageTile(CBinShared<PB>& sh, const FastArgs
       kmin = kk < kmin ? kk : kmin;
       kmax = kk > kmax ? kk : kmax;
       bad |= off[j] >> G::kSlotBits;  // (a key below c_base wraps around to a large offset)
+      if (K64) bad |= t.key.hi(j, a.k_bias);  // (a 64-bit key outside the 2^32 above the -- possibly hinted -- bias)
     }
   }
 #pragma unroll
@@ -3994,17 +4000,44 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
   // the keys (min / max) buys the partitioned LDS paths instead of the global-atomic table.
   int k_load_bits = ks.col[0].bits;
   uint64_t k_bias = 0;
+  bool bias_from_hint = false;  // the min / max pass skipped: the compact scatter checks every selected key against the bias
   if (ks.total_bits == 64 && (keys->type_id == AMDARROW_INT64 || keys->type_id == AMDARROW_UINT64) &&
       n >= (int64_t(1) << 18) && n < (int64_t(1) << 30) && !getenv("AMDARROW_GROUPBY_NO_RANGE_COMPRESSION")) {
-    amdarrow_agg kr;
-    AA_TRY(AggregateLocked(ctx, keys, &kr));
-    if (kr.valid_count > 0 && kr.max - kr.min < 0xFFFFFFFFull) {  // (wrap-around difference: exact for both signednesses)
-      k_bias = kr.min;
+    // a call of a shape whose last call ran on compact records takes that call's bias on trust (it WILL run on compact
+    // records again, or start over: see below)
+    if (!ctx->gb_no_bias_hint && !keys->validity && !getenv("AMDARROW_GROUPBY_PATH") && !getenv("AMDARROW_GROUPBY_NO_HINT") &&
+        !getenv("AMDARROW_GROUPBY_NO_COMPACT")) {
+      int every = kHintProbeEvery;
+      if (const char* env = getenv("AMDARROW_GROUPBY_PROBE_EVERY")) every = std::max(2, atoi(env));
+      for (auto& h : ctx->gb_hints) {
+        if (h.n == n && h.key_type == keys->type_id && h.value_type == (values ? values->type_id : 0) && h.has_mask == (mask != nullptr) &&
+            h.has_value_validity == (values && values->validity != nullptr) && h.stats && h.key_lo <= h.key_hi && h.key_lo >= h.k_bias &&
+            h.key_hi - h.key_lo <= (uint64_t(1) << 21) - 1024 && n <= (int64_t(1) << 28) &&  // (the compact records will take it)
+            (h.uses + 1) % every != 0) {
+          k_bias = h.k_bias;
+          bias_from_hint = true;
+        }
+      }
+    }
+    amdarrow_agg kr{};
+    if (!bias_from_hint) AA_TRY(AggregateLocked(ctx, keys, &kr));
+    if (bias_from_hint || (kr.valid_count > 0 && kr.max - kr.min < 0xFFFFFFFFull)) {  // (wrap-around difference: exact for both signednesses)
+      if (!bias_from_hint) k_bias = kr.min;
       ks.total_bits = 32;
       ks.col[0].bits = 32;
       ks.wide_null_slot = 0;
     }
   }
+  // (a call on a hinted bias that cannot run on compact records after all, or whose scatter finds a key the bias does
+  // not hold for, starts over with the min / max pass)
+  auto start_over_measured = [&]() -> int {
+    for (auto& h : ctx->gb_hints) if (h.n == n && h.key_type == keys->type_id) h.n = -1;
+    ctx->gb_no_bias_hint = true;
+    const int rc = FilterGroupByImpl(ctx, values, keys, mask, group_capacity, out_sums, out_counts, out_keys, out_key_validity, out_first_rows,
+                                     out_num_groups, /*locked=*/true, packed_out, bias_out);
+    ctx->gb_no_bias_hint = false;
+    return rc;
+  };
 
   ValueCol v{};
   if (values) v = ValueCol{values->values, values->validity, values->offset, values->type_id};
@@ -4134,6 +4167,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
           cap = ((cap * compact_rw + 3) / 4 + 7) & ~int64_t(7);  // that number of records, in 16-byte units
         }
       }
+      if (bias_from_hint && !compact) return start_over_measured();
       if (use_bins) cap += kCSpillUnits;  // room at the top of every region for the records that found their bin full
       hist_n = int64_t(kP) * (nblocks + (use_bins ? 1 : 0));  // bins: one more segment per partition, the spill list
     } else if (path == 1) {
@@ -4356,6 +4390,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
 #endif
     memcpy(&G, status + 6, 8);
     const unsigned int overflow = status[0];
+    if (overflow && bias_from_hint) return start_over_measured();
     if (overflow && fast && hinted) {  // the hint was wrong for this input: forget it, start over with the full path 3
       hinted = false;
       hint.n = -1;
@@ -4384,6 +4419,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
         shape.stats = use_bins && status[8] <= status[9] ? 1 : 0;
         shape.key_lo = status[8] + k_bias; shape.key_hi = status[9] + k_bias;
         shape.values_narrow = values && !IsFloat(values->type_id) && status[10] == 0 ? 1 : 0;
+        shape.k_bias = k_bias;
         shape.last_used = hint.last_used;
         hint = shape;
       }
@@ -4393,7 +4429,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
     if (hinted && G <= static_cast<int64_t>(kLocalLimit)) hint.n = -1;
     // a hinted call's scatter measured the same things: the next call's records follow the data
     if (hinted && use_bins && hint.n == shape.n && status[8] <= status[9]) {
-      if (!compact) { hint.stats = 1; hint.key_lo = status[8] + k_bias; hint.key_hi = status[9] + k_bias; }
+      if (!compact) { hint.stats = 1; hint.key_lo = status[8] + k_bias; hint.key_hi = status[9] + k_bias; hint.k_bias = k_bias; }
       if (fa_val_wide && !(compact && compact_rw == 2)) hint.values_narrow = status[10] == 0 ? 1 : 0;
     }
     *out_num_groups = G;

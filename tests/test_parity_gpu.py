@@ -1585,3 +1585,22 @@ def test_filter_groupby_multi_key_hinted_ranges(oracle):
         assert np.array_equal(counts.values_numpy(), oracle.hash_aggregate("count", fv, ids[0], ng).values), step
         for c, (uv, uvalid, unull) in enumerate(uniq):
             assert np.array_equal(np.asarray(okeys[c].values_numpy()), np.asarray(uv)), (step, c)
+
+
+def test_filter_groupby_int64_keys_hinted_bias(oracle):
+    """An int64 key column of a small range: the first call measures min / max (range compression), the calls behind it
+    take that bias on trust -- the compact scatter checks every selected key against it -- and a call whose keys moved
+    (below the bias, far above it, or by more than 2^32) starts over with a measured bias.  The reference's rows every time."""
+    import gpu_api
+    gpu = gpu_api.GpuApi()
+    rng = np.random.default_rng(21)
+    n = 1_400_000
+    for step, (lo, span) in enumerate([(10**12, 300_000), (10**12, 300_000), (10**12 + 5, 299_000), (10**12 - 7_000, 300_000),
+                                        (10**12 - 7_000, 300_000), (10**12 + 2**33, 300_000), (10**12 + 2**33, 300_000), (5, 300_000)]):
+        k = Arr(INT64, rng.integers(0, span, n) + lo)
+        v, m = R(rng, INT64, n, 0.0, 0), R(rng, BOOL, n, 0.0, 0)
+        _check_groupby(oracle, gpu, v, k, m, (step, lo))
+        path, words = _last_groupby_path(gpu)
+        assert path == 2, (step, path, words)
+        if step in (1, 2, 4, 6):
+            assert words == 2, (step, words)
