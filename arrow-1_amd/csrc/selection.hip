@@ -71,13 +71,28 @@ __global__ __launch_bounds__(kThreads) void k_filter_tile_counts(const uint8_t* 
 // Rounds of 8192 entries: a thread owns 8 consecutive ones (two 16-byte loads, one 64-byte run
 // of int64 stores), the 1024 partial sums are scanned across the block.  `host_total`
 // (optional, mapped host memory) receives the total as well, see StatusWords in common.h.
+// With up to kScanParallelChunks rounds the rounds run as that many workgroups instead of one after the other: workgroup
+// b first adds up everything before its round (at most 24 k counts, coalesced) -- a round's barriers and dependent
+// shuffles cost ~5 us, three of them in a row are half the scan of a 100 M-row filter's 24 k tile counts.
+constexpr int kScanParallelChunks = 4;
 __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* counts, int64_t n, int64_t* offsets,
                                                      long long* host_total) {
   constexpr int kPer = 8;
   __shared__ uint64_t s_wave[16];
+  __shared__ uint64_t s_before[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   uint64_t carry = 0;  // identical in every thread
-  for (int64_t base = 0; base < n; base += 1024 * kPer) {
+  const int64_t first = int64_t(blockIdx.x) * 1024 * kPer;  // (gridDim.x == 1: the whole input, round by round)
+  const int64_t last = gridDim.x == 1 ? n : (first + 1024 * kPer < n ? first + 1024 * kPer : n);
+  if (blockIdx.x > 0) {
+    uint64_t mine = 0;
+    for (int64_t i = tid; i < first; i += 1024) mine += counts[i];
+    mine = WaveReduceSum64(mine);
+    if (lane == 0) s_before[wave] = mine;
+    __syncthreads();
+    for (int w = 0; w < 16; ++w) carry += s_before[w];
+  }
+  for (int64_t base = first; base < last; base += 1024 * kPer) {
     const int64_t i0 = base + int64_t(tid) * kPer;
     uint32_t v[kPer];
     if (i0 + kPer <= n && (reinterpret_cast<uintptr_t>(counts + i0) & 15) == 0) {
@@ -110,14 +125,18 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* counts, int
     carry += total;
     __syncthreads();
   }
-  if (tid == 0) {
+  if (tid == 0 && blockIdx.x == gridDim.x - 1) {
     offsets[n] = static_cast<int64_t>(carry);
     if (host_total) *host_total = static_cast<long long>(carry);
   }
 }
+static unsigned ScanTilesGrid(int64_t n) {
+  const int64_t chunks = (n + 8191) / 8192;
+  return chunks >= 2 && chunks <= kScanParallelChunks ? static_cast<unsigned>(chunks) : 1u;
+}
 
 int LaunchScanU32(amdarrow_ctx* ctx, const uint32_t* counts, int64_t n, int64_t* offsets) {
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, counts, n, offsets,
+  hipLaunchKernelGGL(k_scan_tiles, dim3(ScanTilesGrid(n)), dim3(1024), 0, ctx->stream, counts, n, offsets,
                      static_cast<long long*>(nullptr));
   AA_HIP(hipGetLastError());
   return AMDARROW_OK;
@@ -565,7 +584,7 @@ static int RunCompaction(amdarrow_ctx* ctx, FilterArgs a, int width_bytes /*0 = 
   AA_HIP(hipGetLastError());
   // the total goes to mapped host memory; an event behind the scan lets the host pick it up
   // while the compaction (queued right behind) is still running
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, counts, a.ntiles, offsets,
+  hipLaunchKernelGGL(k_scan_tiles, dim3(ScanTilesGrid(a.ntiles)), dim3(1024), 0, ctx->stream, counts, a.ntiles, offsets,
                      reinterpret_cast<long long*>(static_cast<char*>(ctx->pinned_dev) + kStatusOffset));
   AA_HIP(hipGetLastError());
   AA_HIP(hipEventRecord(ctx->status_event, ctx->stream));
