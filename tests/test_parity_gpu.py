@@ -1604,3 +1604,40 @@ def test_filter_groupby_int64_keys_hinted_bias(oracle):
         assert path == 2, (step, path, words)
         if step in (1, 2, 4, 6):
             assert words == 2, (step, words)
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_filter_groupby_hinted_sequences_random(oracle, seed):
+    """Random shapes (key type / range / offset, value type and width, mask density, slices), five calls each with keys
+    that drift, jump or stay: whatever the hints make of the sequence -- compact records, a bias on trust, starting
+    over -- every call returns the reference's rows."""
+    import gpu_api
+    rng = np.random.default_rng(seed)
+    for trial in range(12):
+        gpu = gpu_api.GpuApi()
+        n = int(rng.integers(300_000, 2_000_000))
+        kt = [INT32, UINT32, INT64, UINT64][rng.integers(0, 4)]
+        vt = [INT64, DOUBLE, UINT64][rng.integers(0, 3)]
+        groups = int(rng.choice([3000, 60_000, 400_000, 1_500_000]))
+        base = int(rng.integers(-10**6, 10**6)) if kt in (INT32, INT64) else int(rng.integers(0, 10**6))
+        if kt in (INT64, UINT64) and rng.random() < 0.5:
+            base += 10**13
+        has_mask = rng.random() < 0.7
+        off = int(rng.choice([0, 0, 4, 16]))
+        vnull = float(rng.choice([0.0, 0.0, 0.03]))
+        for step in range(5):
+            shift = int(rng.choice([0, 0, 0, 50_000, -80_000, 3_000_000]))
+            lo = max(base + shift, 0) if kt in (UINT32, UINT64) else base + shift
+            k = Arr(kt, (rng.integers(0, groups, n + off) + lo).astype(orc.NP_OF[kt]), offset=off, length=n)
+            if vt == DOUBLE:
+                v = R(rng, DOUBLE, n, vnull, off)
+            else:
+                wide = rng.random() < 0.4
+                v = R(rng, vt, n, vnull, off, lo=(0 if vt == UINT64 else (-2**62 if wide else -1000)), hi=(2**62 if wide else 1000))
+            m = R(rng, BOOL, n, 0.0, off, hi=float(rng.choice([0.1, 0.5, 0.5, 0.8, 0.95]))) if has_mask else None
+            mo = m if m is not None else Arr(BOOL, np.ones(n + off, bool), offset=off, length=n)
+            for x, y in zip(oracle.filter_groupby_sum(v, k, mo), gpu.filter_groupby_sum(v, k, m)):
+                if x.dtype == np.float64:
+                    assert x.shape == y.shape and np.allclose(x, y, rtol=F64_RTOL), (seed, trial, step)
+                else:
+                    assert np.array_equal(x, y), (seed, trial, step)
