@@ -643,32 +643,61 @@ __global__ __launch_bounds__(kThreads) void k_binary_take_lengths(BinaryTakeArgs
   unsigned long long my_valid = 0;
   const int64_t wave_id = (int64_t(blockIdx.x) * kThreads + tid) >> 6;
   const int64_t nwaves = (int64_t(gridDim.x) * kThreads) >> 6;
-  for (int64_t base = wave_id * 64; base < a.n; base += nwaves * 64) {
-    const int64_t i = base + lane;
-    const int64_t ic = i < a.n ? i : a.n - 1;
-    bool ok = i < a.n;
-    if (a.i_valid) ok = ok && GetBit(a.i_valid, a.i_off + ic);
-    int64_t j;
-    const bool inb = IndexLoad<IdxT>::Load(a.i_data, a.i_off + ic, a.v_len, &j);
-    if (ok && !inb) {
-      ok = false;
-      if (a.boundscheck) atomicMin(a.err_pos, static_cast<unsigned long long>(i));
+  // Four rows per lane and step, every stage's loads stored raw before one is looked at (see k_take).
+  constexpr int kU = 4;
+  for (int64_t base = wave_id * (64 * kU); base < a.n; base += nwaves * (64 * kU)) {
+    IdxT iraw[kU];
+    uint32_t ivb[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t i = base + 64 * u + lane;
+      const int64_t ic = a.i_off + (i < a.n ? i : a.n - 1);
+      iraw[u] = reinterpret_cast<const IdxT*>(a.i_data)[ic];
+      ivb[u] = a.i_valid ? a.i_valid[ic >> 3] : 0xFFu;
     }
-    if (!ok) j = 0;
-    uint32_t len = 0;
-    if (a.v_len > 0) {
-      const bool vbit = a.v_may_null ? GetBit(a.v_valid, a.v_off + j) : true;
-      const int32_t o0 = a.v_offsets[a.v_off + j], o1 = a.v_offsets[a.v_off + j + 1];
-      ok = ok && vbit;
-      len = ok ? static_cast<uint32_t>(o1 - o0) : 0u;
-    } else {
-      ok = false;
+    bool ok[kU];
+    int64_t j[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t i = base + 64 * u + lane;
+      const int64_t ic = a.i_off + (i < a.n ? i : a.n - 1);
+      ok[u] = i < a.n && ((ivb[u] >> (ic & 7)) & 1u);
+      j[u] = static_cast<int64_t>(iraw[u]);
+      // IsOutOfBounds, util/int_util.cc:548-551
+      const bool inb = (static_cast<IdxT>(-1) < 0 && iraw[u] < 0) ? false : static_cast<uint64_t>(iraw[u]) < static_cast<uint64_t>(a.v_len);
+      if (ok[u] && !inb) {
+        ok[u] = false;
+        if (a.boundscheck) atomicMin(a.err_pos, static_cast<unsigned long long>(i));
+      }
+      if (!ok[u]) j[u] = 0;
     }
-    const uint64_t okmask = __ballot(ok);
-    if (i < a.n) a.out_lengths[i] = len;
-    if (lane == 0) {
-      reinterpret_cast<uint64_t*>(a.out_validity)[i >> 6] = okmask;
-      my_valid += __popcll(okmask);
+    int32_t o0[kU], o1[kU];
+    uint32_t vvb[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      o0[u] = 0; o1[u] = 0; vvb[u] = 0xFFu;
+      if (a.v_len > 0) {  // (uniform)
+        o0[u] = a.v_offsets[a.v_off + j[u]];
+        o1[u] = a.v_offsets[a.v_off + j[u] + 1];
+        if (a.v_may_null) vvb[u] = a.v_valid[(a.v_off + j[u]) >> 3];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t i = base + 64 * u + lane;
+      if (base + 64 * u >= a.n) break;  // wave-uniform
+      bool good = false;
+      uint32_t len = 0;
+      if (a.v_len > 0) {
+        good = ok[u] && ((vvb[u] >> ((a.v_off + j[u]) & 7)) & 1u);
+        len = good ? static_cast<uint32_t>(o1[u] - o0[u]) : 0u;
+      }
+      const uint64_t okmask = __ballot(good);
+      if (i < a.n) a.out_lengths[i] = len;
+      if (lane == 0) {
+        reinterpret_cast<uint64_t*>(a.out_validity)[i >> 6] = okmask;
+        my_valid += __popcll(okmask);
+      }
     }
   }
   if (lane == 0 && my_valid) atomicAdd(CounterSlot(a.valid_count), my_valid);
