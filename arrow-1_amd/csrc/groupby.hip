@@ -321,9 +321,7 @@ __global__ __launch_bounds__(kThreads) void k_emit_groups(EmitArgs a) {
       const int64_t s = s0 + u * stride;
       const int64_t sc = s < a.nslots ? s : a.nslots - 1;
       fr[u] = a.t.first[sc];
-      hk[u] = a.t.hkeys[sc];
-      sum[u] = 0; cnt[u] = 0; had_id[u] = kNoRow;
-      if (a.packed || a.sums || a.counts) { sum[u] = a.t.sums[sc]; cnt[u] = a.t.counts[sc]; }  // (uniform)
+      had_id[u] = kNoRow;
       if (a.only_unassigned) had_id[u] = a.t.ids[sc];  // (uniform)
     }
 #pragma unroll
@@ -332,10 +330,16 @@ __global__ __launch_bounds__(kThreads) void k_emit_groups(EmitArgs a) {
       live[u] = s < a.nslots && fr[u] != kNoRow && had_id[u] == kNoRow;
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < U; ++u) {  // second stage: the live slots' columns (half the slots of a directly indexed table are empty) and their ranks' words
+      const int64_t s = s0 + u * stride;
       const uint32_t w = live[u] ? fr[u] >> 6 : 0u;
       word[u] = a.bitmap[w];
       pre[u] = a.prefix[w];
+      hk[u] = 0; sum[u] = 0; cnt[u] = 0;
+      if (live[u]) {
+        hk[u] = a.t.hkeys[s];
+        if (a.packed || a.sums || a.counts) { sum[u] = a.t.sums[s]; cnt[u] = a.t.counts[s]; }
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
