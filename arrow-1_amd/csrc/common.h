@@ -53,6 +53,7 @@ struct amdarrow_ctx {
     // selected valid value of an integer column was an int32 -- what a compact-record call assumes and checks
     int stats = 0, values_narrow = 0; uint64_t key_lo = 1, key_hi = 0;
     uint64_t k_bias = 0;  // the bias of that call's range-compressed 64-bit key column (the next compact call skips the min / max pass)
+    int local_ok = 0;     // that call's per-workgroup pre-aggregation held every group: the next call queues nothing behind it
     uint64_t last_used = 0;
   };
   bool gb_no_bias_hint = false;  // set around the retry of a call whose hinted bias did not hold

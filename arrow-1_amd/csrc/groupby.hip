@@ -4081,12 +4081,16 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
   }
   auto& hint = *slot;
   bool hinted = false;
+  // few groups per row range last time: the pre-aggregation alone is queued (no gated scatter / aggregate launches
+  // behind it, ~5 us each); if it gives up this time the call starts over with everything
+  bool local_only = false;
   if (path == 3 && hint.n == shape.n && hint.key_type == shape.key_type && hint.value_type == shape.value_type &&
       hint.has_mask == shape.has_mask && hint.has_value_validity == shape.has_value_validity &&
       !getenv("AMDARROW_GROUPBY_PATH") && !getenv("AMDARROW_GROUPBY_NO_HINT")) {
     int every = kHintProbeEvery;
     if (const char* env = getenv("AMDARROW_GROUPBY_PROBE_EVERY")) every = std::max(2, atoi(env));
-    if (++hint.uses % every != 0) { path = 2; hinted = true; }
+    if (hint.local_ok) local_only = true;
+    else if (++hint.uses % every != 0) { path = 2; hinted = true; }
   }
   // Compact records (k_part_scatter_compact): a hinted call whose predecessor's selected keys spanned few enough
   // values carries 12-byte records, 8-byte ones if that call's (integer) values were all int32; the kernel checks
@@ -4278,12 +4282,12 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
           AA_HIP(hipGetLastError());
           // heavy hitters found by the workgroups that gave up: fold their rows here, hand the
           // scatter a mask without them (no-op when status[5] is 0)
-          hipLaunchKernelGGL(k_hot_aggregate, dim3(nblocks_local), dim3(kDThreads), 0, ctx->stream, fl, acc_double, hot, misc + 5);
+          if (!local_only) hipLaunchKernelGGL(k_hot_aggregate, dim3(nblocks_local), dim3(kDThreads), 0, ctx->stream, fl, acc_double, hot, misc + 5);
           AA_HIP(hipGetLastError());
           run_if = abort_flag;
         }
         const unsigned int* use_hot = path == 3 ? misc + 5 : nullptr;
-        for (int sub = 0; sub < nsub; ++sub) {  // one pass per sub-problem (nsub == 1 unless a table overflowed before)
+        for (int sub = 0; sub < (local_only && path == 3 ? 0 : nsub); ++sub) {  // one pass per sub-problem (nsub == 1 unless a table overflowed before)
         fa.sub_bits = nsub > 1 ? sub_bits : 0; fa.sub_id = static_cast<uint32_t>(sub);
         FastArgs fh = fa;  // the same scatter on the mask k_hot_aggregate wrote
         fh.m_data = hot.alt_mask; fh.m_valid = nullptr; fh.m_off = 0;
@@ -4394,6 +4398,12 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
 #endif
     memcpy(&G, status + 6, 8);
     const unsigned int overflow = status[0];
+    if (local_only && path == 3 && status[1] != 0) {  // the pre-aggregation gave up after all: everything, from the start
+      local_only = false;
+      hint.n = -1;
+      path = 4;  // -> 3 after the loop's decrement
+      continue;
+    }
     if (overflow && bias_from_hint) return start_over_measured();
     if (overflow && fast && hinted) {  // the hint was wrong for this input: forget it, start over with the full path 3
       hinted = false;
@@ -4424,6 +4434,11 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
         shape.key_lo = status[8] + k_bias; shape.key_hi = status[9] + k_bias;
         shape.values_narrow = values && !IsFloat(values->type_id) && status[10] == 0 ? 1 : 0;
         shape.k_bias = k_bias;
+        shape.last_used = hint.last_used;
+        hint = shape;
+      }
+      else if (status[1] == 0 && !overflow && sub_bits == 0) {  // the pre-aggregation held every group
+        shape.uses = 0; shape.stats = 0; shape.local_ok = 1;
         shape.last_used = hint.last_used;
         hint = shape;
       }
