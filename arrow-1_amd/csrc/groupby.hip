@@ -1387,14 +1387,14 @@ __global__ __launch_bounds__(kFThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
 // Same contract as k_part_scatter_fast (headline shape, private [workgroup][partition][cap] regions,
 // whole 64-byte sectors only), without the per-tile scan / compact staging / per-record partition
 // look-ups: every partition owns a BIN of kBinSlots records in LDS.  A selected row's LDS atomic on
-// the bin's counter IS its slot; after one barrier four lanes per partition copy the bin's complete
-// sectors to the region tail and move the (at most three) left-over records to the bin's front.  Two
-// LDS barriers per tile instead of four, no scan, and the loads are 16 bytes per lane: a thread owns
-// R consecutive rows (one key vector, R / 2 value vectors, one nibble of the mask).
+// the bin's counter IS its slot; after one barrier the bin's complete 128-byte lines go to the region tail
+// (BinFlush) and the (fewer than eight) left-over records move to the bin's front.  Two LDS barriers per tile
+// instead of four, no scan, and the loads are 16 bytes per lane: a thread owns R consecutive rows (one key vector,
+// R / 2 value vectors, one nibble of the mask).
 // A row whose bin is full (arrivals are Poisson with mean tile rows x selectivity / 512; more than
-// 13 in one tile is rare by choice of R) goes to the partition's SPILL list instead: segment
-// `nblocks` of the same region array, filled through a global atomic counter (counts[p][nblocks]).
-// The aggregate kernel reads it as one more segment.
+// 13 in one tile is rare by choice of R) goes to the TOP of the workgroup's region for the partition instead,
+// growing downwards, its slot from an LDS counter (kCSpillUnits records per region; counts[p][b] carries their
+// number in its top byte).  The aggregate kernel folds them after the region's stream.
 constexpr int kBinSlots = 16;
 constexpr int kBThreads = 1024;
 // status[0]: why a partitioned attempt failed
@@ -1658,7 +1658,7 @@ __device__ __forceinline__ void BinFlush(BinShared& sh, int tid, int64_t cap, ui
 // 16-byte path like any hinted call whose assumption failed.
 // A partition's records form a stream of 32-bit words: the bin holds up to 64 of them, whole 128-byte lines
 // (32 words, records may straddle them) leave at a flush and the words behind them move to the bin's front.
-// A record that does not fit the bin goes to the spill list as a 16-byte record, as in the 16-byte scatter.
+// A record that does not fit the bin goes to the top of its region as a 16-byte record, as in the 16-byte scatter.
 constexpr unsigned int kOverflowCompact = 4;  // a selected row did not fit the compact record of a hinted call
 // Two geometries, PB = log2(partitions): 512 partitions with bins of 64 words (12 slot bits, 19 row bits; the
 // 8-byte records) or 256 partitions with bins of 128 words (13 slot bits, 18 row bits -- twice the workgroups --;
@@ -2079,7 +2079,7 @@ __device__ __forceinline__ int ProbeInsert(unsigned int* s_tag, unsigned int* s_
 constexpr int kAggUnroll = 4;                  // records per lane and step (local path)
 constexpr int kPaUnroll = 4;                   // records per lane and step (partition aggregate; 5: +5 %, 6 spills: +10 %)
 constexpr int kAggStep = 64 * kPaUnroll;       // records per wave and step of the partition aggregate
-constexpr int kMaxSegments = 1024 + 1;        // scatter workgroups (kMaxFlags) + the spill list
+constexpr int kMaxSegments = 1024 + 1;        // scatter workgroups (kMaxFlags) + one (once the bin scatters' spill list: always empty now, records that find their bin full sit at the region tops)
 
 // Issue the (unconditional, clamped) streaming loads of one step: records [i0, i0 + kAggStep) of `seg`.
 template <int N>
@@ -4177,7 +4177,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
       }
       if (bias_from_hint && !compact) return start_over_measured();
       if (use_bins) cap += kCSpillUnits;  // room at the top of every region for the records that found their bin full
-      hist_n = int64_t(kP) * (nblocks + (use_bins ? 1 : 0));  // bins: one more segment per partition, the spill list
+      hist_n = int64_t(kP) * (nblocks + (use_bins ? 1 : 0));  // bins: one more (always empty) segment per partition, where the spill list was
     } else if (path == 1) {
       nblocks = static_cast<int>(std::min<int64_t>(ctx->num_cus, (n + kPartRows - 1) / kPartRows));
       rows_per_block = (((n + nblocks - 1) / nblocks + kPartRows - 1) / kPartRows) * kPartRows;
