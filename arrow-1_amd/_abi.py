@@ -57,6 +57,9 @@ SYMBOLS = {
     "amdarrow_free": (C.c_int, [_P, _P]),
     "amdarrow_bytes_allocated": (C.c_int64, [_P]),
     "amdarrow_max_memory": (C.c_int64, [_P]),
+    "amdarrow_pool_cached_bytes": (C.c_int64, [_P]),
+    "amdarrow_pool_trim": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "amdarrow_pool_set_cache_limit": (C.c_int, [_P, C.c_int64]),
     "amdarrow_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_int64]),
     "amdarrow_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_int64]),
     "amdarrow_memcpy_d2d": (C.c_int, [_P, _P, _P, C.c_int64]),

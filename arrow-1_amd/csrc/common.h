@@ -54,8 +54,17 @@ struct amdarrow_ctx {
     int stats = 0, values_narrow = 0; uint64_t key_lo = 1, key_hi = 0;
     uint64_t k_bias = 0;  // the bias of that call's range-compressed 64-bit key column (the next compact call skips the min / max pass)
     int local_ok = 0;     // that call's per-workgroup pre-aggregation held every group: the next call queues nothing behind it
+    // who asked (amdarrow_filter_groupby, the packed multi-key call, hash_accumulate over ids, a Grouper batch): part of the
+    // shape, so that entry points whose calls happen to have equal n and types do not trade each other's assumptions
+    int caller = 0;
+    // a running score of compact-record calls of this shape that had to start over (+2 each, -1 per call that went
+    // through), and how many calls stay on 16-byte records once it reached four (interleaved data sets of one shape
+    // would otherwise pay for two attempts every other call)
+    int compact_misses = 0, compact_off = 0;
     uint64_t last_used = 0;
   };
+  int gb_caller = 0;  // set by the entry point around FilterGroupByImpl (under `mu`)
+  int gb_carry_misses = -1, gb_carry_off = 0;  // back-off state handed to the retry of a call whose hinted bias did not hold (-1: none)
   bool gb_no_bias_hint = false;  // set around the retry of a call whose hinted bias did not hold
   // one hint per call shape, the least recently used one gives way: queries that alternate keep their hints
   static constexpr int kGroupByHints = 4;
@@ -81,6 +90,8 @@ struct amdarrow_ctx {
   std::unordered_map<void*, int64_t> alloc_class;              // block -> size class (bytes actually allocated)
   std::unordered_map<int64_t, std::vector<void*>> free_blocks;  // size class -> cached blocks
   int64_t cached_bytes = 0;
+  int64_t cache_limit = int64_t(16) << 30;  // cached bytes beyond which a freed block goes back to the device (set at creation)
+  std::mutex pool_mu;  // guards the seven pool fields above; never held across a kernel launch, may be taken under `mu`
   std::mutex mu;
 };
 
@@ -88,6 +99,12 @@ namespace amdarrow {
 
 // Ensure the scratch arena holds `bytes`; returns its base (256-B aligned).
 int Scratch(amdarrow_ctx* ctx, size_t bytes, void** out);
+// hipMalloc for the library's own buffers (arena, grouper tables, side buffers, temporaries).  When the device is
+// out of memory the pool's cached blocks (amdarrow_free keeps them) are given back and the allocation is tried once
+// more: memory sitting idle in the cache must never fail a call.
+int DeviceMalloc(amdarrow_ctx* ctx, void** out, size_t bytes);
+// Give every cached block of the pool back to the device (synchronises the context's stream first); returns the bytes freed.
+int64_t DrainPool(amdarrow_ctx* ctx);
 
 // A bump allocator over the scratch arena (sizes rounded to 256 B).
 struct Carver {

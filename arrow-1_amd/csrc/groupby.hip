@@ -3147,14 +3147,23 @@ __global__ __launch_bounds__(kThreads) void k_prepare(unsigned long long* bitmap
 
 // OR the workgroup flags into *summary (status[1]); reset the global table -- only when the
 // local path went through.
+// `gave_up_skip` (a call that queued ONLY the pre-aggregation, see local_only): nothing behind this kernel builds the
+// table when the attempt gives up, so the word every downstream kernel is gated on (status[0]) is raised as well --
+// mark / emit / unpack then touch neither the uninitialised table nor the heavy hitters' scratch -- and the host
+// starts the call over.
+constexpr unsigned int kLocalGaveUp = 8;
 __global__ __launch_bounds__(kThreads) void k_clear_table_unless(GroupTable t, int64_t nslots, const unsigned int* wg_flags,
                                                                  int nflags, unsigned int* summary, HotMem hot,
-                                                                 unsigned int* use_hot) {
+                                                                 unsigned int* use_hot, unsigned int* gave_up_skip) {
   int mine = 0;
   for (int i = threadIdx.x; i < nflags; i += kThreads) mine |= wg_flags[i] != 0;
   const int any = __syncthreads_or(mine);
   if (blockIdx.x == 0 && threadIdx.x == 0) *summary = any ? 1u : 0u;
   if (any) {
+    if (gave_up_skip) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) *gave_up_skip = kLocalGaveUp;
+      return;
+    }
     if (blockIdx.x == 0) BuildHotSet(hot, nflags, use_hot);  // heavy hitters seen by the workgroups that gave up
     return;
   }
@@ -3272,7 +3281,7 @@ int amdarrow_grouper_uniques(amdarrow_grouper* g, int k, void* out_values, uint8
 static int GrouperAllocTable(amdarrow_grouper* g, uint64_t T, char** mem, TableMem* tm) {
   Carver c;
   CarveTable(&c, T, true, tm);
-  AA_HIP(hipMalloc(reinterpret_cast<void**>(mem), c.off));
+  AA_TRY(DeviceMalloc(g->ctx, reinterpret_cast<void**>(mem), c.off));
   return ClearTable(g->ctx, BindTable(*mem, *tm, T, true), true);
 }
 
@@ -3347,8 +3356,8 @@ static int WideIds(amdarrow_grouper* g, const amdarrow_array* keys, uint32_t* ou
     if (w->ids) (void)hipFree(w->ids);
     if (w->packed) (void)hipFree(w->packed);
     w->ids = nullptr; w->packed = nullptr; w->cap = 0;
-    AA_HIP(hipMalloc(reinterpret_cast<void**>(&w->ids), 4 * static_cast<size_t>(K + 1) * static_cast<size_t>(n)));
-    AA_HIP(hipMalloc(reinterpret_cast<void**>(&w->packed), 8 * static_cast<size_t>(n)));
+    AA_TRY(DeviceMalloc(g->ctx, reinterpret_cast<void**>(&w->ids), 4 * static_cast<size_t>(K + 1) * static_cast<size_t>(n)));
+    AA_TRY(DeviceMalloc(g->ctx, reinterpret_cast<void**>(&w->packed), 8 * static_cast<size_t>(n)));
     w->cap = n;
   }
   for (int k = 0; k < K; ++k)
@@ -3383,7 +3392,7 @@ static int WideUniques(amdarrow_grouper* g, int k, void* out_values, uint8_t* ou
   char* mem = nullptr;
   const size_t words = 8 * (static_cast<size_t>(G) + 8), bits = (static_cast<size_t>(std::max(G, Gc)) / 64 + 2) * 8;
   const size_t lst_bytes = 8 * ((static_cast<size_t>(G) + 9) / 2), child_bytes = 8 * (static_cast<size_t>(Gc) + 8);
-  AA_HIP(hipMalloc(reinterpret_cast<void**>(&mem), words + bits + 2 * lst_bytes + child_bytes + bits));
+  AA_TRY(DeviceMalloc(g->ctx, reinterpret_cast<void**>(&mem), words + bits + 2 * lst_bytes + child_bytes + bits));
   auto* pair_words = reinterpret_cast<unsigned long long*>(mem);
   auto* scratch_bits = reinterpret_cast<uint8_t*>(mem + words);
   uint32_t* lst_buf[2] = {reinterpret_cast<uint32_t*>(mem + words + bits), reinterpret_cast<uint32_t*>(mem + words + bits + lst_bytes)};
@@ -3446,8 +3455,8 @@ int amdarrow_grouper_create(amdarrow_ctx* ctx, int nkeys, const int* key_type_id
   g->T = 4096;
   int rc = GrouperAllocTable(g, g->T, &g->table_mem, &g->tm);
   if (rc != AMDARROW_OK) { delete g; return rc; }
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&g->wide_null_id), 256);
-  if (e != hipSuccess) { delete g; return HipError(e, "hipMalloc", __FILE__, __LINE__); }
+  rc = DeviceMalloc(ctx, reinterpret_cast<void**>(&g->wide_null_id), 256);
+  if (rc != AMDARROW_OK) { delete g; return rc; }
   AA_HIP(hipMemsetAsync(g->wide_null_id, 0xFF, 256, ctx->stream));
   *out = g;
   return AMDARROW_OK;
@@ -3469,6 +3478,13 @@ int amdarrow_grouper_num_groups(amdarrow_grouper* g, uint32_t* out) {
   return AMDARROW_OK;
 }
 
+// Which entry point is asking (part of the hint's shape, see GroupByHint::caller); set under ctx->mu.
+struct CallerScope {
+  amdarrow_ctx* ctx; int saved;
+  CallerScope(amdarrow_ctx* c, int id) : ctx(c), saved(c->gb_caller) { c->gb_caller = id; }
+  ~CallerScope() { ctx->gb_caller = saved; }
+};
+enum { kCallerFilterGroupBy = 0, kCallerPackedKeys = 1, kCallerHashAccumulate = 2, kCallerGrouper = 3 };
 static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, const amdarrow_array* keys,
                              const amdarrow_array* mask, int64_t group_capacity, void* out_sums, int64_t* out_counts,
                              void* out_keys, uint8_t* out_key_validity, uint32_t* out_first_rows,
@@ -3576,6 +3592,7 @@ static int GrouperBatchGrouped(amdarrow_grouper* g, const amdarrow_array* keys, 
   int64_t G = 0;
   ulonglong4* packed = nullptr;
   uint64_t bias = 0;  // a 64-bit key column comes back range-compressed (key word + bias) or whole (bias 0)
+  CallerScope who(ctx, kCallerGrouper);
   const int rc = FilterGroupByImpl(ctx, nullptr, &keys[0], nullptr, cap, nullptr, nullptr, nullptr, nullptr, nullptr, &G,
                                    /*locked=*/true, &packed, &bias);
   if (rc == AMDARROW_CAPACITY_ERROR) return 1;
@@ -3599,7 +3616,7 @@ static int GrouperBatchGrouped(amdarrow_grouper* g, const amdarrow_array* keys, 
   if (known + static_cast<uint64_t>(G) > g->gx_cap) {
     const uint64_t gcap = NextPow2(2 * (known + static_cast<uint64_t>(G)));
     unsigned long long* ngx;
-    AA_HIP(hipMalloc(reinterpret_cast<void**>(&ngx), 8 * gcap));
+    AA_TRY(DeviceMalloc(ctx, reinterpret_cast<void**>(&ngx), 8 * gcap));
     if (known) AA_HIP(hipMemcpyAsync(ngx, g->gx, 8 * known, hipMemcpyDeviceToDevice, ctx->stream));
     AA_HIP(hipStreamSynchronize(ctx->stream));
     if (g->gx) AA_HIP(hipFree(g->gx));
@@ -3625,7 +3642,7 @@ static int GrouperBatchGrouped(amdarrow_grouper* g, const amdarrow_array* keys, 
       if (ctx->side_buf) (void)hipFree(ctx->side_buf);
       ctx->side_buf = nullptr;
       ctx->side_cap = 0;
-      AA_HIP(hipMalloc(&ctx->side_buf, need_side));
+      AA_TRY(DeviceMalloc(ctx, &ctx->side_buf, need_side));
       ctx->side_cap = need_side;
     }
     char* sb = static_cast<char*>(ctx->side_buf);
@@ -3749,7 +3766,7 @@ int amdarrow_grouper_consume(amdarrow_grouper* g, const amdarrow_array* keys, ui
   if (g->num_groups + room > g->gx_cap) {
     const uint64_t cap = NextPow2(2 * (g->num_groups + room));
     unsigned long long* ngx;
-    AA_HIP(hipMalloc(reinterpret_cast<void**>(&ngx), 8 * cap));
+    AA_TRY(DeviceMalloc(ctx, reinterpret_cast<void**>(&ngx), 8 * cap));
     if (g->num_groups) AA_HIP(hipMemcpyAsync(ngx, g->gx, 8ull * g->num_groups, hipMemcpyDeviceToDevice, ctx->stream));
     AA_HIP(hipStreamSynchronize(ctx->stream));
     if (g->gx) AA_HIP(hipFree(g->gx));
@@ -3888,7 +3905,7 @@ static int HashAccumulateGrouped(amdarrow_ctx* ctx, int func, const amdarrow_arr
     if (ctx->side_buf) (void)hipFree(ctx->side_buf);
     ctx->side_buf = nullptr;
     ctx->side_cap = 0;
-    AA_HIP(hipMalloc(&ctx->side_buf, need));
+    AA_TRY(DeviceMalloc(ctx, &ctx->side_buf, need));
     ctx->side_cap = need;
   }
   char* sb = static_cast<char*>(ctx->side_buf);
@@ -3900,6 +3917,7 @@ static int HashAccumulateGrouped(amdarrow_ctx* ctx, int func, const amdarrow_arr
   key.values = const_cast<uint32_t*>(ids); key.validity = nullptr; key.length = n; key.offset = 0; key.type_id = AMDARROW_UINT32;
   key.null_count = 0;
   int64_t G = 0;
+  CallerScope who(ctx, kCallerHashAccumulate);
   const int rc = FilterGroupByImpl(ctx, values, &key, nullptr, cap, gsums, gcounts, gkeys, gvalid, nullptr, &G, /*locked=*/true, nullptr);
   if (rc == AMDARROW_CAPACITY_ERROR) return 1;
   if (rc != AMDARROW_OK) return rc;
@@ -4014,8 +4032,8 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
       int every = kHintProbeEvery;
       if (const char* env = getenv("AMDARROW_GROUPBY_PROBE_EVERY")) every = std::max(2, atoi(env));
       for (auto& h : ctx->gb_hints) {
-        if (h.n == n && h.key_type == keys->type_id && h.value_type == (values ? values->type_id : 0) && h.has_mask == (mask != nullptr) &&
-            h.has_value_validity == (values && values->validity != nullptr) && h.stats && h.key_lo <= h.key_hi && h.key_lo >= h.k_bias &&
+        if (h.n == n && h.caller == ctx->gb_caller && h.key_type == keys->type_id && h.value_type == (values ? values->type_id : 0) && h.has_mask == (mask != nullptr) &&
+            h.has_value_validity == (values && values->validity != nullptr) && h.stats && h.compact_off == 0 && h.key_lo <= h.key_hi && h.key_lo >= h.k_bias &&
             h.key_hi - h.key_lo <= (uint64_t(1) << 21) - 1024 && n <= (int64_t(1) << 28) &&  // (the compact records will take it)
             (h.uses + 1) % every != 0) {
           k_bias = h.k_bias;
@@ -4035,7 +4053,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
   // (a call on a hinted bias that cannot run on compact records after all, or whose scatter finds a key the bias does
   // not hold for, starts over with the min / max pass)
   auto start_over_measured = [&]() -> int {
-    for (auto& h : ctx->gb_hints) if (h.n == n && h.key_type == keys->type_id) h.n = -1;
+    for (auto& h : ctx->gb_hints) if (h.n == n && h.caller == ctx->gb_caller && h.key_type == keys->type_id) h.n = -1;
     ctx->gb_no_bias_hint = true;
     const int rc = FilterGroupByImpl(ctx, values, keys, mask, group_capacity, out_sums, out_counts, out_keys, out_key_validity, out_first_rows,
                                      out_num_groups, /*locked=*/true, packed_out, bias_out);
@@ -4067,12 +4085,13 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
   amdarrow_ctx::GroupByHint shape;
   shape.n = n; shape.key_type = keys->type_id; shape.value_type = values ? values->type_id : 0;
   shape.has_mask = mask != nullptr; shape.has_value_validity = values && values->validity != nullptr;
+  shape.caller = ctx->gb_caller;
   // the hint of this shape, or the least recently used slot (a hint learnt by this call goes there)
   amdarrow_ctx::GroupByHint* slot = &ctx->gb_hints[0];
   {
     bool found = false;
     for (auto& h : ctx->gb_hints) {
-      if (h.n == shape.n && h.key_type == shape.key_type && h.value_type == shape.value_type && h.has_mask == shape.has_mask &&
+      if (h.n == shape.n && h.caller == shape.caller && h.key_type == shape.key_type && h.value_type == shape.value_type && h.has_mask == shape.has_mask &&
           h.has_value_validity == shape.has_value_validity) { slot = &h; found = true; break; }
     }
     if (!found)
@@ -4081,11 +4100,20 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
   }
   auto& hint = *slot;
   bool hinted = false;
+  // the back-off state of this shape survives the hint being forgotten and learnt again within the call
+  const bool shape_known = hint.n == shape.n && hint.caller == shape.caller && hint.key_type == shape.key_type && hint.value_type == shape.value_type &&
+                           hint.has_mask == shape.has_mask && hint.has_value_validity == shape.has_value_validity;
+  int carry_misses = shape_known ? hint.compact_misses : 0, carry_off = shape_known ? hint.compact_off : 0;
+  bool compact_allowed = carry_off == 0;
+  if (carry_off > 0) --carry_off;
+  if (ctx->gb_carry_misses >= 0) {  // the retry of a call whose hinted bias did not hold
+    carry_misses = ctx->gb_carry_misses; carry_off = ctx->gb_carry_off; compact_allowed = false;
+    ctx->gb_carry_misses = -1;
+  }
   // few groups per row range last time: the pre-aggregation alone is queued (no gated scatter / aggregate launches
   // behind it, ~5 us each); if it gives up this time the call starts over with everything
   bool local_only = false;
-  if (path == 3 && hint.n == shape.n && hint.key_type == shape.key_type && hint.value_type == shape.value_type &&
-      hint.has_mask == shape.has_mask && hint.has_value_validity == shape.has_value_validity &&
+  if (path == 3 && shape_known &&
       !getenv("AMDARROW_GROUPBY_PATH") && !getenv("AMDARROW_GROUPBY_NO_HINT")) {
     int every = kHintProbeEvery;
     if (const char* env = getenv("AMDARROW_GROUPBY_PROBE_EVERY")) every = std::max(2, atoi(env));
@@ -4109,7 +4137,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
                         (reinterpret_cast<uintptr_t>(keys->values) + (k_load_bits / 8) * static_cast<uintptr_t>(keys->offset)) % 16 == 0 &&
                         (values ? (reinterpret_cast<uintptr_t>(values->values) + 8 * static_cast<uintptr_t>(values->offset)) % 16 == 0
                                 : reinterpret_cast<uintptr_t>(keys->values) % 16 == 0);
-  if (hinted && use_bins && hint.stats && hint.key_lo <= hint.key_hi && hint.key_lo >= k_bias &&
+  if (hinted && use_bins && compact_allowed && hint.stats && hint.key_lo <= hint.key_hi && hint.key_lo >= k_bias &&
       hint.key_hi - k_bias <= 0xFFFFFFFFull && !getenv("AMDARROW_GROUPBY_NO_COMPACT")) {
     int rw = values && !IsFloat(values->type_id) && hint.values_narrow ? 2 : 3;
     if (const char* env = getenv("AMDARROW_GROUPBY_COMPACT_WORDS")) rw = atoi(env) == 2 && rw == 2 ? 2 : 3;
@@ -4272,7 +4300,8 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
           AA_HIP(hipGetLastError());
           const int64_t nslots = static_cast<int64_t>(T) + 2;
           hipLaunchKernelGGL(k_clear_table_unless, dim3(GridFor(nslots, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0,
-                             ctx->stream, t, nslots, wg_flags, nblocks_local, abort_flag, hot, misc + 5);
+                             ctx->stream, t, nslots, wg_flags, nblocks_local, abort_flag, hot, misc + 5,
+                             local_only ? misc : static_cast<unsigned int*>(nullptr));
           if (headline_shape && !getenv("AMDARROW_GROUPBY_OLD_MERGE"))
             hipLaunchKernelGGL(k_local_merge_slots, dim3(kSlots / kMergeSlots), dim3(kMergeThreads), 0, ctx->stream, st,
                                nblocks_local, ks.total_bits, acc_double, t, abort_flag, misc);
@@ -4362,7 +4391,8 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
     }
     int64_t G = 0;
     const HotInject inject{hot, nblocks_local, ks.total_bits, values && IsFloat(values->type_id) ? 1 : 0};
-    AA_TRY(RankFirstRows(ctx, t, 0, r, &G, /*mark_mode=*/path == 3 ? 2 : path == 2 ? 1 : 3, misc, path == 3 ? &inject : nullptr));
+    AA_TRY(RankFirstRows(ctx, t, 0, r, &G, /*mark_mode=*/path == 3 ? 2 : path == 2 ? 1 : 3, misc,
+                          path == 3 && !local_only ? &inject : nullptr));
     // Emit and decode are queued BEFORE the group count is known on the host (they take it from
     // the status words and are bounded by group_capacity), so the one host round trip of the
     // call overlaps with them instead of sitting between two kernels.
@@ -4404,7 +4434,16 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
       path = 4;  // -> 3 after the loop's decrement
       continue;
     }
-    if (overflow && bias_from_hint) return start_over_measured();
+    if (compact && (overflow & kOverflowCompact)) {
+      // a miss weighs two, a compact call that goes through takes one off: a shape that keeps missing (data sets of one
+      // shape that alternate, say) reaches four and its next 16 calls stay on 16-byte records
+      carry_misses += 2;
+      if (carry_misses >= 4) { carry_misses = 0; carry_off = 16; }
+    }
+    if (overflow && bias_from_hint) {
+      ctx->gb_carry_misses = carry_misses; ctx->gb_carry_off = carry_off;  // (start_over_measured forgets the shape's hints; the retry picks the back-off up here)
+      return start_over_measured();
+    }
     if (overflow && fast && hinted) {  // the hint was wrong for this input: forget it, start over with the full path 3
       hinted = false;
       hint.n = -1;
@@ -4450,6 +4489,10 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
     if (hinted && use_bins && hint.n == shape.n && status[8] <= status[9]) {
       if (!compact) { hint.stats = 1; hint.key_lo = status[8] + k_bias; hint.key_hi = status[9] + k_bias; hint.k_bias = k_bias; }
       if (fa_val_wide && !(compact && compact_rw == 2)) hint.values_narrow = status[10] == 0 ? 1 : 0;
+    }
+    if (hint.n == shape.n) {  // the back-off state stays with the shape; a compact call that went through ends a run of misses
+      hint.compact_misses = compact && carry_misses > 0 ? carry_misses - 1 : carry_misses;
+      hint.compact_off = carry_off;
     }
     *out_num_groups = G;
     ctx->gb_last_path = path == 3 && status[1] != 0 ? 2 : path;
@@ -4674,7 +4717,7 @@ int amdarrow_filter_groupby_multi(amdarrow_ctx* ctx, const amdarrow_array* value
     if (ctx->pack_buf) (void)hipFree(ctx->pack_buf);
     ctx->pack_buf = nullptr;
     ctx->pack_cap = 0;
-    AA_HIP(hipMalloc(&ctx->pack_buf, need));
+    AA_TRY(DeviceMalloc(ctx, &ctx->pack_buf, need));
     ctx->pack_cap = need;
   }
   auto* codes = static_cast<uint32_t*>(ctx->pack_buf);
@@ -4696,6 +4739,7 @@ int amdarrow_filter_groupby_multi(amdarrow_ctx* ctx, const amdarrow_array* value
   stand_in.values = codes; stand_in.validity = nullptr; stand_in.length = n; stand_in.offset = 0;
   stand_in.type_id = AMDARROW_UINT32; stand_in.null_count = 0;
   int64_t G = 0;
+  CallerScope who(ctx, kCallerPackedKeys);
   int rc = FilterGroupByImplCall(ctx, values, &stand_in, mask, group_capacity, out_sums, out_counts, packed, dummy_validity, out_first_rows,
                              &G, /*locked=*/true);
   if (hinted) {  // (the group-by has synchronised: this read-back finds the stream idle)

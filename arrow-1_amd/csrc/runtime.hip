@@ -2,6 +2,7 @@
 #include "common.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace amdarrow {
@@ -27,10 +28,35 @@ int Scratch(amdarrow_ctx* ctx, size_t bytes, void** out) {
     ctx->scratch = nullptr;
     ctx->scratch_cap = 0;
     size_t cap = (bytes + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
-    AA_HIP(hipMalloc(&ctx->scratch, cap));
+    AA_TRY(DeviceMalloc(ctx, &ctx->scratch, cap));
     ctx->scratch_cap = cap;
   }
   *out = ctx->scratch;
+  return AMDARROW_OK;
+}
+
+int64_t DrainPool(amdarrow_ctx* ctx) {
+  std::vector<void*> drop;
+  int64_t bytes = 0;
+  {
+    std::lock_guard<std::mutex> lock(ctx->pool_mu);
+    for (auto& kv : ctx->free_blocks) { for (void* q : kv.second) drop.push_back(q); kv.second.clear(); }
+    bytes = ctx->cached_bytes;
+    ctx->cached_bytes = 0;
+  }
+  if (drop.empty()) return 0;
+  (void)hipStreamSynchronize(ctx->stream);  // a cached block may still be read by work queued before its free
+  for (void* q : drop) (void)hipFree(q);
+  return bytes;
+}
+
+int DeviceMalloc(amdarrow_ctx* ctx, void** out, size_t bytes) {
+  hipError_t e = hipMalloc(out, bytes);
+  if (e == hipErrorOutOfMemory) {
+    (void)hipGetLastError();
+    if (DrainPool(ctx) > 0) e = hipMalloc(out, bytes);
+  }
+  if (e != hipSuccess) { *out = nullptr; return HipError(e, "hipMalloc", __FILE__, __LINE__); }
   return AMDARROW_OK;
 }
 
@@ -92,6 +118,12 @@ int amdarrow_ctx_create(int device, void* stream, int private_stream, amdarrow_c
   if (e != hipSuccess) { (void)hipHostFree(ctx->pinned); delete ctx; return HipError(e, "hipEventCreate", __FILE__, __LINE__); }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+  // the pool keeps at most an eighth of the device's memory in freed blocks (36 GB on a 288 GB part); AMDARROW_POOL_CACHE_LIMIT
+  // (bytes) overrides it, 0 turns the cache off
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) ctx->cache_limit = static_cast<int64_t>(total_b / 8);
+  else (void)hipGetLastError();
+  if (const char* env = getenv("AMDARROW_POOL_CACHE_LIMIT")) ctx->cache_limit = atoll(env);
   *out_ctx = ctx;
   return AMDARROW_OK;
 }
@@ -127,8 +159,6 @@ static int64_t SizeClass(int64_t cap) {
   const int64_t step = int64_t(1) << (lg - 3);
   return (cap + step - 1) / step * step;
 }
-constexpr int64_t kPoolCacheLimit = int64_t(16) << 30;  // cached (free) bytes beyond which blocks go back to the device
-
 int amdarrow_malloc(amdarrow_ctx* ctx, int64_t nbytes, void** out_ptr) {
   if (nbytes < 0) return SetError(AMDARROW_INVALID, "amdarrow_malloc: negative size");
   // capacity rounded up to 64 bytes like arrow::MemoryPool (memory_pool.cc:101, buffer.cc:196-216)
@@ -137,7 +167,7 @@ int amdarrow_malloc(amdarrow_ctx* ctx, int64_t nbytes, void** out_ptr) {
   AA_HIP(hipSetDevice(ctx->device));
   void* p = nullptr;
   {
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::mutex> lock(ctx->pool_mu);
     auto it = ctx->free_blocks.find(klass);
     if (it != ctx->free_blocks.end() && !it->second.empty()) {
       p = it->second.back();
@@ -145,26 +175,12 @@ int amdarrow_malloc(amdarrow_ctx* ctx, int64_t nbytes, void** out_ptr) {
       ctx->cached_bytes -= klass;
     }
   }
-  if (!p) {
-    hipError_t e = hipMalloc(&p, static_cast<size_t>(klass));
-    if (e != hipSuccess) {  // out of memory: give the cache back and try once more
-      (void)hipGetLastError();
-      std::vector<void*> drop;
-      {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        for (auto& kv : ctx->free_blocks) { for (void* q : kv.second) drop.push_back(q); kv.second.clear(); }
-        ctx->cached_bytes = 0;
-      }
-      AA_HIP(hipStreamSynchronize(ctx->stream));
-      for (void* q : drop) (void)hipFree(q);
-      AA_HIP(hipMalloc(&p, static_cast<size_t>(klass)));
-    }
-  }
+  if (!p) AA_TRY(DeviceMalloc(ctx, &p, static_cast<size_t>(klass)));  // (out of memory: the cache goes back first)
   if (cap > nbytes) {
     // zero the padding so word-at-a-time bitmap readers see defined bytes
     AA_HIP(hipMemsetAsync(static_cast<char*>(p) + nbytes, 0, static_cast<size_t>(cap - nbytes), ctx->stream));
   }
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::mutex> lock(ctx->pool_mu);
   ctx->allocs[p] = cap;
   ctx->alloc_class[p] = klass;
   ctx->bytes_allocated += cap;
@@ -178,20 +194,41 @@ int amdarrow_free(amdarrow_ctx* ctx, void* ptr) {
   int64_t klass = 0;
   bool keep = false;
   {
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::mutex> lock(ctx->pool_mu);
     auto it = ctx->allocs.find(ptr);
     if (it == ctx->allocs.end()) return SetError(AMDARROW_INVALID, "amdarrow_free: pointer not from this pool");
     ctx->bytes_allocated -= it->second;
     ctx->allocs.erase(it);
     klass = ctx->alloc_class[ptr];
     ctx->alloc_class.erase(ptr);
-    keep = ctx->cached_bytes + klass <= kPoolCacheLimit;
+    keep = ctx->cached_bytes + klass <= ctx->cache_limit;
     if (keep) { ctx->free_blocks[klass].push_back(ptr); ctx->cached_bytes += klass; }
   }
   if (!keep) {
     AA_HIP(hipStreamSynchronize(ctx->stream));
     AA_HIP(hipFree(ptr));
   }
+  return AMDARROW_OK;
+}
+
+// bytes_allocated / max_memory count LIVE buffers at their 64-byte-rounded capacity (MemoryPool::bytes_allocated,
+// memory_pool.h:79-90); what the pool holds on the device beyond that -- size-class rounding of live blocks is not
+// included, freed blocks kept for reuse are -- is amdarrow_pool_cached_bytes, and amdarrow_pool_trim returns it.
+int64_t amdarrow_pool_cached_bytes(amdarrow_ctx* ctx) {
+  std::lock_guard<std::mutex> lock(ctx->pool_mu);
+  return ctx->cached_bytes;
+}
+int amdarrow_pool_trim(amdarrow_ctx* ctx, int64_t* out_freed) {
+  if (!ctx) return SetError(AMDARROW_INVALID, "null context");
+  AA_HIP(hipSetDevice(ctx->device));
+  const int64_t freed = DrainPool(ctx);
+  if (out_freed) *out_freed = freed;
+  return AMDARROW_OK;
+}
+int amdarrow_pool_set_cache_limit(amdarrow_ctx* ctx, int64_t bytes) {
+  if (!ctx || bytes < 0) return SetError(AMDARROW_INVALID, "amdarrow_pool_set_cache_limit: bad argument");
+  { std::lock_guard<std::mutex> lock(ctx->pool_mu); ctx->cache_limit = bytes; }
+  if (amdarrow_pool_cached_bytes(ctx) > bytes) (void)DrainPool(ctx);
   return AMDARROW_OK;
 }
 

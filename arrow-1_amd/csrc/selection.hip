@@ -1128,6 +1128,9 @@ int amdarrow_binary_take_data(amdarrow_ctx* ctx, const amdarrow_binary_array* va
                    indices->type_id == AMDARROW_INT64;
   const int64_t n = indices->length;
   if (n == 0) return AMDARROW_OK;
+  // an empty values array may come without an offsets buffer (length 0: every index is null): no row has bytes, and the
+  // copy kernel reads source offset 0 for rows without bytes
+  if (values->length == 0 || values->offsets == nullptr) return AMDARROW_OK;
   std::lock_guard<std::mutex> lock(ctx->mu);
   BinaryTakeArgs a{};
   a.v_offsets = values->offsets; a.v_data = values->data; a.v_off = values->offset; a.v_len = values->length;

@@ -589,7 +589,7 @@ __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_i
                                                               uint32_t* lookback /* [nblocks][256], zeroed */,
                                                               unsigned int* error, KeyT* keys_out,
                                                               uint32_t* idx_out, uint64_t* out64, int raw_type = 0,
-                                                              KeyT raw_flip = 0, KeyT raw_mask = 0) {
+                                                              KeyT raw_flip = 0, KeyT raw_mask = 0, uint32_t xcd_run = 0) {
   constexpr int kIters = kOTile / kOThreads;  // 16; wave w owns keys [w*1024, (w+1)*1024) of the tile, in order
   __shared__ uint32_t s_whist[kOWaves][256];  // per-wave digit counts, then per-wave running local positions
   __shared__ uint32_t s_dstart[256];          // first local position of each digit
@@ -597,6 +597,7 @@ __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_i
   __shared__ uint32_t s_scan[4];
   __shared__ KeyT s_keys[kOTile];
   __shared__ uint32_t s_idx[kOTile];
+  __shared__ uint16_t s_from[ARANK ? kOTile : 1];  // ARANK: where in the tile a staged key came from (the order check below)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < kOWaves * 256; i += kOThreads) (&s_whist[0][0])[i] = 0;
   __syncthreads();
@@ -606,14 +607,16 @@ __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_i
   // therefore handed to the SAME XCD (inside every group of 8 * kXcdRun workgroups), so that the halves meet in
   // one L2.  A tile's predecessors are dispatched at most one such group later, which the look-back tolerates
   // (the blocks of a group never wait for a later group).
+  // The permutation makes a tile wait, in the look-back, for tiles whose workgroups are dispatched up to a group
+  // LATER than its own: that is only safe while a whole group (8 * xcd_run workgroups) is resident at once, so the
+  // host passes xcd_run = 0 (tile = workgroup id: every predecessor was dispatched earlier) unless the occupancy
+  // query says the device holds a group, and the device has the eight XCDs the runs are dealt to.
   uint32_t tile = blockIdx.x;
-#ifndef SORT_NO_XCD_RUNS
-  {
-    constexpr uint32_t kXcdRun = 16, kGroup = 8 * kXcdRun;
-    const uint32_t g0 = tile / kGroup * kGroup, in = tile - g0;
-    if (g0 + kGroup <= gridDim.x) tile = g0 + (in % 8) * kXcdRun + in / 8;  // (the ragged last group keeps tile = blockIdx)
+  if (xcd_run) {
+    const uint32_t group = 8 * xcd_run;
+    const uint32_t g0 = tile / group * group, in = tile - g0;
+    if (g0 + group <= gridDim.x) tile = g0 + (in % 8) * xcd_run + in / 8;  // (the ragged last group keeps tile = blockIdx)
   }
-#endif
   const int64_t base = int64_t(tile) * kOTile;
   const int64_t left = n - base;
   const uint32_t count = left >= kOTile ? kOTile : static_cast<uint32_t>(left);
@@ -682,6 +685,7 @@ __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_i
         const uint32_t lpos = s_whist[wave][d] + rk[ARANK ? j : 0];
         s_keys[lpos] = key[j];
         s_idx[lpos] = idx[j];
+        s_from[ARANK ? lpos : 0] = static_cast<uint16_t>(li);
       }
       continue;
     }
@@ -746,9 +750,16 @@ __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_i
     s_gbase[tid] = dbase[tid] + excl;
   }
   if (__syncthreads_or(gave_up)) return;  // positions unknown: write nothing
+  bool disorder = false;
   for (uint32_t i = tid; i < count; i += kOThreads) {
     const KeyT k = s_keys[i];
     const uint32_t d = (k >> shift) & 255;
+    // ARANK is VERIFIED, not trusted: inside a digit's run the staged keys must appear in the order they had in the
+    // tile (that is what "stable" means for this pass; the atomics hand out distinct ranks by construction, so the
+    // only thing that could go wrong is their order).  A tile that fails raises error word 2 and the host redoes the
+    // sort with the ballot ranking -- correctness never rests on the order in which the hardware serves the lanes of
+    // one ds_add_rtn, only the speed does.
+    if (ARANK && i > s_dstart[d]) disorder |= s_from[ARANK ? i - 1 : 0] > s_from[ARANK ? i : 0];
     const uint32_t gpos = s_gbase[d] + (i - s_dstart[d]);
     if (LAST) {
       out64[gpos] = s_idx[i];
@@ -757,6 +768,7 @@ __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_i
       idx_out[gpos] = s_idx[i];
     }
   }
+  if (ARANK && disorder) __hip_atomic_store(error + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- windowed LDS sort: the tail of the hybrid sort ---------------------------------------------------
@@ -1150,6 +1162,19 @@ static bool LdsAtomicsLaneOrdered(amdarrow_ctx* ctx) {
   return ctx->lds_rank_ordered == 1;
 }
 
+// Tiles per XCD run of the one-sweep passes (see k_radix_onesweep), or 0 = tile = workgroup id.  The permuted order
+// needs a whole group of 8 x 16 workgroups resident at once -- asked of the occupancy calculator for this very kernel
+// -- on a device with eight XCDs; anything else (a partitioned or CU-masked device, a smaller part) keeps dispatch order,
+// where the look-back only ever waits for workgroups that were dispatched earlier.
+static uint32_t XcdRunFor(amdarrow_ctx* ctx, const void* kernel) {
+  if (getenv("AMDARROW_SORT_NO_XCD_RUNS")) return 0;
+  constexpr uint32_t kXcdRun = 16;
+  int per_cu = 0, xccs = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kOThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (hipDeviceGetAttribute(&xccs, hipDeviceAttributeNumberOfXccs, ctx->device) != hipSuccess) { (void)hipGetLastError(); xccs = ctx->num_cus == 256 ? 8 : 0; }
+  return xccs == 8 && int64_t(per_cu) * ctx->num_cus >= int64_t(8) * kXcdRun ? kXcdRun : 0;
+}
+
 template <typename KeyT>
 static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks, int type_id, int order, int64_t n,
                     uint64_t* out, const uint64_t* perm = nullptr, bool allow_onesweep = true, bool allow_hybrid = true) {
@@ -1336,7 +1361,7 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
       const KeyT* raw_src = reinterpret_cast<const KeyT*>(hc[0].values) + hc[0].off;
       hipLaunchKernelGGL(pass, dim3(static_cast<unsigned>((n0 + kOTile - 1) / kOTile)), dim3(kOThreads), 0, ctx->stream,
                          raw_src, static_cast<const uint32_t*>(nullptr), n0, shift, db, lookback,
-                         ctl + 15, keys_b, idx_b, out, type_id, raw_xor, key_mask);
+                         ctl + 15, keys_b, idx_b, out, type_id, raw_xor, key_mask, XcdRunFor(ctx, reinterpret_cast<const void*>(pass)));
       AA_HIP(hipGetLastError());
       std::swap(keys_a, keys_b);
       std::swap(idx_a, idx_b);
@@ -1348,7 +1373,7 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
       auto* pass = last ? (arank ? k_radix_onesweep<KeyT, true, true> : k_radix_onesweep<KeyT, true, false>)
                         : (arank ? k_radix_onesweep<KeyT, false, true> : k_radix_onesweep<KeyT, false, false>);
       hipLaunchKernelGGL(pass, dim3(static_cast<unsigned>((n0 + kOTile - 1) / kOTile)), dim3(kOThreads), 0, ctx->stream, keys_a, idx_a, n0, shift, db, lb,
-                         ctl + 15, keys_b, idx_b, out, 0, KeyT(0), KeyT(0));
+                         ctl + 15, keys_b, idx_b, out, 0, KeyT(0), KeyT(0), XcdRunFor(ctx, reinterpret_cast<const void*>(pass)));
       AA_HIP(hipGetLastError());
       std::swap(keys_a, keys_b);
       std::swap(idx_a, idx_b);
@@ -1369,14 +1394,21 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
     std::swap(idx_a, idx_b);
   }
   if (top) {
-    auto* window = arank ? k_window_sort<KeyT, true> : k_window_sort<KeyT, false>;
+    // (the window's own order never rests on the atomics' order: the bucket pass ties on the window position, and its
+    // LSD fallback for crowded windows ranks with ballots)
+    auto* window = k_window_sort<KeyT, false>;
     hipLaunchKernelGGL(window, dim3(static_cast<unsigned>((n0 + kWTile - 1) / kWTile)), dim3(kWThreads), 0, ctx->stream, keys_a, idx_a,
                        n0, top_mask, wd, ctl + 14, out);
     AA_HIP(hipGetLastError());
   }
   if (onesweep) {
-    unsigned int err[2] = {0, 0};  // [0] a run of equal top digits too long for the window, [1] a one-sweep pass gave up
-    AA_TRY(ReadBack(ctx, ctl + 14, 8, err));
+    unsigned int err[3] = {0, 0, 0};  // [0] a run of equal top digits too long for the window, [1] a one-sweep pass gave up,
+                                      // [2] a one-sweep tile whose atomic ranks were not in lane order
+    AA_TRY(ReadBack(ctx, ctl + 14, 12, err));
+    if (err[2]) {  // never seen on gfx950; the device then ranks with ballots from here on
+      ctx->lds_rank_ordered = 0;
+      return SortImpl<KeyT>(ctx, chunks, nchunks, type_id, order, n, out, perm, allow_onesweep, allow_hybrid);
+    }
     if (err[1]) return SortImpl<KeyT>(ctx, chunks, nchunks, type_id, order, n, out, perm, /*allow_onesweep=*/false, false);
     if (err[0]) return SortImpl<KeyT>(ctx, chunks, nchunks, type_id, order, n, out, perm, /*allow_onesweep=*/true, /*allow_hybrid=*/false);
   }
@@ -1439,7 +1471,7 @@ extern "C" int amdarrow_sort_indices_multi(amdarrow_ctx* ctx, const amdarrow_arr
   std::lock_guard<std::mutex> lock(ctx->mu);
   // the stages ping-pong between `out_indices` and one temporary so that the last lands in out_indices
   uint64_t* tmp = nullptr;
-  if (nkeys > 1) AA_HIP(hipMalloc(reinterpret_cast<void**>(&tmp), 8 * static_cast<size_t>(n)));
+  if (nkeys > 1) AA_TRY(DeviceMalloc(ctx, reinterpret_cast<void**>(&tmp), 8 * static_cast<size_t>(n)));
   int rc = AMDARROW_OK;
   const uint64_t* perm = nullptr;
   for (int k = nkeys - 1; k >= 0 && rc == AMDARROW_OK; --k) {

@@ -110,7 +110,7 @@ extern "C" int amdarrow_make_groupings(amdarrow_ctx* ctx, const uint32_t* ids, i
     return AMDARROW_OK;
   }
   uint64_t* sorted = nullptr;
-  AA_HIP(hipMalloc(reinterpret_cast<void**>(&sorted), 8 * static_cast<size_t>(n)));
+  AA_TRY(DeviceMalloc(ctx, reinterpret_cast<void**>(&sorted), 8 * static_cast<size_t>(n)));
   amdarrow_array chunk;
   chunk.values = ids; chunk.validity = nullptr; chunk.length = n; chunk.offset = 0;
   chunk.type_id = AMDARROW_UINT32; chunk.null_count = 0;

@@ -150,6 +150,9 @@ class MemoryPool {
   amdarrow_ctx* ctx() const { return ctx_; }
   int64_t bytes_allocated() const;
   int64_t max_memory() const;
+  // MemoryPool::ReleaseUnused (memory_pool.h:92-96): hand the freed blocks the pool keeps for reuse back to the device
+  void ReleaseUnused();
+  int64_t cached_bytes() const;
 
  private:
   amdarrow_ctx* ctx_ = nullptr;

@@ -84,6 +84,8 @@ MemoryPool::~MemoryPool() {
 }
 int64_t MemoryPool::bytes_allocated() const { return amdarrow_bytes_allocated(ctx_); }
 int64_t MemoryPool::max_memory() const { return amdarrow_max_memory(ctx_); }
+void MemoryPool::ReleaseUnused() { (void)amdarrow_pool_trim(ctx_, nullptr); }
+int64_t MemoryPool::cached_bytes() const { return amdarrow_pool_cached_bytes(ctx_); }
 
 Buffer::~Buffer() {
   if (owned_ && pool_ && data_) amdarrow_free(pool_->ctx(), data_);

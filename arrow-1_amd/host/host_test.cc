@@ -1295,6 +1295,8 @@ static int RunGpu() {
   WideKeyGroupByTests(pool, &ctx);
   ExpressionTests(pool, &ctx);
   CHECK(pool->bytes_allocated() >= 0 && pool->max_memory() > 0);  // the MemoryPool counters (memory_pool.h:38-105)
+  pool->ReleaseUnused();
+  CHECK(pool->cached_bytes() == 0);
   printf("host_test gpu: %d checks, %d failures\n", g_checks, g_failures);
   return g_failures ? 1 : 0;
 }

@@ -102,6 +102,14 @@ int amdarrow_malloc(amdarrow_ctx* ctx, int64_t nbytes, void** out_ptr);
 int amdarrow_free(amdarrow_ctx* ctx, void* ptr);
 int64_t amdarrow_bytes_allocated(amdarrow_ctx* ctx);
 int64_t amdarrow_max_memory(amdarrow_ctx* ctx);
+/* amdarrow_free keeps freed blocks by size class for reuse (a hipFree synchronises the device); the two counters
+ * above count live buffers only.  The cache is bounded (an eighth of the device's memory unless
+ * AMDARROW_POOL_CACHE_LIMIT / amdarrow_pool_set_cache_limit say otherwise), is given back by itself whenever an
+ * allocation of the library would otherwise fail, and on request: amdarrow_pool_trim is MemoryPool::ReleaseUnused
+ * (memory_pool.h:92-96). */
+int64_t amdarrow_pool_cached_bytes(amdarrow_ctx* ctx);
+int amdarrow_pool_trim(amdarrow_ctx* ctx, int64_t* out_freed_bytes /* may be NULL */);
+int amdarrow_pool_set_cache_limit(amdarrow_ctx* ctx, int64_t bytes);
 int amdarrow_memcpy_h2d(amdarrow_ctx* ctx, void* dst_dev, const void* src_host, int64_t nbytes);
 int amdarrow_memcpy_d2h(amdarrow_ctx* ctx, void* dst_host, const void* src_dev, int64_t nbytes);
 int amdarrow_memcpy_d2d(amdarrow_ctx* ctx, void* dst_dev, const void* src_dev, int64_t nbytes); /* async on the stream */

@@ -1641,3 +1641,99 @@ def test_filter_groupby_hinted_sequences_random(oracle, seed):
                     assert x.shape == y.shape and np.allclose(x, y, rtol=F64_RTOL), (seed, trial, step)
                 else:
                     assert np.array_equal(x, y), (seed, trial, step)
+
+
+# ---- round 3: the advisor's findings ----
+def test_filter_groupby_local_only_attempt_that_gives_up_touches_nothing(oracle):
+    """A shape whose last call was held by the per-workgroup pre-aggregation queues ONLY that; when the data then
+    change on the same shape (many groups, or heavy hitters) the attempt gives up and nothing downstream may touch the
+    never-built table or the heavy hitters' scratch.  Fresh context, small n, and a sort in between that fills the
+    arena with unrelated bytes: the restarted call returns the reference's rows."""
+    import gpu_api
+    rng = np.random.default_rng(5)
+    n = 300_000
+
+    def data(kind):
+        base = rng.integers(0, 250_000, n)
+        if kind == "few":
+            base = rng.integers(0, 300, n)
+        elif kind == "hot":
+            base[rng.random(n) < 0.4] = 7
+        return R(rng, INT64, n, 0.0, 0), Arr(INT32, base), R(rng, BOOL, n, 0.0, 0)
+    for second in ("spread", "hot"):
+        gpu = gpu_api.GpuApi()
+        for kind in ("few", "few", "sort", second, "few", "few", "sort", second):
+            if kind == "sort":
+                junk = Arr(UINT64, rng.integers(0, 2**63, 1_000_000).astype(np.uint64))
+                assert np.array_equal(gpu.sort_indices(junk), oracle.sort_indices(junk))
+                continue
+            v, k, m = data(kind)
+            for x, y in zip(oracle.filter_groupby_sum(v, k, m), gpu.filter_groupby_sum(v, k, m)):
+                assert np.array_equal(x, y), (second, kind)
+
+
+def test_pool_cache_is_bounded_and_trimmable(gpu):
+    """amdarrow_free keeps blocks for reuse; the cache is reported, trimmed on request and bounded by the limit."""
+    import ctypes as C
+    lib, h = gpu.ctx.lib, gpu.ctx.handle
+    lib.amdarrow_pool_trim(h, None)
+    ptrs = []
+    for _ in range(4):
+        p = C.c_void_p()
+        assert lib.amdarrow_malloc(h, 3 << 20, C.byref(p)) == 0
+        ptrs.append(p)
+    live = lib.amdarrow_bytes_allocated(h)
+    for p in ptrs:
+        assert lib.amdarrow_free(h, p) == 0
+    assert lib.amdarrow_bytes_allocated(h) == live - 4 * (3 << 20)
+    assert lib.amdarrow_pool_cached_bytes(h) >= 4 * (3 << 20)
+    freed = C.c_int64()
+    assert lib.amdarrow_pool_trim(h, C.byref(freed)) == 0
+    assert freed.value >= 4 * (3 << 20) and lib.amdarrow_pool_cached_bytes(h) == 0
+    assert lib.amdarrow_pool_set_cache_limit(h, 4 << 20) == 0  # room for one block of this class only
+    ptrs = []
+    for _ in range(3):
+        p = C.c_void_p()
+        assert lib.amdarrow_malloc(h, 3 << 20, C.byref(p)) == 0
+        ptrs.append(p)
+    for p in ptrs:
+        assert lib.amdarrow_free(h, p) == 0
+    assert 0 < lib.amdarrow_pool_cached_bytes(h) <= 4 << 20
+    assert lib.amdarrow_pool_set_cache_limit(h, 1 << 34) == 0
+
+
+def test_filter_groupby_compact_backs_off_after_repeated_misses(oracle):
+    """Two data sets of ONE shape that alternate (the second one's values are not int32): every compact attempt on the
+    wrong assumption starts over; after two misses in a row the shape stays on 16-byte records for a while instead of
+    paying for two attempts per call.  The reference's rows every time."""
+    import gpu_api
+    gpu = gpu_api.GpuApi()
+    rng = np.random.default_rng(9)
+    n = 700_000
+    paths = []
+    for step in range(12):
+        wide = step >= 2 and step % 2 == 0
+        k = Arr(INT32, rng.integers(0, 200_000, n).astype(np.int32))
+        v = R(rng, INT64, n, 0.0, 0, lo=(-2**62 if wide else -1000), hi=(2**62 if wide else 1000))
+        m = R(rng, BOOL, n, 0.0, 0)
+        _check_groupby(oracle, gpu, v, k, m, step)
+        paths.append(_last_groupby_path(gpu))
+    assert all(p[0] == 2 for p in paths[1:]), paths
+    # misses at steps 2, 4, 6 (+2 each, -1 for the compact calls between them) reach four at step 6: the calls behind it
+    # do not even try the compact records
+    assert paths[7] == (2, 4) and paths[9] == (2, 4), paths
+
+
+def test_sort_one_sweep_tile_order_is_verified(gpu, oracle, monkeypatch):
+    """The one-sweep passes rank with LDS atomics and VERIFY the order of every staged tile; with dispatch-order tiles
+    (no XCD runs) and with the ballot ranking the result is the same stable order."""
+    rng = np.random.default_rng(17)
+    a = Arr(UINT64, rng.integers(0, 2**20, 600_000).astype(np.uint64))  # many ties: stability is visible
+    want = oracle.sort_indices(a)
+    assert np.array_equal(gpu.sort_indices(a), want)
+    monkeypatch.setenv("AMDARROW_SORT_NO_XCD_RUNS", "1")
+    assert np.array_equal(gpu.sort_indices(a), want)
+    monkeypatch.delenv("AMDARROW_SORT_NO_XCD_RUNS")
+    monkeypatch.setenv("AMDARROW_SORT_BALLOT_RANK", "1")
+    import gpu_api
+    assert np.array_equal(gpu_api.GpuApi().sort_indices(a), want)
