@@ -33,6 +33,11 @@ class CBinaryArray(C.Structure):
                 ("offset", C.c_int64), ("null_count", C.c_int64)]
 
 
+class CVarArray(C.Structure):
+    _fields_ = [("offsets", C.c_void_p), ("offset_bits", C.c_int32), ("data", C.c_void_p), ("validity", C.c_void_p),
+                ("length", C.c_int64), ("offset", C.c_int64), ("null_count", C.c_int64)]
+
+
 class COut(C.Structure):
     _fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("has_validity", C.c_int32)]
 
@@ -105,6 +110,18 @@ SYMBOLS = {
                                                 C.POINTER(C.c_int64)]),
     "amdarrow_filter_groupby": (C.c_int, [_P, _A, _A, _A, C.c_int64, _P, _P, _P, _P, _P, C.POINTER(C.c_int64)]),
     "amdarrow_groupby_last_path": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "amdarrow_take_rows": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64, _A, C.c_int, _P, _P, _O]),
+    "amdarrow_gather_fixed_width": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, C.c_int64, _P]),
+    "amdarrow_var_take_offsets": (C.c_int, [_P, C.POINTER(CVarArray), _P, C.c_int64, _P, C.POINTER(C.c_int64)]),
+    "amdarrow_var_take_data": (C.c_int, [_P, C.POINTER(CVarArray), _P, C.c_int64, _P, _P]),
+    "amdarrow_list_take_child_indices": (C.c_int, [_P, C.POINTER(CVarArray), _P, C.c_int64, _P, _P]),
+    "amdarrow_binary_grouper_create": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+    "amdarrow_binary_grouper_destroy": (C.c_int, [_P]),
+    "amdarrow_binary_grouper_consume": (C.c_int, [_P, C.POINTER(CVarArray), _P]),
+    "amdarrow_binary_grouper_num_groups": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
+    "amdarrow_binary_grouper_uniques_size": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "amdarrow_binary_grouper_uniques": (C.c_int, [_P, _P, _P, _P, _O]),
+    "amdarrow_fixed_size_list_child_indices": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int64, _P, _P]),
 }
 
 

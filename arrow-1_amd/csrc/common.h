@@ -147,6 +147,13 @@ int LaunchScanU32(amdarrow_ctx* ctx, const uint32_t* counts, int64_t n, int64_t*
 // sum_offsets: ceil(n/2048) + 1 int64 of scratch; sum_offsets[ceil(n/2048)] = total.
 int ScanU32InPlace(amdarrow_ctx* ctx, uint32_t* data, int64_t n, uint32_t* sums, int64_t* sum_offsets);
 
+// Device-wide exclusive scan of int64 `lengths` into offsets of 32 or 64 bits (out_offsets[n] = total; *overflow is
+// raised when a 32-bit total passes INT32_MAX - 1).  sums: Scan64Blocks(n) + 1 int64 of scratch; sums[Scan64Blocks(n)] = total.
+// (selection_nested.hip)
+inline int64_t Scan64Blocks(int64_t n) { return (n + 2047) / 2048; }
+int LaunchScan64(amdarrow_ctx* ctx, const long long* lengths, int64_t n, long long* sums, int offset_bits, void* out_offsets,
+                 unsigned int* overflow);
+
 inline int BitWidth(int type_id) {
   switch (type_id) {
     case AMDARROW_BOOL: return 1;

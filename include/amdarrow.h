@@ -163,6 +163,51 @@ int amdarrow_binary_take_data(amdarrow_ctx* ctx, const amdarrow_binary_array* va
                               const amdarrow_array* indices, const int32_t* out_offsets,
                               uint8_t* out_data);
 
+/* ---- the other array_take / array_filter kernels (vector_selection.cc:2133-2176) ------------------------------
+ * fixed_size_binary / decimal128 / decimal256 (FSBImpl :1575-1606), large_binary / large_utf8
+ * (VarBinaryImpl<LargeBinaryType> :1493-1573), list / large_list / map (ListImpl :1608-1680), fixed_size_list (FSLImpl
+ * :1682-1724) and struct (StructImpl :1736-1763) all run on Selection::VisitTake (:1214-1262): an output row is valid
+ * iff its index is valid and the value it names is valid, the output ALWAYS carries a validity bitmap and an exact
+ * null count (FinishCommon :1205-1210), indices are bounds-checked first (TakeExec :1330-1345, IndexError).  Here
+ * that visit is ONE call, amdarrow_take_rows, which resolves every output row to the source row it copies (-1 = null)
+ * -- for a struct that is the whole kernel, its fields are taken with the same indices --, and the per-layout calls
+ * below consume the resolved rows.  Filter of these types is the same Take over amdarrow_take_indices(filter)
+ * (FilterExec visits the same rows; StructFilter :1765-1781 does literally that).  dictionary / extension / null
+ * arrays need no device call of their own (DictionaryTake :1151-1160 takes the indices, NullTake :1132-1140). */
+int amdarrow_take_rows(amdarrow_ctx* ctx, const uint8_t* values_validity /* may be NULL */, int64_t values_length,
+                       int64_t values_offset, int64_t values_null_count, const amdarrow_array* indices, int boundscheck,
+                       int64_t* out_src_rows /* indices.length */, uint8_t* out_validity, amdarrow_out* out);
+/* FSBImpl: out row i = the byte_width bytes of values row (values_offset + src_rows[i]), zero bytes for a null row. */
+int amdarrow_gather_fixed_width(amdarrow_ctx* ctx, const void* values, int64_t values_offset, int byte_width,
+                                const int64_t* src_rows, int64_t n, void* out_values);
+/* An offsets-based array: (large_)binary / utf8 (`data` = the bytes) or (large_)list / map (`data` unused). */
+typedef struct amdarrow_var_array {
+  const void* offsets;      /* int32_t or int64_t, (offset + length + 1) entries */
+  int32_t offset_bits;      /* 32 or 64 */
+  const uint8_t* data;
+  const uint8_t* validity;  /* LSB bitmap or NULL */
+  int64_t length;
+  int64_t offset;
+  int64_t null_count;
+} amdarrow_var_array;
+/* out_offsets[n + 1] (of values->offset_bits) = exclusive scan of the taken slots' lengths, a null row being empty;
+ * *out_total = the bytes (binary) / child rows (list) to allocate.  Invalid("Take operation overflowed binary array
+ * capacity") when a 32-bit total passes INT32_MAX - 1 (:1540-1544). */
+int amdarrow_var_take_offsets(amdarrow_ctx* ctx, const amdarrow_var_array* values, const int64_t* src_rows, int64_t n,
+                              void* out_offsets, int64_t* out_total);
+/* VarBinaryImpl: the bytes behind those offsets. */
+int amdarrow_var_take_data(amdarrow_ctx* ctx, const amdarrow_var_array* values, const int64_t* src_rows, int64_t n,
+                           const void* out_offsets, uint8_t* out_data);
+/* ListImpl: the child indices (int32 for 32-bit offsets, int64 for 64-bit ones: TypeTraits<Type>::OffsetBuilderType)
+ * the caller hands to Take(values.values(), child_indices, NoBoundsCheck) (:1667-1670). */
+int amdarrow_list_take_child_indices(amdarrow_ctx* ctx, const amdarrow_var_array* values, const int64_t* src_rows, int64_t n,
+                                     const void* out_offsets, void* out_child_indices);
+/* FSLImpl: n * list_size int64 child indices, (values_offset + src) * list_size + t, NULL (value 0) for every element
+ * of a null row; out_index_validity in whole 8-byte words.  The reference computes index * list_size without the
+ * array's offset (:1704) -- a defect for sliced inputs that is not replicated; parity is pinned at offset 0. */
+int amdarrow_fixed_size_list_child_indices(amdarrow_ctx* ctx, const int64_t* src_rows, int64_t n, int list_size,
+                                           int64_t values_offset, int64_t* out_indices, uint8_t* out_index_validity);
+
 /* Concatenate of BinaryArrays / StringArrays -- ConcatenateImpl::Visit(BinaryType) + ConcatenateOffsets,
  * array/concatenate.cc:100-160, 203-214: `size` reports the rows and data bytes (only the byte range every
  * chunk references is copied), then the call proper fills out_offsets[rows + 1], out_data and (iff the summed
@@ -248,6 +293,23 @@ int amdarrow_grouper_num_groups(amdarrow_grouper* g, uint32_t* out_num_groups);
 /* GetUniques (:410-428): key column k -> num_groups values + validity bitmap. */
 int amdarrow_grouper_uniques(amdarrow_grouper* g, int k, void* out_values,
                              uint8_t* out_validity, amdarrow_out* out);
+/* Grouper over ONE variable-width key column -- VarLengthKeyEncoder<BinaryType / LargeBinaryType>, hash_aggregate.cc:
+ * 237-311, behind GrouperImpl :313-437 (binary / utf8: offset_bits 32, large_binary / large_utf8: 64).  Keys are equal
+ * iff their bytes and lengths are; a null key is its own group; ids in first-appearance order across Consume calls;
+ * the uniques come back in id order with a validity bitmap only when the null group exists (DecodeNulls :64-94).
+ * Rows are grouped by a 64-bit hash of their bytes and EVERY row is then compared with its group's stored key: should
+ * two different keys ever share a hash the table is rebuilt under another seed from the stored keys and the batch
+ * redone (exact, or -- after four seeds -- a loud error).  Key columns of several kinds combine on the host: a
+ * variable-width column enters the fixed-width amdarrow_grouper as its uint32 ids (equal rows <=> equal id tuples),
+ * a dictionary column as its indices (DictionaryKeyEncoder :198-235). */
+typedef struct amdarrow_binary_grouper amdarrow_binary_grouper;
+int amdarrow_binary_grouper_create(amdarrow_ctx* ctx, int offset_bits, amdarrow_binary_grouper** out);
+int amdarrow_binary_grouper_destroy(amdarrow_binary_grouper* g);
+int amdarrow_binary_grouper_consume(amdarrow_binary_grouper* g, const amdarrow_var_array* keys, uint32_t* out_ids);
+int amdarrow_binary_grouper_num_groups(amdarrow_binary_grouper* g, uint32_t* out_num_groups);
+int amdarrow_binary_grouper_uniques_size(amdarrow_binary_grouper* g, int64_t* out_rows, int64_t* out_data_bytes);
+int amdarrow_binary_grouper_uniques(amdarrow_binary_grouper* g, void* out_offsets /* rows + 1, of offset_bits */,
+                                    uint8_t* out_data, uint8_t* out_validity /* whole 8-byte words */, amdarrow_out* out);
 /* Grouper::MakeGroupings (hash_aggregate.cc:979-1018, api_aggregate.h:360-377): the ListArray<int32> that lists, per
  * group, the rows carrying its id in row order -- given as its two buffers.  ids: device uint32[n], every id <
  * num_groups (AMDARROW_INVALID otherwise; the reference only DCHECKs); out_offsets: int32[num_groups + 1];

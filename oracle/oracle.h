@@ -277,6 +277,41 @@ int64_t orc_filter_groupby_sum(const orc_array* values, const orc_array* keys,
                                const orc_array* mask, void* out_sums, int64_t* out_counts,
                                void* out_keys, uint8_t* out_key_validity);
 
+/* ---- round 3: the array_take / array_filter kernels over non-primitive values (vector_selection.cc:2133-2176) and
+ * Grouper keys of variable width (hash_aggregate.cc:198-311), driven through the REAL reference only (ref_*): an Arrow
+ * array of any of those types is handed over as a flat list of nodes (root = node 0, the children of a node are
+ * nodes[first_child .. first_child + nchildren)), the reference's result is held by the driver until the next call and
+ * read back node by node.  The restatement of these kernels is numpy (tests/nested.py), not C. */
+enum {
+  ORC_K_PRIM = 0, ORC_K_BINARY = 1, ORC_K_LARGE_BINARY = 2, ORC_K_FSB = 3, ORC_K_LIST = 4, ORC_K_LARGE_LIST = 5,
+  ORC_K_MAP = 6, ORC_K_FSL = 7, ORC_K_STRUCT = 8, ORC_K_DICT = 9, ORC_K_NULL = 10, ORC_K_DECIMAL128 = 11,
+  ORC_K_DECIMAL256 = 12, ORC_K_UTF8 = 13, ORC_K_LARGE_UTF8 = 14
+};
+typedef struct orc_node {
+  int32_t kind;       /* ORC_K_* */
+  int32_t type_id;    /* PRIM: the value type; DICT: the index type */
+  int32_t byte_width; /* FSB */
+  int32_t list_size;  /* FSL */
+  const void* buf1;   /* PRIM values | offsets (32 / 64 bit) | FSB / decimal bytes | DICT indices */
+  const uint8_t* buf2; /* binary data */
+  const uint8_t* validity;
+  int64_t length, offset, null_count;
+  int64_t buf1_bytes, buf2_bytes; /* results only */
+  int32_t nchildren, first_child; /* LIST / MAP / FSL: the values; STRUCT: the fields; DICT: the dictionary */
+} orc_node;
+int ref_nested_select(const orc_node* nodes, int nnodes, const orc_array* selection, int is_filter, int option);
+int ref_nested_result_count(void);
+int ref_nested_result_node(int i, orc_node* out);
+/* internal::Grouper over key columns given as node trees (binary / large_binary / utf8 / dictionary keys next to
+ * primitive ones): `roots[k]` = the node of key column k (the types are taken from the nodes at creation; buffers
+ * may be NULL there).  consume -> ids; uniques(k) -> held like a select result. */
+typedef struct ref_ngrouper ref_ngrouper;
+ref_ngrouper* ref_nested_grouper_new(const orc_node* nodes, int nnodes, const int* roots, int nkeys);
+void ref_nested_grouper_free(ref_ngrouper* g);
+int ref_nested_grouper_consume(ref_ngrouper* g, const orc_node* nodes, int nnodes, const int* roots, uint32_t* out_ids);
+uint32_t ref_nested_grouper_num_groups(const ref_ngrouper* g);
+int ref_nested_grouper_uniques(ref_ngrouper* g, int k);  /* result held: ref_nested_result_* */
+
 #ifdef __cplusplus
 }
 #endif

@@ -673,3 +673,197 @@ int64_t ref_filter_groupby_sum(const orc_array* values, const orc_array* keys, c
 }
 
 }  // extern "C"
+
+// ---- round 3: arrays of any of the array_take / array_filter value types as node lists -----------------------------
+namespace {
+std::shared_ptr<DataType> NodeType(const orc_node* nodes, int i);
+std::shared_ptr<DataType> ChildType(const orc_node* nodes, const orc_node& n, int c) { return NodeType(nodes, n.first_child + c); }
+std::shared_ptr<DataType> NodeType(const orc_node* nodes, int i) {
+  const orc_node& n = nodes[i];
+  switch (n.kind) {
+    case ORC_K_PRIM: return TypeOf(n.type_id);
+    case ORC_K_BINARY: return binary();
+    case ORC_K_UTF8: return utf8();
+    case ORC_K_LARGE_BINARY: return large_binary();
+    case ORC_K_LARGE_UTF8: return large_utf8();
+    case ORC_K_FSB: return fixed_size_binary(n.byte_width);
+    case ORC_K_DECIMAL128: return decimal128(20, 3);
+    case ORC_K_DECIMAL256: return decimal256(40, 3);
+    case ORC_K_LIST: return list(ChildType(nodes, n, 0));
+    case ORC_K_LARGE_LIST: return large_list(ChildType(nodes, n, 0));
+    case ORC_K_MAP: {
+      const orc_node& st = nodes[n.first_child];
+      return map(NodeType(nodes, st.first_child), NodeType(nodes, st.first_child + 1));
+    }
+    case ORC_K_FSL: return fixed_size_list(ChildType(nodes, n, 0), n.list_size);
+    case ORC_K_STRUCT: {
+      std::vector<std::shared_ptr<Field>> f;
+      for (int c = 0; c < n.nchildren; ++c) f.push_back(field("f" + std::to_string(c), ChildType(nodes, n, c)));
+      return struct_(f);
+    }
+    case ORC_K_DICT: return dictionary(TypeOf(n.type_id), ChildType(nodes, n, 0));
+    case ORC_K_NULL: return null();
+  }
+  return nullptr;
+}
+std::shared_ptr<Buffer> Bits(const uint8_t* p, int64_t n) { return p ? std::make_shared<Buffer>(p, BitUtil::BytesForBits(n)) : nullptr; }
+std::shared_ptr<ArrayData> NodeData(const orc_node* nodes, int i, std::shared_ptr<DataType> type = nullptr) {
+  const orc_node& n = nodes[i];
+  if (!type) type = NodeType(nodes, i);
+  const int64_t end = n.offset + n.length;
+  const int64_t nc = n.validity ? n.null_count : 0;
+  auto validity = Bits(n.validity, end);
+  auto raw = [](const void* p, int64_t bytes) { return std::make_shared<Buffer>(reinterpret_cast<const uint8_t*>(p), bytes); };
+  switch (n.kind) {
+    case ORC_K_PRIM: return ArrayData::Make(type, n.length, {validity, raw(n.buf1, BufBytes(BitWidth(n.type_id), end))}, nc, n.offset);
+    case ORC_K_BINARY: case ORC_K_UTF8: {
+      const int32_t* off = static_cast<const int32_t*>(n.buf1);
+      return ArrayData::Make(type, n.length, {validity, raw(off, (end + 1) * 4), raw(n.buf2, end ? off[end] : 0)}, nc, n.offset);
+    }
+    case ORC_K_LARGE_BINARY: case ORC_K_LARGE_UTF8: {
+      const int64_t* off = static_cast<const int64_t*>(n.buf1);
+      return ArrayData::Make(type, n.length, {validity, raw(off, (end + 1) * 8), raw(n.buf2, end ? off[end] : 0)}, nc, n.offset);
+    }
+    case ORC_K_FSB: return ArrayData::Make(type, n.length, {validity, raw(n.buf1, end * n.byte_width)}, nc, n.offset);
+    case ORC_K_DECIMAL128: return ArrayData::Make(type, n.length, {validity, raw(n.buf1, end * 16)}, nc, n.offset);
+    case ORC_K_DECIMAL256: return ArrayData::Make(type, n.length, {validity, raw(n.buf1, end * 32)}, nc, n.offset);
+    case ORC_K_LIST: case ORC_K_MAP:
+      return ArrayData::Make(type, n.length, {validity, raw(n.buf1, (end + 1) * 4)}, {NodeData(nodes, n.first_child, type->field(0)->type())}, nc, n.offset);
+    case ORC_K_LARGE_LIST:
+      return ArrayData::Make(type, n.length, {validity, raw(n.buf1, (end + 1) * 8)}, {NodeData(nodes, n.first_child)}, nc, n.offset);
+    case ORC_K_FSL: return ArrayData::Make(type, n.length, {validity}, {NodeData(nodes, n.first_child)}, nc, n.offset);
+    case ORC_K_STRUCT: {
+      std::vector<std::shared_ptr<ArrayData>> kids;
+      for (int c = 0; c < n.nchildren; ++c) kids.push_back(NodeData(nodes, n.first_child + c, type->field(c)->type()));
+      return ArrayData::Make(type, n.length, {validity}, kids, nc, n.offset);
+    }
+    case ORC_K_DICT: {
+      auto d = ArrayData::Make(type, n.length, {validity, raw(n.buf1, BufBytes(BitWidth(n.type_id), end))}, nc, n.offset);
+      d->dictionary = NodeData(nodes, n.first_child);
+      return d;
+    }
+    case ORC_K_NULL: return ArrayData::Make(type, n.length, {nullptr}, n.length, n.offset);
+  }
+  return nullptr;
+}
+
+struct Held {
+  std::shared_ptr<ArrayData> root;
+  std::vector<orc_node> nodes;
+  std::vector<std::shared_ptr<ArrayData>> keep;
+} g_held;
+void FillAt(size_t at, const std::shared_ptr<ArrayData>& d);
+int KindOf(const DataType& t) {
+  switch (t.id()) {
+    case Type::BINARY: return ORC_K_BINARY;
+    case Type::STRING: return ORC_K_UTF8;
+    case Type::LARGE_BINARY: return ORC_K_LARGE_BINARY;
+    case Type::LARGE_STRING: return ORC_K_LARGE_UTF8;
+    case Type::FIXED_SIZE_BINARY: return ORC_K_FSB;
+    case Type::DECIMAL128: return ORC_K_DECIMAL128;
+    case Type::DECIMAL256: return ORC_K_DECIMAL256;
+    case Type::LIST: return ORC_K_LIST;
+    case Type::LARGE_LIST: return ORC_K_LARGE_LIST;
+    case Type::MAP: return ORC_K_MAP;
+    case Type::FIXED_SIZE_LIST: return ORC_K_FSL;
+    case Type::STRUCT: return ORC_K_STRUCT;
+    case Type::DICTIONARY: return ORC_K_DICT;
+    case Type::NA: return ORC_K_NULL;
+    default: return ORC_K_PRIM;
+  }
+}
+int IdOf(const DataType& t) {
+  for (int id = 1; id <= 12; ++id) { auto c = TypeOf(id); if (c && c->Equals(t)) return id; }
+  return 0;
+}
+void FillAt(size_t at, const std::shared_ptr<ArrayData>& d) {
+  g_held.keep.push_back(d);
+  orc_node n{};
+  n.kind = KindOf(*d->type);
+  n.length = d->length; n.offset = d->offset; n.null_count = d->null_count.load();
+  n.validity = d->buffers.size() > 0 && d->buffers[0] ? d->buffers[0]->data() : nullptr;
+  if (n.kind == ORC_K_PRIM) n.type_id = IdOf(*d->type);
+  if (n.kind == ORC_K_DICT) n.type_id = IdOf(*checked_cast<const DictionaryType&>(*d->type).index_type());
+  if (n.kind == ORC_K_FSB) n.byte_width = checked_cast<const FixedSizeBinaryType&>(*d->type).byte_width();
+  if (n.kind == ORC_K_DECIMAL128) n.byte_width = 16;
+  if (n.kind == ORC_K_DECIMAL256) n.byte_width = 32;
+  if (n.kind == ORC_K_FSL) n.list_size = checked_cast<const FixedSizeListType&>(*d->type).list_size();
+  if (d->buffers.size() > 1 && d->buffers[1]) { n.buf1 = d->buffers[1]->data(); n.buf1_bytes = d->buffers[1]->size(); }
+  if (d->buffers.size() > 2 && d->buffers[2]) { n.buf2 = d->buffers[2]->data(); n.buf2_bytes = d->buffers[2]->size(); }
+  std::vector<std::shared_ptr<ArrayData>> kids = d->child_data;
+  if (n.kind == ORC_K_DICT) kids = {d->dictionary};
+  n.nchildren = static_cast<int>(kids.size());
+  n.first_child = static_cast<int>(g_held.nodes.size());
+  g_held.nodes[at] = n;
+  const size_t first = g_held.nodes.size();
+  g_held.nodes.resize(first + kids.size());
+  for (size_t c = 0; c < kids.size(); ++c) FillAt(first + c, kids[c]);
+}
+void Hold(const std::shared_ptr<ArrayData>& d) {
+  g_held.root = d;
+  g_held.nodes.clear();
+  g_held.keep.clear();
+  g_held.nodes.resize(1);
+  FillAt(0, d);
+}
+}  // namespace
+
+extern "C" {
+int ref_nested_select(const orc_node* nodes, int nnodes, const orc_array* selection, int is_filter, int option) {
+  (void)nnodes;
+  auto values = NodeData(nodes, 0);
+  Result<Datum> res = Status::Invalid("unset");
+  if (is_filter) {
+    FilterOptions opts(static_cast<FilterOptions::NullSelectionBehavior>(option));
+    res = CallFunction("filter", {Datum(values), Datum(Wrap(selection))}, &opts, Ctx());
+  } else {
+    TakeOptions opts(option != 0);
+    res = CallFunction("take", {Datum(values), Datum(Wrap(selection))}, &opts, Ctx());
+  }
+  if (!res.ok()) return Fail(res.status());
+  Hold(res->array());
+  return 0;
+}
+int ref_nested_result_count(void) { return static_cast<int>(g_held.nodes.size()); }
+int ref_nested_result_node(int i, orc_node* out) {
+  if (i < 0 || i >= static_cast<int>(g_held.nodes.size())) return ORC_INVALID;
+  *out = g_held.nodes[i];
+  return 0;
+}
+
+struct ref_ngrouper {
+  std::unique_ptr<compute::internal::Grouper> impl;
+  int nkeys;
+};
+ref_ngrouper* ref_nested_grouper_new(const orc_node* nodes, int nnodes, const int* roots, int nkeys) {
+  (void)nnodes;
+  std::vector<ValueDescr> descrs;
+  for (int k = 0; k < nkeys; ++k) descrs.push_back(ValueDescr::Array(NodeType(nodes, roots[k])));
+  auto res = compute::internal::Grouper::Make(descrs, Ctx());
+  if (!res.ok()) { Fail(res.status()); return nullptr; }
+  auto* g = new ref_ngrouper;
+  g->impl = std::move(*res);
+  g->nkeys = nkeys;
+  return g;
+}
+void ref_nested_grouper_free(ref_ngrouper* g) { delete g; }
+int ref_nested_grouper_consume(ref_ngrouper* g, const orc_node* nodes, int nnodes, const int* roots, uint32_t* out_ids) {
+  (void)nnodes;
+  std::vector<Datum> cols;
+  for (int k = 0; k < g->nkeys; ++k) cols.emplace_back(NodeData(nodes, roots[k]));
+  auto batch = ExecBatch::Make(cols);
+  if (!batch.ok()) return Fail(batch.status());
+  auto res = g->impl->Consume(*batch);
+  if (!res.ok()) return Fail(res.status());
+  const ArrayData& d = *res->array();
+  std::memcpy(out_ids, d.buffers[1]->data() + d.offset * 4, d.length * 4);
+  return 0;
+}
+uint32_t ref_nested_grouper_num_groups(const ref_ngrouper* g) { return g->impl->num_groups(); }
+int ref_nested_grouper_uniques(ref_ngrouper* g, int k) {
+  auto res = g->impl->GetUniques();
+  if (!res.ok()) return Fail(res.status());
+  Hold(res->values[k].array());
+  return 0;
+}
+}  // extern "C"

@@ -209,3 +209,74 @@ class GpuApi:
     def filter_groupby_sum(self, values, keys, mask):
         r = self._wrap(lambda: compute.filter_groupby(self.ctx, up(values), up(keys), up(mask) if mask is not None else None))
         return r.sums_numpy(), r.counts_numpy(), r.keys_numpy(), r.key_validity_numpy()
+
+
+# ---- round 3: the non-primitive array_take / array_filter kernels (tests/nested.py trees <-> arrow1_amd.nested) ----
+def up_nested(a):
+    import torch
+    import nested as T
+    from arrow1_amd import nested as P
+
+    def buf(x):
+        if x is None:
+            return None
+        raw = np.packbits(x, bitorder="little") if x.dtype == bool else np.ascontiguousarray(x).view(np.uint8).ravel()
+        t = device.alloc_bytes(len(raw), "cuda", zero=True)
+        t[:len(raw)] = torch.from_numpy(raw.copy())
+        return t
+    return P.DeviceNested(a.kind, a.length, a.offset, buf(a.valid), a.null_count, buf(a.buf1), buf(a.buf2),
+                          [up_nested(c) for c in a.children], a.type_id, a.byte_width, a.list_size)
+
+
+def down_nested(d):
+    import nested as T
+    end = d.offset + d.length
+    valid = None
+    if d.validity is not None and d.kind != T.K_NULL:
+        valid = np.unpackbits(d.validity[:(end + 7) // 8].cpu().numpy(), bitorder="little")[:end].astype(bool)
+    buf1 = buf2 = None
+    if d.kind in (T.K_PRIM, T.K_DICT):
+        raw = d.buf1.cpu().numpy()
+        if d.type_id == orc.BOOL:
+            buf1 = np.unpackbits(raw, bitorder="little")[:end].astype(bool)
+        else:
+            buf1 = raw[:end * np.dtype(orc.NP_OF[d.type_id]).itemsize].view(orc.NP_OF[d.type_id]).copy()
+    elif d.kind in T.VAR32 + T.VAR64:
+        dt = np.int32 if d.kind in T.VAR32 else np.int64
+        buf1 = d.buf1[:(end + 1) * np.dtype(dt).itemsize].cpu().numpy().view(dt).copy()
+        if d.kind in T.BINARY_KINDS:
+            buf2 = d.buf2[:int(buf1[end])].cpu().numpy().copy() if end else np.zeros(0, np.uint8)
+    elif d.kind in T.FIXED_KINDS:
+        buf1 = d.buf1[:end * d.byte_width].cpu().numpy().copy()
+    return T.N(d.kind, d.length, d.offset, valid, d.null_count, buf1, buf2, [down_nested(c) for c in d.children], d.type_id,
+               d.byte_width, d.list_size)
+
+
+class GpuNested:
+    def __init__(self, ctx=None):
+        self.ctx = ctx or device.Context(0)
+
+    def select(self, values, sel, is_filter, option):
+        from arrow1_amd import nested as P
+        try:
+            if is_filter:
+                return down_nested(P.filter(self.ctx, up_nested(values), up(sel), option))
+            return down_nested(P.take(self.ctx, up_nested(values), up(sel), bool(option)))
+        except _abi.AmdArrowError as e:
+            raise orc.StatusError(e.code, e.msg)
+
+
+    def group(self, batches):
+        """batches: list of lists of nested.N key columns -> (ids per batch, num_groups, uniques per column as N)"""
+        from arrow1_amd import nested as P
+        g = P.Grouper(self.ctx, [(c.kind, c.type_id) for c in batches[0]])
+        try:
+            ids = []
+            for cols in batches:
+                try:
+                    ids.append(g.consume([up_nested(c) for c in cols]).values_numpy())
+                except _abi.AmdArrowError as e:
+                    raise orc.StatusError(e.code, e.msg)
+            return ids, g.num_groups(), [down_nested(g.uniques(c)) for c in range(len(batches[0]))]
+        finally:
+            g.close()

@@ -1737,3 +1737,95 @@ def test_sort_one_sweep_tile_order_is_verified(gpu, oracle, monkeypatch):
     monkeypatch.setenv("AMDARROW_SORT_BALLOT_RANK", "1")
     import gpu_api
     assert np.array_equal(gpu_api.GpuApi().sort_indices(a), want)
+
+
+# ---- round 3: the remaining array_take / array_filter kernels ----
+def test_nested_selection_committed_reference_outputs(gpu):
+    """take / filter of (large_)binary, fixed_size_binary, decimal128 / 256, (large_)list, map, fixed_size_list, struct,
+    dictionary and null arrays through the C ABI against the committed outputs of the real reference, buffer for buffer
+    (offsets, bytes, zeroed null slots, validity presence, null counts, child arrays), bounds errors included."""
+    import gpu_api
+    import nested
+    bad = nested.check_against_golden(gpu_api.GpuNested(gpu.ctx))
+    assert not bad, "\n".join(bad[:10])
+
+
+@pytest.mark.parametrize("kind", ["large_utf8", "fsb", "decimal128", "list", "large_list", "map", "fsl", "struct", "dict", "null"])
+def test_nested_selection_random_against_restatement(gpu, kind):
+    """Larger random arrays (thousands of rows: many waves, long rows / lists that take the cooperative copy, slices)
+    against the numpy restatement of the reference's Selection kernels."""
+    import gpu_api
+    import nested
+    k = nested.KIND_NAMES.index(kind)
+    rng = np.random.default_rng(100 + k)
+    g, o = gpu_api.GpuNested(gpu.ctx), nested.OracleNested()
+    for trial in range(4):
+        n = int(rng.integers(2_000, 9_000))
+        v = nested.rand_node(rng, k, n, float(rng.choice([0, 0.05, 0.4])), int(rng.choice([0, 5])))
+        idx = nested.rand_indices(rng, n, int(rng.integers(1_000, 12_000)), float(rng.choice([0, 0.1])), int(rng.choice([0, 3])))
+        for sel, flt, opt in ((idx, 0, 1), (R(rng, BOOL, n, float(rng.choice([0, 0.1])), int(rng.choice([0, 7]))), 1, trial % 2)):
+            ok, msg = o.select(v, sel, flt, opt).same(g.select(v, sel, flt, opt))
+            assert ok, (kind, trial, flt, msg)
+
+
+def test_nested_take_bounds_and_refusals(gpu):
+    import gpu_api
+    import nested
+    rng = np.random.default_rng(5)
+    g = gpu_api.GpuNested(gpu.ctx)
+    v = nested.rand_node(rng, nested.K_STRUCT, 50, 0.2)
+    with pytest.raises(orc.StatusError) as e:
+        g.select(v, Arr(INT32, np.array([3, 50, 2], np.int32)), 0, 1)
+    assert e.value.code == orc.INDEX_ERROR and e.value.msg == "Index 50 out of bounds"
+    with pytest.raises(orc.StatusError) as e:
+        g.select(nested.rand_node(rng, nested.K_FSB, 9, 0.0), Arr(INT8, np.array([1, -1], np.int8)), 0, 1)
+    assert e.value.msg == "Index -1 out of bounds"
+    # an out-of-range index under a null is never looked at (VisitTake :1244-1256)
+    r = g.select(v, Arr(INT32, np.array([3, 500, 2], np.int32), np.array([True, False, True])), 0, 1)
+    assert r.length == 3 and not r.validity()[1]
+    with pytest.raises(orc.StatusError) as e:
+        g.select(nested.rand_node(rng, nested.K_DEC256, 9, 0.0), R(rng, BOOL, 9, 0.0, 0), 1, 0)
+    assert e.value.code == orc.NOT_IMPLEMENTED
+
+
+# ---- round 3: Grouper keys of variable width and dictionary keys (SURVEY c1) ----
+def test_grouper_variable_width_and_dictionary_keys_committed_reference_outputs(gpu):
+    import gpu_api
+    import nested
+    bad = nested.check_groups_against_golden(gpu_api.GpuNested(gpu.ctx).group)
+    assert not bad, "\n".join(bad[:10])
+
+
+@pytest.mark.parametrize("shape", ["utf8", "large_binary", "utf8+int32", "int32+binary+dict"])
+def test_grouper_variable_width_keys_large_batches(gpu, shape, monkeypatch):
+    """Batches of 300 k rows (the hash column takes the partitioned group-by), thousands of distinct strings of 0..40 bytes,
+    nulls, three Consume calls: ids and uniques equal the restatement's.  Then the same with the first hash seed crippled
+    to 6 bits, so that distinct keys DO collide: the grouper notices (every row is compared with its group's key),
+    rebuilds under the next seed from its stored keys and returns the same ids."""
+    import gpu_api
+    import nested as T
+    kinds = {"utf8": [T.K_UTF8], "large_binary": [T.K_LARGE_BINARY], "utf8+int32": [T.K_UTF8, T.K_PRIM],
+             "int32+binary+dict": [T.K_PRIM, T.K_BINARY, T.K_DICT]}[shape]
+    rng = np.random.default_rng(31)
+    batches = T.rand_key_batches(rng, kinds, 300_000, 3, 0.05, pool_size=5000, maxlen=40)
+    want = T.oracle_group(batches)
+    for weak in (None, "6"):
+        if weak:
+            monkeypatch.setenv("AMDARROW_BINARY_GROUPER_WEAK_FIRST_HASH", weak)
+        got = gpu_api.GpuNested(gpu.ctx).group(batches)
+        assert got[1] == want[1], (shape, weak)
+        assert all(np.array_equal(x, y) for x, y in zip(got[0], want[0])), (shape, weak)
+        for ua, ub in zip(want[2], got[2]):
+            ok, msg = T.same_where_valid(ua, ub)
+            assert ok, (shape, weak, msg)
+
+
+def test_grouper_dictionary_keys_refuse_differing_dictionaries(gpu):
+    import gpu_api
+    import nested as T
+    rng = np.random.default_rng(2)
+    b1 = T.rand_key_batches(rng, [T.K_DICT], 50, 1)
+    b2 = T.rand_key_batches(rng, [T.K_DICT], 50, 1)
+    with pytest.raises(orc.StatusError) as e:
+        gpu_api.GpuNested(gpu.ctx).group(b1 + b2)
+    assert e.value.code == orc.NOT_IMPLEMENTED and e.value.msg == "Unifying differing dictionaries"
