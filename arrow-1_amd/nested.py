@@ -243,7 +243,10 @@ class Grouper:
         kind, t = self.cols[c]
         u = self.inner.uniques(c)
         if kind in BINARY_KINDS:  # the unique tuples name the column's keys by id: gather them from the column's store
-            return take(self.ctx, self.bin[c].uniques(), u, False) if u.length else self.bin[c].uniques()
+            r = take(self.ctx, self.bin[c].uniques(), u, False) if u.length else self.bin[c].uniques()
+            if r.null_count == 0:  # DecodeNulls :64-94: a validity bitmap only when a key is null
+                r.validity = None
+            return r
         if kind == K_DICT:
             d = self.dicts[c]
             return DeviceNested(K_DICT, u.length, 0, u.validity, u.null_count, u.values, children=[d] if d is not None else [], type_id=t)
