@@ -99,7 +99,13 @@ struct Type {
               STRUCT,       // the {min, max} / {values, counts} results
               DICTIONARY,   // dictionary_encode's result: int32 indices + ArrayData::dictionary
               BINARY, STRING,   // 32-bit offsets; buffers = validity | offsets | data (Filter / Take only)
-              LIST };           // list<...> with int32 offsets: Grouper::MakeGroupings / ApplyGroupings; buffers = validity | offsets, child_data[0] = the values
+              LIST,             // list<...> with int32 offsets: Grouper::MakeGroupings / ApplyGroupings; buffers = validity | offsets, child_data[0] = the values
+              // the other value types array_take / array_filter accept (vector_selection.cc:2133-2176)
+              LARGE_BINARY, LARGE_STRING,   // 64-bit offsets
+              FIXED_SIZE_BINARY, DECIMAL128, DECIMAL256,  // buffers = validity | byte_width bytes per slot
+              LARGE_LIST, FIXED_SIZE_LIST, MAP,  // MAP: a list of struct<key, item> (32-bit offsets)
+              EXTENSION,                    // storage_type() carries the layout
+              MAX_ID };
 };
 class DataType {
  public:
@@ -111,10 +117,26 @@ class DataType {
   // DictionaryType::value_type (type.h:1360-1400); null for the other types and for dictionary_()
   const std::shared_ptr<DataType>& value_type() const { return value_type_; }
   void set_value_type(std::shared_ptr<DataType> t) { value_type_ = std::move(t); }
+  // DictionaryType::index_type (int32 unless said otherwise); FixedSizeBinaryType::byte_width / Decimal widths;
+  // FixedSizeListType::list_size; StructType fields (child i of the ArrayData); ExtensionType::storage_type + name
+  const std::shared_ptr<DataType>& index_type() const { return index_type_; }
+  void set_index_type(std::shared_ptr<DataType> t) { index_type_ = std::move(t); }
+  int byte_width() const { return byte_width_; }
+  void set_byte_width(int w) { byte_width_ = w; }
+  int list_size() const { return list_size_; }
+  void set_list_size(int n) { list_size_ = n; }
+  const std::vector<std::pair<std::string, std::shared_ptr<DataType>>>& fields() const { return fields_; }
+  void set_fields(std::vector<std::pair<std::string, std::shared_ptr<DataType>>> f) { fields_ = std::move(f); }
+  const std::shared_ptr<DataType>& storage_type() const { return value_type_; }  // EXTENSION
+  const std::string& extension_name() const { return name_; }
+  void set_extension_name(std::string n) { name_ = std::move(n); }
 
  private:
   Type::type id_;
-  std::shared_ptr<DataType> value_type_;
+  std::shared_ptr<DataType> value_type_, index_type_;
+  int byte_width_ = 0, list_size_ = 0;
+  std::vector<std::pair<std::string, std::shared_ptr<DataType>>> fields_;
+  std::string name_;
 };
 std::shared_ptr<DataType> null();
 std::shared_ptr<DataType> boolean();
@@ -135,6 +157,19 @@ std::shared_ptr<DataType> list_();  // list(<type of child_data[0]>)
 std::shared_ptr<DataType> binary();
 std::shared_ptr<DataType> utf8();
 inline bool is_binary_like(Type::type id) { return id == Type::BINARY || id == Type::STRING; }  // type_traits.h
+inline bool is_large_binary_like(Type::type id) { return id == Type::LARGE_BINARY || id == Type::LARGE_STRING; }
+std::shared_ptr<DataType> large_binary();
+std::shared_ptr<DataType> large_utf8();
+std::shared_ptr<DataType> fixed_size_binary(int byte_width);
+std::shared_ptr<DataType> decimal128(int precision, int scale);  // (precision / scale ride along in the name only)
+std::shared_ptr<DataType> decimal256(int precision, int scale);
+std::shared_ptr<DataType> list(std::shared_ptr<DataType> value_type);
+std::shared_ptr<DataType> large_list(std::shared_ptr<DataType> value_type);
+std::shared_ptr<DataType> fixed_size_list(std::shared_ptr<DataType> value_type, int list_size);
+std::shared_ptr<DataType> map(std::shared_ptr<DataType> key_type, std::shared_ptr<DataType> item_type);
+std::shared_ptr<DataType> struct_(std::vector<std::pair<std::string, std::shared_ptr<DataType>>> fields);
+std::shared_ptr<DataType> dictionary(std::shared_ptr<DataType> index_type, std::shared_ptr<DataType> value_type);
+std::shared_ptr<DataType> extension(std::string name, std::shared_ptr<DataType> storage_type);
 std::shared_ptr<DataType> TypeFromId(Type::type id);
 bool is_integer(Type::type id);
 bool is_signed_integer(Type::type id);
@@ -203,6 +238,7 @@ struct ArrayData {
   // The C-ABI view (= PrimitiveArg, kernels/util_internal.h:35-47)
   amdarrow_array abi() const;
   amdarrow_binary_array binary_abi() const;  // BINARY / STRING: buffers[1] offsets, buffers[2] data
+  amdarrow_var_array var_abi() const;        // any offsets-based layout: (LARGE_)BINARY / STRING, (LARGE_)LIST, MAP
 };
 
 // Host -> device construction helpers (what a caller with host Arrow arrays does first).
@@ -732,9 +768,14 @@ class Grouper {
 
  private:
   Grouper() = default;
+  // key column k as the fixed-width grouper sees it: variable-width columns by the dense ids of their own grouper,
+  // dictionary columns by their indices (DictionaryKeyEncoder, hash_aggregate.cc:198-235)
+  Result<std::vector<std::shared_ptr<ArrayData>>> FixedColumns(const ExecBatch& batch, bool insert);
   amdarrow_grouper* impl_ = nullptr;
   ExecContext* ctx_ = nullptr;
   std::vector<ValueDescr> descrs_;
+  std::vector<amdarrow_binary_grouper*> var_;             // per key column, null unless (large_)binary / utf8
+  std::vector<std::shared_ptr<ArrayData>> dictionaries_;  // per key column: the dictionary of the first batch
 };
 struct Aggregate {
   std::string function;

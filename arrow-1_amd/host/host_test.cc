@@ -173,7 +173,7 @@ static int RunCpu() {
     auto direct = CallFunction("hash_sum", {Datum(arr), Datum(arr), Datum(arr)}, &dctx);
     CHECK(direct.status().IsNotImplemented() && direct.status().message() == "Direct execution of HASH_AGGREGATE functions");
     CHECK((*dev->GetFunction("filter"))->kind() == Function::META);
-    CHECK((*dev->GetFunction("array_take"))->num_kernels() == 3);  // primitive, binary, utf8
+    CHECK((*dev->GetFunction("array_take"))->num_kernels() == 16);  // primitive, binary, utf8 + the 13 other value types
     CHECK((*dev->GetFunction("array_sort_indices"))->num_kernels() == 10);
     // a product call without a device pool must raise, not compute on the CPU
     auto nofallback = CallFunction("add", {Datum(arr), Datum(arr)}, &dctx);
@@ -885,6 +885,229 @@ static void WideKeyGroupByTests(const std::shared_ptr<MemoryPool>& pool, ExecCon
 }
 
 // Expression + the scanner's per-batch step (expression_test.cc: Bind / ExecuteScalarExpression cases; scanner.cc:456-500)
+// The other array_take / array_filter value types and variable-width / dictionary Grouper keys, on the reference's own
+// literals: vector_selection_test.cc:496-500, 507-515, 587-615, 1100-1104, 1135-1148, 1182-1188, 1190-1208, 1246-1275;
+// hash_aggregate_test.cc:295-336 (Grouper over utf8 / dictionary keys), 338-376 (StringInt64Key), 606-646 (GroupBy).
+static std::shared_ptr<ArrayData> DevOffsets32(const std::shared_ptr<MemoryPool>& pool, const std::vector<int32_t>& v) {
+  return *ArrayFromHost(pool, int32(), v.data(), static_cast<int64_t>(v.size()));
+}
+static std::shared_ptr<ArrayData> DevList(const std::shared_ptr<MemoryPool>& pool, std::shared_ptr<DataType> type, const std::vector<int64_t>& offsets,
+                                          const std::vector<bool>& valid, std::shared_ptr<ArrayData> child) {
+  const bool large = type->id() == Type::LARGE_LIST;
+  std::shared_ptr<ArrayData> off;
+  if (large) off = *ArrayFromHost(pool, int64(), offsets.data(), static_cast<int64_t>(offsets.size()));
+  else { std::vector<int32_t> o32(offsets.begin(), offsets.end()); off = DevOffsets32(pool, o32); }
+  const int64_t n = static_cast<int64_t>(offsets.size()) - 1;
+  std::vector<int> vb;
+  bool any_null = false;
+  for (int64_t i = 0; i < n; ++i) { const bool v = valid.empty() || valid[i]; vb.push_back(v ? 1 : -1); any_null |= !v; }
+  auto bits = DevBool(pool, vb);
+  auto out = ArrayData::Make(type, n, {any_null ? bits->buffers[0] : nullptr, off->buffers[1]}, any_null ? kUnknownNullCount : 0);
+  out->child_data = {std::move(child)};
+  return out;
+}
+// list<int32> as (null | vector) per slot, for comparisons
+using IntList = std::pair<bool, std::vector<Opt<int32_t>>>;
+static std::vector<IntList> HostList(const std::shared_ptr<MemoryPool>& pool, const ArrayData& a) {
+  std::vector<IntList> out;
+  const bool large = a.type->id() == Type::LARGE_LIST;
+  auto offs = ArrayData::Make(large ? int64() : int32(), a.length + 1, {nullptr, a.buffers[1]}, 0, a.offset);
+  std::vector<int64_t> o;
+  if (large) for (auto& x : Host<int64_t>(pool, *offs)) o.push_back(x.v);
+  else for (auto& x : Host<int32_t>(pool, *offs)) o.push_back(x.v);
+  auto child = Host<int32_t>(pool, *a.child_data[0]);
+  auto validity = ArrayData::Make(boolean(), a.length, {nullptr, a.buffers[0]}, 0, a.offset);
+  std::vector<int> vb = a.buffers[0] ? HostBool(pool, *validity) : std::vector<int>(a.length, 1);
+  for (int64_t i = 0; i < a.length; ++i) {
+    IntList e{vb[i] > 0, {}};
+    if (e.first) for (int64_t j = o[i]; j < o[i + 1]; ++j) e.second.push_back(child[j]);
+    out.push_back(e);
+  }
+  return out;
+}
+static bool SameLists(const std::vector<IntList>& a, const std::vector<IntList>& b) {
+  if (a.size() != b.size()) return false;
+  for (size_t i = 0; i < a.size(); ++i) {
+    if (a[i].first != b[i].first) return false;
+    if (a[i].first && !Same(a[i].second, b[i].second)) return false;
+  }
+  return true;
+}
+static std::vector<std::pair<std::string, bool>> Strs(std::initializer_list<const char*> items) {
+  std::vector<std::pair<std::string, bool>> out;
+  for (const char* x : items) out.push_back(x ? std::make_pair(std::string(x), true) : std::make_pair(std::string(), false));
+  return out;
+}
+static void NestedSelectionTests(const std::shared_ptr<MemoryPool>& pool, ExecContext* ctx) {
+  using I = int32_t;
+  const IntList LN{false, {}};
+  auto L = [](std::initializer_list<Opt<I>> v) { return IntList{true, std::vector<Opt<I>>(v)}; };
+  {  // the registry carries every kernel of vector_selection.cc:2133-2176
+    auto* reg = ctx->func_registry();
+    CHECK((*reg->GetFunction("array_take"))->num_kernels() == 16);    // primitive + 2 binary-like + 13 (large binary-like counts twice)
+    CHECK((*reg->GetFunction("array_filter"))->num_kernels() == 15);  // no decimal256 (:2139)
+  }
+  for (auto type : {list(int32()), large_list(int32())}) {  // TakeListInt32 :1135-1148, TakeLargeListInt32 :1182-1188
+    auto child = Dev<I>(pool, int32(), {V(I, 1), V(I, 2), V(I, 3)});
+    auto values = DevList(pool, type, {0, 0, 2, 2, 3}, {true, true, false, true}, child);  // [[], [1,2], null, [3]]
+    auto r = Take(Datum(values), Datum(Dev<I>(pool, int32(), {V(I, 3), V(I, 2), V(I, 1)})), TakeOptions::Defaults(), ctx);
+    CHECK(r.ok());
+    if (r.ok()) CHECK(SameLists(HostList(pool, *r->array()), {L({V(I, 3)}), LN, L({V(I, 1), V(I, 2)})}));
+    r = Take(Datum(values), Datum(Dev<I>(pool, int32(), {N(I), V(I, 3), V(I, 0)})), TakeOptions::Defaults(), ctx);
+    if (r.ok()) { CHECK(SameLists(HostList(pool, *r->array()), {LN, L({V(I, 3)}), L({})})); CHECK(r->array()->null_count == 1); }
+    r = Take(Datum(values), Datum(Dev<I>(pool, int32(), {V(I, 0), V(I, 0), V(I, 0), V(I, 0), V(I, 0), V(I, 0), V(I, 1)})), TakeOptions::Defaults(), ctx);
+    if (r.ok()) CHECK(SameLists(HostList(pool, *r->array()), {L({}), L({}), L({}), L({}), L({}), L({}), L({V(I, 1), V(I, 2)})}));
+    CHECK(Take(Datum(values), Datum(Dev<I>(pool, int32(), {V(I, 4)})), TakeOptions::Defaults(), ctx).status().IsIndexError());
+    // FilterListInt32 :507-515
+    auto f = Filter(Datum(values), Datum(DevBool(pool, {0, 1, 1, -1})), FilterOptions(FilterOptions::DROP), ctx);
+    CHECK(f.ok());
+    if (f.ok()) CHECK(SameLists(HostList(pool, *f->array()), {L({V(I, 1), V(I, 2)}), LN}));
+    f = Filter(Datum(values), Datum(DevBool(pool, {0, 1, 1, -1})), FilterOptions(FilterOptions::EMIT_NULL), ctx);
+    if (f.ok()) CHECK(SameLists(HostList(pool, *f->array()), {L({V(I, 1), V(I, 2)}), LN, LN}));
+  }
+  {  // TakeFixedSizeListInt32 :1190-1208: [null, [1, null, 3], [4, 5, 6], [7, 8, null]]
+    auto child = Dev<I>(pool, int32(), {V(I, 0), V(I, 0), V(I, 0), V(I, 1), N(I), V(I, 3), V(I, 4), V(I, 5), V(I, 6), V(I, 7), V(I, 8), N(I)});
+    auto bits = DevBool(pool, {-1, 1, 1, 1});
+    auto values = ArrayData::Make(fixed_size_list(int32(), 3), 4, {bits->buffers[0]}, 1);
+    values->child_data = {child};
+    auto r = Take(Datum(values), Datum(Dev<I>(pool, int32(), {N(I), V(I, 2), V(I, 0), V(I, 3)})), TakeOptions::Defaults(), ctx);
+    CHECK(r.ok());
+    if (r.ok()) {
+      const auto& a = *r->array();
+      CHECK(a.length == 4 && a.null_count == 2 && a.child_data[0]->length == 12);
+      auto got = Host<I>(pool, *a.child_data[0]);
+      CHECK(Same(std::vector<Opt<I>>(got.begin() + 3, got.begin() + 6), {V(I, 4), V(I, 5), V(I, 6)}));
+      CHECK(Same(std::vector<Opt<I>>(got.begin() + 9, got.end()), {V(I, 7), V(I, 8), N(I)}));
+      CHECK(!got[0].valid && !got[1].valid && !got[2].valid);  // list_size null child indices per null slot (:1708)
+    }
+  }
+  {  // TakeStruct :1246-1275 / FilterStruct :587-615: struct<a int32, b utf8> = [null, {1, ""}, {2, "hello"}, {4, "eh"}]
+    auto bits = DevBool(pool, {-1, 1, 1, 1});
+    auto values = ArrayData::Make(struct_({{"a", int32()}, {"b", utf8()}}), 4, {bits->buffers[0]}, 1);
+    values->child_data = {Dev<I>(pool, int32(), {V(I, 0), V(I, 1), V(I, 2), V(I, 4)}), *BinaryFromHost(pool, utf8(), {"", "", "hello", "eh"})};
+    values->child_names = {"a", "b"};
+    auto r = Take(Datum(values), Datum(Dev<I>(pool, int32(), {V(I, 3), V(I, 1), V(I, 0)})), TakeOptions::Defaults(), ctx);
+    CHECK(r.ok());
+    if (r.ok()) {
+      const auto& a = *r->array();
+      CHECK(a.length == 3 && a.null_count == 1 && a.child_data.size() == 2);
+      CHECK(Same(Host<I>(pool, *a.child_data[0]), {V(I, 4), V(I, 1), V(I, 0)}));
+      CHECK(*BinaryToHost(*a.child_data[1], pool) == Strs({"eh", "", ""}));
+      auto validity = ArrayData::Make(boolean(), 3, {nullptr, a.buffers[0]}, 0);
+      CHECK(HostBool(pool, *validity) == std::vector<int>({1, 1, 0}));
+    }
+    auto f = Filter(Datum(values), Datum(DevBool(pool, {0, 1, 1, -1})), FilterOptions(FilterOptions::EMIT_NULL), ctx);
+    CHECK(f.ok());
+    if (f.ok()) {
+      CHECK(f->array()->length == 3 && f->array()->null_count == 1);
+      CHECK(Same(Host<I>(pool, *f->array()->child_data[0]), {V(I, 1), V(I, 2), N(I)}));
+    }
+  }
+  {  // TakeDictionary :1100-1104 / FilterDictionary :496-500 over dictionary(int8, utf8) ["a", "b", "c", "d", "e"]
+    auto dict = *BinaryFromHost(pool, utf8(), {"a", "b", "c", "d", "e"});
+    auto idx = Dev<int8_t>(pool, int8(), {N(int8_t), V(int8_t, 4), V(int8_t, 2)});
+    auto values = ArrayData::Make(dictionary(int8(), utf8()), 3, idx->buffers, 1);
+    values->dictionary = dict;
+    auto r = Take(Datum(values), Datum(Dev<I>(pool, int32(), {V(I, 0), V(I, 1), V(I, 0)})), TakeOptions::Defaults(), ctx);
+    CHECK(r.ok());
+    if (r.ok()) {
+      CHECK(r->array()->type->id() == Type::DICTIONARY && r->array()->dictionary == dict);
+      CHECK(Same(Host<int8_t>(pool, *ArrayData::Make(int8(), 3, r->array()->buffers, r->array()->null_count)), {N(int8_t), V(int8_t, 4), N(int8_t)}));
+    }
+    auto f = Filter(Datum(values), Datum(DevBool(pool, {-1, 1, 0})), FilterOptions(FilterOptions::EMIT_NULL), ctx);
+    CHECK(f.ok());
+    if (f.ok()) CHECK(Same(Host<int8_t>(pool, *ArrayData::Make(int8(), 2, f->array()->buffers, f->array()->null_count)), {N(int8_t), V(int8_t, 4)}));
+  }
+  {  // fixed_size_binary(3), decimal128 and large_utf8 through the same kernels (:1030-1051 run them over every type)
+    const char raw[] = "abcdefghijkl";
+    auto bytes = *ArrayFromHost(pool, uint8(), raw, 12);
+    auto values = ArrayData::Make(fixed_size_binary(3), 4, {nullptr, bytes->buffers[1]}, 0);
+    auto r = Take(Datum(values), Datum(Dev<I>(pool, int32(), {V(I, 3), N(I), V(I, 0)})), TakeOptions::Defaults(), ctx);
+    CHECK(r.ok());
+    if (r.ok()) {
+      auto got = Host<uint8_t>(pool, *ArrayData::Make(uint8(), 9, {nullptr, r->array()->buffers[1]}, 0));
+      std::string str;
+      for (auto& g : got) str.push_back(static_cast<char>(g.v));
+      CHECK(str == std::string("jkl\0\0\0abc", 9) && r->array()->null_count == 1);
+    }
+    CHECK(Filter(Datum(ArrayData::Make(decimal256(40, 3), 0, {nullptr, bytes->buffers[1]}, 0)), Datum(DevBool(pool, {})),
+                 FilterOptions::Defaults(), ctx).status().IsNotImplemented());
+    std::vector<int64_t> lo = {0, 2, 2, 7};
+    auto loff = *ArrayFromHost(pool, int64(), lo.data(), 4);
+    auto ldata = *ArrayFromHost(pool, uint8(), "hihello", 7);
+    auto large = ArrayData::Make(large_utf8(), 3, {nullptr, loff->buffers[1]}, 0);
+    large->buffers.push_back(ldata->buffers[1]);
+    auto t = Take(Datum(large), Datum(Dev<I>(pool, int32(), {V(I, 2), V(I, 0), N(I)})), TakeOptions::Defaults(), ctx);
+    CHECK(t.ok());
+    if (t.ok()) {
+      auto o = Host<int64_t>(pool, *ArrayData::Make(int64(), 4, {nullptr, t->array()->buffers[1]}, 0));
+      CHECK(Same(o, {V(int64_t, 0), V(int64_t, 5), V(int64_t, 7), V(int64_t, 7)}));
+    }
+  }
+  {  // Grouper StringInt64Key, hash_aggregate_test.cc:338-376
+    auto g = internal::Grouper::Make({ValueDescr::Array(utf8()), ValueDescr::Array(int64())}, ctx);
+    CHECK(g.ok());
+    if (g.ok()) {
+      auto consume = [&](std::initializer_list<const char*> s, std::vector<Opt<int64_t>> v, std::vector<Opt<uint32_t>> want) {
+        std::vector<std::string> items; std::vector<bool> valid;
+        for (const char* x : s) { items.push_back(x ? x : ""); valid.push_back(x != nullptr); }
+        auto ids = (*g)->Consume(ExecBatch({Datum(*BinaryFromHost(pool, utf8(), items, valid)), Datum(Dev<int64_t>(pool, int64(), v))}, static_cast<int64_t>(v.size())));
+        CHECK(ids.ok());
+        if (ids.ok()) CHECK(Same(Host<uint32_t>(pool, *ids->array()), want));
+      };
+      using L64 = int64_t; using U = uint32_t;
+      consume({"eh", "eh"}, {V(L64, 0), V(L64, 0)}, {V(U, 0), V(U, 0)});
+      consume({"eh", "eh"}, {V(L64, 0), N(L64)}, {V(U, 0), V(U, 1)});
+      consume({"eh", "bee"}, {V(L64, 1), V(L64, 1)}, {V(U, 2), V(U, 3)});
+      consume({"eh", "bee"}, {N(L64), V(L64, 1)}, {V(U, 1), V(U, 3)});
+      auto u = (*g)->GetUniques();
+      CHECK(u.ok());
+      if (u.ok()) {
+        CHECK(*BinaryToHost(*u->values[0].array(), pool) == Strs({"eh", "eh", "eh", "bee"}));
+        CHECK(Same(Host<L64>(pool, *u->values[1].array()), {V(L64, 0), N(L64), V(L64, 1), V(L64, 1)}));
+      }
+    }
+  }
+  for (int dict_keys = 0; dict_keys < 2; ++dict_keys) {  // GroupBy SumOnlyStringAndDictKeys, hash_aggregate_test.cc:606-646
+    using D = double;
+    auto arg = Dev<D>(pool, float64(), {V(D, 1.0), N(D), V(D, 0.0), N(D), V(D, 4.0), V(D, 3.25), V(D, 0.125), V(D, -0.25), V(D, 0.75), N(D)});
+    std::shared_ptr<ArrayData> key;
+    auto words = *BinaryFromHost(pool, utf8(), {"alfa", "beta", "gama"});
+    if (!dict_keys) {
+      key = *BinaryFromHost(pool, utf8(), {"alfa", "alfa", "beta", "gama", "", "alfa", "beta", "beta", "", "gama"},
+                            {true, true, true, true, false, true, true, true, false, true});
+    } else {
+      auto idx = Dev<I>(pool, int32(), {V(I, 0), V(I, 0), V(I, 1), V(I, 2), N(I), V(I, 0), V(I, 1), V(I, 1), N(I), V(I, 2)});
+      key = ArrayData::Make(dictionary(int32(), utf8()), 10, idx->buffers, 2);
+      key->dictionary = words;
+    }
+    auto r = internal::GroupBy({Datum(arg)}, {Datum(key)}, {{"hash_sum", nullptr}}, ctx);
+    CHECK(r.ok());
+    if (r.ok()) {
+      CHECK(r->length == 4 && r->field_names == std::vector<std::string>({"hash_sum", "key_0"}));
+      CHECK(Same(Host<D>(pool, *r->columns[0]), {V(D, 4.25), V(D, -0.125), N(D), V(D, 4.75)}));
+      if (!dict_keys) CHECK(*BinaryToHost(*r->columns[1], pool) == Strs({"alfa", "beta", "gama", nullptr}));
+      else {
+        CHECK(r->columns[1]->type->id() == Type::DICTIONARY && r->columns[1]->dictionary == words);
+        CHECK(Same(Host<I>(pool, *ArrayData::Make(int32(), 4, r->columns[1]->buffers, r->columns[1]->null_count)), {V(I, 0), V(I, 1), V(I, 2), N(I)}));
+      }
+    }
+  }
+  {  // differing dictionaries: NotImplemented("Unifying differing dictionaries"), hash_aggregate_test.cc:324-336
+    auto g = internal::Grouper::Make({ValueDescr::Array(dictionary(int32(), utf8()))}, ctx);
+    auto mk = [&](std::vector<std::string> words) {
+      auto idx = Dev<I>(pool, int32(), {V(I, 0), V(I, 1)});
+      auto a = ArrayData::Make(dictionary(int32(), utf8()), 2, idx->buffers, 0);
+      a->dictionary = *BinaryFromHost(pool, utf8(), words);
+      return a;
+    };
+    CHECK((*g)->Consume(ExecBatch({Datum(mk({"ex", "why"}))}, 2)).ok());
+    CHECK((*g)->Consume(ExecBatch({Datum(mk({"ex", "why"}))}, 2)).ok());  // equal content, other buffers
+    auto bad = (*g)->Consume(ExecBatch({Datum(mk({"different", "dictionary"}))}, 2));
+    CHECK(bad.status().IsNotImplemented() && bad.status().message() == "Unifying differing dictionaries");
+  }
+}
+
 static void ExpressionTests(const std::shared_ptr<MemoryPool>& pool, ExecContext* ctx) {
   auto a = Dev<int32_t>(pool, int32(), {V(int32_t, 1), V(int32_t, 5), N(int32_t), V(int32_t, 3), V(int32_t, 9), V(int32_t, 4)});
   auto b = Dev<double>(pool, float64(), {V(double, 0.5), V(double, 1.5), V(double, 2.5), N(double), V(double, 4.5), V(double, 5.5)});
@@ -1294,6 +1517,7 @@ static int RunGpu() {
   GroupingsTests(pool, &ctx);
   WideKeyGroupByTests(pool, &ctx);
   ExpressionTests(pool, &ctx);
+  NestedSelectionTests(pool, &ctx);
   CHECK(pool->bytes_allocated() >= 0 && pool->max_memory() > 0);  // the MemoryPool counters (memory_pool.h:38-105)
   pool->ReleaseUnused();
   CHECK(pool->cached_bytes() == 0);

@@ -106,6 +106,178 @@ Status ExecFilterBinary(KernelContext* ctx, const ExecBatch& batch, Datum* out) 
   return Status::OK();
 }
 
+// ---- the other array_take / array_filter kernels (vector_selection.cc:1127-1781, registered :2133-2176) -------------
+// FSBImpl, VarBinaryImpl<LargeBinaryType>, ListImpl<List / LargeList / Map>, FSLImpl, StructImpl over Selection::VisitTake,
+// NullTake / NullFilter, DictionaryTake / DictionaryFilter, ExtensionTake / ExtensionFilter.  One recursive function per
+// direction: the device resolves every output row to its source row once (amdarrow_take_rows = VisitTake + FinishCommon),
+// the per-layout calls consume the resolved rows, child arrays are taken with the generated child indices exactly as
+// the reference's Finish() does.
+Result<std::shared_ptr<ArrayData>> TakeAny(KernelContext* ctx, const ArrayData& values, const ArrayData& indices, bool boundscheck);
+Result<std::shared_ptr<ArrayData>> FilterAny(KernelContext* ctx, const ArrayData& values, const ArrayData& filter,
+                                             FilterOptions::NullSelectionBehavior null_sel);
+
+std::shared_ptr<DataType> IndexTypeOf(const DataType& dict_type) { return dict_type.index_type() ? dict_type.index_type() : int32(); }
+// the indices of a dictionary array as a primitive array of the index type (DictionaryArray::indices)
+std::shared_ptr<ArrayData> DictIndices(const ArrayData& d) {
+  return ArrayData::Make(IndexTypeOf(*d.type), d.length, {d.buffers[0], d.buffers[1]}, d.null_count, d.offset);
+}
+Result<std::shared_ptr<ArrayData>> PrimitiveTake(KernelContext* ctx, const ArrayData& values, const ArrayData& indices, bool boundscheck) {
+  amdarrow_array v = values.abi(), i = indices.abi();
+  AMD_ASSIGN_OR_RAISE(auto vbuf, ctx->Allocate(ValueBytes(*values.type, indices.length)));
+  AMD_ASSIGN_OR_RAISE(auto nbuf, ctx->AllocateBitmap(indices.length));
+  amdarrow_out o;
+  const int rc = amdarrow_take(ctx->abi(), &v, &i, boundscheck, vbuf->mutable_data(), nbuf->mutable_data(), &o);
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  return ArrayData::Make(values.type, o.length, {nbuf, vbuf}, o.null_count);
+}
+
+Result<std::shared_ptr<ArrayData>> TakeAny(KernelContext* ctx, const ArrayData& values, const ArrayData& indices, bool boundscheck) {
+  const Type::type id = values.type->id();
+  const int64_t n = indices.length;
+  if (values.type->bit_width() > 0) return PrimitiveTake(ctx, values, indices, boundscheck);
+  if (is_binary_like(id)) return TakeBinary(ctx, values, indices, boundscheck);
+  if (id == Type::DICTIONARY) {  // DictionaryTake :1151-1160
+    AMD_ASSIGN_OR_RAISE(auto t, PrimitiveTake(ctx, *DictIndices(values), indices, boundscheck));
+    auto out = ArrayData::Make(values.type, t->length, t->buffers, t->null_count);
+    out->dictionary = values.dictionary;
+    return out;
+  }
+  if (id == Type::EXTENSION) {  // ExtensionTake :1177-1187: the storage array, re-wrapped
+    auto storage = std::make_shared<ArrayData>(values);
+    storage->type = values.type->storage_type();
+    AMD_ASSIGN_OR_RAISE(auto t, TakeAny(ctx, *storage, indices, boundscheck));
+    t->type = values.type;
+    return t;
+  }
+  // Selection::VisitTake: bounds check, validity, null count, and the source row of every output row
+  amdarrow_array i = indices.abi();
+  AMD_ASSIGN_OR_RAISE(auto rows, ctx->Allocate(8 * n));
+  AMD_ASSIGN_OR_RAISE(auto nbuf, ctx->AllocateBitmap(n));
+  amdarrow_out o;
+  const uint8_t* vvalid = !values.buffers.empty() && values.buffers[0] ? values.buffers[0]->data() : nullptr;
+  int rc = amdarrow_take_rows(ctx->abi(), vvalid, values.length, values.offset, vvalid ? values.null_count : 0, &i, boundscheck,
+                              reinterpret_cast<int64_t*>(rows->mutable_data()), nbuf->mutable_data(), &o);
+  if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+  const auto* src = reinterpret_cast<const int64_t*>(rows->data());
+  if (id == Type::NA) {  // NullTake :1132-1140
+    auto out = ArrayData::Make(values.type, n, {nullptr}, n);
+    return out;
+  }
+  if (id == Type::FIXED_SIZE_BINARY || id == Type::DECIMAL128 || id == Type::DECIMAL256) {  // FSBImpl :1575-1606
+    const int w = values.type->byte_width();
+    AMD_ASSIGN_OR_RAISE(auto dbuf, ctx->Allocate(n * w));
+    rc = amdarrow_gather_fixed_width(ctx->abi(), values.buffers[1] ? values.buffers[1]->data() : nullptr, values.offset, w, src, n,
+                                     dbuf->mutable_data());
+    if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+    return ArrayData::Make(values.type, n, {nbuf, dbuf}, o.null_count);
+  }
+  if (is_large_binary_like(id) || id == Type::LIST || id == Type::LARGE_LIST || id == Type::MAP) {
+    amdarrow_var_array v = values.var_abi();
+    const int ow = v.offset_bits / 8;
+    AMD_ASSIGN_OR_RAISE(auto obuf, ctx->Allocate(ow * (n + 1)));
+    int64_t total = 0;
+    rc = amdarrow_var_take_offsets(ctx->abi(), &v, src, n, obuf->mutable_data(), &total);
+    if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+    if (is_large_binary_like(id)) {  // VarBinaryImpl<LargeBinaryType> :1493-1573
+      AMD_ASSIGN_OR_RAISE(auto dbuf, ctx->Allocate(total));
+      rc = amdarrow_var_take_data(ctx->abi(), &v, src, n, obuf->data(), dbuf->mutable_data());
+      if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+      auto out = ArrayData::Make(values.type, n, {nbuf, obuf}, o.null_count);
+      out->buffers.push_back(dbuf);
+      return out;
+    }
+    // ListImpl :1608-1680: child = Take(values.values(), child_indices, NoBoundsCheck)
+    AMD_ASSIGN_OR_RAISE(auto cbuf, ctx->Allocate(ow * total));
+    rc = amdarrow_list_take_child_indices(ctx->abi(), &v, src, n, obuf->data(), cbuf->mutable_data());
+    if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+    auto child_idx = ArrayData::Make(ow == 4 ? int32() : int64(), total, {nullptr, cbuf}, 0);
+    AMD_ASSIGN_OR_RAISE(auto child, TakeAny(ctx, *values.child_data[0], *child_idx, false));
+    auto out = ArrayData::Make(values.type, n, {nbuf, obuf}, o.null_count);
+    out->child_data = {child};
+    return out;
+  }
+  if (id == Type::FIXED_SIZE_LIST) {  // FSLImpl :1682-1724
+    const int ls = values.type->list_size();
+    AMD_ASSIGN_OR_RAISE(auto cbuf, ctx->Allocate(8 * n * ls));
+    AMD_ASSIGN_OR_RAISE(auto cbits, ctx->AllocateBitmap(n * ls));
+    rc = amdarrow_fixed_size_list_child_indices(ctx->abi(), src, n, ls, values.offset, reinterpret_cast<int64_t*>(cbuf->mutable_data()),
+                                                cbits->mutable_data());
+    if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+    auto child_idx = ArrayData::Make(int64(), n * ls, {o.null_count ? cbits : nullptr, cbuf}, o.null_count * ls);
+    AMD_ASSIGN_OR_RAISE(auto child, TakeAny(ctx, *values.child_data[0], *child_idx, false));
+    auto out = ArrayData::Make(values.type, n, {nbuf}, o.null_count);
+    out->child_data = {child};
+    return out;
+  }
+  if (id == Type::STRUCT) {  // StructImpl :1736-1763: the fields are taken with the same selection, no bounds check
+    auto out = ArrayData::Make(values.type, n, {nbuf}, o.null_count);
+    out->child_names = values.child_names;
+    for (const auto& field : values.child_data) {
+      AMD_ASSIGN_OR_RAISE(auto taken, TakeAny(ctx, *field->Slice(values.offset, values.length), indices, false));
+      out->child_data.push_back(taken);
+    }
+    return out;
+  }
+  return Status::NotImplemented("take: values of type " + values.type->ToString());
+}
+
+Result<std::shared_ptr<ArrayData>> FilterAny(KernelContext* ctx, const ArrayData& values, const ArrayData& filter,
+                                             FilterOptions::NullSelectionBehavior null_sel) {
+  const Type::type id = values.type->id();
+  if (id == Type::DICTIONARY) {  // DictionaryFilter :1162-1172
+    AMD_ASSIGN_OR_RAISE(auto t, FilterAny(ctx, *DictIndices(values), filter, null_sel));
+    auto out = ArrayData::Make(values.type, t->length, t->buffers, t->null_count);
+    out->dictionary = values.dictionary;
+    return out;
+  }
+  if (id == Type::EXTENSION) {  // ExtensionFilter :1189-1199
+    auto storage = std::make_shared<ArrayData>(values);
+    storage->type = values.type->storage_type();
+    AMD_ASSIGN_OR_RAISE(auto t, FilterAny(ctx, *storage, filter, null_sel));
+    t->type = values.type;
+    return t;
+  }
+  if (values.type->bit_width() > 0) {  // PrimitiveFilter through its own kernel
+    Datum out;
+    FilterOptions opts(null_sel);
+    KernelContext kctx(ctx->exec_context());
+    kctx.SetOptions(&opts);
+    ExecBatch batch;
+    batch.values = {Datum(std::make_shared<ArrayData>(values)), Datum(std::make_shared<ArrayData>(filter))};
+    batch.length = values.length;
+    AMD_RETURN_NOT_OK(ExecFilter(&kctx, batch, &out));
+    return out.array();
+  }
+  if (id == Type::NA) {  // NullFilter :1142-1147
+    amdarrow_array f = filter.abi();
+    int64_t out_len = 0;
+    const int rc = amdarrow_filter_output_size(ctx->abi(), &f, static_cast<int>(null_sel), &out_len);
+    if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+    return ArrayData::Make(values.type, out_len, {nullptr}, out_len);
+  }
+  // FilterExec<Impl> visits the rows GetTakeIndices lists, in that order (StructFilter :1765-1781 says so itself)
+  AMD_ASSIGN_OR_RAISE(auto indices, GetTakeIndices(filter, null_sel, ctx->exec_context()));
+  AMD_ASSIGN_OR_RAISE(auto taken, TakeAny(ctx, values, *indices, /*boundscheck=*/false));
+  if (is_binary_like(id) || is_large_binary_like(id)) {  // BinaryFilter's conventions, :1090-1112
+    const int64_t vnc = values.buffers[0] ? values.null_count : 0, fnc = filter.buffers[0] ? filter.null_count : 0;
+    if (vnc == 0 && fnc == 0) taken->buffers[0] = nullptr;
+    taken->null_count = (vnc == 0 && (null_sel == FilterOptions::DROP || fnc == 0)) ? 0 : kUnknownNullCount;
+  }
+  return taken;
+}
+Status ExecTakeAny(KernelContext* ctx, const ExecBatch& batch, Datum* out) {
+  const auto* opts = static_cast<const TakeOptions*>(ctx->options());
+  AMD_ASSIGN_OR_RAISE(auto r, TakeAny(ctx, *batch[0].array(), *batch[1].array(), !opts || opts->boundscheck));
+  *out = Datum(r);
+  return Status::OK();
+}
+Status ExecFilterAny(KernelContext* ctx, const ExecBatch& batch, Datum* out) {
+  const auto* opts = static_cast<const FilterOptions*>(ctx->options());
+  AMD_ASSIGN_OR_RAISE(auto r, FilterAny(ctx, *batch[0].array(), *batch[1].array(), opts ? opts->null_selection_behavior : FilterOptions::DROP));
+  *out = Datum(r);
+  return Status::OK();
+}
+
 // ---- array_sort_indices (vector_sort.cc:558-575) ---------------------------------------------------
 Status SortChunks(KernelContext* ctx, const std::vector<std::shared_ptr<ArrayData>>& chunks, SortOrder order, Datum* out) {
   std::vector<amdarrow_array> abi;
@@ -869,6 +1041,16 @@ void RegisterVectorSelection(FunctionRegistry* registry) {
       kb.exec = ExecFilterBinary;
       (void)f->AddKernel(std::move(kb));
     }
+    // LargeBinaryLike, FIXED_SIZE_BINARY, null, DECIMAL (= DECIMAL128: there is no decimal256 filter kernel), DICTIONARY,
+    // EXTENSION, LIST, LARGE_LIST, FIXED_SIZE_LIST, STRUCT, MAP (:2135-2147)
+    for (Type::type t : {Type::LARGE_BINARY, Type::LARGE_STRING, Type::FIXED_SIZE_BINARY, Type::NA, Type::DECIMAL128, Type::DICTIONARY,
+                         Type::EXTENSION, Type::LIST, Type::LARGE_LIST, Type::FIXED_SIZE_LIST, Type::STRUCT, Type::MAP}) {
+      VectorKernel ka;
+      ka.signature.in_types = {InputType::Exact(t), InputType::Exact(Type::BOOL)};
+      ka.signature.out_type = FirstArgOut();
+      ka.exec = ExecFilterAny;
+      (void)f->AddKernel(std::move(ka));
+    }
     (void)registry->AddFunction(std::move(f));
     (void)registry->AddFunction(std::make_shared<FilterMetaFunction>());
   }
@@ -888,6 +1070,17 @@ void RegisterVectorSelection(FunctionRegistry* registry) {
       kb.exec = ExecTakeBinary;
       kb.can_execute_chunkwise = false;
       (void)f->AddKernel(std::move(kb));
+    }
+    // LargeBinaryLike, FIXED_SIZE_BINARY, null, DECIMAL128, DECIMAL256, DICTIONARY, EXTENSION, LIST, LARGE_LIST,
+    // FIXED_SIZE_LIST, STRUCT, MAP (:2166-2176)
+    for (Type::type t : {Type::LARGE_BINARY, Type::LARGE_STRING, Type::FIXED_SIZE_BINARY, Type::NA, Type::DECIMAL128, Type::DECIMAL256,
+                         Type::DICTIONARY, Type::EXTENSION, Type::LIST, Type::LARGE_LIST, Type::FIXED_SIZE_LIST, Type::STRUCT, Type::MAP}) {
+      VectorKernel ka;
+      ka.signature.in_types = {InputType::Exact(t), InputType::Integer()};
+      ka.signature.out_type = FirstArgOut();
+      ka.exec = ExecTakeAny;
+      ka.can_execute_chunkwise = false;
+      (void)f->AddKernel(std::move(ka));
     }
     (void)registry->AddFunction(std::move(f));
     (void)registry->AddFunction(std::make_shared<TakeMetaFunction>());
@@ -1074,34 +1267,98 @@ void RegisterHashAggregateBasic(FunctionRegistry* registry) {
 // ---- Grouper (api_aggregate.h:313-340, hash_aggregate.cc:313-437) ---------------------------------------
 Grouper::~Grouper() {
   if (impl_) amdarrow_grouper_destroy(impl_);
+  for (auto* v : var_) if (v) amdarrow_binary_grouper_destroy(v);
 }
 Result<std::unique_ptr<Grouper>> Grouper::Make(const std::vector<ValueDescr>& descrs, ExecContext* ctx) {
   auto g = std::unique_ptr<Grouper>(new Grouper());
   g->ctx_ = ctx;
   g->descrs_ = descrs;
+  g->var_.assign(descrs.size(), nullptr);
+  g->dictionaries_.assign(descrs.size(), nullptr);
   std::vector<int> types;
-  for (const auto& d : descrs) types.push_back(static_cast<int>(d.type->id()));
+  for (size_t k = 0; k < descrs.size(); ++k) {  // GrouperImpl::Make, hash_aggregate.cc:313-356
+    const auto& t = *descrs[k].type;
+    if (is_binary_like(t.id()) || is_large_binary_like(t.id())) {  // VarLengthKeyEncoder<BinaryType / LargeBinaryType>
+      const int rc = amdarrow_binary_grouper_create(ctx->memory_pool()->ctx(), is_binary_like(t.id()) ? 32 : 64, &g->var_[k]);
+      if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+      types.push_back(static_cast<int>(Type::UINT32));
+    } else if (t.id() == Type::DICTIONARY) {  // DictionaryKeyEncoder: the index, fixed width
+      types.push_back(static_cast<int>(IndexTypeOf(t)->id()));
+    } else if (t.bit_width() > 0) {
+      types.push_back(static_cast<int>(t.id()));
+    } else {
+      return Status::NotImplemented("Keys of type " + t.ToString());  // :353
+    }
+  }
   const int rc = amdarrow_grouper_create(ctx->memory_pool()->ctx(), static_cast<int>(types.size()), types.data(), &g->impl_);
   if (rc != AMDARROW_OK) return Status::FromAbi(rc);
   return g;
 }
-Result<Datum> Grouper::Consume(const ExecBatch& batch) {
-  std::vector<amdarrow_array> keys;
-  for (const auto& v : batch.values) {
-    if (!v.is_array()) return Status::NotImplemented("Grouper::Consume: array keys only");
-    keys.push_back(v.array()->abi());
+namespace {
+// Array::Equals for two (small) dictionaries: same type and length, same validity, same values where valid
+Result<bool> SameDictionary(const ArrayData& a, const ArrayData& b, ExecContext* ctx) {
+  if (a.type->id() != b.type->id() || a.length != b.length) return false;
+  if (a.buffers == b.buffers && a.offset == b.offset) return true;
+  const auto& pool = ctx->memory_pool();
+  if (is_binary_like(a.type->id())) {
+    AMD_ASSIGN_OR_RAISE(auto x, BinaryToHost(a, pool));
+    AMD_ASSIGN_OR_RAISE(auto y, BinaryToHost(b, pool));
+    return x == y;
   }
+  if (a.type->bit_width() <= 0) return Status::NotImplemented("comparing dictionaries of type " + a.type->ToString());
+  const int64_t nb = ValueBytes(*a.type, a.length);
+  std::vector<uint8_t> va(nb + 8), vb(nb + 8), ba((a.length + 7) / 8 + 8), bb((a.length + 7) / 8 + 8);
+  AMD_RETURN_NOT_OK(CopyValuesToHost(a, pool, va.data(), ba.data()));
+  AMD_RETURN_NOT_OK(CopyValuesToHost(b, pool, vb.data(), bb.data()));
+  const int w = a.type->bit_width();
+  for (int64_t i = 0; i < a.length; ++i) {
+    const bool xa = (ba[i >> 3] >> (i & 7)) & 1, xb = (bb[i >> 3] >> (i & 7)) & 1;
+    if (xa != xb) return false;
+    if (!xa) continue;
+    if (w == 1) { if (((va[i >> 3] >> (i & 7)) & 1) != ((vb[i >> 3] >> (i & 7)) & 1)) return false; }
+    else if (memcmp(&va[i * (w / 8)], &vb[i * (w / 8)], w / 8) != 0) return false;
+  }
+  return true;
+}
+}  // namespace
+Result<std::vector<std::shared_ptr<ArrayData>>> Grouper::FixedColumns(const ExecBatch& batch, bool insert) {
+  std::vector<std::shared_ptr<ArrayData>> cols;
+  for (size_t k = 0; k < batch.values.size(); ++k) {
+    if (!batch.values[k].is_array()) return Status::NotImplemented("Grouper: array keys only");
+    const auto& a = batch.values[k].array();
+    if (k < var_.size() && var_[k]) {
+      if (!insert) return Status::NotImplemented("Grouper::Lookup over variable-width keys");
+      amdarrow_var_array v = a->var_abi();
+      AMD_ASSIGN_OR_RAISE(auto ids, AllocateBuffer(4 * std::max<int64_t>(a->length, 1), ctx_->memory_pool()));
+      const int rc = amdarrow_binary_grouper_consume(var_[k], &v, reinterpret_cast<uint32_t*>(ids->mutable_data()));
+      if (rc != AMDARROW_OK) return Status::FromAbi(rc);
+      cols.push_back(ArrayData::Make(uint32(), a->length, {nullptr, ids}, 0));
+    } else if (a->type->id() == Type::DICTIONARY) {
+      if (!dictionaries_[k]) dictionaries_[k] = a->dictionary;
+      else if (a->dictionary) {
+        AMD_ASSIGN_OR_RAISE(const bool same, SameDictionary(*dictionaries_[k], *a->dictionary, ctx_));
+        if (!same) return Status::NotImplemented("Unifying differing dictionaries");  // :207-211
+      }
+      cols.push_back(DictIndices(*a));
+    } else {
+      cols.push_back(a);
+    }
+  }
+  return cols;
+}
+Result<Datum> Grouper::Consume(const ExecBatch& batch) {
+  AMD_ASSIGN_OR_RAISE(auto cols, FixedColumns(batch, true));
+  std::vector<amdarrow_array> keys;
+  for (const auto& c : cols) keys.push_back(c->abi());
   AMD_ASSIGN_OR_RAISE(auto buf, AllocateBuffer(4 * batch.length, ctx_->memory_pool()));
   const int rc = amdarrow_grouper_consume(impl_, keys.data(), reinterpret_cast<uint32_t*>(buf->mutable_data()));
   if (rc != AMDARROW_OK) return Status::FromAbi(rc);
   return Datum(ArrayData::Make(uint32(), batch.length, {nullptr, buf}, 0));
 }
 Result<Datum> Grouper::Lookup(const ExecBatch& batch) {
+  AMD_ASSIGN_OR_RAISE(auto cols, FixedColumns(batch, false));
   std::vector<amdarrow_array> keys;
-  for (const auto& v : batch.values) {
-    if (!v.is_array()) return Status::NotImplemented("Grouper::Lookup: array keys only");
-    keys.push_back(v.array()->abi());
-  }
+  for (const auto& c : cols) keys.push_back(c->abi());
   AMD_ASSIGN_OR_RAISE(auto buf, AllocateBuffer(4 * batch.length, ctx_->memory_pool()));
   const int rc = amdarrow_grouper_lookup(impl_, keys.data(), reinterpret_cast<uint32_t*>(buf->mutable_data()));
   if (rc != AMDARROW_OK) return Status::FromAbi(rc);
@@ -1143,13 +1400,41 @@ Result<ExecBatch> Grouper::GetUniques() {
   const uint32_t ng = num_groups();
   ExecBatch out({}, ng);
   for (size_t k = 0; k < descrs_.size(); ++k) {
-    const auto& t = descrs_[k].type;
+    auto t = descrs_[k].type;
+    const bool is_var = var_[k] != nullptr, is_dict = t->id() == Type::DICTIONARY;
+    if (is_var) t = uint32();            // the unique tuples name the column's keys by the column grouper's ids
+    else if (is_dict) t = IndexTypeOf(*t);
     AMD_ASSIGN_OR_RAISE(auto vbuf, AllocateBuffer(ValueBytes(*t, ng), ctx_->memory_pool()));
     AMD_ASSIGN_OR_RAISE(auto nbuf, AllocateBitmap(ng, ctx_->memory_pool()));
     amdarrow_out o;
     const int rc = amdarrow_grouper_uniques(impl_, static_cast<int>(k), vbuf->mutable_data(), nbuf->mutable_data(), &o);
     if (rc != AMDARROW_OK) return Status::FromAbi(rc);
-    out.values.push_back(Datum(ArrayData::Make(t, ng, {o.has_validity ? nbuf : nullptr, vbuf}, o.null_count)));
+    auto col = ArrayData::Make(t, ng, {o.has_validity ? nbuf : nullptr, vbuf}, o.null_count);
+    if (is_var) {  // VarLengthKeyEncoder::Decode :270-307: the keys themselves, a validity bitmap only when one is null
+      const auto& pool = ctx_->memory_pool();
+      const bool large = is_large_binary_like(descrs_[k].type->id());
+      int64_t rows = 0, nbytes = 0;
+      int rc2 = amdarrow_binary_grouper_uniques_size(var_[k], &rows, &nbytes);
+      if (rc2 != AMDARROW_OK) return Status::FromAbi(rc2);
+      AMD_ASSIGN_OR_RAISE(auto obuf, AllocateBuffer((large ? 8 : 4) * (rows + 1), pool));
+      AMD_ASSIGN_OR_RAISE(auto dbuf, AllocateBuffer(nbytes, pool));
+      AMD_ASSIGN_OR_RAISE(auto vb, AllocateBitmap(rows, pool));
+      amdarrow_out so;
+      rc2 = amdarrow_binary_grouper_uniques(var_[k], obuf->mutable_data(), dbuf->mutable_data(), vb->mutable_data(), &so);
+      if (rc2 != AMDARROW_OK) return Status::FromAbi(rc2);
+      auto store = ArrayData::Make(descrs_[k].type, so.length, {so.has_validity ? vb : nullptr, obuf}, so.null_count);
+      store->buffers.push_back(dbuf);
+      if (ng > 0) {
+        KernelContext kctx(ctx_);
+        AMD_ASSIGN_OR_RAISE(store, TakeAny(&kctx, *store, *col, false));
+        if (store->null_count == 0) store->buffers[0] = nullptr;
+      }
+      col = store;
+    } else if (is_dict) {  // DictionaryKeyEncoder::Decode :217-231
+      col->type = descrs_[k].type;
+      col->dictionary = dictionaries_[k];
+    }
+    out.values.push_back(Datum(col));
   }
   return out;
 }
