@@ -128,9 +128,10 @@ static Status BinaryExec(DeviceState* dev, bool compare, int op, KernelContext* 
   ARROW_ASSIGN_OR_RAISE(auto vbuf, ctx->Allocate(ValueBytes(*out_type, n) + 8));
   ARROW_ASSIGN_OR_RAISE(auto nbuf, ctx->AllocateBitmap(n + 64));
   amdarrow_out o;
-  const int rc = compare ? amdarrow_compare(dev->ctx, op, &a, &b, nullptr, 0, vbuf->mutable_data(), nbuf->mutable_data(), &o)
-                         : amdarrow_arith(dev->ctx, op, &a, &b, nullptr, 0, vbuf->mutable_data(), nbuf->mutable_data(), &o);
+  const int rc = compare ? amdarrow_compare(dev->ctx, op, &a, nullptr, &b, nullptr, vbuf->mutable_data(), nbuf->mutable_data(), &o)
+                         : amdarrow_arith(dev->ctx, op, &a, nullptr, &b, nullptr, vbuf->mutable_data(), nbuf->mutable_data(), &o);
   RETURN_NOT_OK(FromAbi(rc));
+  RETURN_NOT_OK(FromAbi(amdarrow_ctx_synchronize(dev->ctx)));  // (values are complete in stream order; this caller reads them on the host)
   ArrayData* out_arr = out->mutable_array();
   out_arr->buffers = {o.has_validity ? std::shared_ptr<Buffer>(nbuf) : nullptr, std::shared_ptr<Buffer>(vbuf)};
   out_arr->length = o.length;
@@ -371,7 +372,20 @@ static int RunGpu() {
         auto w = CallFunction(fn, {Datum(values), Datum(other)}, &cpu_ctx);
         auto g = CallFunction(fn, {Datum(values), Datum(other)}, &gpu_ctx);
         CHECK(w.ok() && g.ok());
-        if (w.ok() && g.ok()) CHECK(SameArrays(*w, *g));
+        if (!w.ok()) fprintf(stderr, "  %s (reference kernels): %s\n", fn, w.status().ToString().c_str());
+        if (!g.ok()) fprintf(stderr, "  %s (plugin registry): %s\n", fn, g.status().ToString().c_str());
+        if (w.ok() && g.ok()) {
+          CHECK(SameArrays(*w, *g));
+          if (!SameArrays(*w, *g)) {
+            auto x = w->array(), y = g->array();
+            fprintf(stderr, "  %s n=%lld: type %s vs %s, length %lld vs %lld, nulls %lld vs %lld, validity %d vs %d\n", fn, (long long)n,
+                    x->type->ToString().c_str(), y->type->ToString().c_str(), (long long)x->length, (long long)y->length,
+                    (long long)x->GetNullCount(), (long long)y->GetNullCount(), x->buffers[0] != nullptr, y->buffers[0] != nullptr);
+            auto ax = MakeArray(x), ay = MakeArray(y);
+            for (int64_t i = 0, shown = 0; i < x->length && shown < 4; ++i)
+              if (!ax->RangeEquals(i, i + 1, i, *ay)) { ++shown; fprintf(stderr, "    row %lld: %s vs %s\n", (long long)i, ax->GetScalar(i).ValueOrDie()->ToString().c_str(), ay->GetScalar(i).ValueOrDie()->ToString().c_str()); }
+          }
+        }
       }
     }
   }
