@@ -103,6 +103,7 @@ def merge_dense(part, st, rank, group=None):
     G = part.num_groups
     st.acc.zero_()
     st.owner.fill_(_INF)
+    st.bad.zero_()
     idx = part.keys.to(torch.int64) - st.kmin
     idx = torch.where(part.key_valid, idx, torch.full_like(idx, st.R))
     oob = (idx < 0) | (idx > st.R)
@@ -123,6 +124,93 @@ def merge_dense(part, st, rank, group=None):
     keys = (order + st.kmin)
     key_valid = order != st.R
     return Partial(keys, key_valid, sums, counts if not is_f else counts.to(torch.int64)), n_present
+
+
+# ---- which protocol, and what happens when the data leave the plan ---------------------------------------------
+class ShardedMerge:
+    """The protocol state machine of the sharded group-by, independent of where the tables live (HBM + RCCL in
+    GroupByMerger, torch CPU tensors + gloo in the tests).
+
+    The first step plans: one 16-byte all-reduce gives the global key range; a small integer range takes the dense
+    protocol (two all-reduces per step into accumulators laid out once, with head-room), anything else the gather
+    protocol.  A later step whose keys leave the dense range is NOT an error: every rank sees the same out-of-range
+    count (it travels inside the SUM all-reduce), so at wait() all ranks together redo THAT step with the gather
+    protocol -- the step's local table is still there -- and the next step re-plans over the union of the old range
+    and the range that step brought.  All collectives are issued in program order on every rank.
+
+    make_state(kmin, R) -> state for one slot; dense_step(part, state) -> (Partial, n_present, bad) with `bad` a
+    one-element tensor every rank agrees on; gather_step(part) -> Partial."""
+
+    def __init__(self, world, make_state, dense_step, gather_step, group=None, integer_keys=True, slots=2):
+        self.world, self.group, self.integer_keys, self.slots = world, group, integer_keys, slots
+        self.make_state, self.dense_step, self.gather_step = make_state, dense_step, gather_step
+        self.plan = None      # None: not planned; False: gather protocol; (kmin, R): dense protocol
+        self.states = None
+        self.seen = None      # the key range every step so far has shown (the union the next plan must cover)
+        self.replans = 0
+
+    def _make_plan(self, part):
+        lo, hi = key_range(part, self.group)
+        if self.seen is not None and hi >= lo:
+            lo, hi = min(lo, self.seen[0]), max(hi, self.seen[1])
+        elif self.seen is not None:
+            lo, hi = self.seen
+        if hi >= lo:
+            self.seen = (lo, hi)
+        R = hi - lo + 1
+        if self.integer_keys and 0 < R <= DENSE_LIMIT:
+            pad = max(1024, R // 8)  # head-room: later batches may see keys a little outside the range so far
+            self.plan = (lo - pad, R + 2 * pad)
+            self.states = [self.make_state(*self.plan) for _ in range(self.slots)]
+        else:
+            self.plan, self.states = False, None
+
+    def step(self, part, slot=0, run_dense=None):
+        """-> PendingMerge.  `run_dense(state)` (optional) replaces dense_step(part, state): GroupByMerger queues the
+        device merge on its side stream there."""
+        if self.plan is None:
+            self._make_plan(part)
+        if self.plan is False:
+            return PendingMerge(self, part, self.gather_step(part), None, None)
+        merged, n_present, bad = (run_dense or (lambda st: self.dense_step(part, st)))(self.states[slot])
+        return PendingMerge(self, part, merged, n_present, bad)
+
+    def _left_the_plan(self, part):
+        """Collective (every rank is here, in the same step): the step again on the gather protocol, re-plan next time."""
+        self.replans += 1
+        lo, hi = key_range(part, self.group)
+        if hi >= lo:
+            self.seen = (min(lo, self.seen[0]), max(hi, self.seen[1])) if self.seen else (lo, hi)
+        self.plan, self.states = None, None
+        return self.gather_step(part)
+
+
+class PendingMerge:
+    def __init__(self, owner, part, merged, n_present, bad, event=None):
+        self.owner, self.part, self.merged, self.n_present, self.bad, self.event = owner, part, merged, n_present, bad, event
+        self.done = False
+
+    def wait(self):
+        if self.done:
+            return self
+        if self.event is not None:
+            self.event.synchronize()
+        if self.bad is not None and int(self.bad.item()) != 0:
+            self.merged, self.n_present = self.owner._left_the_plan(self.part), None
+        self.done = True
+        return self
+
+    @property
+    def num_groups(self):
+        self.wait()
+        if self.n_present is None:
+            return self.merged.num_groups
+        return int(self.n_present.item()) if torch.is_tensor(self.n_present) else int(self.n_present)
+
+    def tensors(self):
+        G = self.num_groups
+        p = self.merged
+        return p.keys[:G], p.key_valid[:G], p.sums[:G], p.counts[:G]
 
 
 # ---- dense protocol on the device: the HIP kernels of csrc/dist_merge.hip around the two all-reduces ----
@@ -324,30 +412,6 @@ def _unpack_bits(buf, n):
     return ((buf[:(n + 7) // 8].unsqueeze(1) & w) != 0).reshape(-1)[:n]
 
 
-class MergedResult:
-    """Merged group table of one step.  Tensors are valid after `wait()`."""
-
-    def __init__(self, part, n_present, event, bad=None):
-        self._part, self._n, self._event, self._bad = part, n_present, event, bad
-
-    def wait(self):
-        if self._event is not None:
-            self._event.synchronize()
-        if self._bad is not None and int(self._bad.item()) != 0:
-            raise RuntimeError("sharded group-by: keys left the dense range the plan was made for")
-        return self
-
-    @property
-    def num_groups(self):
-        self.wait()
-        return int(self._n.item()) if torch.is_tensor(self._n) else int(self._n)
-
-    def tensors(self):
-        G = self.num_groups
-        p = self._part
-        return p.keys[:G], p.key_valid[:G], p.sums[:G], p.counts[:G]
-
-
 class GroupByMerger:
     """Sharded Filter -> GroupBy{hash_sum, hash_count} on the HIP kernels."""
 
@@ -362,7 +426,7 @@ class GroupByMerger:
         if self.key_torch is None:
             raise NotImplementedError("sharded group-by: key type %d" % key_type)
         self._merge_bufs = None
-        self._dense = None          # [DenseState, DenseState] once planned; False = use the gather protocol
+        self._sm = ShardedMerge(world, self._make_state, None, self._gather_step)
         self._side = torch.cuda.Stream(device=ctx.device) if world > 1 else None
         self._side_ctx = None
         self._slot = 0
@@ -395,21 +459,23 @@ class GroupByMerger:
         rs.counts = rc.sums  # merged valid-value counts (int64)
         return rs
 
-    def _plan(self, part):
-        """First call: decide the protocol from the global key range (one tiny all-reduce)."""
-        lo, hi = key_range(part)
-        R = hi - lo + 1
-        if self.key_torch in (torch.int8, torch.uint8, torch.int16, torch.int32, torch.int64) and 0 < R <= DENSE_LIMIT:
-            # head-room: later batches may see keys a little outside the first batch's range
-            pad = max(1024, R // 8)
-            self._dense = [DenseDeviceState(lo - pad, R + 2 * pad, self.is_float, self.key_torch, self.cap, part.keys.device)
-                           for _ in range(2)]
-        else:
-            self._dense = False
+    def _gather_step(self, part):
+        """the gather protocol for one step: all-gather + re-aggregation on the device; the table is copied out of the
+        merge buffers (the next fallback reuses them)"""
+        p = self._partial_of(merge_partials(part, self._local_merge, self.world))
+        return Partial(p.keys.clone(), p.key_valid.clone(), p.sums.clone(), p.counts.clone())
+
+    def _make_state(self, kmin, R):
+        return DenseDeviceState(kmin, R, self.is_float, self.key_torch, self.cap, self.ctx.device)
+
+    @property
+    def replans(self):
+        return self._sm.replans
 
     def filter_groupby(self, values, keys, mask, buffers=None):
-        """One step.  world == 1: the fused kernel's own result.  world > 1: a MergedResult whose
-        merge runs on a side stream (dense protocol) and overlaps the caller's next step."""
+        """One step.  world == 1: the fused kernel's own result.  world > 1: a PendingMerge whose merge runs on a side
+        stream (dense protocol) and overlaps the caller's next step; a step whose keys leave the planned dense range is
+        redone on the gather protocol when it is waited for, and the plan is widened (ShardedMerge)."""
         from . import compute
         if self.world == 1:
             return compute.filter_groupby(self.ctx, values, keys, mask, buffers=buffers)
@@ -420,25 +486,26 @@ class GroupByMerger:
         if self._pending[slot] is not None:   # the buffers of step i-2 are about to be overwritten
             self._pending[slot].wait()
         r = compute.filter_groupby(self.ctx, values, keys, mask, buffers=self._bufs[slot])
-        if self._dense is None:
-            self._plan(self._partial_of(r))
-        if self._dense is False:
-            merged = merge_partials(self._partial_of(r), self._local_merge, self.world)
-            return merged
-        if self._side_ctx is None:  # the merge kernels run on the side stream: a context of their own, bound to it
-            from .device import Context
+
+        def run_dense(state):
+            if self._side_ctx is None:  # the merge kernels run on the side stream: a context of their own, bound to it
+                from .device import Context
+                with torch.cuda.stream(self._side):
+                    self._side_ctx = Context(self.ctx.device.index)
+            main = torch.cuda.current_stream(self.ctx.device)
+            done_local = torch.cuda.Event()
+            done_local.record(main)
             with torch.cuda.stream(self._side):
-                self._side_ctx = Context(self.ctx.device.index)
-        main = torch.cuda.current_stream(self.ctx.device)
-        done_local = torch.cuda.Event()
-        done_local.record(main)
-        with torch.cuda.stream(self._side):
-            self._side.wait_event(done_local)
-            mpart, n_present = merge_dense_device(self._side_ctx, self.key_type, r.keys, r.key_validity, r.sums, r.counts, r.num_groups,
-                                                  self._dense[slot], self.rank, self.world)
-            ev = torch.cuda.Event()
-            ev.record(self._side)
-        res = MergedResult(mpart, n_present, ev, self._dense[slot].bad)
+                self._side.wait_event(done_local)
+                mpart, n_present = merge_dense_device(self._side_ctx, self.key_type, r.keys, r.key_validity, r.sums, r.counts, r.num_groups,
+                                                      state, self.rank, self.world)
+                self._event = torch.cuda.Event()
+                self._event.record(self._side)
+            return mpart, n_present, state.bad
+
+        self._event = None
+        res = self._sm.step(self._partial_of(r), slot, run_dense)
+        res.event = self._event
         self._pending[slot] = res
         return res
 

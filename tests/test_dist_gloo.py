@@ -104,6 +104,76 @@ def test_sharded_groupby_matches_single_process(null_keys):
     assert q.get(timeout=5) is True
 
 
+def _replan_worker(rank, world, port, q):
+    """Five steps through ShardedMerge (torch CPU tensors, gloo): step 0 plans the dense protocol over keys [0, 500);
+    step 1: rank 1's keys jump to [40000, 40500) -- far outside the head-room -- so the step is redone on the gather
+    protocol when it is waited for and the plan is widened; step 2 runs dense on the widened plan; steps 3, 4: keys spread
+    over a range too large for the dense accumulators -> step 3 is redone on the gather protocol, the re-plan at step 4
+    picks the gather protocol for good."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
+    import orc
+    from __graft_entry__ import load_package
+    load_package()
+    from arrow1_amd import dist as adist
+    o = orc.Api("orc")
+    n = 8000
+    per = n // world
+
+    def local_merge(keys_t, kv_t, sums_t, counts_t, live_t):
+        karr = orc.Arr(orc.INT64, keys_t.numpy(), kv_t.numpy())
+        marr = orc.Arr(orc.BOOL, live_t.numpy())
+        s2, _, k2, kv2 = o.filter_groupby_sum(orc.Arr(orc.INT64, sums_t.numpy()), karr, marr)
+        c2, _, _, _ = o.filter_groupby_sum(orc.Arr(orc.INT64, counts_t.numpy()), karr, marr)
+        return adist.Partial(torch.from_numpy(k2), torch.from_numpy(kv2), torch.from_numpy(s2), torch.from_numpy(c2))
+
+    def dense_step(part, st):
+        merged, n_present = adist.merge_dense(part, st, rank)
+        return merged, n_present, st.bad
+
+    sm = adist.ShardedMerge(world, lambda kmin, R: adist.DenseState(kmin, R, torch.int64, torch.device("cpu")), dense_step,
+                            lambda part: adist.merge_partials(part, local_merge, world), slots=1)
+    ok, protocols = True, []
+    for step in range(5):
+        rng = np.random.default_rng(100 + step)
+        vals = rng.integers(-100, 101, n)
+        keys = rng.integers(0, 500, n).astype(np.int64)
+        if step == 1:
+            keys[per:] += 40_000   # rank 1's rows
+        if step >= 3:
+            keys = rng.integers(0, 1 << 40, n).astype(np.int64)
+        mask = rng.random(n) < 0.6
+        sl = slice(rank * per, (rank + 1) * per)
+        s, c, k, kv = o.filter_groupby_sum(orc.Arr(orc.INT64, vals[sl]), orc.Arr(orc.INT64, keys[sl]), orc.Arr(orc.BOOL, mask[sl]))
+        part = adist.Partial(torch.from_numpy(k), torch.from_numpy(kv), torch.from_numpy(s), torch.from_numpy(c))
+        res = sm.step(part)
+        protocols.append("gather" if sm.plan is False else "dense")
+        gk, gkv, gs, gc = res.tensors()
+        es, ec, ek, ekv = o.filter_groupby_sum(orc.Arr(orc.INT64, vals), orc.Arr(orc.INT64, keys), orc.Arr(orc.BOOL, mask))
+        ok &= (res.num_groups == len(es) and np.array_equal(gs.numpy(), es) and np.array_equal(gc.numpy(), ec) and
+               np.array_equal(gk.numpy().astype(np.int64), ek))
+    # (the protocol is noted when the step is queued: steps 1 and 3 are queued dense and redone at wait())
+    ok &= protocols == ["dense", "dense", "dense", "dense", "gather"] and sm.replans == 2
+    q.put(bool(ok))
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def test_sharded_groupby_replans_when_keys_leave_the_dense_range():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replan_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.daemon = True
+        p.start()
+    _join_all(procs, 120)
+    assert q.get(timeout=5) is True and q.get(timeout=5) is True
+
+
 # ---- sharded sort_indices (sample sort) over gloo, the oracle standing in for the local sort kernel ----
 def _sort_worker(rank, world, port, n, case, q):
     sys.path.insert(0, ROOT)

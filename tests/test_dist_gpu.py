@@ -95,6 +95,59 @@ def test_two_ranks_one_gpu_dense_merge():
     assert q.get(timeout=5) is True
 
 
+def _replan_worker(rank, world, port, n, q):
+    """GroupByMerger over steps whose keys move: step 1's keys on rank 1 jump far outside the dense plan (the step is
+    redone on the gather protocol at wait(), the plan is widened), step 2 runs dense again on the widened plan.  Every
+    step's merged table equals the single-process GroupBy over both shards."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as tdist
+    tdist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
+    torch.cuda.set_device(0)
+    import orc
+    from __graft_entry__ import load_package
+    load_package()
+    from arrow1_amd import _abi, device, dist as adist
+    ctx = device.Context(0)
+    per = ((n // world + 63) // 64) * 64
+    lo, hi = rank * per, min(n, (rank + 1) * per)
+    merger = adist.GroupByMerger(ctx, rank, world, key_type=_abi.INT32, value_type=_abi.INT64, group_capacity=1 << 17)
+    o = orc.Api("orc")
+    ok = True
+    for step in range(3):
+        rng = np.random.default_rng(50 + step)
+        vals = rng.integers(-100, 101, n)
+        keys = rng.integers(0, 30_000, n).astype(np.int32)
+        if step == 1:
+            keys[per:] += 5_000_000
+        mask = rng.random(n) < 0.5
+        r = merger.filter_groupby(device.DeviceArray.from_numpy(_abi.INT64, vals[lo:hi]), device.DeviceArray.from_numpy(_abi.INT32, keys[lo:hi]),
+                                  device.DeviceArray.from_numpy(_abi.BOOL, mask[lo:hi]))
+        k, kv, s, c = r.tensors()  # waits: a step that left the plan is redone here, on every rank
+        es, ec, ek, ekv = o.filter_groupby_sum(orc.Arr(orc.INT64, vals), orc.Arr(orc.INT32, keys), orc.Arr(orc.BOOL, mask))
+        ok &= r.num_groups == len(es) and np.array_equal(s.cpu().numpy(), es) and np.array_equal(c.cpu().numpy(), ec)
+        ok &= np.array_equal(k.cpu().numpy().astype(np.int64), ek.astype(np.int64))
+    ok &= merger.replans == 1
+    merger.finish()
+    q.put(bool(ok))
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_keys_leave_the_dense_plan():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replan_worker, args=(r, 2, port, 400_000, q)) for r in range(2)]
+    for p in procs:
+        p.daemon = True
+        p.start()
+    _join_all(procs, 300)
+    assert q.get(timeout=5) is True and q.get(timeout=5) is True
+
+
 def _sort_worker(rank, world, port, n, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
