@@ -15,10 +15,14 @@
 #include <tuple>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
 #include <limits>
+#include <mutex>
+#include <thread>
 
 #include "amdarrow_compute.h"
 #include "expression.h"
+#include "sharded_groupby.h"
 
 using namespace amdarrow;           // NOLINT
 using namespace amdarrow::compute;  // NOLINT
@@ -1108,6 +1112,155 @@ static void NestedSelectionTests(const std::shared_ptr<MemoryPool>& pool, ExecCo
   }
 }
 
+// ---- BASELINE config 5 in C++: ShardedGroupBy (sharded_groupby.h).  Two RANKS AS THREADS on the one GPU, each with its
+// own MemoryPool / ExecContext, the collectives staged through host memory (RCCL refuses two ranks per device); and the
+// RCCL transport itself on a communicator of one rank.
+struct ThreadWorld {
+  int world;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0, generation = 0;
+  std::vector<std::vector<uint8_t>> slots;
+  explicit ThreadWorld(int w) : world(w), slots(w) {}
+  void Barrier() {
+    std::unique_lock<std::mutex> lock(mu);
+    const int gen = generation;
+    if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); }
+    else cv.wait(lock, [&] { return generation != gen; });
+  }
+};
+class ThreadCollectives : public internal::Collectives {
+ public:
+  ThreadCollectives(std::shared_ptr<ThreadWorld> w, int rank, amdarrow_ctx* abi) : w_(std::move(w)), rank_(rank), abi_(abi) {}
+  int rank() const override { return rank_; }
+  int world() const override { return w_->world; }
+  Status AllReduce(void* buf, int64_t count, Word word, Op op, void*) override {
+    auto& mine = w_->slots[rank_];
+    mine.resize(8 * count);
+    if (amdarrow_memcpy_d2h(abi_, mine.data(), buf, 8 * count) != 0) return Status::Invalid("d2h");
+    w_->Barrier();
+    std::vector<uint8_t> out(8 * count);
+    for (int64_t i = 0; i < count; ++i) {
+      if (word == INT64) {
+        int64_t acc; memcpy(&acc, &w_->slots[0][8 * i], 8);
+        for (int r = 1; r < w_->world; ++r) { int64_t v; memcpy(&v, &w_->slots[r][8 * i], 8); acc = op == SUM ? acc + v : std::min(acc, v); }
+        memcpy(&out[8 * i], &acc, 8);
+      } else {
+        double acc; memcpy(&acc, &w_->slots[0][8 * i], 8);
+        for (int r = 1; r < w_->world; ++r) { double v; memcpy(&v, &w_->slots[r][8 * i], 8); acc = op == SUM ? acc + v : std::min(acc, v); }
+        memcpy(&out[8 * i], &acc, 8);
+      }
+    }
+    w_->Barrier();
+    return amdarrow_memcpy_h2d(abi_, buf, out.data(), 8 * count) == 0 ? Status::OK() : Status::Invalid("h2d");
+  }
+  Status AllGather(const void* send, void* recv, int64_t bytes, void*) override {
+    auto& mine = w_->slots[rank_];
+    mine.resize(bytes);
+    if (amdarrow_memcpy_d2h(abi_, mine.data(), send, bytes) != 0) return Status::Invalid("d2h");
+    w_->Barrier();
+    std::vector<uint8_t> out;
+    for (int r = 0; r < w_->world; ++r) out.insert(out.end(), w_->slots[r].begin(), w_->slots[r].begin() + bytes);
+    w_->Barrier();
+    return amdarrow_memcpy_h2d(abi_, recv, out.data(), bytes * w_->world) == 0 ? Status::OK() : Status::Invalid("h2d");
+  }
+
+ private:
+  std::shared_ptr<ThreadWorld> w_;
+  int rank_;
+  amdarrow_ctx* abi_;
+};
+
+struct ShardStep { std::vector<int64_t> vals; std::vector<int32_t> keys; std::vector<int> mask; };
+static std::vector<ShardStep> MakeShardSteps(int64_t n) {
+  std::vector<ShardStep> steps(5);
+  uint64_t x = 0x0ff1ce;
+  auto next = [&x] { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+  for (int s = 0; s < 5; ++s) {
+    auto& st = steps[s];
+    for (int64_t i = 0; i < n; ++i) {
+      st.vals.push_back(static_cast<int64_t>(next() % 201) - 100);
+      int32_t k = static_cast<int32_t>(next() % 30000);
+      if (s == 1 && i >= n / 2) k += 5000000;                         // rank 1's rows leave the dense plan at step 1
+      if (s >= 3) k = static_cast<int32_t>(next() % 2000000000);      // a range no dense plan holds: gather for good
+      st.keys.push_back(k);
+      st.mask.push_back(next() % 2 ? 1 : 0);
+    }
+  }
+  return steps;
+}
+static void ShardedGroupByTests(const std::shared_ptr<MemoryPool>& pool, ExecContext* ctx) {
+  using L = int64_t; using K = int32_t;
+  const int64_t n = 400000;
+  const auto steps = MakeShardSteps(n);
+  // what one process computes over all rows: Filter, Filter, GroupBy (the reference's definition of the merged table)
+  std::vector<std::vector<Opt<L>>> want_sums(steps.size()), want_counts(steps.size());
+  std::vector<std::vector<Opt<K>>> want_keys(steps.size());
+  for (size_t s = 0; s < steps.size(); ++s) {
+    std::vector<Opt<L>> v; std::vector<Opt<K>> k;
+    for (int64_t i = 0; i < n; ++i) if (steps[s].mask[i]) { v.push_back(V(L, steps[s].vals[i])); k.push_back(V(K, steps[s].keys[i])); }
+    auto r = internal::GroupBy({Datum(Dev<L>(pool, int64(), v)), Datum(Dev<L>(pool, int64(), v))}, {Datum(Dev<K>(pool, int32(), k))},
+                               {{"hash_sum", nullptr}, {"hash_count", nullptr}}, ctx);
+    CHECK(r.ok());
+    if (!r.ok()) return;
+    want_sums[s] = Host<L>(pool, *r->columns[0]);
+    want_counts[s] = Host<L>(pool, *r->columns[1]);
+    want_keys[s] = Host<K>(pool, *r->columns[2]);
+  }
+  const int world = 2;
+  auto tw = std::make_shared<ThreadWorld>(world);
+  std::vector<int> ok(world, 0), replans(world, -1), dense_at_end(world, -1);
+  auto rank_main = [&](int rank) {
+    auto rpool = MemoryPool::Make(0);
+    if (!rpool.ok()) return;
+    auto reg = FunctionRegistry::Make();
+    internal::RegisterHashAggregateBasic(reg.get());
+    ExecContext rctx(*rpool, reg.get());
+    auto coll = std::make_shared<ThreadCollectives>(tw, rank, (*rpool)->ctx());
+    auto sg = internal::ShardedGroupBy::Make(&rctx, coll, int32(), int64(), 1 << 20);
+    if (!sg.ok()) return;
+    const int64_t lo = rank * (n / world), hi = (rank + 1) * (n / world);
+    bool good = true;
+    for (size_t s = 0; s < steps.size(); ++s) {
+      std::vector<Opt<L>> v; std::vector<Opt<K>> k; std::vector<int> m;
+      for (int64_t i = lo; i < hi; ++i) { v.push_back(V(L, steps[s].vals[i])); k.push_back(V(K, steps[s].keys[i])); m.push_back(steps[s].mask[i]); }
+      auto r = (*sg)->Run(Datum(Dev<L>(*rpool, int64(), v)), Datum(Dev<K>(*rpool, int32(), k)), Datum(DevBool(*rpool, m)));
+      if (!r.ok()) { fprintf(stderr, "rank %d step %zu: %s\n", rank, s, r.status().ToString().c_str()); good = false; tw->Barrier(); continue; }
+      good = good && r->length == static_cast<int64_t>(want_sums[s].size());
+      good = good && Same(Host<L>(*rpool, *r->columns[0]), want_sums[s]) && Same(Host<L>(*rpool, *r->columns[1]), want_counts[s]) &&
+             Same(Host<K>(*rpool, *r->columns[2]), want_keys[s]);
+    }
+    ok[rank] = good;
+    replans[rank] = (*sg)->replans();
+    dense_at_end[rank] = (*sg)->dense();
+  };
+  std::vector<std::thread> threads;
+  for (int r = 0; r < world; ++r) threads.emplace_back(rank_main, r);
+  for (auto& t : threads) t.join();
+  for (int r = 0; r < world; ++r) {
+    CHECK(ok[r] == 1);
+    CHECK(replans[r] == 2);        // step 1 (keys jumped) and step 3 (keys spread out): redone on the gather protocol
+    CHECK(dense_at_end[r] == 0);   // ... and from step 4 on the plan is the gather protocol
+  }
+  {  // the RCCL transport: a communicator of one rank, the protocol forced to run (ncclAllReduce x2, then ncclAllGather)
+    auto self = internal::MakeRcclSelfCollectives(0);
+    CHECK(self.ok());
+    if (self.ok()) {
+      auto sg = internal::ShardedGroupBy::Make(ctx, *self, int32(), int64(), 1 << 20);
+      CHECK(sg.ok());
+      (*sg)->set_merge_even_alone(true);
+      for (size_t s : {size_t(0), size_t(4)}) {  // step 0: dense plan; step 4: a key range that needs the gather protocol
+        std::vector<Opt<L>> v; std::vector<Opt<K>> k; std::vector<int> m;
+        for (int64_t i = 0; i < n; ++i) { v.push_back(V(L, steps[s].vals[i])); k.push_back(V(K, steps[s].keys[i])); m.push_back(steps[s].mask[i]); }
+        auto r = (*sg)->Run(Datum(Dev<L>(pool, int64(), v)), Datum(Dev<K>(pool, int32(), k)), Datum(DevBool(pool, m)));
+        CHECK(r.ok());
+        if (r.ok()) CHECK(Same(Host<L>(pool, *r->columns[0]), want_sums[s]) && Same(Host<L>(pool, *r->columns[1]), want_counts[s]) &&
+                          Same(Host<K>(pool, *r->columns[2]), want_keys[s]));
+      }
+    }
+  }
+}
+
 static void ExpressionTests(const std::shared_ptr<MemoryPool>& pool, ExecContext* ctx) {
   auto a = Dev<int32_t>(pool, int32(), {V(int32_t, 1), V(int32_t, 5), N(int32_t), V(int32_t, 3), V(int32_t, 9), V(int32_t, 4)});
   auto b = Dev<double>(pool, float64(), {V(double, 0.5), V(double, 1.5), V(double, 2.5), N(double), V(double, 4.5), V(double, 5.5)});
@@ -1518,6 +1671,7 @@ static int RunGpu() {
   WideKeyGroupByTests(pool, &ctx);
   ExpressionTests(pool, &ctx);
   NestedSelectionTests(pool, &ctx);
+  ShardedGroupByTests(pool, &ctx);
   CHECK(pool->bytes_allocated() >= 0 && pool->max_memory() > 0);  // the MemoryPool counters (memory_pool.h:38-105)
   pool->ReleaseUnused();
   CHECK(pool->cached_bytes() == 0);

@@ -314,8 +314,127 @@ def cpu_baseline(workload, sel):
         if time.time() - t0 > 10.0 or reps >= 20:
             break
     dt = (time.time() - t0) / reps
-    return {"value": n / dt, "unit": "rows/s", "cores": 1, "kind": kind,
-            "sample": "%d rows (same generator family), %d reps of %s" % (n, reps, what)}
+    out = {"value": n / dt, "unit": "rows/s", "cores": 1, "kind": kind,
+           "sample": "%d rows (same generator family), %d reps of %s" % (n, reps, what)}
+    # the same function from `cores` host threads, each on a contiguous row range of the sample (the
+    # reference's compute layer is single-threaded; this is what a caller gets by sharding rows over the host's cores).
+    # Group-by partials are merged by key on the host inside the timed region.  ctypes releases the GIL for the calls.
+    if workload in ("filter_groupby_sum_i64", "hash_agg_f64", "filter_i64", "compare_i64"):
+        import concurrent.futures as cf
+        cores = max(1, min(os.cpu_count() or 1, 64))
+        per = (n + cores - 1) // cores
+        cuts = [(i * per, min(n, (i + 1) * per)) for i in range(cores) if i * per < n]
+
+        def sl(a, lo, hi):
+            return orc.Arr(a.type_id, a.data[lo:hi], None if a.valid is None else a.valid[lo:hi])
+        if workload in ("filter_groupby_sum_i64", "hash_agg_f64"):
+            parts = [(sl(vals, lo, hi), sl(keys, lo, hi), sl(mask, lo, hi)) for lo, hi in cuts]
+            apis = [orc.Api("ref" if kind == "reference" else "orc") for _ in cuts]
+
+            def run(i):
+                return apis[i].filter_groupby_sum(*parts[i])
+
+            def merge(rs):
+                allk = np.concatenate([r[2] for r in rs])
+                uk, inv = np.unique(allk, return_inverse=True)
+                sums = np.zeros(len(uk), rs[0][0].dtype)
+                cnts = np.zeros(len(uk), np.int64)
+                np.add.at(sums, inv, np.concatenate([r[0] for r in rs]))
+                np.add.at(cnts, inv, np.concatenate([r[1] for r in rs]))
+                return sums, cnts
+        else:
+            if workload == "filter_i64":
+                parts = [(sl(vals, lo, hi), sl(mask, lo, hi)) for lo, hi in cuts]
+                fn = "filter"
+            else:
+                parts = [(orc.GT, sl(a, lo, hi), sl(b, lo, hi)) for lo, hi in cuts]
+                fn = "compare"
+            apis = [orc.Api("ref" if kind == "reference" else "orc") for _ in cuts]
+
+            def run(i):
+                return getattr(apis[i], fn)(*parts[i])
+
+            def merge(rs):
+                return rs
+        with cf.ThreadPoolExecutor(len(cuts)) as ex:
+            list(ex.map(run, range(len(cuts))))  # warm
+            t0 = time.time()
+            reps = 0
+            while True:
+                merge(list(ex.map(run, range(len(cuts)))))
+                reps += 1
+                if time.time() - t0 > 6.0 or reps >= 20:
+                    break
+            dts = (time.time() - t0) / reps
+        out["row_range_sharded"] = {"value": n / dts, "unit": "rows/s", "cores": len(cuts), "host_cpus": os.cpu_count(),
+                                    "note": "%d threads x contiguous row ranges of the same sample%s" %
+                                            (len(cuts), ", partials merged by key on the host" if "groupby" in workload or "agg" in workload else "")}
+    return out
+
+
+def _timed(fn, reps):
+    """median of `reps` HIP-event timings of fn() on the current stream, in ms"""
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return sorted(ts)[len(ts) // 2]
+
+
+def headline_extras(ctx, inp, n, dev, sel):
+    """The same workload off its steady state, measured in this process OUTSIDE the timed region (the headline `value` is
+    the steady state of repeated calls of one shape, whose records the context's hint makes compact):
+      cold_ms_per_step         a call that takes nothing over from its predecessor (AMDARROW_GROUPBY_NO_HINT=1: what the
+                               first call of a shape, or a caller whose data change shape every call, sees)
+      wide_values_ms_per_step  int64 values over the whole 64-bit range (12-byte records instead of 8-byte ones), steady state"""
+    out = {}
+    bufs = compute.GroupByBuffers(ctx.device, 1 << 21, _abi.INT32)
+    call = lambda: compute.filter_groupby(ctx, inp["values"], inp["keys"], inp["mask"], buffers=bufs)  # noqa: E731
+    os.environ["AMDARROW_GROUPBY_NO_HINT"] = "1"
+    try:
+        call()
+        out["cold_ms_per_step"] = _timed(call, 7)
+    finally:
+        del os.environ["AMDARROW_GROUPBY_NO_HINT"]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(SEED + 1000)
+    wide = torch.randint(-2**63, 2**63 - 1, (n,), dtype=torch.int64, device=dev, generator=gen)
+    warr = device.DeviceArray(_abi.INT64, wide.view(torch.uint8), None, n)
+    wcall = lambda: compute.filter_groupby(ctx, warr, inp["keys"], inp["mask"], buffers=bufs)  # noqa: E731
+    for _ in range(3):
+        wcall()
+    out["wide_values_ms_per_step"] = _timed(wcall, 7)
+    call()  # (leave the context's hint as the timed loop left it)
+    return out
+
+
+def transfer_line(workload, inp, n, dev, res, step_s):
+    """Measured H2D / D2H next to the kernel time (reported separately, never part of `value`): the step's
+    input buffers from pinned host memory, and its result back."""
+    in_bytes = 0
+    for k, v in inp.items():
+        if k.startswith("_"):
+            continue
+        for t in (getattr(v, "values", None), getattr(v, "validity", None), getattr(v, "offsets", None), getattr(v, "data", None)):
+            if torch.is_tensor(t):
+                in_bytes += t.numel() * t.element_size()
+    in_bytes = min(in_bytes, 2 << 30)
+    host = torch.empty(in_bytes, dtype=torch.uint8).pin_memory()
+    devbuf = torch.empty(in_bytes, dtype=torch.uint8, device=dev)
+    h2d = _timed(lambda: devbuf.copy_(host, non_blocking=True), 3)
+    out_bytes = 0
+    if hasattr(res, "num_groups") and hasattr(res, "sums"):
+        out_bytes = int(res.num_groups) * 20
+    elif hasattr(res, "length"):
+        out_bytes = min(int(res.length) * 8, in_bytes)
+    d2h = _timed(lambda: host[:max(out_bytes, 1)].copy_(devbuf[:max(out_bytes, 1)], non_blocking=True), 3) if out_bytes else 0.0
+    return {"h2d_ms": h2d, "h2d_bytes": in_bytes, "h2d_gbps": in_bytes / h2d / 1e6, "d2h_ms": d2h, "d2h_bytes": out_bytes,
+            "rows_per_s_with_transfers": n / (step_s + (h2d + d2h) / 1e3),
+            "note": "pinned host memory over PCIe, not overlapped with the kernels; `value` counts HBM-resident inputs only"}
 
 
 def pmc_traffic(workload):
@@ -376,6 +495,7 @@ def main():
     ap.add_argument("--value-range", default="small", choices=["small", "full"],
                     help="headline workload: int64 values uniform in [-100, 100] (SURVEY 8d) or over the whole 64-bit range")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the cold / wide-value legs and the H2D / D2H line (profiling runs)")
     args = ap.parse_args()
     global NUM_GROUPS, NUM_CHUNKS, KEY_BITS, HOT_FRAC, WIDE_KEYS, VALUE_RANGE
     VALUE_RANGE = args.value_range
@@ -412,10 +532,12 @@ def main():
         tdist.barrier()
         torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]  # one per step: median / min
     t0 = time.perf_counter()
     ev0.record()  # the kernels run on torch's current stream (device.Context binds it)
-    for _ in range(args.steps):
+    for i in range(args.steps):
         res = step()
+        marks[i].record()
     finish()  # every step's merged result is complete inside the timed region
     ev1.record()
     torch.cuda.synchronize()
@@ -424,6 +546,7 @@ def main():
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
+    per_step = sorted((marks[i - 1] if i else ev0).elapsed_time(marks[i]) for i in range(args.steps))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
@@ -438,13 +561,17 @@ def main():
         out = {
             "metric": "rows/sec + achieved HBM GB/s, Filter+GroupBy-sum 100M int64 @1/2/4/8 GPU",
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_median": per_step[len(per_step) // 2], "ms_per_step_min": per_step[0],
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"filter_groupby_sum_i64": "int64", "filter_i64": "u64", "take_i64": "u64",
                                             "take_random_i64": "u64", "sort_u64": "u64", "sort_f64": "f64", "hash_agg_f64": "f64",
                                             "compare_i64": "int64", "mask_and_kleene": "u64", "agg_f64": "f64", "sort_2key": "u64", "filter_utf8": "u8", "groupby_2key_i64": "int64"}[args.workload],
             "data": "synthetic (device-generated, seed 0x0ff1ce + rank; HBM-resident before timing)",
             "config": {"workload": args.workload + ": " + WORKLOADS[args.workload], "rows_per_gpu": n,
-                       "selectivity": sel, "groups": NUM_GROUPS, "sharding": "row-range, %d shard(s)" % world},
+                       "selectivity": sel, "groups": NUM_GROUPS, "sharding": "row-range, %d shard(s)" % world,
+                       # weak scaling: every rank holds --rows rows whatever N is (BASELINE config 5's 1 B rows on 8 GPUs is
+                       # `--gpus 8 --rows 125000000`; the default keeps the per-GPU work of the N = 1 line)
+                       "total_rows": n * world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "note": "algorithmic %.3f B/row x %d rows / HIP-event time per step (%.3f ms) on the kernel stream; "
@@ -455,10 +582,12 @@ def main():
         traffic, src = pmc_traffic(args.workload)
         if traffic is not None and headline_default:
             out["roofline"]["traffic"] = traffic
+            out["roofline"]["traffic_from"] = "committed profile (%s): the builder's box, not this run" % src
             out["roofline"]["note"] += "; traffic = FETCH_SIZE + WRITE_SIZE bytes per steady-state step over all kernels of the op, from %s" % src
         if headline_default:
             dom = dominant_kernel(args.workload, bpr * n)
             if dom:
+                dom["from"] = "committed profile: the builder's box, not this run"
                 out["roofline"]["dominant_kernel"] = dom
         if hasattr(res, "num_groups"):
             out["config"]["result_groups"] = int(res.num_groups)
@@ -468,6 +597,10 @@ def main():
             ctx.lib.amdarrow_groupby_last_path(ctx.handle, C.byref(gp), C.byref(gw))
             out["config"]["groupby_path"] = {3: "per-workgroup LDS pre-aggregation", 2: "one-pass partition", 1: "two-pass partition",
                                              0: "global table"}.get(gp.value, "?") + (", %d-byte records" % (4 * gw.value) if gw.value else "")
+        if headline_default and world == 1 and not args.no_extras:
+            out["config"].update(headline_extras(ctx, inp, n, dev, sel))
+        if world == 1 and not args.no_extras:
+            out["transfer"] = transfer_line(args.workload, inp, n, dev, res, elapsed / args.steps)
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.workload, sel)

@@ -11,7 +11,7 @@ out=$R/gpurun_out/round_$tag
 mkdir -p $out
 for w in filter_groupby_sum_i64 groupby_2key_i64 hash_agg_f64 filter_i64 filter_utf8 take_i64 take_random_i64 sort_u64 sort_f64 sort_2key compare_i64 mask_and_kleene agg_f64; do
   rm -rf $R/gpurun_out/tmp_prof
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/tmp_prof -- python3 bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > $out/${w}.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/tmp_prof -- python3 bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $out/${w}.log 2>&1
   cp $(ls $R/gpurun_out/tmp_prof/*/*kernel_stats.csv | head -1) $out/${tag}_${w}_kernel_stats.csv
   grep -h '^{' $out/${w}.log > $out/${tag}_${w}_bench.json
   echo "$w: $(cut -c95-200 $out/${tag}_${w}_bench.json)"
