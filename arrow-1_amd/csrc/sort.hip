@@ -243,13 +243,19 @@ __global__ __launch_bounds__(kThreads) void k_sort_count_all_sortable(const Sort
 // The digit histograms of a column without nulls or NaNs, straight from its values: what k_sort_partition builds on
 // the way, without its copy of the keys and indices -- the first radix pass then reads the column itself (RAW in
 // k_radix_onesweep) and numbers the rows as it goes.
-template <typename KeyT>
+// NQ: only the histograms of the TOP NQ digits are built (the LDS atomics are what bounds this kernel: eight per 64-bit
+// key take 0.21 ms per 100 M keys); which of the lower digits vary at all falls out of an OR / AND over the keys
+// (orand[0] |= key, orand[1] &= key), which is all the hybrid plan needs to know about them -- they are sorted in LDS by
+// the window kernel, never by a global pass.  A plan that does need their histograms runs the kernel again with NQ = all.
+template <typename KeyT, int NQ>
 __global__ __launch_bounds__(kThreads) void k_sort_hist(const void* values, int64_t off, int type_id, int64_t n, KeyT key_mask, KeyT flip,
-                                                        unsigned int* ghist) {
+                                                        unsigned int* ghist, unsigned long long* orand) {
   constexpr int kPasses = sizeof(KeyT);
+  constexpr int kFirst = kPasses - NQ;
   __shared__ unsigned int s_h[kPasses * 256];
   for (int i = threadIdx.x; i < kPasses * 256; i += kThreads) s_h[i] = 0;
   __syncthreads();
+  KeyT k_or = 0, k_and = ~KeyT(0);
   constexpr int kIters = kCTile / kThreads;
   const int64_t ntiles = (n + kCTile - 1) / kCTile;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -266,12 +272,53 @@ __global__ __launch_bounds__(kThreads) void k_sort_hist(const void* values, int6
 #pragma unroll
     for (int j = 0; j < kIters; ++j) {
       if (!in[j]) continue;
+      k_or |= key[j]; k_and &= key[j];
 #pragma unroll
-      for (int q = 0; q < kPasses; ++q) atomicAdd(&s_h[q * 256 + ((key[j] >> (8 * q)) & 255)], 1u);
+      for (int q = kFirst; q < kPasses; ++q) atomicAdd(&s_h[q * 256 + ((key[j] >> (8 * q)) & 255)], 1u);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    k_or |= __shfl_xor(k_or, o);
+    k_and &= __shfl_xor(k_and, o);
+  }
+  if ((threadIdx.x & 63) == 0 && orand) {  // slotted (common.h): same-address device atomics are serialised at ~35 ns each
+    unsigned long long* slot = CounterSlot(orand);
+    atomicOr(&slot[0], static_cast<unsigned long long>(k_or));                          // bits some key has set
+    atomicOr(&slot[1], static_cast<unsigned long long>(~k_and) & static_cast<unsigned long long>(key_mask));  // bits some key has clear
+  }
+  __syncthreads();
+  for (int i = threadIdx.x + kFirst * 256; i < kPasses * 256; i += kThreads)
+    if (s_h[i]) atomicAdd(&ghist[i], s_h[i]);
+}
+// Histograms of up to four 8-bit digits at ARBITRARY bit positions of the (already transformed) keys: the hybrid plan
+// aligns its top digit with the highest bit that varies among the keys instead of with a byte boundary (see SortImpl).
+struct HistShifts { int n; int shift[4]; };
+template <typename KeyT>
+__global__ __launch_bounds__(kThreads) void k_hist_shifts(const KeyT* keys, int64_t n, HistShifts hs, unsigned int* ghist /* [4][256] */) {
+  __shared__ unsigned int s_h[4 * 256];
+  for (int i = threadIdx.x; i < 4 * 256; i += kThreads) s_h[i] = 0;
+  __syncthreads();
+  constexpr int kIters = kCTile / kThreads;
+  const int64_t ntiles = (n + kCTile - 1) / kCTile;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    KeyT key[kIters];
+    bool in[kIters];
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      const int64_t r = tile * kCTile + j * kThreads + threadIdx.x;
+      in[j] = r < n;
+      key[j] = keys[in[j] ? r : n - 1];
+    }
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      if (!in[j]) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (q < hs.n) atomicAdd(&s_h[q * 256 + ((key[j] >> hs.shift[q]) & 255)], 1u);
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < kPasses * 256; i += kThreads)
+  for (int i = threadIdx.x; i < hs.n * 256; i += kThreads)
     if (s_h[i]) atomicAdd(&ghist[i], s_h[i]);
 }
 __global__ __launch_bounds__(kThreads) void k_iota_indices(int64_t n, uint64_t* out) {
@@ -596,8 +643,9 @@ __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_i
   __shared__ uint32_t s_gbase[256];           // global position of this tile's run of each digit
   __shared__ uint32_t s_scan[4];
   __shared__ KeyT s_keys[kOTile];
-  __shared__ uint32_t s_idx[kOTile];
-  __shared__ uint16_t s_from[ARANK ? kOTile : 1];  // ARANK: where in the tile a staged key came from (the order check below)
+  // a staged key's row index (low half) and where in the tile it came from (high half: the order check below) travel as
+  // ONE 8-byte LDS word -- as many LDS instructions per key as without the check
+  __shared__ unsigned long long s_pair[kOTile];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < kOWaves * 256; i += kOThreads) (&s_whist[0][0])[i] = 0;
   __syncthreads();
@@ -684,8 +732,7 @@ __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_i
       if (live) {
         const uint32_t lpos = s_whist[wave][d] + rk[ARANK ? j : 0];
         s_keys[lpos] = key[j];
-        s_idx[lpos] = idx[j];
-        s_from[ARANK ? lpos : 0] = static_cast<uint16_t>(li);
+        s_pair[lpos] = static_cast<unsigned long long>(li) << 32 | idx[j];
       }
       continue;
     }
@@ -703,7 +750,7 @@ __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_i
       if (rank == 0) s_whist[wave][d] = old + __popcll(m);
       const uint32_t lpos = old + rank;
       s_keys[lpos] = key[j];
-      s_idx[lpos] = idx[j];
+      s_pair[lpos] = idx[j];
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -751,21 +798,32 @@ __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_i
   }
   if (__syncthreads_or(gave_up)) return;  // positions unknown: write nothing
   bool disorder = false;
-  for (uint32_t i = tid; i < count; i += kOThreads) {
-    const KeyT k = s_keys[i];
+  for (uint32_t i0 = 0; i0 < count; i0 += kOThreads) {  // (every lane takes part in the lane shift below)
+    const uint32_t i = i0 + tid;
+    const bool in = i < count;
+    const KeyT k = s_keys[in ? i : 0];
+    const unsigned long long pair = s_pair[in ? i : 0];
     const uint32_t d = (k >> shift) & 255;
     // ARANK is VERIFIED, not trusted: inside a digit's run the staged keys must appear in the order they had in the
     // tile (that is what "stable" means for this pass; the atomics hand out distinct ranks by construction, so the
     // only thing that could go wrong is their order).  A tile that fails raises error word 2 and the host redoes the
     // sort with the ballot ranking -- correctness never rests on the order in which the hardware serves the lanes of
     // one ds_add_rtn, only the speed does.
-    if (ARANK && i > s_dstart[d]) disorder |= s_from[ARANK ? i - 1 : 0] > s_from[ARANK ? i : 0];
-    const uint32_t gpos = s_gbase[d] + (i - s_dstart[d]);
+    const uint32_t dstart = s_dstart[d];
+    if (ARANK) {
+      // the predecessor's origin: from the lane below (a DPP wave shift, no LDS traffic), lane 0 of a wave from LDS
+      const uint32_t from = static_cast<uint32_t>(pair >> 32);
+      uint32_t prev = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(from), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+      if (lane == 0 && i > 0) prev = static_cast<uint32_t>(s_pair[in ? i - 1 : 0] >> 32);
+      if (in && i > dstart) disorder |= prev > from;
+    }
+    if (!in) continue;
+    const uint32_t gpos = s_gbase[d] + (i - dstart);
     if (LAST) {
-      out64[gpos] = s_idx[i];
+      out64[gpos] = static_cast<uint32_t>(pair);
     } else {
       keys_out[gpos] = k;
-      idx_out[gpos] = s_idx[i];
+      idx_out[gpos] = static_cast<uint32_t>(pair);
     }
   }
   if (ARANK && disorder) __hip_atomic_store(error + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -789,39 +847,41 @@ constexpr int kWBuckets = 1 << kWBucketBits;  // buckets of the window's one-pas
 constexpr int kWMaxBucket = 24;             // more keys than this in one bucket: LSD passes instead
 struct WindowDigits { int n; int shift[8]; };
 
-template <typename KeyT, bool ARANK>
+// A crowded window (keys clustered inside it) is not sorted here: its flag is raised and k_window_lsd, a kernel of its
+// own with the register budget of its ballot-ranked LSD passes, takes it -- kept in this kernel the fallback's registers
+// cost every window a wave per SIMD (222 VGPRs: two workgroups per CU instead of three, 1.21 -> 1.52 ms).
+template <typename KeyT>
 __global__ __launch_bounds__(kWThreads) void k_window_sort(const KeyT* keys, const uint32_t* idx_in, int64_t n, KeyT top_mask,
-                                                          WindowDigits digits, unsigned int* error, uint64_t* out64) {
-  constexpr int kIters = kWSpan / kWThreads;  // 16; wave w owns local positions [w*1024, (w+1)*1024), in order
+                                                          unsigned int* error, unsigned int* crowded /* [windows], zeroed */,
+                                                          uint64_t* out64) {
+  constexpr int kIters = kWSpan / kWThreads;  // 16; wave w owns candidate positions [w*1024, (w+1)*1024), in order
   __shared__ KeyT s_keys[kWSpan];
-  __shared__ uint32_t s_idx[kWSpan];  // LSD passes: the row indices; bucket pass: 16-bit bucket counters + 16-bit positions
-  __shared__ uint32_t s_whist[kWWaves][256];
+  __shared__ uint32_t s_idx[kWSpan];  // 16-bit bucket counters + 16-bit positions
   __shared__ uint32_t s_scan[16];
   __shared__ uint32_t s_lo, s_hi, s_big;
-  __shared__ KeyT s_or, s_and, s_min, s_max;
   uint32_t* s_cnt2 = s_idx;                                             // kWBuckets / 2 words: two 16-bit counters each
   uint16_t* s_pos = reinterpret_cast<uint16_t*>(s_idx + kWBuckets / 2);  // kWSpan window positions, in sorted order
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t p0 = int64_t(blockIdx.x) * kWTile;
   const int64_t left = n - p0;
   const uint32_t cand = left >= kWSpan ? kWSpan : static_cast<uint32_t>(left);  // candidate keys [p0, p0 + cand)
-  if (tid == 0) { s_lo = kWSpan; s_hi = kWSpan; s_or = 0; s_and = ~KeyT(0); s_min = ~KeyT(0); s_max = 0; s_big = 0; }
+  if (tid == 0) { s_lo = kWSpan; s_hi = kWSpan; s_big = 0; }
 
+  // Keys and row indices of every candidate in one round of loads.  They STAY in these registers, at their candidate
+  // position li: the window [lo, hi) is a range of candidates, a key's window position is li - lo.  Only the keys are
+  // staged in LDS (the heads of the runs are found by comparing neighbours).
   KeyT key[kIters];
   uint32_t idx[kIters];
 #pragma unroll
-  for (int j = 0; j < kIters; ++j) {  // keys and row indices of every candidate in one round of loads
+  for (int j = 0; j < kIters; ++j) {
     const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
     key[j] = li < cand ? keys[p0 + li] : KeyT(0);
     idx[j] = li < cand ? idx_in[p0 + li] : 0u;
   }
   const KeyT before = p0 > 0 ? keys[p0 - 1] : KeyT(0);
 #pragma unroll
-  for (int j = 0; j < kIters; ++j) {
-    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
-    s_keys[li] = key[j];
-    s_idx[li] = idx[j];
-  }
+  for (int j = 0; j < kIters; ++j) s_keys[wave * (kIters * 64) + j * 64 + lane] = key[j];
+  for (int i = tid; i < kWBuckets / 2; i += kWThreads) s_cnt2[i] = 0;
   __syncthreads();
   // segment heads: lo = first head inside the tile, hi = first head at or after the tile's end
   uint32_t lo = kWSpan, hi = kWSpan;
@@ -849,70 +909,37 @@ __global__ __launch_bounds__(kWThreads) void k_window_sort(const KeyT* keys, con
     hi = cand;  // the input ends inside the window
   }
   const uint32_t count = hi - lo;
-  // bring the window to local positions [0, count)
-  KeyT k_or = 0, k_and = ~KeyT(0), k_min = ~KeyT(0), k_max = 0;
-#pragma unroll
-  for (int j = 0; j < kIters; ++j) {
-    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
-    const bool live = li < count;
-    key[j] = live ? s_keys[lo + li] : KeyT(0);
-    idx[j] = live ? s_idx[lo + li] : 0u;
-    if (live) {
-      k_or |= key[j]; k_and &= key[j];
-      k_min = key[j] < k_min ? key[j] : k_min;
-      k_max = key[j] > k_max ? key[j] : k_max;
-    }
-  }
-  // bits that differ somewhere in the window: a digit without any is already in order
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    k_or |= __shfl_xor(k_or, o);
-    k_and &= __shfl_xor(k_and, o);
-    const KeyT a = __shfl_xor(k_min, o), b = __shfl_xor(k_max, o);
-    k_min = a < k_min ? a : k_min;
-    k_max = b > k_max ? b : k_max;
-  }
-  if (lane == 0) {
-    if (sizeof(KeyT) == 8) {
-      atomicOr(reinterpret_cast<unsigned long long*>(&s_or), static_cast<unsigned long long>(k_or));
-      atomicAnd(reinterpret_cast<unsigned long long*>(&s_and), static_cast<unsigned long long>(k_and));
-      atomicMin(reinterpret_cast<unsigned long long*>(&s_min), static_cast<unsigned long long>(k_min));
-      atomicMax(reinterpret_cast<unsigned long long*>(&s_max), static_cast<unsigned long long>(k_max));
-    } else {
-      atomicOr(reinterpret_cast<unsigned int*>(&s_or), static_cast<unsigned int>(k_or));
-      atomicAnd(reinterpret_cast<unsigned int*>(&s_and), static_cast<unsigned int>(k_and));
-      atomicMin(reinterpret_cast<unsigned int*>(&s_min), static_cast<unsigned int>(k_min));
-      atomicMax(reinterpret_cast<unsigned int*>(&s_max), static_cast<unsigned int>(k_max));
-    }
-  }
-  __syncthreads();
-  const KeyT varying = s_or ^ s_and;
 
   // ---- bucket pass: ONE counting pass instead of one LSD pass per varying digit ----------------------
-  // bucket = (key - min) >> shift with shift such that the window's key range spans <= kWBuckets
-  // buckets: monotone in the key, so after the keys are grouped by bucket only the few keys that
-  // share a bucket are out of order, and every thread finishes its own stretch of the window with an
-  // insertion sort on (key, window position) -- the position makes the result stable whatever order
-  // the counting atomics handed out inside a bucket.  Spread-out keys put < 1 key in a bucket on
-  // average.  A crowded bucket (keys clustered inside the window) sends the window to the LSD passes.
+  // bucket = (key - base) >> shift, monotone in the key: once the keys are grouped by bucket only the few keys that share
+  // a bucket are out of order, and every thread finishes its own stretch of the window with an insertion sort on
+  // (key, window position) -- the position makes the result stable whatever order the counting atomics handed out
+  // inside a bucket.  The window's key range needs no reduction over its keys: the window is ordered by the digits the
+  // global passes sorted, so its FIRST key carries the smallest and its LAST key the largest value of everything at
+  // and above the lowest of those digits; below it anything goes.  base = first key with the low part cleared,
+  // range = (last - first) at that granularity + the whole low part.  Spread-out keys put < 1 key in a bucket on
+  // average; a crowded bucket (keys clustered inside the window) sends the window to the LSD passes.
+  uint32_t brank[kIters], bucket[kIters];
   {
-    const KeyT kmin = s_min, range = s_max - kmin;
-    const int bits = range == 0 ? 0 : (sizeof(KeyT) == 8 ? 64 - __clzll(static_cast<long long>(range)) : 32 - __clz(static_cast<int>(range)));
+    const int low_bits = sizeof(KeyT) == 8 ? __ffsll(static_cast<long long>(top_mask)) - 1 : __ffs(static_cast<int>(top_mask)) - 1;
+    const KeyT low_mask = (KeyT(1) << low_bits) - 1;
+    const KeyT base = s_keys[lo] & ~low_mask;
+    const KeyT range = ((s_keys[hi - 1] & ~low_mask) - base) | low_mask;
+    const int bits = sizeof(KeyT) == 8 ? 64 - __clzll(static_cast<long long>(range)) : 32 - __clz(static_cast<int>(range));
     const int bshift = bits > kWBucketBits ? bits - kWBucketBits : 0;
-    for (int i = tid; i < kWBuckets / 2; i += kWThreads) s_cnt2[i] = 0;
-    __syncthreads();
-    uint32_t brank[kIters], bucket[kIters];
 #pragma unroll
     for (int j = 0; j < kIters; ++j) {
       const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
       bucket[j] = 0; brank[j] = 0;
-      if (li < count) {
-        bucket[j] = static_cast<uint32_t>((key[j] - kmin) >> bshift);
+      if (li >= lo && li < hi) {
+        bucket[j] = static_cast<uint32_t>((key[j] - base) >> bshift);
         const int half = (bucket[j] & 1) * 16;
         brank[j] = (atomicAdd(&s_cnt2[bucket[j] >> 1], 1u << half) >> half) & 0xFFFFu;
       }
     }
-    __syncthreads();
+  }
+  __syncthreads();
+  {
     // exclusive scan of the bucket counts: thread t owns buckets [t * per, (t + 1) * per)
     constexpr int kPer = kWBuckets / kWThreads;  // 16
     uint32_t cnt[kPer], start = 0, biggest = 0;
@@ -943,10 +970,10 @@ __global__ __launch_bounds__(kWThreads) void k_window_sort(const KeyT* keys, con
 #pragma unroll
       for (int j = 0; j < kIters; ++j) {
         const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
-        if (li < count) {
+        if (li >= lo && li < hi) {
           const uint32_t at = ((s_cnt2[bucket[j] >> 1] >> ((bucket[j] & 1) * 16)) & 0xFFFFu) + brank[j];
-          s_keys[at] = key[j];
-          s_pos[at] = static_cast<uint16_t>(li);
+          s_keys[at] = key[j];  // (the staged candidates are done with: every thread holds its own in registers)
+          s_pos[at] = static_cast<uint16_t>(li - lo);
         }
       }
       __syncthreads();
@@ -969,14 +996,101 @@ __global__ __launch_bounds__(kWThreads) void k_window_sort(const KeyT* keys, con
 #pragma unroll
       for (int j = 0; j < kIters; ++j) {
         const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
-        if (li < count) s_rows[li] = idx[j];
+        if (li >= lo && li < hi) s_rows[li - lo] = idx[j];
       }
       __syncthreads();
       for (uint32_t i = tid; i < count; i += kWThreads) out64[p0 + lo + i] = s_rows[s_pos[i]];
       return;
     }
-    __syncthreads();  // crowded: the LSD passes below reuse s_idx
   }
+  if (tid == 0) {  // crowded: k_window_lsd sorts this window (error word 3 tells the host that there is work for it)
+    crowded[blockIdx.x] = 1u;
+    __hip_atomic_store(error + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// The windows k_window_sort found crowded (more than kWMaxBucket keys in one bucket): stable LSD passes over the digits
+// that vary in the window, ranked with ballots (match-any on the digit bits) -- nothing here rests on the order in which
+// LDS atomics hand out their return values.  Same window geometry; a workgroup whose flag is down returns at once.
+template <typename KeyT>
+__global__ __launch_bounds__(kWThreads) void k_window_lsd(const KeyT* keys, const uint32_t* idx_in, int64_t n, KeyT top_mask,
+                                                         WindowDigits digits, const unsigned int* crowded, uint64_t* out64) {
+  constexpr bool ARANK = false;
+  constexpr int kIters = kWSpan / kWThreads;
+  __shared__ KeyT s_keys[kWSpan];
+  __shared__ uint32_t s_idx[kWSpan];
+  __shared__ uint32_t s_whist[kWWaves][256];
+  __shared__ uint32_t s_scan[16];
+  __shared__ uint32_t s_lo, s_hi;
+  __shared__ KeyT s_or, s_and;
+  if (!crowded[blockIdx.x]) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t p0 = int64_t(blockIdx.x) * kWTile;
+  const int64_t left = n - p0;
+  const uint32_t cand = left >= kWSpan ? kWSpan : static_cast<uint32_t>(left);
+  if (tid == 0) { s_lo = kWSpan; s_hi = kWSpan; s_or = 0; s_and = ~KeyT(0); }
+  KeyT key[kIters];
+  uint32_t idx[kIters];
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+    key[j] = li < cand ? keys[p0 + li] : KeyT(0);
+    idx[j] = li < cand ? idx_in[p0 + li] : 0u;
+  }
+  const KeyT before = p0 > 0 ? keys[p0 - 1] : KeyT(0);
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) s_keys[wave * (kIters * 64) + j * 64 + lane] = key[j];
+  __syncthreads();
+  uint32_t lo = kWSpan, hi = kWSpan;
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+    if (li < cand) {
+      const KeyT prev = li > 0 ? s_keys[li - 1] : before;
+      const bool head = (p0 + li == 0) || ((prev ^ key[j]) & top_mask) != 0;
+      if (head && li < kWTile && li < lo) lo = li;
+      if (head && li >= kWTile && li < hi) hi = li;
+    }
+  }
+  if (lo < kWSpan) atomicMin(&s_lo, lo);
+  if (hi < kWSpan) atomicMin(&s_hi, hi);
+  __syncthreads();
+  lo = s_lo;
+  hi = s_hi == kWSpan ? cand : s_hi;  // (k_window_sort has checked that the window holds its last run)
+  const uint32_t count = hi - lo;
+  // bring the window to local positions [0, count): the passes below index keys and rows that way
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+    if (li >= lo && li < hi) { s_keys[li - lo] = key[j]; s_idx[li - lo] = idx[j]; }
+  }
+  __syncthreads();
+  KeyT k_or = 0, k_and = ~KeyT(0);
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+    const bool live = li < count;
+    key[j] = live ? s_keys[li] : KeyT(0);
+    idx[j] = live ? s_idx[li] : 0u;
+    if (live) { k_or |= key[j]; k_and &= key[j]; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    k_or |= __shfl_xor(k_or, o);
+    k_and &= __shfl_xor(k_and, o);
+  }
+  if (lane == 0) {
+    if (sizeof(KeyT) == 8) {
+      atomicOr(reinterpret_cast<unsigned long long*>(&s_or), static_cast<unsigned long long>(k_or));
+      atomicAnd(reinterpret_cast<unsigned long long*>(&s_and), static_cast<unsigned long long>(k_and));
+    } else {
+      atomicOr(reinterpret_cast<unsigned int*>(&s_or), static_cast<unsigned int>(k_or));
+      atomicAnd(reinterpret_cast<unsigned int*>(&s_and), static_cast<unsigned int>(k_and));
+    }
+  }
+  __syncthreads();
+  const KeyT varying = s_or ^ s_and;  // bits that differ somewhere in the window: a digit without any is already in order
 
   for (int p = 0; p < digits.n; ++p) {
     const int shift = digits.shift[p];
@@ -1207,6 +1321,7 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   const size_t o_idx_a = cv.Take(4 * n);
   const size_t o_idx_b = cv.Take(4 * n);
   const size_t o_ghist = cv.Take(4 * 256 * kPasses);
+  const size_t o_orand = cv.Take(kCounterBytes);  // k_sort_hist: which key bits are set / clear somewhere (slotted)
   const size_t o_bhist = cv.Take(4 * hist_n);
   const size_t o_sums = cv.Take(4 * scan_nb);
   const size_t o_sumoff = cv.Take(8 * (scan_nb + 1));
@@ -1268,8 +1383,16 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   int64_t n0 = n;
   // MakeKey of a signed integer flips the sign bit; together with the order's `flip` one XOR constant
   const KeyT raw_xor = flip ^ (IsSignedInt(type_id) ? KeyT(1) << (8 * sizeof(KeyT) - 1) : KeyT(0));
+  auto* orand = reinterpret_cast<unsigned long long*>(b + o_orand);
+  constexpr int kTopDigits = kPasses < 4 ? kPasses : 4;  // digits whose histograms the first hist pass builds
+  bool top_only = false;                                 // ... and whether the lower digits' histograms are missing
   if (raw_try) {
-    hipLaunchKernelGGL((k_sort_hist<KeyT>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, hc[0].values, hc[0].off, type_id, n, key_mask, raw_xor, ghist);
+    AA_TRY(ClearCounters(ctx, orand));
+    top_only = kPasses > kTopDigits && allow_hybrid && !getenv("AMDARROW_SORT_FULL_HIST");
+    if (top_only)
+      hipLaunchKernelGGL((k_sort_hist<KeyT, kTopDigits>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, hc[0].values, hc[0].off, type_id, n, key_mask, raw_xor, ghist, orand);
+    else
+      hipLaunchKernelGGL((k_sort_hist<KeyT, kPasses>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, hc[0].values, hc[0].off, type_id, n, key_mask, raw_xor, ghist, orand);
     AA_HIP(hipGetLastError());
   } else {
     AA_TRY(run_partition());
@@ -1283,11 +1406,44 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   std::vector<unsigned int> h(256 * kPasses);
   for (int p = 0; p < kPasses; p += 4)  // ReadBack moves at most 4 KiB
     AA_TRY(ReadBack(ctx, ghist + 256 * p, 4 * 256 * (kPasses - p < 4 ? kPasses - p : 4), h.data() + 256 * p));
-  std::vector<int> active;
-  for (int p = 0; p < npasses; ++p) {
-    bool trivial = false;
-    for (int d = 0; d < 256; ++d) if (h[p * 256 + d] == static_cast<unsigned int>(n0)) trivial = true;
-    if (!trivial) active.push_back(p);
+  unsigned long long oa[2] = {0, 0};
+  if (raw_try) {  // OR over the slots (ReadCounters adds them up: read the block and OR instead)
+    unsigned long long slots[kCounterSlots * kCounterStride];
+    AA_TRY(ReadBack(ctx, orand, kCounterBytes, slots));
+    for (int sl = 0; sl < kCounterSlots; ++sl) { oa[0] |= slots[sl * kCounterStride]; oa[1] |= slots[sl * kCounterStride + 1]; }
+  }
+  const unsigned long long varying_bits = oa[0] & oa[1];  // a bit varies iff some key has it set and some key has it clear
+  auto find_active = [&](bool low_from_bits) {
+    std::vector<int> act;
+    for (int p = 0; p < npasses; ++p) {
+      if (low_from_bits && p < kPasses - kTopDigits) {  // no histogram: the digit varies iff one of its bits does
+        if ((varying_bits >> (8 * p)) & 255) act.push_back(p);
+        continue;
+      }
+      bool trivial = false;
+      for (int d = 0; d < 256; ++d) if (h[p * 256 + d] == static_cast<unsigned int>(n0)) trivial = true;
+      if (!trivial) act.push_back(p);
+    }
+    return act;
+  };
+  std::vector<int> active = find_active(top_only);
+  // the lower digits' histograms after all (a plan without the hybrid, or one whose global passes reach below the top digits)
+  auto ensure_full_hist = [&]() -> int {
+    if (!top_only) return AMDARROW_OK;
+    top_only = false;
+    AA_HIP(hipMemsetAsync(ghist, 0, 4 * 256 * kPasses, ctx->stream));
+    hipLaunchKernelGGL((k_sort_hist<KeyT, kPasses>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, hc[0].values, hc[0].off, type_id, n, key_mask, raw_xor, ghist,
+                       static_cast<unsigned long long*>(nullptr));
+    AA_HIP(hipGetLastError());
+    for (int p = 0; p < kPasses; p += 4)
+      AA_TRY(ReadBack(ctx, ghist + 256 * p, 4 * 256 * (kPasses - p < 4 ? kPasses - p : 4), h.data() + 256 * p));
+    active = find_active(false);
+    return AMDARROW_OK;
+  };
+  if (top_only) {  // the (up to four) highest active digits are the ones a hybrid plan may pass over: their histograms must be real
+    const size_t look = std::min<size_t>(4, active.size());
+    for (size_t q = 0; q < look; ++q)
+      if (active[active.size() - 1 - q] < kPasses - kTopDigits) { AA_TRY(ensure_full_hist()); break; }
   }
   if (active.empty()) {
     if (raw_try) hipLaunchKernelGGL(k_iota_indices, dim3(GridFor(n0, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, n0, out);
@@ -1333,30 +1489,87 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
       if (expected <= 0.8 * (kWSpan - kWTile)) top = m;
     }
   }
+  // Bit-aligned digits (partition path: the transformed keys are in keys_a).  A byte boundary is an arbitrary place to cut:
+  // float64 in [0, 1) has a top byte that is all but constant (two values, one of them rare) and pays a whole pass for it.
+  // With the top digit starting at the highest bit that varies -- read off the top active byte's histogram -- the same
+  // runs need one pass less (four -> three for that column).  The four digits' exact histograms cost one more pass over
+  // the keys with four LDS atomics each (k_hist_shifts); the plan is taken only if it saves a global pass.
+  std::vector<int> pass_shift;          // the global passes' digit positions, lowest first
+  std::vector<const uint32_t*> pass_db; // ... and their digit bases
+  int low_shift = -1;                   // bit-aligned plan: the lowest bit the global passes sort by
+  if (onesweep && allow_hybrid && !raw_try && !heavy_values && n0 >= hybrid_min && static_cast<int>(active.size()) >= 4 &&
+      !getenv("AMDARROW_SORT_NO_HYBRID") && !getenv("AMDARROW_SORT_BYTE_DIGITS") && !min_env) {
+    const int ptop = active.back();
+    unsigned orv = 0, andv = 255;
+    for (int d = 0; d < 256; ++d) if (h[ptop * 256 + d]) { orv |= d; andv &= d; }
+    const int T = 8 * ptop + (31 - __builtin_clz((orv ^ andv) | 1u));  // the highest varying bit
+    if ((T + 1) % 8 != 0 && T >= 31) {
+      HistShifts hs{};
+      hs.n = 4;
+      for (int k = 0; k < 4; ++k) hs.shift[k] = std::max(T + 1 - 8 * (k + 1), 0);
+      auto* ghist2 = reinterpret_cast<unsigned int*>(bhist);          // (the three-kernel passes' block histograms: free on this path)
+      auto* dbase2 = reinterpret_cast<uint32_t*>(bhist) + 4 * 256;
+      AA_HIP(hipMemsetAsync(ghist2, 0, 4 * 4 * 256, ctx->stream));
+      hipLaunchKernelGGL((k_hist_shifts<KeyT>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, keys_a, n0, hs, ghist2);
+      AA_HIP(hipGetLastError());
+      std::vector<unsigned int> h2(4 * 256);
+      AA_TRY(ReadBack(ctx, ghist2, 4 * 4 * 256, h2.data()));
+      int top_c = 0;
+      double expected = static_cast<double>(n0);
+      for (int m = 1; m <= 4 && top_c == 0; ++m) {
+        unsigned int mx = 0;
+        for (int d = 0; d < 256; ++d) mx = std::max(mx, h2[(m - 1) * 256 + d]);
+        expected *= static_cast<double>(mx) / static_cast<double>(n0);
+        if (m >= 2 && hs.shift[m - 1] >= 16 && expected <= 0.8 * (kWSpan - kWTile)) top_c = m;  // (at least two digits left for the window)
+      }
+      if (top_c && (top == 0 || top_c < top)) {
+        hipLaunchKernelGGL(k_digit_bases, dim3(4), dim3(kThreads), 0, ctx->stream, ghist2, dbase2);
+        AA_HIP(hipGetLastError());
+        top = top_c;
+        low_shift = hs.shift[top_c - 1];
+        for (int k = top_c - 1; k >= 0; --k) { pass_shift.push_back(hs.shift[k]); pass_db.push_back(dbase2 + 256 * k); }
+      }
+    }
+  }
+  if (!top && top_only) AA_TRY(ensure_full_hist());  // every active digit becomes a global pass: all their histograms
   WindowDigits wd{};
   KeyT top_mask = 0;
-  if (top) {
+  const KeyT* window_keys = nullptr;
+  const uint32_t* window_idx = nullptr;
+  unsigned window_n = 0;
+  if (top && low_shift >= 0) {  // bit-aligned plan
+    const int hi_bit = pass_shift.back() + 8;
+    top_mask = (hi_bit >= int(8 * sizeof(KeyT)) ? ~KeyT(0) : (KeyT(1) << hi_bit) - 1) & ~((KeyT(1) << low_shift) - 1);
+    for (int sh = low_shift - 8; wd.n < 8; sh -= 8) {  // the crowded windows' LSD digits: everything below the global passes
+      wd.shift[wd.n++] = std::max(sh, 0);               // (digits may overlap at the bottom: harmless for a stable LSD sort)
+      if (sh <= 0) break;
+    }
+    std::reverse(wd.shift, wd.shift + wd.n);            // lowest first
+  } else if (top) {
     for (int p : active) wd.shift[wd.n++] = 8 * p;
     for (int q = 0; q < top; ++q) top_mask |= KeyT(255) << (8 * active[active.size() - 1 - q]);
     active.erase(active.begin(), active.end() - top);  // the global passes: the top digits, lowest first
+  }
+  if (low_shift < 0) {
+    for (int p : active) { pass_shift.push_back(8 * p); pass_db.push_back(dbase + 256 * p); }
   }
   if (onesweep) {
     hipLaunchKernelGGL(k_digit_bases, dim3(kPasses), dim3(kThreads), 0, ctx->stream, ghist, dbase);
     AA_HIP(hipGetLastError());
     AA_HIP(hipMemsetAsync(ctl, 0, 256, ctx->stream));
-    AA_HIP(hipMemsetAsync(lookback, 0, 4 * static_cast<size_t>(hn0) * active.size(), ctx->stream));
+    AA_HIP(hipMemsetAsync(lookback, 0, 4 * static_cast<size_t>(hn0) * pass_shift.size(), ctx->stream));
   }
-  const bool raw_first = raw_try && onesweep && !(active.size() == 1 && !top);  // (the first pass is not the one that writes the result)
+  const bool raw_first = raw_try && onesweep && !(pass_shift.size() == 1 && !top);  // (the first pass is not the one that writes the result)
   if (raw_try && !raw_first) {  // the partition after all (its histograms are the ones already read)
     AA_HIP(hipMemsetAsync(ghist, 0, 4 * 256 * kPasses, ctx->stream));
     AA_TRY(run_partition());
     if (onesweep) { hipLaunchKernelGGL(k_digit_bases, dim3(kPasses), dim3(kThreads), 0, ctx->stream, ghist, dbase); AA_HIP(hipGetLastError()); }
   }
-  for (size_t a = 0; a < active.size(); ++a) {
-    const int shift = 8 * active[a];
-    const bool last = a + 1 == active.size() && !top;
+  for (size_t a = 0; a < pass_shift.size(); ++a) {
+    const int shift = pass_shift[a];
+    const bool last = a + 1 == pass_shift.size() && !top;
     if (onesweep && a == 0 && raw_first) {
-      const uint32_t* db = dbase + 256 * active[a];
+      const uint32_t* db = pass_db[a];
       auto* pass = arank ? k_radix_onesweep<KeyT, false, true, true> : k_radix_onesweep<KeyT, false, false, true>;
       const KeyT* raw_src = reinterpret_cast<const KeyT*>(hc[0].values) + hc[0].off;
       hipLaunchKernelGGL(pass, dim3(static_cast<unsigned>((n0 + kOTile - 1) / kOTile)), dim3(kOThreads), 0, ctx->stream,
@@ -1369,7 +1582,7 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
     }
     if (onesweep) {
       uint32_t* lb = lookback + static_cast<size_t>(hn0) * a;
-      const uint32_t* db = dbase + 256 * active[a];
+      const uint32_t* db = pass_db[a];
       auto* pass = last ? (arank ? k_radix_onesweep<KeyT, true, true> : k_radix_onesweep<KeyT, true, false>)
                         : (arank ? k_radix_onesweep<KeyT, false, true> : k_radix_onesweep<KeyT, false, false>);
       hipLaunchKernelGGL(pass, dim3(static_cast<unsigned>((n0 + kOTile - 1) / kOTile)), dim3(kOThreads), 0, ctx->stream, keys_a, idx_a, n0, shift, db, lb,
@@ -1396,15 +1609,22 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   if (top) {
     // (the window's own order never rests on the atomics' order: the bucket pass ties on the window position, and its
     // LSD fallback for crowded windows ranks with ballots)
-    auto* window = k_window_sort<KeyT, false>;
-    hipLaunchKernelGGL(window, dim3(static_cast<unsigned>((n0 + kWTile - 1) / kWTile)), dim3(kWThreads), 0, ctx->stream, keys_a, idx_a,
-                       n0, top_mask, wd, ctl + 14, out);
+    const unsigned nwin = static_cast<unsigned>((n0 + kWTile - 1) / kWTile);
+    auto* crowded = reinterpret_cast<unsigned int*>(bhist);  // (the three-kernel passes' block histograms: unused on this path, 256 words per 4096 keys)
+    AA_HIP(hipMemsetAsync(crowded, 0, 4 * static_cast<size_t>(nwin), ctx->stream));
+    hipLaunchKernelGGL((k_window_sort<KeyT>), dim3(nwin), dim3(kWThreads), 0, ctx->stream, keys_a, idx_a, n0, top_mask, ctl + 14, crowded, out);
     AA_HIP(hipGetLastError());
+    window_keys = keys_a; window_idx = idx_a; window_n = nwin;
   }
   if (onesweep) {
-    unsigned int err[3] = {0, 0, 0};  // [0] a run of equal top digits too long for the window, [1] a one-sweep pass gave up,
-                                      // [2] a one-sweep tile whose atomic ranks were not in lane order
-    AA_TRY(ReadBack(ctx, ctl + 14, 12, err));
+    unsigned int err[4] = {0, 0, 0, 0};  // [0] a run of equal top digits too long for the window, [1] a one-sweep pass gave up,
+                                         // [2] a one-sweep tile whose atomic ranks were not in lane order, [3] crowded windows are waiting
+    AA_TRY(ReadBack(ctx, ctl + 14, 16, err));
+    if (err[3] && !err[0] && !err[1] && !err[2]) {
+      hipLaunchKernelGGL((k_window_lsd<KeyT>), dim3(window_n), dim3(kWThreads), 0, ctx->stream, window_keys, window_idx, n0, top_mask, wd,
+                         reinterpret_cast<const unsigned int*>(bhist), out);
+      AA_HIP(hipGetLastError());
+    }
     if (err[2]) {  // never seen on gfx950; the device then ranks with ballots from here on
       ctx->lds_rank_ordered = 0;
       return SortImpl<KeyT>(ctx, chunks, nchunks, type_id, order, n, out, perm, allow_onesweep, allow_hybrid);

@@ -321,7 +321,7 @@ def cpu_baseline(workload, sel):
     # Group-by partials are merged by key on the host inside the timed region.  ctypes releases the GIL for the calls.
     if workload in ("filter_groupby_sum_i64", "hash_agg_f64", "filter_i64", "compare_i64"):
         import concurrent.futures as cf
-        cores = max(1, min(os.cpu_count() or 1, 64))
+        cores = max(1, min(os.cpu_count() or 1, 16))  # the box's CPU share for one GPU
         per = (n + cores - 1) // cores
         cuts = [(i * per, min(n, (i + 1) * per)) for i in range(cores) if i * per < n]
 
