@@ -30,11 +30,13 @@ namespace amdarrow {
 constexpr int kThreads = 256;
 constexpr int kCTile = 2048;   // classify tile: 256 threads x 8
 constexpr int kRTile = 4096;   // radix tile: 16 keys per lane of a 256-thread block
+constexpr int kOTileRows = 8192;  // one-sweep tile (= kOTile below)
 
 struct SortChunk {
   const void* values; const uint8_t* valid; int64_t off; int64_t length;
   int64_t row_start;   // logical index of the chunk's first row
   int64_t tile_start;  // first classify tile of the chunk
+  int64_t otile_start; // first one-sweep tile (kOTile rows) of the chunk: the classified raw first pass, see SortRawClassified
 };
 
 int LaunchScanU32(amdarrow_ctx* ctx, const uint32_t* counts, int64_t n, int64_t* offsets);  // selection.hip
@@ -291,9 +293,104 @@ __global__ __launch_bounds__(kThreads) void k_sort_hist(const void* values, int6
   for (int i = threadIdx.x + kFirst * 256; i < kPasses * 256; i += kThreads)
     if (s_h[i]) atomicAdd(&ghist[i], s_h[i]);
 }
+struct HistShifts { int n; int shift[4]; };
+__device__ __forceinline__ int FindChunkO(const SortChunk* chunks, int nchunks, int64_t otile) {
+  int lo = 0, hi = nchunks - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (chunks[mid].otile_start <= otile) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+// ---- the classified raw path (SortRawClassified): nullable / floating-point / chunked columns without a copy ----------
+// One workgroup per one-sweep tile (kOTileRows rows of ONE chunk, 512 threads x 16 rows).  MODE 0: the rows' classes are
+// counted -- counts[class][tile]: sortable | NaN | null -- and the sortable keys' OR / OR-of-complement collected (which
+// bits vary); MODE 1: the histograms of the plan's digits (hs) over the sortable keys.  Loads raw for the whole tile
+// before anything is looked at.
+constexpr int kRcThreads = 512;
+template <typename KeyT, int MODE>
+__global__ __launch_bounds__(kRcThreads) void k_rawc_scan(const SortChunk* chunks, int nchunks, int type_id, int64_t notiles, int64_t tile_stride,
+                                                          KeyT key_mask, KeyT flip, uint32_t* counts, unsigned long long* orand, HistShifts hs,
+                                                          unsigned int* ghist) {
+  constexpr bool kCount = (MODE & 1) != 0, kHist = (MODE & 2) != 0;
+  constexpr int kIters = kOTileRows / kRcThreads;  // 16
+  constexpr int kWaves = kRcThreads / 64;
+  __shared__ unsigned int s_h[kHist ? 4 * 256 : 1];
+  __shared__ uint32_t s_cls[2][3][kWaves];  // double-buffered by tile parity: one barrier per tile
+  if (kHist) { for (int i = threadIdx.x; i < 4 * 256; i += kRcThreads) s_h[i] = 0; }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  KeyT k_or = 0, k_orn = 0;
+  int parity = 0;
+  for (int64_t tile = int64_t(blockIdx.x) * tile_stride; tile < notiles; tile += int64_t(gridDim.x) * tile_stride, parity ^= 1) {
+    const SortChunk c = chunks[FindChunkO(chunks, nchunks, tile)];
+    const int64_t r0 = (tile - c.otile_start) * kOTileRows;
+    KeyT key[kIters];
+    uint32_t vb[kIters];
+    int64_t ri[kIters];
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      const int64_t r = r0 + j * kRcThreads + threadIdx.x;
+      ri[j] = c.off + (r < c.length ? r : c.length - 1);
+      vb[j] = 0xFFu;
+    }
+    LoadRawKeys<KeyT, kIters>(type_id, c.values, ri, key);
+    if (c.valid) {
+#pragma unroll
+      for (int j = 0; j < kIters; ++j) vb[j] = c.valid[ri[j] >> 3];
+    }
+    uint32_t tot[3] = {0, 0, 0};  // (per thread; reduced once per tile)
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      const int64_t r = r0 + j * kRcThreads + threadIdx.x;
+      int cls = 3;
+      KeyT k = 0;
+      if (r < c.length) {
+        if (!((vb[j] >> (ri[j] & 7)) & 1u)) cls = 2;
+        else {
+          bool is_nan;
+          k = (KeyFromRaw<KeyT>(type_id, key[j], &is_nan) ^ flip) & key_mask;
+          cls = is_nan ? 1 : 0;
+        }
+      }
+      if (kCount) {
+        tot[1] += cls == 1; tot[2] += cls == 2;
+        if (cls == 0) { ++tot[0]; k_or |= k; k_orn |= ~k & key_mask; }
+      }
+      if (kHist && cls == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (q < hs.n) atomicAdd(&s_h[q * 256 + ((k >> hs.shift[q]) & 255)], 1u);
+      }
+    }
+    if (kCount) {
+      unsigned long long packed = tot[0] | static_cast<unsigned long long>(tot[1]) << 16 | static_cast<unsigned long long>(tot[2]) << 32;  // (<= 1024 per wave each)
+      packed = WaveReduceSum64(packed);
+      if (lane == 0) { s_cls[parity][0][wave] = packed & 0xFFFFu; s_cls[parity][1][wave] = (packed >> 16) & 0xFFFFu; s_cls[parity][2][wave] = static_cast<uint32_t>(packed >> 32); }
+      __syncthreads();
+      if (threadIdx.x < 3) {
+        uint32_t t = 0;
+        for (int w = 0; w < kWaves; ++w) t += s_cls[parity][threadIdx.x][w];
+        counts[threadIdx.x * notiles + tile] = t;
+      }
+    }
+  }
+  if (kCount) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { k_or |= __shfl_xor(k_or, o); k_orn |= __shfl_xor(k_orn, o); }
+    if (lane == 0) {
+      unsigned long long* slot = CounterSlot(orand);
+      atomicOr(&slot[0], static_cast<unsigned long long>(k_or));
+      atomicOr(&slot[1], static_cast<unsigned long long>(k_orn));
+    }
+  }
+  if (kHist) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < hs.n * 256; i += kRcThreads)
+      if (s_h[i]) atomicAdd(&ghist[i], s_h[i]);
+  }
+}
+
 // Histograms of up to four 8-bit digits at ARBITRARY bit positions of the (already transformed) keys: the hybrid plan
 // aligns its top digit with the highest bit that varies among the keys instead of with a byte boundary (see SortImpl).
-struct HistShifts { int n; int shift[4]; };
 template <typename KeyT>
 __global__ __launch_bounds__(kThreads) void k_hist_shifts(const KeyT* keys, int64_t n, HistShifts hs, unsigned int* ghist /* [4][256] */) {
   __shared__ unsigned int s_h[4 * 256];
@@ -620,6 +717,7 @@ __global__ __launch_bounds__(kThreads) void k_digit_bases(const unsigned int* gh
 constexpr int kOThreads = 512;            // one-sweep block
 constexpr int kOTile = 8192;              // keys per one-sweep tile (<= 2 * kRTile: the look-back array is sized by kRTile tiles)
 static_assert(kOTile >= kRTile, "look-back array");
+static_assert(kOThreads / 64 == 8, "k_radix_onesweep reads eight wave slots of s_tail");
 constexpr int kOWaves = kOThreads / 64;
 
 // ARANK: a key's rank among the keys of its wave with the same digit is what the LDS atomic that
@@ -630,13 +728,19 @@ constexpr int kOWaves = kOThreads / 64;
 // the instructions) stays as the variant for a device that fails the check.
 // RAW: the first pass over a column without nulls or NaNs -- keys_in is the column itself (the key transformation is
 // applied here: raw_type, raw_flip, raw_mask), the row numbers are the positions.
-template <typename KeyT, bool LAST, bool ARANK, bool RAW = false>
+// RAW == 2: the first pass over a column that may hold nulls / NaNs and may come in chunks (SortRawClassified): a tile
+// is kOTile ROWS of one chunk; the rows are classified here -- nulls and NaNs go straight to their final places at the
+// end of out64 (their positions come from the scanned class counts, rc_offsets[class][tile]), the sortable keys take
+// part in the pass; the row numbers are the logical positions.
+struct RawcArgs { const SortChunk* chunks; int nchunks; const uint32_t* offsets; int64_t notiles; };
+template <typename KeyT, bool LAST, bool ARANK, int RAW = 0>
 __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_in, const uint32_t* idx_in, int64_t n, int shift,
                                                               const uint32_t* dbase /* [256] of this pass */,
                                                               uint32_t* lookback /* [nblocks][256], zeroed */,
                                                               unsigned int* error, KeyT* keys_out,
                                                               uint32_t* idx_out, uint64_t* out64, int raw_type = 0,
-                                                              KeyT raw_flip = 0, KeyT raw_mask = 0, uint32_t xcd_run = 0) {
+                                                              KeyT raw_flip = 0, KeyT raw_mask = 0, uint32_t xcd_run = 0,
+                                                              RawcArgs rc = RawcArgs{nullptr, 0, nullptr, 0}) {
   constexpr int kIters = kOTile / kOThreads;  // 16; wave w owns keys [w*1024, (w+1)*1024) of the tile, in order
   __shared__ uint32_t s_whist[kOWaves][256];  // per-wave digit counts, then per-wave running local positions
   __shared__ uint32_t s_dstart[256];          // first local position of each digit
@@ -667,34 +771,98 @@ __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_i
   }
   const int64_t base = int64_t(tile) * kOTile;
   const int64_t left = n - base;
-  const uint32_t count = left >= kOTile ? kOTile : static_cast<uint32_t>(left);
+  uint32_t count = RAW == 2 ? 0u : (left >= kOTile ? kOTile : static_cast<uint32_t>(left));  // RAW == 2: the tile's ROWS, set below
 
   KeyT key[kIters];
   uint32_t idx[kIters];
+  uint32_t alive = 0;  // bit j: key[j] takes part in the pass
+  __shared__ uint32_t s_tail[2][kOWaves];  // RAW == 2: NaN / null rows per wave
+  uint32_t tail_cls = 0, tail_rank[RAW == 2 ? kIters : 1];  // RAW == 2: this thread's NaN / null rows (written behind the first barrier)
+  if constexpr (RAW == 2) {
+    const SortChunk c = rc.chunks[FindChunkO(rc.chunks, rc.nchunks, tile)];
+    const int64_t r0 = (int64_t(tile) - c.otile_start) * kOTile;
+    const int64_t rows_left = c.length - r0;
+    count = rows_left >= kOTile ? kOTile : static_cast<uint32_t>(rows_left > 0 ? rows_left : 0);
+    int64_t ri[kIters];
+    uint32_t vb[kIters];
 #pragma unroll
-  for (int j = 0; j < kIters; ++j) {
-    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
-    key[j] = 0; idx[j] = 0;
-    if (li < count) {
-      key[j] = keys_in[base + li];
-      idx[j] = RAW ? static_cast<uint32_t>(base + li) : idx_in[base + li];
+    for (int j = 0; j < kIters; ++j) {
+      const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+      ri[j] = c.off + r0 + (li < count ? li : (count ? count - 1 : 0));
+      vb[j] = 0xFFu;
+      idx[j] = static_cast<uint32_t>(c.row_start + r0 + li);
     }
-  }
-  if (RAW) {  // integers as wide as the key: the transformation is one XOR (sign bit and order) and the mask -- behind
-              // the loop, so that no load is waited for before the next one is issued
+    LoadRawKeys<KeyT, kIters>(raw_type, c.values, ri, key);
+    if (c.valid) {
 #pragma unroll
-    for (int j = 0; j < kIters; ++j) key[j] = (key[j] ^ raw_flip) & raw_mask;
+      for (int j = 0; j < kIters; ++j) vb[j] = c.valid[ri[j] >> 3];
+    }
+    // classes, and the NaN / null rows' ranks inside the tile (row order = (wave, step, lane) order)
+    uint32_t run[2] = {0, 0};
+    uint32_t trank[kIters];
+    uint32_t tcls = 0;  // two bits per step: 0 sortable / dead, 1 NaN, 2 null
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+      int cls = 3;
+      if (li < count) {
+        if (!((vb[j] >> (ri[j] & 7)) & 1u)) cls = 2;
+        else {
+          bool is_nan;
+          key[j] = (KeyFromRaw<KeyT>(raw_type, key[j], &is_nan) ^ raw_flip) & raw_mask;
+          cls = is_nan ? 1 : 0;
+        }
+      }
+      if (cls == 0) alive |= 1u << j; else key[j] = 0;
+      const uint64_t m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
+      trank[j] = cls == 1 ? run[0] + RankBelowLane(m1) : cls == 2 ? run[1] + RankBelowLane(m2) : 0u;
+      if (cls == 1 || cls == 2) tcls |= static_cast<uint32_t>(cls) << (2 * j);
+      run[0] += __popcll(m1);
+      run[1] += __popcll(m2);
+    }
+    if (lane == 0) { s_tail[0][wave] = run[0]; s_tail[1][wave] = run[1]; }
+    tail_cls = tcls;
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) tail_rank[RAW == 2 ? j : 0] = trank[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+      key[j] = 0; idx[j] = 0;
+      if (li < count) {
+        alive |= 1u << j;
+        key[j] = keys_in[base + li];
+        idx[j] = RAW ? static_cast<uint32_t>(base + li) : idx_in[base + li];
+      }
+    }
+    if (RAW) {  // integers as wide as the key: the transformation is one XOR (sign bit and order) and the mask -- behind
+                // the loop, so that no load is waited for before the next one is issued
+#pragma unroll
+      for (int j = 0; j < kIters; ++j) key[j] = (key[j] ^ raw_flip) & raw_mask;
+    }
   }
   uint32_t rk[ARANK ? kIters : 1];
 #pragma unroll
   for (int j = 0; j < kIters; ++j) {
-    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
-    if (li < count) {
+    if ((alive >> j) & 1u) {
       const uint32_t r = atomicAdd(&s_whist[wave][(key[j] >> shift) & 255], 1u);
       if (ARANK) rk[ARANK ? j : 0] = r;
     }
   }
   __syncthreads();
+  if constexpr (RAW == 2) {  // the NaN / null rows go to their final places (tile order, row order inside the tile)
+    if (__builtin_amdgcn_readfirstlane(s_tail[0][0] | s_tail[0][1] | s_tail[0][2] | s_tail[0][3] | s_tail[0][4] | s_tail[0][5] | s_tail[0][6] | s_tail[0][7] |
+                                       s_tail[1][0] | s_tail[1][1] | s_tail[1][2] | s_tail[1][3] | s_tail[1][4] | s_tail[1][5] | s_tail[1][6] | s_tail[1][7])) {
+      uint32_t woff[2] = {0, 0};
+      for (int w = 0; w < wave; ++w) { woff[0] += s_tail[0][w]; woff[1] += s_tail[1][w]; }
+      const uint32_t tail_base[2] = {rc.offsets[1 * rc.notiles + tile], rc.offsets[2 * rc.notiles + tile]};
+#pragma unroll
+      for (int j = 0; j < kIters; ++j) {
+        const uint32_t cls = (tail_cls >> (2 * j)) & 3u;
+        if (cls) out64[tail_base[cls - 1] + woff[cls - 1] + tail_rank[RAW == 2 ? j : 0]] = idx[j];
+      }
+    }
+  }
   uint32_t tot = 0;
   if (tid < 256) {  // thread d: totals of digit d -> publish; exclusive scan over digits, per-wave bases
     uint32_t c[kOWaves];
@@ -726,7 +894,7 @@ __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_i
 #pragma unroll
   for (int j = 0; j < kIters; ++j) {
     const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
-    const bool live = li < count;
+    const bool live = (alive >> j) & 1u;
     const uint32_t d = (key[j] >> shift) & 255;
     if (ARANK) {
       if (live) {
@@ -797,6 +965,7 @@ __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_i
     s_gbase[tid] = dbase[tid] + excl;
   }
   if (__syncthreads_or(gave_up)) return;  // positions unknown: write nothing
+  if (RAW == 2) count = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];  // the keys that took part (the digit totals' sum)
   bool disorder = false;
   for (uint32_t i0 = 0; i0 < count; i0 += kOThreads) {  // (every lane takes part in the lane shift below)
     const uint32_t i = i0 + tid;
@@ -1289,6 +1458,168 @@ static uint32_t XcdRunFor(amdarrow_ctx* ctx, const void* kernel) {
   return xccs == 8 && int64_t(per_cu) * ctx->num_cus >= int64_t(8) * kXcdRun ? kXcdRun : 0;
 }
 
+// Nullable / floating-point / chunked columns WITHOUT the partition's copy (0.63 ms per 100 M float64: it reads the
+// column and writes 12 bytes per row that the first radix pass reads again).  The rows' classes are counted per
+// one-sweep tile (k_rawc_scan<0>, which also tells which key bits vary), the plan's digits -- aligned with the highest
+// varying bit -- get their histograms from the column itself (k_rawc_scan<1>), and the FIRST one-sweep pass reads the
+// chunks directly: it classifies the rows again, drops NaNs and nulls at their final places behind the sortable rows
+// (stable: tile order, row order inside the tile) and sorts the rest by the lowest of the plan's digits.  Only taken
+// when the hybrid plan applies (large input, spread-out keys, runs that fit the windows); returns *done = false
+// otherwise and SortImpl goes its usual way.
+template <typename KeyT>
+static int SortRawClassified(amdarrow_ctx* ctx, const std::vector<SortChunk>& hc, int type_id, int order, int64_t n, uint64_t* out,
+                             bool arank, bool* done) {
+  *done = false;
+  const int nchunks = static_cast<int>(hc.size());
+  const int key_bits = BitWidth(type_id);
+  const KeyT key_mask = ~KeyT(0);
+  const KeyT flip = order == AMDARROW_DESCENDING ? key_mask : 0;
+  (void)key_bits;
+  int64_t notiles = 0;
+  for (const auto& c : hc) notiles += (c.length + kOTileRows - 1) / kOTileRows;
+  if (notiles == 0) return AMDARROW_OK;
+  const int64_t scan_nb = (3 * notiles + 2047) / 2048;
+  const int64_t nwin = (n + kWTile - 1) / kWTile;
+  const int64_t nb_max = std::max<int64_t>(notiles, (n + kOTile - 1) / kOTile);
+  Carver cv;
+  const size_t o_chunks = cv.Take(sizeof(SortChunk) * nchunks);
+  const size_t o_counts = cv.Take(4 * 3 * notiles);
+  const size_t o_sums = cv.Take(4 * scan_nb);
+  const size_t o_sumoff = cv.Take(8 * (scan_nb + 1));
+  const size_t o_keys_a = cv.Take(sizeof(KeyT) * n);
+  const size_t o_keys_b = cv.Take(sizeof(KeyT) * n);
+  const size_t o_idx_a = cv.Take(4 * n);
+  const size_t o_idx_b = cv.Take(4 * n);
+  const size_t o_ghist = cv.Take(4 * 4 * 256);
+  const size_t o_dbase = cv.Take(4 * 4 * 256);
+  const size_t o_orand = cv.Take(kCounterBytes);
+  const size_t o_ctl = cv.Take(256);
+  const size_t o_lookback = cv.Take(4 * 256 * static_cast<size_t>(nb_max) * 4);
+  const size_t o_crowded = cv.Take(4 * static_cast<size_t>(nwin));
+  void* base;
+  AA_TRY(Scratch(ctx, cv.off, &base));
+  char* b = static_cast<char*>(base);
+  auto* d_chunks = reinterpret_cast<SortChunk*>(b + o_chunks);
+  auto* counts = reinterpret_cast<uint32_t*>(b + o_counts);
+  auto* sums = reinterpret_cast<uint32_t*>(b + o_sums);
+  auto* sumoff = reinterpret_cast<int64_t*>(b + o_sumoff);
+  KeyT* keys_a = reinterpret_cast<KeyT*>(b + o_keys_a);
+  KeyT* keys_b = reinterpret_cast<KeyT*>(b + o_keys_b);
+  uint32_t* idx_a = reinterpret_cast<uint32_t*>(b + o_idx_a);
+  uint32_t* idx_b = reinterpret_cast<uint32_t*>(b + o_idx_b);
+  auto* ghist = reinterpret_cast<unsigned int*>(b + o_ghist);
+  auto* dbase = reinterpret_cast<uint32_t*>(b + o_dbase);
+  auto* orand = reinterpret_cast<unsigned long long*>(b + o_orand);
+  auto* ctl = reinterpret_cast<unsigned int*>(b + o_ctl);
+  auto* lookback = reinterpret_cast<uint32_t*>(b + o_lookback);
+  auto* crowded = reinterpret_cast<unsigned int*>(b + o_crowded);
+  AA_HIP(hipMemcpyAsync(d_chunks, hc.data(), sizeof(SortChunk) * nchunks, hipMemcpyHostToDevice, ctx->stream));
+  AA_HIP(hipStreamSynchronize(ctx->stream));  // hc is pageable host memory
+  // 1. classes per tile, and which key bits vary
+  // (a first look at every 64th tile tells where the keys' highest varying bit probably is: the full pass then builds
+  // the plan's histograms next to the counts, and only a wrong guess costs a second pass over the column)
+  auto read_varying = [&](unsigned long long* out_bits) -> int {
+    unsigned long long sl[kCounterSlots * kCounterStride], bs = 0, bc = 0;
+    AA_TRY(ReadBack(ctx, orand, kCounterBytes, sl));
+    for (int q = 0; q < kCounterSlots; ++q) { bs |= sl[q * kCounterStride]; bc |= sl[q * kCounterStride + 1]; }
+    *out_bits = bs & bc;
+    return AMDARROW_OK;
+  };
+  auto shifts_for = [](int T) { HistShifts h{}; h.n = 4; for (int k = 0; k < 4; ++k) h.shift[k] = std::max(T + 1 - 8 * (k + 1), 0); return h; };
+  const int grid = GridFor(notiles, 1, ctx->num_cus * 4);
+  AA_TRY(ClearCounters(ctx, orand));
+  hipLaunchKernelGGL((k_rawc_scan<KeyT, 1>), dim3(GridFor((notiles + 63) / 64, 1, ctx->num_cus * 4)), dim3(kRcThreads), 0, ctx->stream, d_chunks, nchunks,
+                     type_id, notiles, int64_t(64), key_mask, flip, counts, orand, HistShifts{}, static_cast<unsigned int*>(nullptr));
+  AA_HIP(hipGetLastError());
+  unsigned long long guess_bits = 0;
+  AA_TRY(read_varying(&guess_bits));
+  const int T_guess = guess_bits ? 63 - __builtin_clzll(guess_bits) : int(8 * sizeof(KeyT)) - 1;
+  HistShifts hs = shifts_for(T_guess);
+  AA_TRY(ClearCounters(ctx, orand));
+  AA_HIP(hipMemsetAsync(ghist, 0, 4 * 4 * 256, ctx->stream));
+  hipLaunchKernelGGL((k_rawc_scan<KeyT, 3>), dim3(grid), dim3(kRcThreads), 0, ctx->stream, d_chunks, nchunks, type_id, notiles, int64_t(1), key_mask, flip, counts,
+                     orand, hs, ghist);
+  AA_HIP(hipGetLastError());
+  AA_TRY(ScanU32InPlace(ctx, counts, 3 * notiles, sums, sumoff));
+  uint32_t n0_32 = 0;
+  AA_TRY(ReadBack(ctx, counts + notiles, 4, &n0_32));  // start of the NaN region = number of sortable rows
+  const int64_t n0 = n0_32;
+  unsigned long long varying = 0;
+  AA_TRY(read_varying(&varying));
+  if (n0 < (int64_t(1) << 21) || varying == 0) return AMDARROW_OK;  // small or constant: the usual way
+  // 2. the plan: digits aligned with the highest varying bit
+  const int T = 63 - __builtin_clzll(varying);
+  if (T < 31) return AMDARROW_OK;
+  if (T != T_guess) {  // the sample missed the keys that carry the top bit: the histograms again, at the right place
+    hs = shifts_for(T);
+    AA_HIP(hipMemsetAsync(ghist, 0, 4 * 4 * 256, ctx->stream));
+    hipLaunchKernelGGL((k_rawc_scan<KeyT, 2>), dim3(grid), dim3(kRcThreads), 0, ctx->stream, d_chunks, nchunks, type_id, notiles, int64_t(1), key_mask, flip,
+                       counts, orand, hs, ghist);
+    AA_HIP(hipGetLastError());
+  }
+  std::vector<unsigned int> h2(4 * 256);
+  AA_TRY(ReadBack(ctx, ghist, 4 * 4 * 256, h2.data()));
+  int top = 0;
+  double expected = static_cast<double>(n0);
+  for (int m = 1; m <= 4 && top == 0; ++m) {
+    unsigned int mx = 0;
+    for (int d = 0; d < 256; ++d) mx = std::max(mx, h2[(m - 1) * 256 + d]);
+    expected *= static_cast<double>(mx) / static_cast<double>(n0);
+    if (m >= 2 && hs.shift[m - 1] >= 16 && expected <= 0.8 * (kWSpan - kWTile)) top = m;
+  }
+  if (top == 0) return AMDARROW_OK;
+  // (a value that owns ~n / 4096 rows or more hides from the digit histograms when there are many such values: the
+  // window kernel notices the run and the sort is redone without the hybrid -- SortImpl's sample check needs the
+  // partitioned keys, which this path does not have; the retry below covers it)
+  // 3. the passes: the first reads the chunks, the others the keys it wrote
+  hipLaunchKernelGGL(k_digit_bases, dim3(4), dim3(kThreads), 0, ctx->stream, ghist, dbase);
+  AA_HIP(hipGetLastError());
+  AA_HIP(hipMemsetAsync(ctl, 0, 256, ctx->stream));
+  AA_HIP(hipMemsetAsync(lookback, 0, 4 * 256 * static_cast<size_t>(nb_max) * top, ctx->stream));
+  const int low_shift = hs.shift[top - 1];
+  for (int a = 0; a < top; ++a) {
+    const int k = top - 1 - a;  // lowest digit first
+    uint32_t* lb = lookback + 256 * static_cast<size_t>(nb_max) * a;
+    const uint32_t* db = dbase + 256 * k;
+    if (a == 0) {
+      auto* pass = arank ? k_radix_onesweep<KeyT, false, true, 2> : k_radix_onesweep<KeyT, false, false, 2>;
+      hipLaunchKernelGGL(pass, dim3(static_cast<unsigned>(notiles)), dim3(kOThreads), 0, ctx->stream, static_cast<const KeyT*>(nullptr),
+                         static_cast<const uint32_t*>(nullptr), n, hs.shift[k], db, lb, ctl + 15, keys_b, idx_b, out, type_id, flip, key_mask,
+                         XcdRunFor(ctx, reinterpret_cast<const void*>(pass)), RawcArgs{d_chunks, nchunks, counts, notiles});
+    } else {
+      auto* pass = arank ? k_radix_onesweep<KeyT, false, true> : k_radix_onesweep<KeyT, false, false>;
+      hipLaunchKernelGGL(pass, dim3(static_cast<unsigned>((n0 + kOTile - 1) / kOTile)), dim3(kOThreads), 0, ctx->stream, keys_a, idx_a, n0, hs.shift[k], db, lb,
+                         ctl + 15, keys_b, idx_b, out, 0, KeyT(0), KeyT(0), XcdRunFor(ctx, reinterpret_cast<const void*>(pass)), RawcArgs{nullptr, 0, nullptr, 0});
+    }
+    AA_HIP(hipGetLastError());
+    std::swap(keys_a, keys_b);
+    std::swap(idx_a, idx_b);
+  }
+  // 4. the windows
+  const int hi_bit = hs.shift[0] + 8;
+  const KeyT top_mask = (hi_bit >= int(8 * sizeof(KeyT)) ? ~KeyT(0) : (KeyT(1) << hi_bit) - 1) & ~((KeyT(1) << low_shift) - 1);
+  WindowDigits wd{};
+  for (int sh = low_shift - 8; wd.n < 8; sh -= 8) {
+    wd.shift[wd.n++] = std::max(sh, 0);
+    if (sh <= 0) break;
+  }
+  std::reverse(wd.shift, wd.shift + wd.n);
+  const unsigned nw = static_cast<unsigned>((n0 + kWTile - 1) / kWTile);
+  AA_HIP(hipMemsetAsync(crowded, 0, 4 * static_cast<size_t>(nw), ctx->stream));
+  hipLaunchKernelGGL((k_window_sort<KeyT>), dim3(nw), dim3(kWThreads), 0, ctx->stream, keys_a, idx_a, n0, top_mask, ctl + 14, crowded, out);
+  AA_HIP(hipGetLastError());
+  unsigned int err[4] = {0, 0, 0, 0};
+  AA_TRY(ReadBack(ctx, ctl + 14, 16, err));
+  if (err[2]) { ctx->lds_rank_ordered = 0; return AMDARROW_OK; }  // (SortImpl redoes everything with the ballot ranking)
+  if (err[0] || err[1]) return AMDARROW_OK;                       // a run too long for the windows / a pass gave up: the usual way
+  if (err[3]) {
+    hipLaunchKernelGGL((k_window_lsd<KeyT>), dim3(nw), dim3(kWThreads), 0, ctx->stream, keys_a, idx_a, n0, top_mask, wd, crowded, out);
+    AA_HIP(hipGetLastError());
+  }
+  *done = true;
+  return AMDARROW_OK;
+}
+
 template <typename KeyT>
 static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks, int type_id, int order, int64_t n,
                     uint64_t* out, const uint64_t* perm = nullptr, bool allow_onesweep = true, bool allow_hybrid = true) {
@@ -1301,12 +1632,24 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
 
   // chunk table + classify tiles
   std::vector<SortChunk> hc(nchunks);
-  int64_t row = 0, tiles = 0;
+  int64_t row = 0, tiles = 0, otiles = 0;
   for (int c = 0; c < nchunks; ++c) {
     hc[c] = SortChunk{chunks[c].values, MayHaveNulls(&chunks[c]) ? chunks[c].validity : nullptr, chunks[c].offset,
-                      chunks[c].length, row, tiles};
+                      chunks[c].length, row, tiles, otiles};
+    otiles += (chunks[c].length + kOTileRows - 1) / kOTileRows;
     row += chunks[c].length;
     tiles += (chunks[c].length + kCTile - 1) / kCTile;
+  }
+  {  // nullable / floating-point / chunked columns: the classified raw path first (no partition copy)
+    bool plain = !IsFloat(type_id) && nchunks == 1;
+    for (const auto& c : hc) plain = plain && c.valid == nullptr;
+    if (!perm && !plain && allow_onesweep && allow_hybrid && n >= (int64_t(1) << 21) && n < (int64_t(1) << 30) &&
+        BitWidth(type_id) == 8 * int(sizeof(KeyT)) && !getenv("AMDARROW_SORT_THREE_KERNEL") && !getenv("AMDARROW_SORT_NO_RAW_FIRST_PASS") &&
+        !getenv("AMDARROW_SORT_NO_HYBRID") && !getenv("AMDARROW_SORT_HYBRID_MIN")) {
+      bool done = false;
+      AA_TRY(SortRawClassified<KeyT>(ctx, hc, type_id, order, n, out, LdsAtomicsLaneOrdered(ctx), &done));
+      if (done) return AMDARROW_OK;
+    }
   }
   const int64_t ntiles = perm ? (n + kCTile - 1) / kCTile : tiles;
   const int64_t nblocks = (n + kRTile - 1) / kRTile;
@@ -1574,7 +1917,8 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
       const KeyT* raw_src = reinterpret_cast<const KeyT*>(hc[0].values) + hc[0].off;
       hipLaunchKernelGGL(pass, dim3(static_cast<unsigned>((n0 + kOTile - 1) / kOTile)), dim3(kOThreads), 0, ctx->stream,
                          raw_src, static_cast<const uint32_t*>(nullptr), n0, shift, db, lookback,
-                         ctl + 15, keys_b, idx_b, out, type_id, raw_xor, key_mask, XcdRunFor(ctx, reinterpret_cast<const void*>(pass)));
+                         ctl + 15, keys_b, idx_b, out, type_id, raw_xor, key_mask, XcdRunFor(ctx, reinterpret_cast<const void*>(pass)),
+                         RawcArgs{nullptr, 0, nullptr, 0});
       AA_HIP(hipGetLastError());
       std::swap(keys_a, keys_b);
       std::swap(idx_a, idx_b);
@@ -1586,7 +1930,8 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
       auto* pass = last ? (arank ? k_radix_onesweep<KeyT, true, true> : k_radix_onesweep<KeyT, true, false>)
                         : (arank ? k_radix_onesweep<KeyT, false, true> : k_radix_onesweep<KeyT, false, false>);
       hipLaunchKernelGGL(pass, dim3(static_cast<unsigned>((n0 + kOTile - 1) / kOTile)), dim3(kOThreads), 0, ctx->stream, keys_a, idx_a, n0, shift, db, lb,
-                         ctl + 15, keys_b, idx_b, out, 0, KeyT(0), KeyT(0), XcdRunFor(ctx, reinterpret_cast<const void*>(pass)));
+                         ctl + 15, keys_b, idx_b, out, 0, KeyT(0), KeyT(0), XcdRunFor(ctx, reinterpret_cast<const void*>(pass)),
+                         RawcArgs{nullptr, 0, nullptr, 0});
       AA_HIP(hipGetLastError());
       std::swap(keys_a, keys_b);
       std::swap(idx_a, idx_b);
