@@ -20,3 +20,5 @@ bash profiles/run_pmc.sh $tag filter_groupby_sum_i64 > $out/${tag}_headline_hbm_
 cat $out/${tag}_headline_hbm_pmc.txt
 bash profiles/run_pmc.sh $tag sort_u64 > $out/${tag}_sort_u64_hbm_pmc.txt 2>&1
 grep PER_STEP_TOTAL $out/${tag}_sort_u64_hbm_pmc.txt
+bash profiles/run_pmc.sh $tag sort_f64 > $out/${tag}_sort_f64_hbm_pmc.txt 2>&1
+grep PER_STEP_TOTAL $out/${tag}_sort_f64_hbm_pmc.txt
