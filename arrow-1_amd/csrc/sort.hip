@@ -734,7 +734,7 @@ constexpr int kOWaves = kOThreads / 64;
 // part in the pass; the row numbers are the logical positions.
 struct RawcArgs { const SortChunk* chunks; int nchunks; const uint32_t* offsets; int64_t notiles; };
 template <typename KeyT, bool LAST, bool ARANK, int RAW = 0>
-__global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_in, const uint32_t* idx_in, int64_t n, int shift,
+__global__ __launch_bounds__(kOThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_radix_onesweep(const KeyT* keys_in, const uint32_t* idx_in, int64_t n, int shift,
                                                               const uint32_t* dbase /* [256] of this pass */,
                                                               uint32_t* lookback /* [nblocks][256], zeroed */,
                                                               unsigned int* error, KeyT* keys_out,
@@ -746,10 +746,11 @@ __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_i
   __shared__ uint32_t s_dstart[256];          // first local position of each digit
   __shared__ uint32_t s_gbase[256];           // global position of this tile's run of each digit
   __shared__ uint32_t s_scan[4];
-  __shared__ KeyT s_keys[kOTile];
-  // a staged key's row index (low half) and where in the tile it came from (high half: the order check below) travel as
-  // ONE 8-byte LDS word -- as many LDS instructions per key as without the check
-  __shared__ unsigned long long s_pair[kOTile];
+  // ONE staging buffer of 8-byte words, used twice: first the keys go through it (LDS position -> global position), then
+  // the row indices -- each with the place in the tile it came from in its high half, for the order check below.  With
+  // a buffer for each the kernel needed 137 KB of LDS, one workgroup per CU, and the CU sat idle in memory while the
+  // tile was ranked and idle in LDS while it streamed; 73 KB lets two workgroups share a CU and overlap.
+  __shared__ unsigned long long s_buf[kOTile];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < kOWaves * 256; i += kOThreads) (&s_whist[0][0])[i] = 0;
   __syncthreads();
@@ -891,16 +892,16 @@ __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_i
     for (int w = 0; w < kOWaves; ++w) s_whist[w][tid] += dstart;
   }
   __syncthreads();
+  uint32_t lpos[kIters];  // where each of this thread's keys is staged (both staging rounds use it)
 #pragma unroll
   for (int j = 0; j < kIters; ++j) {
-    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
     const bool live = (alive >> j) & 1u;
     const uint32_t d = (key[j] >> shift) & 255;
+    lpos[j] = 0;
     if (ARANK) {
       if (live) {
-        const uint32_t lpos = s_whist[wave][d] + rk[ARANK ? j : 0];
-        s_keys[lpos] = key[j];
-        s_pair[lpos] = static_cast<unsigned long long>(li) << 32 | idx[j];
+        lpos[j] = s_whist[wave][d] + rk[ARANK ? j : 0];
+        s_buf[lpos[j]] = static_cast<unsigned long long>(key[j]);
       }
       continue;
     }
@@ -916,9 +917,8 @@ __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_i
       const uint32_t old = s_whist[wave][d];
       __builtin_amdgcn_wave_barrier();
       if (rank == 0) s_whist[wave][d] = old + __popcll(m);
-      const uint32_t lpos = old + rank;
-      s_keys[lpos] = key[j];
-      s_pair[lpos] = idx[j];
+      lpos[j] = old + rank;
+      s_buf[lpos[j]] = static_cast<unsigned long long>(key[j]);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -966,34 +966,52 @@ __global__ __launch_bounds__(kOThreads) void k_radix_onesweep(const KeyT* keys_i
   }
   if (__syncthreads_or(gave_up)) return;  // positions unknown: write nothing
   if (RAW == 2) count = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];  // the keys that took part (the digit totals' sum)
+  // round 1: the keys leave (thread t takes the staged positions t, t + 512, ...: the same ones in both rounds, so a
+  // position's global place is computed once and kept in a register)
+  uint32_t gpos[kIters];
+  uint32_t inrun = 0;  // bit k: position i is not the first of its digit's run (the order check compares it with i - 1)
+#pragma unroll
+  for (int k = 0; k < kIters; ++k) {
+    const uint32_t i = k * kOThreads + tid;
+    gpos[k] = 0;
+    if (i < count) {
+      const KeyT kk = static_cast<KeyT>(s_buf[i]);
+      const uint32_t d = (kk >> shift) & 255;
+      const uint32_t dstart = s_dstart[d];
+      gpos[k] = s_gbase[d] + (i - dstart);
+      if (i > dstart) inrun |= 1u << k;
+      if (!LAST) keys_out[gpos[k]] = kk;
+    }
+  }
+  __syncthreads();
+  // round 2: the row indices, each with its origin in the tile
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+    if ((alive >> j) & 1u) s_buf[lpos[j]] = static_cast<unsigned long long>(li) << 32 | idx[j];
+  }
+  __syncthreads();
   bool disorder = false;
-  for (uint32_t i0 = 0; i0 < count; i0 += kOThreads) {  // (every lane takes part in the lane shift below)
-    const uint32_t i = i0 + tid;
+#pragma unroll
+  for (int k = 0; k < kIters; ++k) {  // (every lane takes part in the lane shift below)
+    const uint32_t i = k * kOThreads + tid;
     const bool in = i < count;
-    const KeyT k = s_keys[in ? i : 0];
-    const unsigned long long pair = s_pair[in ? i : 0];
-    const uint32_t d = (k >> shift) & 255;
+    const unsigned long long pair = s_buf[in ? i : 0];
     // ARANK is VERIFIED, not trusted: inside a digit's run the staged keys must appear in the order they had in the
     // tile (that is what "stable" means for this pass; the atomics hand out distinct ranks by construction, so the
     // only thing that could go wrong is their order).  A tile that fails raises error word 2 and the host redoes the
     // sort with the ballot ranking -- correctness never rests on the order in which the hardware serves the lanes of
     // one ds_add_rtn, only the speed does.
-    const uint32_t dstart = s_dstart[d];
     if (ARANK) {
       // the predecessor's origin: from the lane below (a DPP wave shift, no LDS traffic), lane 0 of a wave from LDS
       const uint32_t from = static_cast<uint32_t>(pair >> 32);
       uint32_t prev = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(from), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-      if (lane == 0 && i > 0) prev = static_cast<uint32_t>(s_pair[in ? i - 1 : 0] >> 32);
-      if (in && i > dstart) disorder |= prev > from;
+      if (lane == 0 && i > 0) prev = static_cast<uint32_t>(s_buf[in ? i - 1 : 0] >> 32);
+      if (in && ((inrun >> k) & 1u)) disorder |= prev > from;
     }
     if (!in) continue;
-    const uint32_t gpos = s_gbase[d] + (i - dstart);
-    if (LAST) {
-      out64[gpos] = static_cast<uint32_t>(pair);
-    } else {
-      keys_out[gpos] = k;
-      idx_out[gpos] = static_cast<uint32_t>(pair);
-    }
+    if (LAST) out64[gpos[k]] = static_cast<uint32_t>(pair);
+    else idx_out[gpos[k]] = static_cast<uint32_t>(pair);
   }
   if (ARANK && disorder) __hip_atomic_store(error + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
