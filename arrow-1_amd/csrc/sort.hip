@@ -311,8 +311,9 @@ constexpr int kRcThreads = 512;
 template <typename KeyT, int MODE>
 __global__ __launch_bounds__(kRcThreads) void k_rawc_scan(const SortChunk* chunks, int nchunks, int type_id, int64_t notiles, int64_t tile_stride,
                                                           KeyT key_mask, KeyT flip, uint32_t* counts, unsigned long long* orand, HistShifts hs,
-                                                          unsigned int* ghist) {
+                                                          unsigned int* ghist, const HistShifts* hs_dev = nullptr) {
   constexpr bool kCount = (MODE & 1) != 0, kHist = (MODE & 2) != 0;
+  if (kHist && hs_dev) hs = *hs_dev;  // (decided by k_guess_shifts, queued in front of this kernel)
   constexpr int kIters = kOTileRows / kRcThreads;  // 16
   constexpr int kWaves = kRcThreads / 64;
   __shared__ unsigned int s_h[kHist ? 4 * 256 : 1];
@@ -1050,160 +1051,285 @@ __device__ __forceinline__ uint32_t WindowOfBlock() {
 // A crowded window (keys clustered inside it) is not sorted here: its flag is raised and k_window_lsd, a kernel of its
 // own with the register budget of its ballot-ranked LSD passes, takes it -- kept in this kernel the fallback's registers
 // cost every window a wave per SIMD (222 VGPRs: two workgroups per CU instead of three, 1.21 -> 1.52 ms).
+#ifdef WS_PHASES  // -DWS_PHASES: cycles per phase of k_window_sort, summed over the workgroups (profiles/bench_src/ws_phases.py reads them)
+__device__ unsigned long long g_ws_phase[64][16];
+#define WPH(i) do { if (threadIdx.x == 0) { const unsigned long long _n = __builtin_readcyclecounter(); wph[i] += _n - wph_last; wph_last = _n; } } while (0)
+#define WPH_FLUSH() do { if (threadIdx.x == 0) { for (int _i = 0; _i < 12; ++_i) atomicAdd(&g_ws_phase[blockIdx.x & 63][_i], wph[_i]); atomicAdd(&g_ws_phase[blockIdx.x & 63][15], 1ull); } } while (0)
+#else
+#define WPH(i)
+#define WPH_FLUSH()
+#endif
+// The key of the lane below (lane 0: `carry`), without touching LDS: a DPP wave shift per 32-bit half.
 template <typename KeyT>
-__global__ __launch_bounds__(kWThreads) void k_window_sort(const KeyT* keys, const uint32_t* idx_in, int64_t n, KeyT top_mask,
-                                                          unsigned int* error, unsigned int* crowded /* [windows], zeroed */,
-                                                          uint64_t* out64) {
-  constexpr int kIters = kWSpan / kWThreads;  // 16; wave w owns candidate positions [w*1024, (w+1)*1024), in order
-  __shared__ KeyT s_keys[kWSpan];
-  __shared__ uint32_t s_idx[kWSpan];  // 16-bit bucket counters + 16-bit positions
+__device__ __forceinline__ KeyT KeyOfLaneBelow(KeyT k, KeyT carry, int lane) {
+  constexpr int kShr1 = 0x138;  // wave_shr:1
+  uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(static_cast<uint32_t>(k)), kShr1, 0xf, 0xf, false));
+  KeyT r = lo;
+  if (sizeof(KeyT) == 8) {
+    const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(static_cast<uint32_t>(static_cast<uint64_t>(k) >> 32)), kShr1, 0xf, 0xf, false));
+    r = static_cast<KeyT>(static_cast<uint64_t>(hi) << 32 | lo);
+  }
+  return lane == 0 ? carry : r;
+}
+template <typename KeyT>
+__device__ __forceinline__ KeyT KeyOfLane63(KeyT k) {
+  uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(k)), 63));
+  if (sizeof(KeyT) == 8) {
+    const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(static_cast<uint64_t>(k) >> 32)), 63));
+    return static_cast<KeyT>(static_cast<uint64_t>(hi) << 32 | lo);
+  }
+  return static_cast<KeyT>(lo);
+}
+// 128 registers: four workgroups per CU (32 KB of LDS each) instead of three -- 904 -> 712 us per 100 M uint64
+template <typename KeyT>
+__global__ __launch_bounds__(kWThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_window_sort(
+    const KeyT* keys, const uint32_t* idx_in, int64_t n, KeyT top_mask, unsigned int* error, unsigned int* crowded /* [windows], zeroed */,
+    uint64_t* out64) {
+  constexpr int kIters = kWSpan / kWThreads;  // 16: step j takes the candidates [j * 256, (j + 1) * 256), a wave 64 consecutive ones
+  // What bounds this kernel is instruction issue (four workgroups share a CU: a wave gets a quarter of its SIMD) and
+  // the LDS traffic of lanes that go to unrelated addresses (64 lanes over 32 banks: an 8-byte access of a wave takes
+  // ~30 cycles instead of 4).  So: no 64-bit key ever goes to LDS; a key costs as few scattered 32-bit accesses as the
+  // algorithm allows -- its bucket's counter (an atomic), the bucket's start (a read), one packed word (a write), the
+  // words of a bucket it shares (reads), its row index at its place in the sorted window (a write) --; and a wave
+  // skips, with a scalar branch, every step whose 64 candidates lie outside the window (half of them on average).
+  __shared__ uint32_t s_cnt[kWBuckets];  // per bucket: its count, then start << 16 | count
+  __shared__ uint32_t s_sub[kWSpan];     // by bucket: sub-bucket bits << 12 | window position; later the row indices in sorted order
   __shared__ uint32_t s_scan[16];
-  __shared__ uint32_t s_lo, s_hi, s_big;
-  uint32_t* s_cnt2 = s_idx;                                             // kWBuckets / 2 words: two 16-bit counters each
-  uint16_t* s_pos = reinterpret_cast<uint16_t*>(s_idx + kWBuckets / 2);  // kWSpan window positions, in sorted order
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ uint32_t s_big;
+  __shared__ unsigned long long s_heads[2][kWWaves];  // per wave: its first head inside the tile / at or after the tile's end (packed, see below)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t win = WindowOfBlock();
   const int64_t p0 = int64_t(win) * kWTile;
   const int64_t left = n - p0;
   const uint32_t cand = left >= kWSpan ? kWSpan : static_cast<uint32_t>(left);  // candidate keys [p0, p0 + cand)
-  if (tid == 0) { s_lo = kWSpan; s_hi = kWSpan; s_big = 0; }
+  if (tid == 0) s_big = 0;
+#ifdef WS_PHASES
+  unsigned long long wph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long wph_last = __builtin_readcyclecounter();
+#endif
 
-  // Keys and row indices of every candidate in one round of loads.  They STAY in these registers, at their candidate
-  // position li: the window [lo, hi) is a range of candidates, a key's window position is li - lo.  Only the keys are
-  // staged in LDS (the heads of the runs are found by comparing neighbours).
-  KeyT key[kIters];
-  uint32_t idx[kIters];
+  // The keys of every candidate in one round of loads (the row indices follow once the window is known, for its keys
+  // only).  The heads of the runs are found by comparing a key with the lane below (DPP), lane 0 with the key in front
+  // of the wave's 64 (a scalar load).
+  KeyT key[kIters], front[kIters];
 #pragma unroll
   for (int j = 0; j < kIters; ++j) {
-    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+    const uint32_t li = j * kWThreads + tid;
     key[j] = li < cand ? keys[p0 + li] : KeyT(0);
-    idx[j] = li < cand ? idx_in[p0 + li] : 0u;
+    const uint32_t b0 = j * kWThreads + wave * 64;  // (wave-uniform: a scalar load)
+    front[j] = b0 < cand && p0 + b0 > 0 ? keys[p0 + b0 - 1] : KeyT(0);
   }
-  const KeyT before = p0 > 0 ? keys[p0 - 1] : KeyT(0);
-#pragma unroll
-  for (int j = 0; j < kIters; ++j) s_keys[wave * (kIters * 64) + j * 64 + lane] = key[j];
-  for (int i = tid; i < kWBuckets / 2; i += kWThreads) s_cnt2[i] = 0;
-  __syncthreads();
-  // segment heads: lo = first head inside the tile, hi = first head at or after the tile's end
-  uint32_t lo = kWSpan, hi = kWSpan;
+  {
+    uint4* z = reinterpret_cast<uint4*>(s_cnt);
+    for (int i = tid; i < kWBuckets / 4; i += kWThreads) z[i] = make_uint4(0, 0, 0, 0);
+  }
+  // segment heads: lo = first head inside the tile, hi = first head at or after the tile's end.  A head travels as ONE
+  // 64-bit word, position << 48 | the part of a key above the window's own digits (the host plans at least two digits
+  // for the window: that part has at most 48 bits) -- for lo the head's own key, for hi the key in FRONT of the head:
+  // the minimum over the workgroup (wave reduction, one word per wave, one barrier) names the window AND its first
+  // and last key, which is all the bucket pass needs to know about the window's key range.
+  const int low_bits = sizeof(KeyT) == 8 ? __ffsll(static_cast<long long>(top_mask)) - 1 : __ffs(static_cast<int>(top_mask)) - 1;
+  constexpr uint32_t kNone = kWSpan + 1;  // (a position no head can have; the input's end may sit at kWSpan itself)
+  constexpr unsigned long long kNoHead = static_cast<unsigned long long>(kNone) << 48;
+  unsigned long long plo = kNoHead, phi = kNoHead;
 #pragma unroll
   for (int j = 0; j < kIters; ++j) {
-    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
-    if (li < cand) {
-      const KeyT prev = li > 0 ? s_keys[li - 1] : before;
-      const bool head = (p0 + li == 0) || ((prev ^ key[j]) & top_mask) != 0;
-      if (head && li < kWTile && li < lo) lo = li;
-      if (head && li >= kWTile && li < hi) hi = li;
-    }
-  }
-  if (lo < kWSpan) atomicMin(&s_lo, lo);
-  if (hi < kWSpan) atomicMin(&s_hi, hi);
-  __syncthreads();
-  lo = s_lo;
-  hi = s_hi;
-  if (lo == kWSpan) return;  // no segment starts here: an earlier tile owns these keys
-  if (hi == kWSpan) {
-    if (p0 + cand < n) {  // the last segment runs past the window
-      if (tid == 0) __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return;
-    }
-    hi = cand;  // the input ends inside the window
-  }
-  const uint32_t count = hi - lo;
-
-  // ---- bucket pass: ONE counting pass instead of one LSD pass per varying digit ----------------------
-  // bucket = (key - base) >> shift, monotone in the key: once the keys are grouped by bucket only the few keys that share
-  // a bucket are out of order, and every thread finishes its own stretch of the window with an insertion sort on
-  // (key, window position) -- the position makes the result stable whatever order the counting atomics handed out
-  // inside a bucket.  The window's key range needs no reduction over its keys: the window is ordered by the digits the
-  // global passes sorted, so its FIRST key carries the smallest and its LAST key the largest value of everything at
-  // and above the lowest of those digits; below it anything goes.  base = first key with the low part cleared,
-  // range = (last - first) at that granularity + the whole low part.  Spread-out keys put < 1 key in a bucket on
-  // average; a crowded bucket (keys clustered inside the window) sends the window to the LSD passes.
-  uint32_t brank[kIters], bucket[kIters];
-  {
-    const int low_bits = sizeof(KeyT) == 8 ? __ffsll(static_cast<long long>(top_mask)) - 1 : __ffs(static_cast<int>(top_mask)) - 1;
-    const KeyT low_mask = (KeyT(1) << low_bits) - 1;
-    const KeyT base = s_keys[lo] & ~low_mask;
-    const KeyT range = ((s_keys[hi - 1] & ~low_mask) - base) | low_mask;
-    const int bits = sizeof(KeyT) == 8 ? 64 - __clzll(static_cast<long long>(range)) : 32 - __clz(static_cast<int>(range));
-    const int bshift = bits > kWBucketBits ? bits - kWBucketBits : 0;
-#pragma unroll
-    for (int j = 0; j < kIters; ++j) {
-      const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
-      bucket[j] = 0; brank[j] = 0;
-      if (li >= lo && li < hi) {
-        bucket[j] = static_cast<uint32_t>((key[j] - base) >> bshift);
-        const int half = (bucket[j] & 1) * 16;
-        brank[j] = (atomicAdd(&s_cnt2[bucket[j] >> 1], 1u << half) >> half) & 0xFFFFu;
+    const uint32_t li = j * kWThreads + tid;
+    const KeyT prev = KeyOfLaneBelow<KeyT>(key[j], front[j], lane);
+    const bool head = li < cand && ((p0 + li == 0) || ((prev ^ key[j]) & top_mask) != 0);
+    if (head) {  // (rare: most steps no lane gets here)
+      if (li < kWTile) {
+        const unsigned long long mine = static_cast<unsigned long long>(li) << 48 | static_cast<unsigned long long>(key[j]) >> low_bits;
+        plo = mine < plo ? mine : plo;
+      } else {
+        const unsigned long long ahead = static_cast<unsigned long long>(li) << 48 | static_cast<unsigned long long>(prev) >> low_bits;
+        phi = ahead < phi ? ahead : phi;
       }
     }
   }
+  if (p0 + cand == n) {  // the input ends inside the window: its end is the last run's end
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      const uint32_t li = j * kWThreads + tid;
+      if (li + 1 == cand) {
+        const unsigned long long end = static_cast<unsigned long long>(cand) << 48 | static_cast<unsigned long long>(key[j]) >> low_bits;
+        phi = end < phi ? end : phi;
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned long long ol = __shfl_xor(plo, d, 64), oh = __shfl_xor(phi, d, 64);
+    plo = ol < plo ? ol : plo;
+    phi = oh < phi ? oh : phi;
+  }
+  if (lane == 0) { s_heads[0][wave] = plo; s_heads[1][wave] = phi; }
   __syncthreads();
+#pragma unroll
+  for (int w = 0; w < kWWaves; ++w) {
+    const unsigned long long ol = s_heads[0][w], oh = s_heads[1][w];
+    plo = ol < plo ? ol : plo;
+    phi = oh < phi ? oh : phi;
+  }
+  WPH(0);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(plo >> 48));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(phi >> 48));
+  if (lo == kNone) return;  // no segment starts here: an earlier tile owns these keys
+  if (hi == kNone) {        // the last segment runs past the window
+    if (tid == 0) __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  const uint32_t count = hi - lo;
+  // does step j hold a key of the window in this wave?  (scalar: whole steps are skipped)
+#define WS_STEP_LIVE(j) (static_cast<uint32_t>((j) * kWThreads + wave * 64 + 64) > lo && static_cast<uint32_t>((j) * kWThreads + wave * 64) < hi)
+  uint32_t idx[kIters];  // the window's row indices: on their way while the keys are ranked
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    idx[j] = 0;
+    if (WS_STEP_LIVE(j)) {
+      const uint32_t li = j * kWThreads + tid;
+      idx[j] = idx_in[p0 + (li < cand ? li : cand - 1)];
+    }
+  }
+
+  // ---- bucket pass: ONE counting pass instead of one LSD pass per varying digit ----------------------
+  // bucket = (key - base) >> shift, monotone in the key: keys of different buckets are in order once every bucket knows
+  // where it starts (a scan of the counts), and a key that is alone in its bucket -- six in ten when the keys are
+  // spread out -- goes straight to its place.  The keys of a bucket that holds several are ranked inside it on
+  // (key, window position): each stages ONE 32-bit word, the 20 key bits below the bucket's << 12 | its position, and
+  // counts the bucket's words that are smaller than its own -- its place in the bucket, stable whatever order the
+  // counting atomics handed out.  Two words that agree in those 20 bits while the keys have more (one pair in a
+  // million among spread-out keys) compare by the keys themselves, fetched from global memory.
+  // The window's key range needs no reduction over its keys: the window is ordered by the digits the global passes
+  // sorted, so its FIRST key carries the smallest and its LAST key the largest value of everything at and above the
+  // lowest of those digits; below it anything goes.  base = first key with the low part cleared, range = (last -
+  // first) at that granularity + the whole low part.  A bucket with more than kWMaxBucket keys (keys clustered
+  // inside the window) sends the window to the LSD passes.
+  constexpr int kSubBits = 20;
+  uint32_t bb[kIters], sub[kIters];  // bb: the key's bucket | its arrival number in the bucket << 16
+  const KeyT low_mask = (KeyT(1) << low_bits) - 1;
+  const KeyT base = static_cast<KeyT>((plo & ((1ull << 48) - 1)) << low_bits);
+  const KeyT range = (static_cast<KeyT>((phi & ((1ull << 48) - 1)) << low_bits) - base) | low_mask;
+  const int bits = sizeof(KeyT) == 8 ? 64 - __clzll(static_cast<long long>(range)) : 32 - __clz(static_cast<int>(range));
+  const int bshift = __builtin_amdgcn_readfirstlane(bits > kWBucketBits ? bits - kWBucketBits : 0);
+  const bool sub_exact = bshift <= kSubBits;  // the packed word holds every key bit below the bucket's
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    bb[j] = 0; sub[j] = 0;
+    if (!WS_STEP_LIVE(j)) continue;
+    const uint32_t li = j * kWThreads + tid;
+    if (li >= lo && li < hi) {
+      const KeyT rel = key[j] - base;
+      const uint32_t bk = static_cast<uint32_t>(rel >> bshift);
+      const uint32_t below = sub_exact ? static_cast<uint32_t>(rel & ((KeyT(1) << bshift) - 1)) << (kSubBits - bshift)
+                                       : static_cast<uint32_t>(rel >> (bshift - kSubBits)) & ((1u << kSubBits) - 1u);
+      sub[j] = below << 12 | (li - lo);
+      bb[j] = bk | atomicAdd(&s_cnt[bk], 1u) << 16;
+    }
+  }
+  __syncthreads();
+  WPH(2);
   {
     // exclusive scan of the bucket counts: thread t owns buckets [t * per, (t + 1) * per)
     constexpr int kPer = kWBuckets / kWThreads;  // 16
-    uint32_t cnt[kPer], start = 0, biggest = 0;
+    uint32_t cnt[kPer], mine = 0, biggest = 0;
 #pragma unroll
-    for (int q = 0; q < kPer / 2; ++q) {
-      const uint32_t w2 = s_cnt2[tid * (kPer / 2) + q];
-      cnt[2 * q] = w2 & 0xFFFFu; cnt[2 * q + 1] = w2 >> 16;
-      start += cnt[2 * q] + cnt[2 * q + 1];
-      biggest = cnt[2 * q] > biggest ? cnt[2 * q] : biggest;
-      biggest = cnt[2 * q + 1] > biggest ? cnt[2 * q + 1] : biggest;
+    for (int q = 0; q < kPer / 4; ++q) {
+      const uint4 c4 = reinterpret_cast<const uint4*>(s_cnt)[tid * (kPer / 4) + q];
+      cnt[4 * q] = c4.x; cnt[4 * q + 1] = c4.y; cnt[4 * q + 2] = c4.z; cnt[4 * q + 3] = c4.w;
     }
-    const uint32_t mine = start;  // keys in this thread's buckets
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) { mine += cnt[q]; biggest = cnt[q] > biggest ? cnt[q] : biggest; }
     const uint32_t incl = WaveInclusiveScan(mine);
     if (lane == 63) s_scan[wave] = incl;
     if (biggest > kWMaxBucket) s_big = 1;
     __syncthreads();
+    WPH(3);
     if (s_big == 0) {
       uint32_t run = incl - mine;
       for (int w = 0; w < wave; ++w) run += s_scan[w];
-      const uint32_t first = run;  // this thread's stretch of the sorted window: [first, first + mine)
 #pragma unroll
-      for (int q = 0; q < kPer / 2; ++q) {
-        const uint32_t a = run; run += cnt[2 * q];
-        const uint32_t b = run; run += cnt[2 * q + 1];
-        s_cnt2[tid * (kPer / 2) + q] = a | (b << 16);  // bucket starts (< 4096) replace the counts
+      for (int q = 0; q < kPer / 4; ++q) {
+        uint4 o;
+        o.x = run << 16 | cnt[4 * q]; run += cnt[4 * q];
+        o.y = run << 16 | cnt[4 * q + 1]; run += cnt[4 * q + 1];
+        o.z = run << 16 | cnt[4 * q + 2]; run += cnt[4 * q + 2];
+        o.w = run << 16 | cnt[4 * q + 3]; run += cnt[4 * q + 3];
+        reinterpret_cast<uint4*>(s_cnt)[tid * (kPer / 4) + q] = o;  // start << 16 | count
       }
       __syncthreads();
+      WPH(4);
+      // a key's bucket: where it starts and how many keys it holds
+      // (all of a thread's reads first: inside the liveness test they went one round trip at a time)
+      uint32_t sc[kIters];
 #pragma unroll
-      for (int j = 0; j < kIters; ++j) {
-        const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
-        if (li >= lo && li < hi) {
-          const uint32_t at = ((s_cnt2[bucket[j] >> 1] >> ((bucket[j] & 1) * 16)) & 0xFFFFu) + brank[j];
-          s_keys[at] = key[j];  // (the staged candidates are done with: every thread holds its own in registers)
-          s_pos[at] = static_cast<uint16_t>(li - lo);
-        }
-      }
-      __syncthreads();
-      for (uint32_t i = first + 1; i < first + mine; ++i) {  // insertion sort of a nearly sorted stretch
-        const KeyT k = s_keys[i];
-        const uint16_t ps = s_pos[i];
-        uint32_t at = i;
-        while (at > first) {
-          const KeyT pk = s_keys[at - 1];
-          const uint16_t pp = s_pos[at - 1];
-          if (pk < k || (pk == k && pp < ps)) break;
-          s_keys[at] = pk; s_pos[at] = pp;
-          --at;
-        }
-        if (at != i) { s_keys[at] = k; s_pos[at] = ps; }
-      }
-      __syncthreads();
-      // the keys are done with: their space carries the row indices from window order to sorted order
-      uint32_t* s_rows = reinterpret_cast<uint32_t*>(s_keys);
+      for (int j = 0; j < kIters; ++j) { sc[j] = 0; if (WS_STEP_LIVE(j)) sc[j] = s_cnt[bb[j] & 0xFFFFu]; }
 #pragma unroll
       for (int j = 0; j < kIters; ++j) {
-        const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
-        if (li >= lo && li < hi) s_rows[li - lo] = idx[j];
+        if (!WS_STEP_LIVE(j)) continue;
+        const uint32_t li = j * kWThreads + tid;
+        if (!(li >= lo && li < hi)) sc[j] = 0;  // (count 0: not a key of this window)
+        if ((sc[j] & 0xFFFFu) > 1) s_sub[(sc[j] >> 16) + (bb[j] >> 16)] = sub[j];  // (a bucket's words sit in the order the atomics handed out)
       }
       __syncthreads();
-      for (uint32_t i = tid; i < count; i += kWThreads) out64[p0 + lo + i] = s_rows[s_pos[i]];
+      WPH(5);
+      // place in the sorted window: bucket start + the bucket's OTHER keys that sort before this one.  The first
+      // kFlat words of a shared bucket are read WITHOUT a branch: a candidate that does not share its bucket reads a
+      // harmless word of its own (s_sub[tid]: no bank conflict) and ignores it -- with the reads inside `if (shared)`
+      // every candidate cost the wave a dependent LDS round trip of its own.  A key's own word never counts (it is
+      // not smaller than itself).  Larger buckets, and words that tie in the staged key bits, finish in a slow path
+      // few steps enter.
+      constexpr uint32_t kFlat = 4;
+#pragma unroll
+      for (int j = 0; j < kIters; ++j) {
+        if (!WS_STEP_LIVE(j)) continue;
+        const uint32_t bs = sc[j] >> 16, sz = sc[j] & 0xFFFFu, lim = sz > 1 ? sz : 0u;
+        uint32_t other[kFlat];
+#pragma unroll
+        for (uint32_t q = 0; q < kFlat; ++q) other[q] = s_sub[q < lim ? bs + q : static_cast<uint32_t>(tid)];
+        uint32_t before_me = 0;
+        bool slow = lim > kFlat;
+#pragma unroll
+        for (uint32_t q = 0; q < kFlat; ++q) {
+          const uint32_t x = other[q] ^ sub[j];
+          before_me += q < lim && other[q] < sub[j] ? 1u : 0u;
+          slow = slow || (q < lim && !sub_exact && x != 0 && (x >> 12) == 0);  // another key with the same staged bits
+        }
+        if (slow) {  // everything again, ties by the keys themselves (both from global memory), then by the position
+          before_me = 0;
+          for (uint32_t q = 0; q < sz; ++q) {
+            const uint32_t o = s_sub[bs + q];
+            if (o == sub[j]) continue;
+            if (!sub_exact && ((o ^ sub[j]) >> 12) == 0) {
+              const KeyT ok = keys[p0 + lo + (o & 0xFFFu)], mk = keys[p0 + lo + (sub[j] & 0xFFFu)];
+              before_me += (ok < mk || (ok == mk && o < sub[j])) ? 1u : 0u;
+            } else {
+              before_me += o < sub[j] ? 1u : 0u;
+            }
+          }
+        }
+        sc[j] = bs + before_me;  // (dead candidates: never used)
+      }
+      __syncthreads();
+      WPH(6);
+      // the staged words are done with: their space carries the row indices in sorted order
+      uint32_t* s_rows = s_sub;
+#pragma unroll
+      for (int j = 0; j < kIters; ++j) {
+        if (!WS_STEP_LIVE(j)) continue;
+        const uint32_t li = j * kWThreads + tid;
+        if (li >= lo && li < hi) s_rows[sc[j]] = idx[j];
+      }
+      __syncthreads();
+      WPH(7);
+      for (uint32_t i = tid; i < count; i += kWThreads) out64[p0 + lo + i] = s_rows[i];
+      WPH(8);
+      WPH_FLUSH();
       return;
     }
   }
+#undef WS_STEP_LIVE
   if (tid == 0) {  // crowded: k_window_lsd sorts this window (error word 3 tells the host that there is work for it)
     crowded[win] = 1u;
     __hip_atomic_store(error + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1390,33 +1516,130 @@ int ScanU32InPlace(amdarrow_ctx* ctx, uint32_t* data, int64_t n, uint32_t* sums,
 // Do 4096 keys sampled at a fixed stride contain the same key twice?  A value that shows up twice in
 // such a sample holds on the order of n / 4096 rows or more -- a run of equal keys no window can take.
 // The digit histograms cannot see that (a thousand distinct heavy values fill every digit evenly),
-// so the hybrid path asks this one workgroup first.  LDS hash set, linear probing.
+// so the hybrid plan asks one workgroup first (LDS hash set, linear probing; part of k_sort_plan).
 constexpr int kSampleKeys = 4096;
+
+// Everything the host's plan needs to know about a column, in ONE small record that one workgroup writes straight into
+// mapped host memory (the host waits for an event behind it): per digit histogram the largest count, whether a single
+// value holds every key, and the OR / AND of the digit values that occur; which key bits vary; the number of sortable
+// rows; whether the stride sample holds a value twice (all of a thread's sample loads are in flight before its first
+// insertion: one dependent load after the other, the test alone took 22 us).  Five separate read-backs of 4 KiB each -- a stream synchronisation and
+// an idle queue every time, ~30 us apiece -- used to carry the same information.
+struct PlanDigit { uint32_t max, trivial, orv, andv; };
+struct PlanSummary {
+  uint32_t n0, dup;
+  unsigned long long bits_set, bits_clear;
+  int guess_shift0;  // SortRawClassified: the top digit's shift the histograms were built at (see k_guess_shifts)
+  int pad;
+  PlanDigit digit[8];
+};
+constexpr size_t kPlanOffset = kStatusOffset + 256;  // behind the group-by's status words in the pinned block
+static_assert(kPlanOffset + sizeof(PlanSummary) <= 8192, "pinned block");
 template <typename KeyT>
-__global__ __launch_bounds__(256) void k_sample_has_duplicates(const KeyT* keys, int64_t n, unsigned int* out) {
+__global__ __launch_bounds__(256) void k_sort_plan(const unsigned int* ghist, int ndigits, const uint32_t* n0_dev, uint32_t n0_imm,
+                                                   const unsigned long long* orand, const KeyT* sample, const HistShifts* hs_dev,
+                                                   PlanSummary* out) {
   constexpr int kSlots = 2 * kSampleKeys;
   __shared__ KeyT s_set[kSlots];
   __shared__ unsigned int s_dup;
+  __shared__ uint32_t s_red[4][4];
   using Word = typename std::conditional<sizeof(KeyT) == 8, unsigned long long, unsigned int>::type;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t n0 = n0_dev ? *n0_dev : n0_imm;
   const KeyT kEmpty = ~KeyT(0);
-  for (int i = threadIdx.x; i < kSlots; i += 256) s_set[i] = kEmpty;
-  if (threadIdx.x == 0) s_dup = 0;
-  __syncthreads();
-  const int64_t stride = n / kSampleKeys;
-  for (int i = threadIdx.x; i < kSampleKeys; i += 256) {
-    KeyT k = keys[int64_t(i) * stride];
-    if (k == kEmpty) continue;  // the one value the set cannot hold; it does not decide anything
-    uint64_t h = static_cast<uint64_t>(k) * 0x9E3779B97F4A7C15ull;
-    uint32_t slot = static_cast<uint32_t>(h >> 40) & (kSlots - 1);
-    for (;;) {
-      const KeyT seen = static_cast<KeyT>(atomicCAS(reinterpret_cast<Word*>(&s_set[slot]), static_cast<Word>(kEmpty), static_cast<Word>(k)));
-      if (seen == kEmpty) break;
-      if (seen == k) { s_dup = 1; break; }
-      slot = (slot + 1) & (kSlots - 1);
+  if (tid == 0) s_dup = 0;
+  if (sample && n0 >= kSampleKeys) {
+    constexpr int kPer = kSampleKeys / 256;
+    KeyT k[kPer];
+    const int64_t stride = n0 / kSampleKeys;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) k[j] = sample[int64_t(j * 256 + tid) * stride];
+    for (int i = tid; i < kSlots; i += 256) s_set[i] = kEmpty;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      if (k[j] == kEmpty) continue;  // the one value the set cannot hold; it does not decide anything
+      const uint64_t h = static_cast<uint64_t>(k[j]) * 0x9E3779B97F4A7C15ull;
+      uint32_t slot = static_cast<uint32_t>(h >> 40) & (kSlots - 1);
+      for (;;) {
+        const KeyT seen = static_cast<KeyT>(atomicCAS(reinterpret_cast<Word*>(&s_set[slot]), static_cast<Word>(kEmpty), static_cast<Word>(k[j])));
+        if (seen == kEmpty) break;
+        if (seen == k[j]) { s_dup = 1; break; }
+        slot = (slot + 1) & (kSlots - 1);
+      }
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) *out = s_dup;
+  for (int q = 0; q < ndigits; ++q) {
+    const uint32_t h = ghist[q * 256 + tid];
+    uint32_t mx = h, tr = h == n0 ? 1u : 0u, orv = h ? tid : 0u, andv = h ? tid : 255u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t m2 = __shfl_xor(mx, o);
+      mx = m2 > mx ? m2 : mx;
+      tr |= __shfl_xor(tr, o); orv |= __shfl_xor(orv, o); andv &= __shfl_xor(andv, o);
+    }
+    if (lane == 0) { s_red[wave][0] = mx; s_red[wave][1] = tr; s_red[wave][2] = orv; s_red[wave][3] = andv; }
+    __syncthreads();
+    if (tid == 0) {
+      PlanDigit d{s_red[0][0], s_red[0][1], s_red[0][2], s_red[0][3]};
+      for (int w = 1; w < 4; ++w) {
+        d.max = s_red[w][0] > d.max ? s_red[w][0] : d.max;
+        d.trivial |= s_red[w][1]; d.orv |= s_red[w][2]; d.andv &= s_red[w][3];
+      }
+      out->digit[q] = d;
+    }
+    __syncthreads();
+  }
+  if (wave == 0) {
+    unsigned long long bs = 0, bc = 0;
+    if (orand && lane < kCounterSlots) { bs = orand[lane * kCounterStride]; bc = orand[lane * kCounterStride + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { bs |= __shfl_xor(bs, o); bc |= __shfl_xor(bc, o); }
+    if (lane == 0) {
+      out->n0 = n0; out->dup = s_dup; out->bits_set = bs; out->bits_clear = bc;
+      out->guess_shift0 = hs_dev ? hs_dev->shift[0] : 0;
+    }
+  }
+}
+// Queue k_sort_plan and wait for its record.
+template <typename KeyT>
+static int ReadPlan(amdarrow_ctx* ctx, const unsigned int* ghist, int ndigits, const uint32_t* n0_dev, uint32_t n0_imm,
+                    const unsigned long long* orand, const KeyT* sample, const HistShifts* hs_dev, PlanSummary* plan) {
+  auto* out = reinterpret_cast<PlanSummary*>(static_cast<char*>(ctx->pinned_dev) + kPlanOffset);
+  hipLaunchKernelGGL((k_sort_plan<KeyT>), dim3(1), dim3(256), 0, ctx->stream, ghist, ndigits, n0_dev, n0_imm, orand, sample, hs_dev, out);
+  AA_HIP(hipGetLastError());
+  AA_HIP(hipEventRecord(ctx->status_event, ctx->stream));
+  AA_HIP(hipEventSynchronize(ctx->status_event));
+  memcpy(plan, static_cast<const char*>(ctx->pinned) + kPlanOffset, sizeof(PlanSummary));
+  return AMDARROW_OK;
+}
+// The chunk table goes to the device through the pinned block when it fits (a copy from pageable memory has to be
+// waited for; this one is stream-ordered like everything behind it).
+static int UploadChunks(amdarrow_ctx* ctx, SortChunk* d_chunks, const std::vector<SortChunk>& hc) {
+  const size_t bytes = sizeof(SortChunk) * hc.size();
+  if (bytes <= 4096) {
+    AA_HIP(hipStreamSynchronize(ctx->stream));  // (nothing of an earlier call may still be reading the block; idle in practice)
+    memcpy(ctx->pinned, hc.data(), bytes);
+    AA_HIP(hipMemcpyAsync(d_chunks, ctx->pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return AMDARROW_OK;
+  }
+  AA_HIP(hipMemcpyAsync(d_chunks, hc.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+  AA_HIP(hipStreamSynchronize(ctx->stream));  // hc is pageable host memory
+  return AMDARROW_OK;
+}
+// The highest varying key bit of the sampled tiles -> the digit positions the full pass builds its histograms at
+// (SortRawClassified), decided on the device: the full pass is queued right behind the sample.
+template <typename KeyT>
+__global__ void k_guess_shifts(const unsigned long long* orand, HistShifts* hs_out) {
+  unsigned long long bs = 0, bc = 0;
+  for (int s = 0; s < kCounterSlots; ++s) { bs |= orand[s * kCounterStride]; bc |= orand[s * kCounterStride + 1]; }
+  const unsigned long long varying = bs & bc;
+  const int T = varying ? 63 - __clzll(static_cast<long long>(varying)) : int(8 * sizeof(KeyT)) - 1;
+  HistShifts h{};
+  h.n = 4;
+  for (int k = 0; k < 4; ++k) { const int s = T + 1 - 8 * (k + 1); h.shift[k] = s > 0 ? s : 0; }
+  *hs_out = h;
 }
 
 // One workgroup ranks pseudo-random digits (uniform over 256 values, over 4 values, all equal) both
@@ -1546,58 +1769,48 @@ static int SortRawClassified(amdarrow_ctx* ctx, const std::vector<SortChunk>& hc
   auto* ctl = reinterpret_cast<unsigned int*>(b + o_ctl);
   auto* lookback = reinterpret_cast<uint32_t*>(b + o_lookback);
   auto* crowded = reinterpret_cast<unsigned int*>(b + o_crowded);
-  AA_HIP(hipMemcpyAsync(d_chunks, hc.data(), sizeof(SortChunk) * nchunks, hipMemcpyHostToDevice, ctx->stream));
-  AA_HIP(hipStreamSynchronize(ctx->stream));  // hc is pageable host memory
+  AA_TRY(UploadChunks(ctx, d_chunks, hc));
   // 1. classes per tile, and which key bits vary
   // (a first look at every 64th tile tells where the keys' highest varying bit probably is: the full pass then builds
-  // the plan's histograms next to the counts, and only a wrong guess costs a second pass over the column)
-  auto read_varying = [&](unsigned long long* out_bits) -> int {
-    unsigned long long sl[kCounterSlots * kCounterStride], bs = 0, bc = 0;
-    AA_TRY(ReadBack(ctx, orand, kCounterBytes, sl));
-    for (int q = 0; q < kCounterSlots; ++q) { bs |= sl[q * kCounterStride]; bc |= sl[q * kCounterStride + 1]; }
-    *out_bits = bs & bc;
-    return AMDARROW_OK;
-  };
+  // the plan's histograms next to the counts, and only a wrong guess costs a second pass over the column.  The guess
+  // stays on the device -- k_guess_shifts hands the digit positions to the full pass -- and the host learns everything
+  // it plans with from ONE record, see k_sort_plan)
   auto shifts_for = [](int T) { HistShifts h{}; h.n = 4; for (int k = 0; k < 4; ++k) h.shift[k] = std::max(T + 1 - 8 * (k + 1), 0); return h; };
   const int grid = GridFor(notiles, 1, ctx->num_cus * 4);
+  auto* hs_dev = reinterpret_cast<HistShifts*>(ctl + 32);  // (the control block is cleared only after the plan has been read)
   AA_TRY(ClearCounters(ctx, orand));
   hipLaunchKernelGGL((k_rawc_scan<KeyT, 1>), dim3(GridFor((notiles + 63) / 64, 1, ctx->num_cus * 4)), dim3(kRcThreads), 0, ctx->stream, d_chunks, nchunks,
-                     type_id, notiles, int64_t(64), key_mask, flip, counts, orand, HistShifts{}, static_cast<unsigned int*>(nullptr));
+                     type_id, notiles, int64_t(64), key_mask, flip, counts, orand, HistShifts{}, static_cast<unsigned int*>(nullptr), static_cast<const HistShifts*>(nullptr));
+  hipLaunchKernelGGL((k_guess_shifts<KeyT>), dim3(1), dim3(1), 0, ctx->stream, orand, hs_dev);
   AA_HIP(hipGetLastError());
-  unsigned long long guess_bits = 0;
-  AA_TRY(read_varying(&guess_bits));
-  const int T_guess = guess_bits ? 63 - __builtin_clzll(guess_bits) : int(8 * sizeof(KeyT)) - 1;
-  HistShifts hs = shifts_for(T_guess);
   AA_TRY(ClearCounters(ctx, orand));
   AA_HIP(hipMemsetAsync(ghist, 0, 4 * 4 * 256, ctx->stream));
   hipLaunchKernelGGL((k_rawc_scan<KeyT, 3>), dim3(grid), dim3(kRcThreads), 0, ctx->stream, d_chunks, nchunks, type_id, notiles, int64_t(1), key_mask, flip, counts,
-                     orand, hs, ghist);
+                     orand, HistShifts{}, ghist, static_cast<const HistShifts*>(hs_dev));
   AA_HIP(hipGetLastError());
   AA_TRY(ScanU32InPlace(ctx, counts, 3 * notiles, sums, sumoff));
-  uint32_t n0_32 = 0;
-  AA_TRY(ReadBack(ctx, counts + notiles, 4, &n0_32));  // start of the NaN region = number of sortable rows
-  const int64_t n0 = n0_32;
-  unsigned long long varying = 0;
-  AA_TRY(read_varying(&varying));
+  PlanSummary plan;
+  AA_TRY(ReadPlan<KeyT>(ctx, ghist, 4, counts + notiles /* start of the NaN region = number of sortable rows */, 0, orand,
+                        static_cast<const KeyT*>(nullptr), hs_dev, &plan));
+  const int64_t n0 = plan.n0;
+  const unsigned long long varying = plan.bits_set & plan.bits_clear;
   if (n0 < (int64_t(1) << 21) || varying == 0) return AMDARROW_OK;  // small or constant: the usual way
   // 2. the plan: digits aligned with the highest varying bit
   const int T = 63 - __builtin_clzll(varying);
   if (T < 31) return AMDARROW_OK;
-  if (T != T_guess) {  // the sample missed the keys that carry the top bit: the histograms again, at the right place
-    hs = shifts_for(T);
+  HistShifts hs = shifts_for(T);
+  if (hs.shift[0] != plan.guess_shift0) {  // the sample missed the keys that carry the top bit: the histograms again, at the right place
     AA_HIP(hipMemsetAsync(ghist, 0, 4 * 4 * 256, ctx->stream));
     hipLaunchKernelGGL((k_rawc_scan<KeyT, 2>), dim3(grid), dim3(kRcThreads), 0, ctx->stream, d_chunks, nchunks, type_id, notiles, int64_t(1), key_mask, flip,
-                       counts, orand, hs, ghist);
+                       counts, orand, hs, ghist, static_cast<const HistShifts*>(nullptr));
     AA_HIP(hipGetLastError());
+    AA_TRY(ReadPlan<KeyT>(ctx, ghist, 4, counts + notiles, 0, static_cast<const unsigned long long*>(nullptr), static_cast<const KeyT*>(nullptr),
+                          static_cast<const HistShifts*>(nullptr), &plan));
   }
-  std::vector<unsigned int> h2(4 * 256);
-  AA_TRY(ReadBack(ctx, ghist, 4 * 4 * 256, h2.data()));
   int top = 0;
   double expected = static_cast<double>(n0);
   for (int m = 1; m <= 4 && top == 0; ++m) {
-    unsigned int mx = 0;
-    for (int d = 0; d < 256; ++d) mx = std::max(mx, h2[(m - 1) * 256 + d]);
-    expected *= static_cast<double>(mx) / static_cast<double>(n0);
+    expected *= static_cast<double>(plan.digit[m - 1].max) / static_cast<double>(n0);
     if (m >= 2 && hs.shift[m - 1] >= 16 && expected <= 0.8 * (kWSpan - kWTile)) top = m;
   }
   if (top == 0) return AMDARROW_OK;
@@ -1721,29 +1934,30 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   auto* ctl = reinterpret_cast<unsigned int*>(b + o_ctl);
   auto* lookback = reinterpret_cast<uint32_t*>(b + o_lookback);
 
-  AA_HIP(hipMemcpyAsync(d_chunks, hc.data(), sizeof(SortChunk) * nchunks, hipMemcpyHostToDevice, ctx->stream));
-  AA_HIP(hipStreamSynchronize(ctx->stream));  // hc is pageable host memory
+  AA_TRY(UploadChunks(ctx, d_chunks, hc));
 
   // 1. stable 3-way partition: sortable | NaN | null (+ the digit histograms of the sortable keys)
   AA_HIP(hipMemsetAsync(ghist, 0, 4 * 256 * kPasses, ctx->stream));
   const int grid_t = GridFor(ntiles, 1, ctx->num_cus * 8);
   bool all_sortable = !perm && !IsFloat(type_id);
   for (const auto& c : hc) all_sortable = all_sortable && c.valid == nullptr;
-  if (all_sortable)
-    hipLaunchKernelGGL(k_sort_count_all_sortable, dim3(static_cast<unsigned>((ntiles + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream,
-                       d_chunks, nchunks, ntiles, counts);
-  else if (perm)
-    hipLaunchKernelGGL((k_sort_count<KeyT, true>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, d_chunks, nchunks, type_id,
-                       ntiles, perm, n, counts);
-  else
-    hipLaunchKernelGGL((k_sort_count<KeyT, false>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, d_chunks, nchunks, type_id,
-                       ntiles, perm, n, counts);
-  AA_HIP(hipGetLastError());
-  AA_TRY(ScanU32InPlace(ctx, counts, 3 * ntiles, sums, sumoff));  // counts -> offsets (rows < 2^32)
+  auto count_and_scan = [&]() -> int {  // the tiles' class counts -> the partition's offsets (rows < 2^32)
+    if (all_sortable)
+      hipLaunchKernelGGL(k_sort_count_all_sortable, dim3(static_cast<unsigned>((ntiles + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream,
+                         d_chunks, nchunks, ntiles, counts);
+    else if (perm)
+      hipLaunchKernelGGL((k_sort_count<KeyT, true>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, d_chunks, nchunks, type_id,
+                         ntiles, perm, n, counts);
+    else
+      hipLaunchKernelGGL((k_sort_count<KeyT, false>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, d_chunks, nchunks, type_id,
+                         ntiles, perm, n, counts);
+    AA_HIP(hipGetLastError());
+    return ScanU32InPlace(ctx, counts, 3 * ntiles, sums, sumoff);
+  };
   // One chunk of integers without a validity buffer, as wide as the sort key: every row is sortable and the partition
   // below would be a copy.  Only its histograms are built (k_sort_hist) and the FIRST radix pass reads the column
   // itself; if the plan below leaves no pass that can (no pass at all, or a single last one), the partition runs
-  // after all.
+  // after all (and only then are the tiles counted).
   const bool raw_try = all_sortable && nchunks == 1 && allow_onesweep && n < (int64_t(1) << 30) && BitWidth(type_id) == 8 * int(sizeof(KeyT)) &&
                        !getenv("AMDARROW_SORT_THREE_KERNEL") && !getenv("AMDARROW_SORT_NO_RAW_FIRST_PASS");
   auto run_partition = [&]() -> int {
@@ -1756,12 +1970,16 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
     AA_HIP(hipGetLastError());
     return AMDARROW_OK;
   };
-  int64_t n0 = n;
   // MakeKey of a signed integer flips the sign bit; together with the order's `flip` one XOR constant
   const KeyT raw_xor = flip ^ (IsSignedInt(type_id) ? KeyT(1) << (8 * sizeof(KeyT) - 1) : KeyT(0));
   auto* orand = reinterpret_cast<unsigned long long*>(b + o_orand);
   constexpr int kTopDigits = kPasses < 4 ? kPasses : 4;  // digits whose histograms the first hist pass builds
   bool top_only = false;                                 // ... and whether the lower digits' histograms are missing
+  const char* min_env = getenv("AMDARROW_SORT_HYBRID_MIN");  // testing knob: smallest input that takes the hybrid path
+  const int64_t hybrid_min = min_env ? atoll(min_env) : (int64_t(1) << 21);
+  // the stride sample (see k_sort_plan) is looked at whenever the hybrid plan can come into question at all
+  const bool want_sample = allow_onesweep && allow_hybrid && n < (int64_t(1) << 30) && n >= hybrid_min && !min_env /* the testing knob forces the attempt */ &&
+                           !getenv("AMDARROW_SORT_THREE_KERNEL") && !getenv("AMDARROW_SORT_NO_HYBRID");
   if (raw_try) {
     AA_TRY(ClearCounters(ctx, orand));
     top_only = kPasses > kTopDigits && allow_hybrid && !getenv("AMDARROW_SORT_FULL_HIST");
@@ -1771,24 +1989,19 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
       hipLaunchKernelGGL((k_sort_hist<KeyT, kPasses>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, hc[0].values, hc[0].off, type_id, n, key_mask, raw_xor, ghist, orand);
     AA_HIP(hipGetLastError());
   } else {
+    AA_TRY(count_and_scan());
     AA_TRY(run_partition());
-    uint32_t n0_32 = 0;
-    AA_TRY(ReadBack(ctx, counts + ntiles, 4, &n0_32));  // start of the NaN region = number of sortable rows
-    n0 = n0_32;
   }
+  // 2. what the histograms of every digit say (built by the partition kernel / k_sort_hist), in one record; skip digits on which all keys agree
+  // (equal keys stay equal under the key transformation: the column itself serves as the sample where the partition did not run)
+  PlanSummary plan;
+  AA_TRY(ReadPlan<KeyT>(ctx, ghist, kPasses, raw_try ? nullptr : counts + ntiles /* start of the NaN region = number of sortable rows */,
+                        static_cast<uint32_t>(raw_try ? n : 0), raw_try ? orand : nullptr,
+                        want_sample ? (raw_try ? reinterpret_cast<const KeyT*>(hc[0].values) + hc[0].off : keys_a) : nullptr,
+                        static_cast<const HistShifts*>(nullptr), &plan));
+  const int64_t n0 = plan.n0;
   if (n0 == 0) return AMDARROW_OK;
-
-  // 2. histograms of every digit (built by the partition kernel); skip digits on which all keys agree
-  std::vector<unsigned int> h(256 * kPasses);
-  for (int p = 0; p < kPasses; p += 4)  // ReadBack moves at most 4 KiB
-    AA_TRY(ReadBack(ctx, ghist + 256 * p, 4 * 256 * (kPasses - p < 4 ? kPasses - p : 4), h.data() + 256 * p));
-  unsigned long long oa[2] = {0, 0};
-  if (raw_try) {  // OR over the slots (ReadCounters adds them up: read the block and OR instead)
-    unsigned long long slots[kCounterSlots * kCounterStride];
-    AA_TRY(ReadBack(ctx, orand, kCounterBytes, slots));
-    for (int sl = 0; sl < kCounterSlots; ++sl) { oa[0] |= slots[sl * kCounterStride]; oa[1] |= slots[sl * kCounterStride + 1]; }
-  }
-  const unsigned long long varying_bits = oa[0] & oa[1];  // a bit varies iff some key has it set and some key has it clear
+  const unsigned long long varying_bits = plan.bits_set & plan.bits_clear;  // a bit varies iff some key has it set and some key has it clear
   auto find_active = [&](bool low_from_bits) {
     std::vector<int> act;
     for (int p = 0; p < npasses; ++p) {
@@ -1796,9 +2009,7 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
         if ((varying_bits >> (8 * p)) & 255) act.push_back(p);
         continue;
       }
-      bool trivial = false;
-      for (int d = 0; d < 256; ++d) if (h[p * 256 + d] == static_cast<unsigned int>(n0)) trivial = true;
-      if (!trivial) act.push_back(p);
+      if (!plan.digit[p].trivial) act.push_back(p);
     }
     return act;
   };
@@ -1811,8 +2022,10 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
     hipLaunchKernelGGL((k_sort_hist<KeyT, kPasses>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, hc[0].values, hc[0].off, type_id, n, key_mask, raw_xor, ghist,
                        static_cast<unsigned long long*>(nullptr));
     AA_HIP(hipGetLastError());
-    for (int p = 0; p < kPasses; p += 4)
-      AA_TRY(ReadBack(ctx, ghist + 256 * p, 4 * 256 * (kPasses - p < 4 ? kPasses - p : 4), h.data() + 256 * p));
+    PlanSummary full;
+    AA_TRY(ReadPlan<KeyT>(ctx, ghist, kPasses, static_cast<const uint32_t*>(nullptr), static_cast<uint32_t>(n), static_cast<const unsigned long long*>(nullptr),
+                          static_cast<const KeyT*>(nullptr), static_cast<const HistShifts*>(nullptr), &full));
+    for (int p = 0; p < kPasses; ++p) plan.digit[p] = full.digit[p];
     active = find_active(false);
     return AMDARROW_OK;
   };
@@ -1839,28 +2052,14 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   // independent (n0 x the largest share of each top digit); the window kernel checks the real
   // lengths and reports a run that does not fit, in which case the sort is redone without it.
   int top = 0;
-  const char* min_env = getenv("AMDARROW_SORT_HYBRID_MIN");  // testing knob: smallest input that takes the hybrid path
-  const int64_t hybrid_min = min_env ? atoll(min_env) : (int64_t(1) << 21);
-  bool heavy_values = false;
-  if (onesweep && allow_hybrid && n0 >= hybrid_min && n0 >= kSampleKeys && static_cast<int>(active.size()) >= 4 &&
-      !min_env /* the testing knob forces the attempt */ && !getenv("AMDARROW_SORT_NO_HYBRID")) {
-    // (equal keys stay equal under the key transformation: the column itself serves where the partition did not run)
-    const KeyT* sample_from = raw_try ? reinterpret_cast<const KeyT*>(hc[0].values) + hc[0].off : keys_a;
-    hipLaunchKernelGGL((k_sample_has_duplicates<KeyT>), dim3(1), dim3(256), 0, ctx->stream, sample_from, n0, ctl + 13);
-    AA_HIP(hipGetLastError());
-    unsigned int dup = 0;
-    AA_TRY(ReadBack(ctx, ctl + 13, 4, &dup));
-    heavy_values = dup != 0;
-  }
+  const bool heavy_values = want_sample && plan.dup != 0;  // (a sample of fewer than kSampleKeys sortable rows reports nothing: no hybrid below that anyway)
   if (onesweep && allow_hybrid && !heavy_values && n0 >= hybrid_min && !getenv("AMDARROW_SORT_NO_HYBRID")) {
     for (int m = 2; m <= 4 && top == 0; ++m) {
       if (static_cast<int>(active.size()) < m + 2) break;
       double expected = static_cast<double>(n0);
       for (int q = 0; q < m; ++q) {
         const int p = active[active.size() - 1 - q];
-        unsigned int mx = 0;
-        for (int d = 0; d < 256; ++d) mx = std::max(mx, h[p * 256 + d]);
-        expected *= static_cast<double>(mx) / static_cast<double>(n0);
+        expected *= static_cast<double>(plan.digit[p].max) / static_cast<double>(n0);
       }
       if (expected <= 0.8 * (kWSpan - kWTile)) top = m;
     }
@@ -1876,8 +2075,7 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   if (onesweep && allow_hybrid && !raw_try && !heavy_values && n0 >= hybrid_min && static_cast<int>(active.size()) >= 4 &&
       !getenv("AMDARROW_SORT_NO_HYBRID") && !getenv("AMDARROW_SORT_BYTE_DIGITS") && !min_env) {
     const int ptop = active.back();
-    unsigned orv = 0, andv = 255;
-    for (int d = 0; d < 256; ++d) if (h[ptop * 256 + d]) { orv |= d; andv &= d; }
+    const unsigned orv = plan.digit[ptop].orv, andv = plan.digit[ptop].andv;  // over the digit values that occur
     const int T = 8 * ptop + (31 - __builtin_clz((orv ^ andv) | 1u));  // the highest varying bit
     if ((T + 1) % 8 != 0 && T >= 31) {
       HistShifts hs{};
@@ -1888,14 +2086,13 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
       AA_HIP(hipMemsetAsync(ghist2, 0, 4 * 4 * 256, ctx->stream));
       hipLaunchKernelGGL((k_hist_shifts<KeyT>), dim3(grid_t), dim3(kThreads), 0, ctx->stream, keys_a, n0, hs, ghist2);
       AA_HIP(hipGetLastError());
-      std::vector<unsigned int> h2(4 * 256);
-      AA_TRY(ReadBack(ctx, ghist2, 4 * 4 * 256, h2.data()));
+      PlanSummary p2;
+      AA_TRY(ReadPlan<KeyT>(ctx, ghist2, 4, static_cast<const uint32_t*>(nullptr), static_cast<uint32_t>(n0), static_cast<const unsigned long long*>(nullptr),
+                            static_cast<const KeyT*>(nullptr), static_cast<const HistShifts*>(nullptr), &p2));
       int top_c = 0;
       double expected = static_cast<double>(n0);
       for (int m = 1; m <= 4 && top_c == 0; ++m) {
-        unsigned int mx = 0;
-        for (int d = 0; d < 256; ++d) mx = std::max(mx, h2[(m - 1) * 256 + d]);
-        expected *= static_cast<double>(mx) / static_cast<double>(n0);
+        expected *= static_cast<double>(p2.digit[m - 1].max) / static_cast<double>(n0);
         if (m >= 2 && hs.shift[m - 1] >= 16 && expected <= 0.8 * (kWSpan - kWTile)) top_c = m;  // (at least two digits left for the window)
       }
       if (top_c && (top == 0 || top_c < top)) {
@@ -1938,6 +2135,7 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   const bool raw_first = raw_try && onesweep && !(pass_shift.size() == 1 && !top);  // (the first pass is not the one that writes the result)
   if (raw_try && !raw_first) {  // the partition after all (its histograms are the ones already read)
     AA_HIP(hipMemsetAsync(ghist, 0, 4 * 256 * kPasses, ctx->stream));
+    AA_TRY(count_and_scan());
     AA_TRY(run_partition());
     if (onesweep) { hipLaunchKernelGGL(k_digit_bases, dim3(kPasses), dim3(kThreads), 0, ctx->stream, ghist, dbase); AA_HIP(hipGetLastError()); }
   }
@@ -2017,6 +2215,17 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
 
 using namespace amdarrow;
 
+#ifdef WS_PHASES
+extern "C" int amdarrow_debug_sort_phases(unsigned long long* out16) {  // sums over the workgroups since the last call; [15] = workgroups
+  unsigned long long h[64][16];
+  AA_HIP(hipDeviceSynchronize());
+  AA_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ws_phase), sizeof(h)));
+  for (int i = 0; i < 16; ++i) { out16[i] = 0; for (int s = 0; s < 64; ++s) out16[i] += h[s][i]; }
+  memset(h, 0, sizeof(h));
+  AA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ws_phase), h, sizeof(h)));
+  return AMDARROW_OK;
+}
+#endif
 extern "C" int amdarrow_sort_indices(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks, int order,
                                      uint64_t* out_indices) {
   if (nchunks < 0) return SetError(AMDARROW_INVALID, "sort_indices: negative chunk count");
