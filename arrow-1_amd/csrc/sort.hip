@@ -697,7 +697,7 @@ __global__ __launch_bounds__(kThreads) void k_radix_scatter(const KeyT* keys_in,
 // bounded by kSpinLimit; if it ever expires the pass reports it and the host redoes the sort
 // with the three-kernel passes, which need no inter-block ordering.
 constexpr uint32_t kLbAggregate = 1u << 30, kLbInclusive = 2u << 30, kLbValue = (1u << 30) - 1;
-constexpr int kLbWindow = 8;
+constexpr int kLbWindow = 8;  // (16 / 32 words per round trip, or the first window's loads issued ahead of the key staging: slower -- the wait is for predecessors that have not counted yet, not for round trips)
 constexpr int kSpinLimit = 1 << 18;  // polls of one predecessor word (~0.3 s) before the pass gives up
 
 // dbase[pass][d] = number of keys whose digit `pass` is < d (exclusive scan of the global histogram)
@@ -734,6 +734,14 @@ constexpr int kOWaves = kOThreads / 64;
 // end of out64 (their positions come from the scanned class counts, rc_offsets[class][tile]), the sortable keys take
 // part in the pass; the row numbers are the logical positions.
 struct RawcArgs { const SortChunk* chunks; int nchunks; const uint32_t* offsets; int64_t notiles; };
+#ifdef WS_PHASES  // -DWS_PHASES: cycles per phase, summed over the workgroups (profiles/bench_src/ws_phases.py reads them)
+__device__ unsigned long long g_os_phase[64][16];
+#define OPH(i) do { if (threadIdx.x == 0) { const unsigned long long _n = __builtin_readcyclecounter(); oph[i] += _n - oph_last; oph_last = _n; } } while (0)
+#define OPH_FLUSH() do { if (threadIdx.x == 0) { for (int _i = 0; _i < 12; ++_i) atomicAdd(&g_os_phase[blockIdx.x & 63][_i], oph[_i]); atomicAdd(&g_os_phase[blockIdx.x & 63][15], 1ull); } } while (0)
+#else
+#define OPH(i)
+#define OPH_FLUSH()
+#endif
 template <typename KeyT, bool LAST, bool ARANK, int RAW = 0>
 __global__ __launch_bounds__(kOThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_radix_onesweep(const KeyT* keys_in, const uint32_t* idx_in, int64_t n, int shift,
                                                               const uint32_t* dbase /* [256] of this pass */,
@@ -753,6 +761,10 @@ __global__ __launch_bounds__(kOThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
   // tile was ranked and idle in LDS while it streamed; 73 KB lets two workgroups share a CU and overlap.
   __shared__ unsigned long long s_buf[kOTile];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef WS_PHASES
+  unsigned long long oph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long oph_last = __builtin_readcyclecounter();
+#endif
   for (int i = tid; i < kOWaves * 256; i += kOThreads) (&s_whist[0][0])[i] = 0;
   __syncthreads();
   // Tile of this workgroup.  Workgroups go to the eight XCDs round robin, each XCD with its own L2, and the
@@ -852,6 +864,7 @@ __global__ __launch_bounds__(kOThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
     }
   }
   __syncthreads();
+  OPH(0);  // loads + counting atomics
   if constexpr (RAW == 2) {  // the NaN / null rows go to their final places (tile order, row order inside the tile)
     if (__builtin_amdgcn_readfirstlane(s_tail[0][0] | s_tail[0][1] | s_tail[0][2] | s_tail[0][3] | s_tail[0][4] | s_tail[0][5] | s_tail[0][6] | s_tail[0][7] |
                                        s_tail[1][0] | s_tail[1][1] | s_tail[1][2] | s_tail[1][3] | s_tail[1][4] | s_tail[1][5] | s_tail[1][6] | s_tail[1][7])) {
@@ -893,6 +906,7 @@ __global__ __launch_bounds__(kOThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
     for (int w = 0; w < kOWaves; ++w) s_whist[w][tid] += dstart;
   }
   __syncthreads();
+  OPH(1);  // digit totals, publish, scan
   uint32_t lpos[kIters];  // where each of this thread's keys is staged (both staging rounds use it)
 #pragma unroll
   for (int j = 0; j < kIters; ++j) {
@@ -923,6 +937,7 @@ __global__ __launch_bounds__(kOThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
     }
     __builtin_amdgcn_wave_barrier();
   }
+  OPH(2);  // keys staged
   bool gave_up = false;
   if (tid < 256) {  // thread d: keys with digit d in all earlier tiles
     uint32_t excl = 0;
@@ -965,7 +980,9 @@ __global__ __launch_bounds__(kOThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
     }
     s_gbase[tid] = dbase[tid] + excl;
   }
+  OPH(3);  // look-back (thread 0's digit)
   if (__syncthreads_or(gave_up)) return;  // positions unknown: write nothing
+  OPH(4);  // ... and everybody else's
   if (RAW == 2) count = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];  // the keys that took part (the digit totals' sum)
   // round 1: the keys leave (thread t takes the staged positions t, t + 512, ...: the same ones in both rounds, so a
   // position's global place is computed once and kept in a register)
@@ -985,6 +1002,7 @@ __global__ __launch_bounds__(kOThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
     }
   }
   __syncthreads();
+  OPH(5);  // round 1: keys out
   // round 2: the row indices, each with its origin in the tile
 #pragma unroll
   for (int j = 0; j < kIters; ++j) {
@@ -992,6 +1010,7 @@ __global__ __launch_bounds__(kOThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
     if ((alive >> j) & 1u) s_buf[lpos[j]] = static_cast<unsigned long long>(li) << 32 | idx[j];
   }
   __syncthreads();
+  OPH(6);  // row indices staged
   bool disorder = false;
 #pragma unroll
   for (int k = 0; k < kIters; ++k) {  // (every lane takes part in the lane shift below)
@@ -1015,6 +1034,8 @@ __global__ __launch_bounds__(kOThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
     else idx_out[gpos[k]] = static_cast<uint32_t>(pair);
   }
   if (ARANK && disorder) __hip_atomic_store(error + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  OPH(7);  // round 2: row indices out
+  OPH_FLUSH();
 }
 
 // ---- windowed LDS sort: the tail of the hybrid sort ---------------------------------------------------
@@ -1707,7 +1728,8 @@ static bool LdsAtomicsLaneOrdered(amdarrow_ctx* ctx) {
 // where the look-back only ever waits for workgroups that were dispatched earlier.
 static uint32_t XcdRunFor(amdarrow_ctx* ctx, const void* kernel) {
   if (getenv("AMDARROW_SORT_NO_XCD_RUNS")) return 0;
-  constexpr uint32_t kXcdRun = 16;
+  uint32_t kXcdRun = 16;
+  if (const char* env = getenv("AMDARROW_SORT_XCD_RUN")) kXcdRun = static_cast<uint32_t>(std::max(1, atoi(env)));  // (tuning knob)
   int per_cu = 0, xccs = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kOThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
   if (hipDeviceGetAttribute(&xccs, hipDeviceAttributeNumberOfXccs, ctx->device) != hipSuccess) { (void)hipGetLastError(); xccs = ctx->num_cus == 256 ? 8 : 0; }
@@ -2223,6 +2245,15 @@ extern "C" int amdarrow_debug_sort_phases(unsigned long long* out16) {  // sums 
   for (int i = 0; i < 16; ++i) { out16[i] = 0; for (int s = 0; s < 64; ++s) out16[i] += h[s][i]; }
   memset(h, 0, sizeof(h));
   AA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ws_phase), h, sizeof(h)));
+  return AMDARROW_OK;
+}
+extern "C" int amdarrow_debug_onesweep_phases(unsigned long long* out16) {  // the same for k_radix_onesweep (all passes together)
+  unsigned long long h[64][16];
+  AA_HIP(hipDeviceSynchronize());
+  AA_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_os_phase), sizeof(h)));
+  for (int i = 0; i < 16; ++i) { out16[i] = 0; for (int s = 0; s < 64; ++s) out16[i] += h[s][i]; }
+  memset(h, 0, sizeof(h));
+  AA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_os_phase), h, sizeof(h)));
   return AMDARROW_OK;
 }
 #endif

@@ -22,7 +22,9 @@ for _ in range(2):
 torch.cuda.synchronize()
 out = (C.c_ulonglong * 16)()
 fn = C.CDLL(bench._abi.LIB_PATH).amdarrow_debug_sort_phases  # (the library is loaded already: same handle, same counters)
+fn2 = C.CDLL(bench._abi.LIB_PATH).amdarrow_debug_onesweep_phases
 fn(out)  # clears
+fn2(out)
 for _ in range(3):
     step()
 torch.cuda.synchronize()
@@ -30,3 +32,7 @@ fn(out)
 wgs = max(1, out[15])
 print(workload, "workgroups", wgs, "cycles/wg per phase:", " ".join("%d:%.0f" % (i, out[i] / wgs) for i in range(9)),
       "total %.0f" % (sum(out[:9]) / wgs))
+fn2(out)
+wgs = max(1, out[15])
+print(workload, "one-sweep workgroups", wgs, "cycles/wg per phase (0 loads + count, 1 totals / scan, 2 keys staged, 3 look-back, 4 barrier behind it, "
+      "5 keys out, 6 indices staged, 7 indices out):", " ".join("%d:%.0f" % (i, out[i] / wgs) for i in range(8)), "total %.0f" % (sum(out[:8]) / wgs))
