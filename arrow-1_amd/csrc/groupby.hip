@@ -182,6 +182,7 @@ struct HotMem {
   unsigned int* part_cnt;        // [nwg][kHotCap + 1]
   uint32_t* part_first;          // [nwg][kHotCap + 1]
   uint8_t* alt_mask;       // selection mask without the hot rows, bit offset 0
+  uint32_t* wg_stats;      // [nwg][4] what a workgroup of k_local_aggregate_vec saw: smallest / largest key of its table (the scatter's key order), a value that is not an int32, -
 };
 __device__ void InjectHotGroups(const HotMem& hot, int nwg, int k_bits, int acc_double, const GroupTable& t,
                                 unsigned long long* bitmap, int64_t gtid, int64_t gthreads);
@@ -3033,6 +3034,7 @@ __global__ __launch_bounds__(kBThreads) void k_local_aggregate_vec(FastArgs a, i
   const void* keys = static_cast<const char*>(a.k_data) + a.k_off * 4;
   const uint64_t* vals = reinterpret_cast<const uint64_t*>(a.v.data) + a.v.off;
   auto stopped = [&]() { return __hip_atomic_load(&sh.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; };
+  uint32_t vwide = 0;
   auto fold = [&](const BinTile<R, false>& t, int64_t tile0) -> bool {
     const int64_t r0 = tile0 + int64_t(tid) * R;
     const int64_t left = hi - r0;
@@ -3047,6 +3049,7 @@ __global__ __launch_bounds__(kBThreads) void k_local_aggregate_vec(FastArgs a, i
       live[j] = (mbits >> j) & 1u;
       const bool vv = (vbits >> j) & 1u;
       const uint64_t v = t.v(j);
+      if (live[j] && vv) vwide |= static_cast<uint32_t>((v + 0x80000000ull) >> 32);  // (a selected value that is not an int32)
       rec[j] = make_uint4(t.key.k(j, 0), static_cast<uint32_t>(r0 + j) | (vv ? kRecValValid : 0u), static_cast<uint32_t>(v),
                           static_cast<uint32_t>(v >> 32));
     }
@@ -3081,6 +3084,35 @@ __global__ __launch_bounds__(kBThreads) void k_local_aggregate_vec(FastArgs a, i
     if (__any(!fold(t0, tile0))) LocalGiveUp(sh, wg_flags);
   }
   __syncthreads();
+  {
+    // What this row range looked like, for a host that plans the partition path from it (FilterGroupByImpl, "guessed"
+    // compact records): the key range of the table -- up to kLocalLimit distinct keys from the range's first rows when
+    // the attempt gave up, all of its keys otherwise -- in the scatter's key order, and whether a selected value was
+    // not an int32.  256 workgroups spread over the input: half a million keys sampled for nothing.
+    __shared__ unsigned int s_kmin, s_kmax;
+    if (tid == 0) { s_kmin = 0xFFFFFFFFu; s_kmax = 0; }
+    const unsigned int any_wide = __syncthreads_or(vwide != 0);
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
+    for (int s = tid; s < kSlots; s += kBThreads) {
+      const unsigned int tag = sh.tag[s];
+      if (tag == kTagFree) continue;
+      const uint32_t kk = tag ^ a.k_flip;
+      kmin = kk < kmin ? kk : kmin;
+      kmax = kk > kmax ? kk : kmax;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const uint32_t omin = __shfl_xor(kmin, d, 64), omax = __shfl_xor(kmax, d, 64);
+      kmin = omin < kmin ? omin : kmin;
+      kmax = omax > kmax ? omax : kmax;
+    }
+    if ((tid & 63) == 0 && kmin <= kmax) { atomicMin(&s_kmin, kmin); atomicMax(&s_kmax, kmax); }
+    __syncthreads();
+    if (tid == 0 && hot.wg_stats) {
+      uint32_t* out = hot.wg_stats + 4 * blockIdx.x;
+      out[0] = s_kmin; out[1] = s_kmax; out[2] = any_wide ? 1u : 0u; out[3] = 0;
+    }
+  }
   if (stopped()) {  // a stale staging table is never read: the merge is gated on the flags
     ReportHotCandidates(sh, hot, tid, /*raw_tags=*/true);
     return;
@@ -3152,21 +3184,43 @@ __global__ __launch_bounds__(kThreads) void k_prepare(unsigned long long* bitmap
 // mark / emit / unpack then touch neither the uninitialised table nor the heavy hitters' scratch -- and the host
 // starts the call over.
 constexpr unsigned int kLocalGaveUp = 8;
+// `probe` (optional, mapped host memory): {1, gave up, heavy hitters, smallest key, largest key, a wide value} for a host
+// that waits for this kernel before it queues the rest (FilterGroupByImpl's guessed compact records).
 __global__ __launch_bounds__(kThreads) void k_clear_table_unless(GroupTable t, int64_t nslots, const unsigned int* wg_flags,
                                                                  int nflags, unsigned int* summary, HotMem hot,
-                                                                 unsigned int* use_hot, unsigned int* gave_up_skip) {
+                                                                 unsigned int* use_hot, unsigned int* gave_up_skip,
+                                                                 unsigned int* probe) {
   int mine = 0;
   for (int i = threadIdx.x; i < nflags; i += kThreads) mine |= wg_flags[i] != 0;
   const int any = __syncthreads_or(mine);
   if (blockIdx.x == 0 && threadIdx.x == 0) *summary = any ? 1u : 0u;
+  __shared__ unsigned int s_pmin, s_pmax, s_pwide;
+  if (probe && blockIdx.x == 0) {  // (uniform over the block)
+    if (threadIdx.x == 0) { s_pmin = 0xFFFFFFFFu; s_pmax = 0; s_pwide = 0; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nflags; i += kThreads) {
+      const uint32_t lo = hot.wg_stats[4 * i], hi = hot.wg_stats[4 * i + 1];
+      if (lo <= hi) { atomicMin(&s_pmin, lo); atomicMax(&s_pmax, hi); }
+      if (hot.wg_stats[4 * i + 2]) s_pwide = 1;
+    }
+    __syncthreads();
+  }
   if (any) {
     if (gave_up_skip) {
       if (blockIdx.x == 0 && threadIdx.x == 0) *gave_up_skip = kLocalGaveUp;
       return;
     }
     if (blockIdx.x == 0) BuildHotSet(hot, nflags, use_hot);  // heavy hitters seen by the workgroups that gave up
-    return;
   }
+  if (probe && blockIdx.x == 0) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      probe[1] = any ? 1u : 0u; probe[2] = any ? *use_hot : 0u; probe[3] = s_pmin; probe[4] = s_pmax; probe[5] = s_pwide;
+      __threadfence_system();
+      probe[0] = 1u;
+    }
+  }
+  if (any) return;
   for (int64_t s = int64_t(blockIdx.x) * kThreads + threadIdx.x; s < nslots; s += int64_t(gridDim.x) * kThreads) {
     t.hkeys[s] = kEmpty; t.first[s] = kNoRow; t.sums[s] = 0; t.counts[s] = 0;
   }
@@ -4137,22 +4191,33 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
                         (reinterpret_cast<uintptr_t>(keys->values) + (k_load_bits / 8) * static_cast<uintptr_t>(keys->offset)) % 16 == 0 &&
                         (values ? (reinterpret_cast<uintptr_t>(values->values) + 8 * static_cast<uintptr_t>(values->offset)) % 16 == 0
                                 : reinterpret_cast<uintptr_t>(keys->values) % 16 == 0);
-  if (hinted && use_bins && compact_allowed && hint.stats && hint.key_lo <= hint.key_hi && hint.key_lo >= k_bias &&
-      hint.key_hi - k_bias <= 0xFFFFFFFFull && !getenv("AMDARROW_GROUPBY_NO_COMPACT")) {
-    int rw = values && !IsFloat(values->type_id) && hint.values_narrow ? 2 : 3;
+  // (key_lo / key_hi: the selected keys' range in the scatter's key order plus the bias; narrow: the selected values were all int32)
+  auto plan_compact = [&](uint64_t key_lo, uint64_t key_hi, bool narrow) -> bool {
+    if (!(use_bins && compact_allowed && key_lo <= key_hi && key_lo >= k_bias && key_hi - k_bias <= 0xFFFFFFFFull) ||
+        getenv("AMDARROW_GROUPBY_NO_COMPACT"))
+      return false;
+    int rw = values && !IsFloat(values->type_id) && narrow ? 2 : 3;
     if (const char* env = getenv("AMDARROW_GROUPBY_COMPACT_WORDS")) rw = atoi(env) == 2 && rw == 2 ? 2 : 3;
     int pb = rw == 2 ? 9 : 8;  // 8-byte records: 512 partitions, bins of 64 words; 12-byte records: 256 partitions, bins of 128
     if (const char* env = getenv("AMDARROW_GROUPBY_COMPACT_PARTS")) pb = atoi(env) == 256 ? 8 : atoi(env) == 512 ? 9 : pb;
     const int slot_bits = 21 - pb;
-    const uint32_t first = static_cast<uint32_t>(hint.key_lo - k_bias) >> pb;
-    const uint32_t span = (static_cast<uint32_t>(hint.key_hi - k_bias) >> pb) - first + 1;
-    if (span <= (1u << slot_bits)) {
-      const uint32_t slack = ((1u << slot_bits) - span) / 2;  // the window is centred on the range seen last time
-      c_base = first > slack ? first - slack : 0;
-      compact_rw = rw;
-      compact_pb = pb;
-    }
-  }
+    const uint32_t first = static_cast<uint32_t>(key_lo - k_bias) >> pb;
+    const uint32_t span = (static_cast<uint32_t>(key_hi - k_bias) >> pb) - first + 1;
+    if (span > (1u << slot_bits)) return false;
+    const uint32_t slack = ((1u << slot_bits) - span) / 2;  // the window is centred on the range seen last time
+    c_base = first > slack ? first - slack : 0;
+    compact_rw = rw;
+    compact_pb = pb;
+    return true;
+  };
+  if (hinted && hint.stats) plan_compact(hint.key_lo, hint.key_hi, hint.values_narrow != 0);
+  // A call that knows nothing about its data (the first of a shape, every kHintProbeEvery-th, every call of a caller
+  // whose data keep changing) used to pay for that with 16-byte records, 0.68-0.78 ms against 0.52.  The optimistic
+  // per-workgroup pre-aggregation it starts with IS a sample of the input -- 256 row ranges, up to 2048 distinct keys of
+  // each -- so the host now waits for that one kernel (one round trip, ~20 us), and if it gave up without heavy
+  // hitters the call goes on with compact records planned from the sample's key range and value width: GUESSED, and
+  // checked per row like a hinted call's; a miss starts over on the full path, once.
+  bool guess_tried = false, guessed = false;
   GroupTable t{};
   RankMem r{};
   unsigned long long* gx = nullptr;
@@ -4230,6 +4295,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
     const size_t off_hot_pcnt = c.Take(4 * size_t(nwg_hot) * (kHotCap + 1));
     const size_t off_hot_pfirst = c.Take(4 * size_t(nwg_hot) * (kHotCap + 1));
     const size_t off_hot_mask = c.Take(path == 3 ? static_cast<size_t>(n / 8 + 64) : 0);
+    const size_t off_hot_stats = c.Take(16 * size_t(kMaxFlags));
     void* base;
     AA_TRY(Scratch(ctx, c.off, &base));
     char* b = static_cast<char*>(base);
@@ -4242,6 +4308,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
     hot.part_cnt = reinterpret_cast<unsigned int*>(b + off_hot_pcnt);
     hot.part_first = reinterpret_cast<uint32_t*>(b + off_hot_pfirst);
     hot.alt_mask = reinterpret_cast<uint8_t*>(b + off_hot_mask);
+    hot.wg_stats = reinterpret_cast<uint32_t*>(b + off_hot_stats);
     t = BindTable(b, tm, T, false);
     r = BindRank(b, roff, n);
     gx = reinterpret_cast<unsigned long long*>(b + off_gx);
@@ -4299,9 +4366,31 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
 #undef AA_LVEC
           AA_HIP(hipGetLastError());
           const int64_t nslots = static_cast<int64_t>(T) + 2;
+          // (the guess needs the vectorised pre-aggregation, which reports what it saw, and a shape the compact scatter takes)
+          const bool probe = !local_only && !guess_tried && headline_shape && use_bins && k_load_bits == 32 && !getenv("AMDARROW_GROUPBY_OLD_LOCAL") &&
+                             compact_allowed && sub_bits == 0 && n <= (int64_t(1) << 28) && !getenv("AMDARROW_GROUPBY_PATH") &&
+                             !getenv("AMDARROW_GROUPBY_NO_COMPACT") && !getenv("AMDARROW_GROUPBY_NO_GUESS");
+          volatile unsigned int* probe_host = reinterpret_cast<volatile unsigned int*>(static_cast<char*>(ctx->pinned) + kStatusOffset + 128);
+          if (probe) probe_host[0] = 0;
           hipLaunchKernelGGL(k_clear_table_unless, dim3(GridFor(nslots, kThreads, ctx->num_cus * 8)), dim3(kThreads), 0,
                              ctx->stream, t, nslots, wg_flags, nblocks_local, abort_flag, hot, misc + 5,
-                             local_only ? misc : static_cast<unsigned int*>(nullptr));
+                             local_only ? misc : static_cast<unsigned int*>(nullptr),
+                             probe ? reinterpret_cast<unsigned int*>(static_cast<char*>(ctx->pinned_dev) + kStatusOffset + 128) : static_cast<unsigned int*>(nullptr));
+          if (probe) {
+            AA_HIP(hipGetLastError());
+            AA_HIP(hipEventRecord(ctx->status_event, ctx->stream));
+            AA_HIP(hipEventSynchronize(ctx->status_event));
+            guess_tried = true;
+            if (probe_host[0] == 1 && probe_host[1] == 0) {
+              local_only = true;  // every row range held its groups: nothing but the merge is queued behind (the table is cleared)
+            } else if (probe_host[0] == 1 && probe_host[2] == 0 &&
+                       plan_compact(uint64_t(probe_host[3]) + k_bias, uint64_t(probe_host[4]) + k_bias, probe_host[5] == 0)) {
+              guessed = true;
+              hinted = true;
+              path = 3;  // -> 2 after the loop's decrement: the partition path on compact records, from the top
+              continue;
+            }
+          }
           if (headline_shape && !getenv("AMDARROW_GROUPBY_OLD_MERGE"))
             hipLaunchKernelGGL(k_local_merge_slots, dim3(kSlots / kMergeSlots), dim3(kMergeThreads), 0, ctx->stream, st,
                                nblocks_local, ks.total_bits, acc_double, t, abort_flag, misc);
@@ -4444,7 +4533,9 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
       ctx->gb_carry_misses = carry_misses; ctx->gb_carry_off = carry_off;  // (start_over_measured forgets the shape's hints; the retry picks the back-off up here)
       return start_over_measured();
     }
-    if (overflow && fast && hinted) {  // the hint was wrong for this input: forget it, start over with the full path 3
+    if (overflow && fast && hinted) {  // the hint (or the guess) was wrong for this input: forget it, start over with the full path 3
+      guessed = false;
+      guess_tried = true;  // (one compact attempt per call: what broke a hinted call's assumption -- a few far keys, one wide value -- hides from a sample too)
       hinted = false;
       hint.n = -1;
       path = 4;  // -> 3 after the loop's decrement
@@ -4482,6 +4573,15 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
         hint = shape;
       }
       else hint.n = -1;
+    }
+    if (guessed) {  // the guess held: the next call of this shape takes over what this one's scatter measured, like after any unhinted call
+      shape.uses = shape_known ? hint.uses : 0;
+      shape.stats = status[8] <= status[9] ? 1 : 0;
+      shape.key_lo = status[8] + k_bias; shape.key_hi = status[9] + k_bias;
+      shape.values_narrow = compact_rw == 2 ? 1 : (values && !IsFloat(values->type_id) && fa_val_wide && status[10] == 0 ? 1 : 0);
+      shape.k_bias = k_bias;
+      shape.last_used = hint.last_used;
+      hint = shape;
     }
     // a hinted call that found few groups: the local attempt it skipped would have held them all -- next call, try it again
     if (hinted && G <= static_cast<int64_t>(kLocalLimit)) hint.n = -1;
