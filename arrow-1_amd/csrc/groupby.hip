@@ -2888,6 +2888,155 @@ __global__ __launch_bounds__(kDThreads) void k_hot_aggregate(FastArgs a, int acc
   }
 }
 
+// Step 3 with the bin scatter's loader (32-bit keys without validity, 64-bit values, a mask without validity, all on
+// 16-byte boundaries -- the shapes k_local_aggregate_vec takes): a thread owns four consecutive rows, three tiles in
+// flight, the values arrive with the keys instead of one dependent load per hot row.  A key that carries a tenth of the
+// rows would have a tenth of a wave's lanes add to ONE LDS word, served one lane after the other: the rows of the (up
+// to three) most frequent hot keys of a wave step are reduced across the wave first -- one set of atomics per key and
+// step -- and only what is left goes lane by lane.  k_hot_aggregate (one row per lane, generic loaders): 0.82 ms per
+// 100 M rows with one hot key; this kernel streams at the scatter's rate.
+template <bool MASK, bool VVALID>
+__global__ __launch_bounds__(kBThreads) void k_hot_aggregate_vec(FastArgs a, int acc_double, HotMem hot, const unsigned int* use_hot) {
+  if (!*use_hot) return;
+  __shared__ uint32_t s_map_tag[kHotMapSlots];
+  __shared__ unsigned short s_map_idx[kHotMapSlots];
+  __shared__ unsigned long long s_sum[kHotCap + 1];
+  __shared__ unsigned int s_cnt[kHotCap + 1];
+  __shared__ uint32_t s_first[kHotCap + 1];
+  constexpr int R = 4, kRows = kBThreads * R;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned int nhot = hot.count[0];
+  for (int i = tid; i < kHotMapSlots; i += kBThreads) s_map_tag[i] = kTagFree;
+  for (int i = tid; i <= kHotCap; i += kBThreads) { s_sum[i] = 0; s_cnt[i] = 0; s_first[i] = kNoRow; }
+  __syncthreads();
+  // the map holds the RAW keys (the hot set speaks fmix32 tags, a bijection: inverted once here instead of hashing four
+  // keys per thread and tile), at slot RawSlot(key).  The one key that equals the free marker is left out: its rows
+  // stay in the mask and reach their group through the partitions like any cold key's (InjectHot skips a hot key no
+  // row was folded for).
+  static_assert(kHotMapSlots == kSlots, "RawSlot");
+  for (unsigned int h = tid; h < nhot; h += kBThreads) {  // keys are distinct: plain linear-probing insert
+    const uint32_t key = Fmix32Inv(hot.tags[h]);
+    if (key == kTagFree) continue;
+    uint32_t slot = RawSlot(key);
+    while (atomicCAS(&s_map_tag[slot], kTagFree, key) != kTagFree) slot = (slot + 1) & (kHotMapSlots - 1);
+    s_map_idx[slot] = static_cast<unsigned short>(h);
+  }
+  __syncthreads();
+  const int64_t lo = int64_t(blockIdx.x) * a.rows_per_block;
+  const int64_t hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
+  const void* keys = static_cast<const char*>(a.k_data) + a.k_off * 4;
+  const uint64_t* vals = reinterpret_cast<const uint64_t*>(a.v.data) + a.v.off;
+  unsigned long long* alt = reinterpret_cast<unsigned long long*>(hot.alt_mask);
+  auto fold = [&](const BinTile<R, false>& t, int64_t tile0) {
+    const int64_t r0 = tile0 + int64_t(tid) * R;
+    const int64_t left = hi - r0;
+    const uint32_t live_bits = left >= R ? (1u << R) - 1u : (left > 0 ? (1u << left) - 1u : 0u);
+    const int64_t rb = left > 0 ? r0 : hi - 1;
+    const uint32_t mbits = MASK ? (FewBits<R>(t.m0, t.m1, a.m_off + rb) & live_bits) : live_bits;
+    const uint32_t vbits = VVALID ? FewBits<R>(t.v0, t.v1, a.v.off + rb) : live_bits;
+    int h[R];
+    uint32_t tag[R], first_probe[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {  // (every row's first probe is on its way before any is looked at)
+      tag[j] = t.key.k(j, 0);
+      first_probe[j] = s_map_tag[RawSlot(tag[j])];
+    }
+    uint32_t keep = mbits;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      h[j] = -1;
+      if (((mbits >> j) & 1u) && tag[j] != kTagFree) {
+        uint32_t slot = RawSlot(tag[j]), seen = first_probe[j];
+        for (;;) {
+          if (seen == tag[j]) { h[j] = s_map_idx[slot]; break; }
+          if (seen == kTagFree) break;
+          slot = (slot + 1) & (kHotMapSlots - 1);
+          seen = s_map_tag[slot];
+        }
+        if (h[j] >= 0) keep &= ~(1u << j);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const bool vv = (vbits >> j) & 1u;
+      const unsigned long long bits = t.v(j);
+      // the wave's most frequent hot keys of this step, one after the other: their rows are folded across the wave
+      for (int round = 0; round < 3; ++round) {
+        const uint64_t pending = __ballot(h[j] >= 0);
+        if (__popcll(pending) < 8) break;  // (wave-uniform) a handful of rows: lane by lane is cheaper than a reduction
+        const int cur = __builtin_amdgcn_readlane(h[j], __builtin_ctzll(pending));
+        const bool mine = h[j] == cur;
+        const uint64_t m = __ballot(mine);
+        if (__popcll(m) < 6) break;      // the step's hot rows are spread over many keys
+        const uint64_t mv = __ballot(mine && vv);
+        unsigned long long part = 0;
+        if (acc_double) {
+          double d = mine && vv ? __longlong_as_double(bits) : 0.0;
+#pragma unroll
+          for (int o = 32; o >= 1; o >>= 1) d += __longlong_as_double(__shfl_xor(static_cast<unsigned long long>(__double_as_longlong(d)), o, 64));
+          part = static_cast<unsigned long long>(__double_as_longlong(d));
+        } else {
+          part = WaveReduceSum64(mine && vv ? bits : 0ull);
+        }
+        if (lane == __builtin_ctzll(m)) {  // the lowest lane of the key's rows holds its smallest row of this step
+          atomicMin(&s_first[cur], static_cast<uint32_t>(r0 + j));
+          if (mv) {
+            if (acc_double) atomicAdd(reinterpret_cast<double*>(&s_sum[cur]), __longlong_as_double(part));
+            else atomicAdd(&s_sum[cur], part);
+            atomicAdd(&s_cnt[cur], static_cast<unsigned int>(__popcll(mv)));
+          }
+        }
+        if (mine) h[j] = -1;
+      }
+      if (h[j] >= 0) {  // what is left: lane by lane
+        atomicMin(&s_first[h[j]], static_cast<uint32_t>(r0 + j));
+        if (vv) {
+          if (acc_double) atomicAdd(reinterpret_cast<double*>(&s_sum[h[j]]), __longlong_as_double(bits));
+          else atomicAdd(&s_sum[h[j]], bits);
+          atomicAdd(&s_cnt[h[j]], 1u);
+        }
+      }
+    }
+    // the mask without the hot rows: 16 lanes' nibbles make a word
+    unsigned long long w = static_cast<unsigned long long>(keep) << (4 * (lane & 15));
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) w |= __shfl_xor(w, o, 64);
+    if ((lane & 15) == 0 && r0 < hi) alt[r0 >> 6] = w;
+  };
+  BinTile<R, false> t0{}, t1{}, t2{};
+  int64_t tile0 = lo;
+  if (lo + kRows <= hi) {
+    const int64_t last_whole = lo + ((hi - lo) / kRows - 1) * kRows;
+    auto at = [&](int64_t t) { return t <= last_whole ? t : last_whole; };  // (past the end: the last whole tile again, dropped)
+    BinLoadTile<MASK, VVALID, R, false>(a, keys, vals, lo, tid, t0);
+    BinLoadTile<MASK, VVALID, R, false>(a, keys, vals, at(lo + kRows), tid, t1);
+    BinLoadTile<MASK, VVALID, R, false>(a, keys, vals, at(lo + 2 * kRows), tid, t2);
+#define AA_HOT_STEP(CUR, TILE0)                                                              \
+    do {                                                                                       \
+      if ((TILE0) <= last_whole) fold(CUR, (TILE0));                                           \
+      BinLoadTile<MASK, VVALID, R, false>(a, keys, vals, at((TILE0) + 3 * kRows), tid, CUR);   \
+    } while (0)
+    for (; tile0 <= last_whole; tile0 += 3 * kRows) {
+      AA_HOT_STEP(t0, tile0);
+      AA_HOT_STEP(t1, tile0 + kRows);
+      AA_HOT_STEP(t2, tile0 + 2 * kRows);
+    }
+#undef AA_HOT_STEP
+    tile0 = last_whole + kRows;
+  }
+  if (tile0 < hi) {  // the partial tile at the end of the input
+    BinLoadTail<MASK, VVALID, R, false>(a, keys, vals, tile0, hi, tid, t0);
+    fold(t0, tile0);
+  }
+  __syncthreads();
+  const int64_t base = int64_t(blockIdx.x) * (kHotCap + 1);
+  for (int i = tid; i <= kHotCap; i += kBThreads) {
+    hot.part_sum[base + i] = s_sum[i];
+    hot.part_cnt[base + i] = s_cnt[i];
+    hot.part_first[base + i] = s_first[i];
+  }
+}
+
 // Step 5: hot group h -> a free slot of its partition's slice.  Called grid-stride from k_mark_first.
 __device__ __forceinline__ void InjectHot(const HotMem& hot, int nwg, int k_bits, int acc_double, const GroupTable& t,
                                           unsigned long long* bitmap, int64_t gtid, int64_t gthreads) {
@@ -4400,7 +4549,15 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
           AA_HIP(hipGetLastError());
           // heavy hitters found by the workgroups that gave up: fold their rows here, hand the
           // scatter a mask without them (no-op when status[5] is 0)
-          if (!local_only) hipLaunchKernelGGL(k_hot_aggregate, dim3(nblocks_local), dim3(kDThreads), 0, ctx->stream, fl, acc_double, hot, misc + 5);
+          if (!local_only) {
+            if (headline_shape && use_bins && k_load_bits == 32 && !getenv("AMDARROW_GROUPBY_OLD_LOCAL") && !getenv("AMDARROW_GROUPBY_OLD_HOT")) {
+#define AA_HOTV(MM, VV) hipLaunchKernelGGL((k_hot_aggregate_vec<MM, VV>), dim3(nblocks_local), dim3(kBThreads), 0, ctx->stream, fl, acc_double, hot, misc + 5)
+              if (M && V) AA_HOTV(true, true); else if (M) AA_HOTV(true, false); else if (V) AA_HOTV(false, true); else AA_HOTV(false, false);
+#undef AA_HOTV
+            } else {
+              hipLaunchKernelGGL(k_hot_aggregate, dim3(nblocks_local), dim3(kDThreads), 0, ctx->stream, fl, acc_double, hot, misc + 5);
+            }
+          }
           AA_HIP(hipGetLastError());
           run_if = abort_flag;
         }

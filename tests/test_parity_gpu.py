@@ -739,7 +739,7 @@ def test_filter_groupby_wide_and_boolean_keys_on_partitioned_path(gpu, oracle, k
                         assert np.array_equal(x, y), (kt, vt, env)
 
 
-@pytest.mark.parametrize("shape", ["one-hot-40%", "zipf", "hot-null-key", "hot+value-nulls+double", "int16-keys-hot"])
+@pytest.mark.parametrize("shape", ["one-hot-40%", "zipf", "hot-null-key", "hot+value-nulls+double", "int16-keys-hot", "two-hot-no-mask"])
 def test_filter_groupby_heavy_hitters(gpu, oracle, shape):
     """Skewed keys among many distinct ones: the heavy hitters are folded in LDS next to the
     scatter (k_hot_aggregate) and injected into the table afterwards; the partitions only see the
@@ -755,6 +755,9 @@ def test_filter_groupby_heavy_hitters(gpu, oracle, shape):
         base = np.where(z < 400_000, z, base)
     elif shape == "hot-null-key":
         key_valid = rng.random(n) > 0.3
+    elif shape == "two-hot-no-mask":
+        base[rng.random(n) < 0.3] = 5
+        base[rng.random(n) < 0.05] = 399_999
     elif shape == "hot+value-nulls+double":
         base[rng.random(n) < 0.25] = 123_456
         base[rng.random(n) < 0.10] = 9
@@ -766,7 +769,10 @@ def test_filter_groupby_heavy_hitters(gpu, oracle, shape):
     v = R(rng, vt, n, .05 if "value-nulls" in shape else 0.01, 2)
     k = Arr(kt, base, key_valid)
     m = R(rng, BOOL, n, 0.0, 3)
-    for x, y in zip(oracle.filter_groupby_sum(v, k, m), gpu.filter_groupby_sum(v, k, m)):
+    gm = m
+    if shape == "two-hot-no-mask":  # (the oracle's group-by wants a mask)
+        m, gm = Arr(BOOL, np.ones(n, bool)), None
+    for x, y in zip(oracle.filter_groupby_sum(v, k, m), gpu.filter_groupby_sum(v, k, gm)):
         if x.dtype == np.float64:
             assert _within(x, y, _f64_bound(oracle, v, k, m)), shape  # (hot groups add hundreds of thousands of values: the bound scales with their sum|x|)
         else:
