@@ -937,7 +937,57 @@ __global__ __launch_bounds__(kOThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
     }
     __builtin_amdgcn_wave_barrier();
   }
+  __syncthreads();
   OPH(2);  // keys staged
+  // The tile's keys and row indices go through the staging buffer BEFORE the look-back is waited for: what the look-back
+  // yields -- the global place of each digit's run -- is only needed by the stores, and the predecessors it waits for
+  // publish their counts while this tile is busy in LDS.  (With the look-back between the two staging rounds a tile sat
+  // idle for a fifth of its time: its predecessors in tile order are dispatched up to a group of workgroups later.)
+  if (RAW == 2) count = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];  // the keys that took part (the digit totals' sum)
+  // round 1: the keys in digit order (thread t takes the staged positions t, t + 512, ...: the same ones in both rounds)
+  KeyT skey[kIters];
+  uint32_t inrun = 0;     // bit k: position i is not the first of its digit's run (the order check compares it with i - 1)
+#pragma unroll
+  for (int k = 0; k < kIters; ++k) {
+    const uint32_t i = k * kOThreads + tid;
+    skey[k] = 0;
+    if (i < count) {
+      skey[k] = static_cast<KeyT>(s_buf[i]);
+      if (i > s_dstart[(skey[k] >> shift) & 255]) inrun |= 1u << k;
+    }
+  }
+  __syncthreads();
+  OPH(5);  // round 1: keys back in digit order
+  // round 2: the row indices, each with its origin in the tile
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
+    if ((alive >> j) & 1u) s_buf[lpos[j]] = static_cast<unsigned long long>(li) << 32 | idx[j];
+  }
+  __syncthreads();
+  OPH(6);  // row indices staged
+  bool disorder = false;
+  uint32_t sidx[kIters];
+#pragma unroll
+  for (int k = 0; k < kIters; ++k) {  // (every lane takes part in the lane shift below)
+    const uint32_t i = k * kOThreads + tid;
+    const bool in = i < count;
+    const unsigned long long pair = s_buf[in ? i : 0];
+    sidx[k] = static_cast<uint32_t>(pair);
+    // ARANK is VERIFIED, not trusted: inside a digit's run the staged keys must appear in the order they had in the
+    // tile (that is what "stable" means for this pass; the atomics hand out distinct ranks by construction, so the
+    // only thing that could go wrong is their order).  A tile that fails raises error word 2 and the host redoes the
+    // sort with the ballot ranking -- correctness never rests on the order in which the hardware serves the lanes of
+    // one ds_add_rtn, only the speed does.
+    if (ARANK) {
+      // the predecessor's origin: from the lane below (a DPP wave shift, no LDS traffic), lane 0 of a wave from LDS
+      const uint32_t from = static_cast<uint32_t>(pair >> 32);
+      uint32_t prev = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(from), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+      if (lane == 0 && i > 0) prev = static_cast<uint32_t>(s_buf[in ? i - 1 : 0] >> 32);
+      if (in && ((inrun >> k) & 1u)) disorder |= prev > from;
+    }
+  }
+  if (ARANK && disorder) __hip_atomic_store(error + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   bool gave_up = false;
   if (tid < 256) {  // thread d: keys with digit d in all earlier tiles
     uint32_t excl = 0;
@@ -945,6 +995,10 @@ __global__ __launch_bounds__(kOThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
       // A window of kLbWindow predecessors per round trip: the words of one round are loaded
       // back to back and consumed nearest-first; the walk stops at the first inclusive word and
       // re-polls from the first word that is not published yet.
+      // (Measured and dropped: 16 / 32 words per round trip; the first window's loads issued ahead of the staging
+      // rounds; two levels -- a tile adds up its predecessors inside its group of sixteen, then walks over group words
+      // published by each group's last tile: 526 / 487 -> 601 / 565 us per pass, the extra hop through a tile that is
+      // dispatched last in its group costs more than the shorter walk saves.)
       int64_t j = int64_t(tile) - 1;
       int spins = 0;
       for (bool done = false; !done;) {
@@ -983,57 +1037,19 @@ __global__ __launch_bounds__(kOThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
   OPH(3);  // look-back (thread 0's digit)
   if (__syncthreads_or(gave_up)) return;  // positions unknown: write nothing
   OPH(4);  // ... and everybody else's
-  if (RAW == 2) count = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];  // the keys that took part (the digit totals' sum)
-  // round 1: the keys leave (thread t takes the staged positions t, t + 512, ...: the same ones in both rounds, so a
-  // position's global place is computed once and kept in a register)
-  uint32_t gpos[kIters];
-  uint32_t inrun = 0;  // bit k: position i is not the first of its digit's run (the order check compares it with i - 1)
 #pragma unroll
   for (int k = 0; k < kIters; ++k) {
     const uint32_t i = k * kOThreads + tid;
-    gpos[k] = 0;
-    if (i < count) {
-      const KeyT kk = static_cast<KeyT>(s_buf[i]);
-      const uint32_t d = (kk >> shift) & 255;
-      const uint32_t dstart = s_dstart[d];
-      gpos[k] = s_gbase[d] + (i - dstart);
-      if (i > dstart) inrun |= 1u << k;
-      if (!LAST) keys_out[gpos[k]] = kk;
+    if (i >= count) continue;
+    const uint32_t d = (skey[k] >> shift) & 255;  // (neighbouring positions hold the same digit: these two reads are broadcasts)
+    const uint32_t gpos = s_gbase[d] + (i - s_dstart[d]);
+    if (LAST) {
+      out64[gpos] = sidx[k];
+    } else {
+      keys_out[gpos] = skey[k];
+      idx_out[gpos] = sidx[k];
     }
   }
-  __syncthreads();
-  OPH(5);  // round 1: keys out
-  // round 2: the row indices, each with its origin in the tile
-#pragma unroll
-  for (int j = 0; j < kIters; ++j) {
-    const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
-    if ((alive >> j) & 1u) s_buf[lpos[j]] = static_cast<unsigned long long>(li) << 32 | idx[j];
-  }
-  __syncthreads();
-  OPH(6);  // row indices staged
-  bool disorder = false;
-#pragma unroll
-  for (int k = 0; k < kIters; ++k) {  // (every lane takes part in the lane shift below)
-    const uint32_t i = k * kOThreads + tid;
-    const bool in = i < count;
-    const unsigned long long pair = s_buf[in ? i : 0];
-    // ARANK is VERIFIED, not trusted: inside a digit's run the staged keys must appear in the order they had in the
-    // tile (that is what "stable" means for this pass; the atomics hand out distinct ranks by construction, so the
-    // only thing that could go wrong is their order).  A tile that fails raises error word 2 and the host redoes the
-    // sort with the ballot ranking -- correctness never rests on the order in which the hardware serves the lanes of
-    // one ds_add_rtn, only the speed does.
-    if (ARANK) {
-      // the predecessor's origin: from the lane below (a DPP wave shift, no LDS traffic), lane 0 of a wave from LDS
-      const uint32_t from = static_cast<uint32_t>(pair >> 32);
-      uint32_t prev = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(from), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-      if (lane == 0 && i > 0) prev = static_cast<uint32_t>(s_buf[in ? i - 1 : 0] >> 32);
-      if (in && ((inrun >> k) & 1u)) disorder |= prev > from;
-    }
-    if (!in) continue;
-    if (LAST) out64[gpos[k]] = static_cast<uint32_t>(pair);
-    else idx_out[gpos[k]] = static_cast<uint32_t>(pair);
-  }
-  if (ARANK && disorder) __hip_atomic_store(error + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   OPH(7);  // round 2: row indices out
   OPH_FLUSH();
 }
@@ -1772,7 +1788,8 @@ static int SortRawClassified(amdarrow_ctx* ctx, const std::vector<SortChunk>& hc
   const size_t o_dbase = cv.Take(4 * 4 * 256);
   const size_t o_orand = cv.Take(kCounterBytes);
   const size_t o_ctl = cv.Take(256);
-  const size_t o_lookback = cv.Take(4 * 256 * static_cast<size_t>(nb_max) * 4);
+  const size_t lb_words = 256 * static_cast<size_t>(nb_max);  // per pass: a word per tile and digit
+  const size_t o_lookback = cv.Take(4 * lb_words * 4);
   const size_t o_crowded = cv.Take(4 * static_cast<size_t>(nwin));
   void* base;
   AA_TRY(Scratch(ctx, cv.off, &base));
@@ -1843,11 +1860,11 @@ static int SortRawClassified(amdarrow_ctx* ctx, const std::vector<SortChunk>& hc
   hipLaunchKernelGGL(k_digit_bases, dim3(4), dim3(kThreads), 0, ctx->stream, ghist, dbase);
   AA_HIP(hipGetLastError());
   AA_HIP(hipMemsetAsync(ctl, 0, 256, ctx->stream));
-  AA_HIP(hipMemsetAsync(lookback, 0, 4 * 256 * static_cast<size_t>(nb_max) * top, ctx->stream));
+  AA_HIP(hipMemsetAsync(lookback, 0, 4 * lb_words * top, ctx->stream));
   const int low_shift = hs.shift[top - 1];
   for (int a = 0; a < top; ++a) {
     const int k = top - 1 - a;  // lowest digit first
-    uint32_t* lb = lookback + 256 * static_cast<size_t>(nb_max) * a;
+    uint32_t* lb = lookback + lb_words * a;
     const uint32_t* db = dbase + 256 * k;
     if (a == 0) {
       auto* pass = arank ? k_radix_onesweep<KeyT, false, true, 2> : k_radix_onesweep<KeyT, false, false, 2>;
@@ -1938,7 +1955,8 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   const size_t o_sumoff = cv.Take(8 * (scan_nb + 1));
   const size_t o_dbase = cv.Take(4 * 256 * kPasses);
   const size_t o_ctl = cv.Take(256);  // [13] duplicate-sample flag, [14] error word of the window sort, [15] of the one-sweep passes
-  const size_t o_lookback = cv.Take(4 * static_cast<size_t>(hist_n) * kPasses);
+  const size_t lb_words = static_cast<size_t>(hist_n);  // per pass: a word per tile and digit
+  const size_t o_lookback = cv.Take(4 * lb_words * kPasses);
   void* base;
   AA_TRY(Scratch(ctx, cv.off, &base));
   char* b = static_cast<char*>(base);
@@ -2152,7 +2170,7 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
     hipLaunchKernelGGL(k_digit_bases, dim3(kPasses), dim3(kThreads), 0, ctx->stream, ghist, dbase);
     AA_HIP(hipGetLastError());
     AA_HIP(hipMemsetAsync(ctl, 0, 256, ctx->stream));
-    AA_HIP(hipMemsetAsync(lookback, 0, 4 * static_cast<size_t>(hn0) * pass_shift.size(), ctx->stream));
+    AA_HIP(hipMemsetAsync(lookback, 0, 4 * lb_words * pass_shift.size(), ctx->stream));
   }
   const bool raw_first = raw_try && onesweep && !(pass_shift.size() == 1 && !top);  // (the first pass is not the one that writes the result)
   if (raw_try && !raw_first) {  // the partition after all (its histograms are the ones already read)
@@ -2178,7 +2196,7 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
       continue;
     }
     if (onesweep) {
-      uint32_t* lb = lookback + static_cast<size_t>(hn0) * a;
+      uint32_t* lb = lookback + lb_words * a;
       const uint32_t* db = pass_db[a];
       auto* pass = last ? (arank ? k_radix_onesweep<KeyT, true, true> : k_radix_onesweep<KeyT, true, false>)
                         : (arank ? k_radix_onesweep<KeyT, false, true> : k_radix_onesweep<KeyT, false, false>);
