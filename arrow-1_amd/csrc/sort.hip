@@ -1683,7 +1683,7 @@ __global__ void k_guess_shifts(const unsigned long long* orand, HistShifts* hs_o
 // ways and counts the keys whose atomic rank differs from the match-any rank.
 __global__ __launch_bounds__(256) void k_probe_lds_rank(unsigned int* mismatches) {
   __shared__ uint32_t s_cnt[4][256];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, wave = tid >> 6;
   unsigned int bad = 0;
   for (int round = 0; round < 24; ++round) {
     for (int i = tid; i < 4 * 256; i += 256) (&s_cnt[0][0])[i] = 0;

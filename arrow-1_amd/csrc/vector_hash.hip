@@ -10,7 +10,6 @@
 namespace amdarrow {
 
 constexpr int kVThreads = 256;
-constexpr uint32_t kNoNullGroup = 0xFFFFFFFFu;
 
 // The null key's group = the one zero bit of the uniques' validity (at most one group is null).
 __global__ __launch_bounds__(kVThreads) void k_find_null_group(const uint64_t* valid, int64_t num_groups, uint32_t* null_group) {
