@@ -20,14 +20,14 @@ constexpr int kDmTile = 4096;
 
 int LaunchScanU32(amdarrow_ctx* ctx, const uint32_t* counts, int64_t n, int64_t* offsets);  // selection.hip
 
-// acc: [2][R + 2] 8-byte words (row 0 sums, row 1 counts; column R = the null key, column R + 1 of
-// row 0 = number of keys outside the planned range); owner: [R + 2], the last word carries
+// acc: [R + 2][2] 8-byte words ({sum, count} of a key side by side -- one 16-byte access instead of two scattered
+// 8-byte ones; column R = the null key, the sum word of column R + 1 = number of keys outside the planned range);
+// owner: [R + 2], the last word carries
 // -(local group count) through the MIN all-reduce: afterwards it is -(the largest local table), the
 // stride of the slot array.
 __global__ __launch_bounds__(kDmThreads) void k_dense_clear(unsigned long long* acc, unsigned long long* owner, int64_t R) {
   for (int64_t i = int64_t(blockIdx.x) * kDmThreads + threadIdx.x; i < R + 2; i += int64_t(gridDim.x) * kDmThreads) {
-    acc[i] = 0;
-    acc[R + 2 + i] = 0;
+    reinterpret_cast<ulonglong2*>(acc)[i] = make_ulonglong2(0, 0);
     if (i <= R) owner[i] = kNoOwner;
     if (i == R + 1) owner[i] = 0;
   }
@@ -62,16 +62,15 @@ __global__ __launch_bounds__(kDmThreads) void k_dense_scatter(const void* keys, 
       col = LoadKey(keys, key_type, g) - kmin;
       if (col < 0 || col >= R) { ++outside; continue; }
     }
-    acc[col] = sums[g];
     const long long c = counts[g];
-    acc[R + 2 + col] = counts_as_double ? static_cast<unsigned long long>(__double_as_longlong(static_cast<double>(c)))
-                                        : static_cast<unsigned long long>(c);
+    reinterpret_cast<ulonglong2*>(acc)[col] = make_ulonglong2(sums[g], counts_as_double ? static_cast<unsigned long long>(__double_as_longlong(static_cast<double>(c)))
+                                                                                         : static_cast<unsigned long long>(c));
     owner[col] = (static_cast<unsigned long long>(rank) << 32) | static_cast<unsigned long long>(g);
   }
   outside = WaveReduceSum64(outside);
   if ((threadIdx.x & 63) == 0 && outside) {
-    if (counts_as_double) atomicAdd(reinterpret_cast<double*>(&acc[R + 1]), static_cast<double>(outside));
-    else atomicAdd(&acc[R + 1], outside);
+    if (counts_as_double) atomicAdd(reinterpret_cast<double*>(&acc[2 * (R + 1)]), static_cast<double>(outside));
+    else atomicAdd(&acc[2 * (R + 1)], outside);
   }
 }
 
@@ -126,6 +125,7 @@ __global__ __launch_bounds__(kDmThreads) void k_dense_emit(const uint32_t* slots
   if (blockIdx.x == 0 && threadIdx.x == 0) *out_num_groups = offsets[ntiles];
   for (int64_t tile = blockIdx.x; tile < ntiles && tile * kDmTile < nslots; tile += gridDim.x) {
     int64_t base = offsets[tile];
+    if (offsets[tile + 1] == base) continue;  // (uniform) an empty tile: with W ranks the slot array is W tables long and mostly the first rank's is filled
     for (int k = 0; k < kDmTile / kDmThreads; ++k) {  // 16 rounds of 256 slots, in order
       const int64_t i = tile * kDmTile + k * kDmThreads + threadIdx.x;
       const uint32_t v = i < nslots ? slots[i] : 0u;
@@ -146,8 +146,9 @@ __global__ __launch_bounds__(kDmThreads) void k_dense_emit(const uint32_t* slots
             default: static_cast<int64_t*>(out_keys)[pos] = key; break;
           }
           out_key_valid[pos] = col != R;
-          out_sums[pos] = acc[col];
-          const unsigned long long c = acc[R + 2 + col];
+          const ulonglong2 sc = reinterpret_cast<const ulonglong2*>(acc)[col];
+          out_sums[pos] = sc.x;
+          const unsigned long long c = sc.y;
           out_counts[pos] = counts_as_double ? static_cast<long long>(__longlong_as_double(static_cast<long long>(c)))
                                              : static_cast<long long>(c);
         }

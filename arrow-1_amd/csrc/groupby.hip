@@ -211,6 +211,10 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
   // hitters the call goes on with compact records planned from the sample's key range and value width: GUESSED, and
   // checked per row like a hinted call's; a miss starts over on the full path, once.
   bool guess_tried = false, guessed = false;
+  // ... and when it gave up WITH heavy hitters (a skewed key column never earns a hint: every call starts here): the hot
+  // rows are folded next to the scatter as before, and the scatter of the remainder carries 8-byte compact records when
+  // the sample's values are int32 -- same workgroups and regions as the 16-byte bin scatter, so the call goes on in place
+  bool hot_compact = false;
   GroupTable t{};
   RankMem r{};
   unsigned long long* gx = nullptr;
@@ -382,6 +386,15 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
               hinted = true;
               path = 3;  // -> 2 after the loop's decrement: the partition path on compact records, from the top
               continue;
+            } else if (probe_host[0] == 1 && probe_host[1] != 0 && probe_host[2] != 0 && nsub == 1 && m_valid == nullptr &&
+                       !getenv("AMDARROW_GROUPBY_OLD_HOT") &&
+                       plan_compact(uint64_t(probe_host[3]) + k_bias, uint64_t(probe_host[4]) + k_bias, probe_host[5] == 0)) {
+              if (compact_rw == 2 && compact_pb == 9 && rows_per_block <= (int64_t(1) << 19)) {
+                hot_compact = true;  // (8-byte records: the geometry of this iteration's bin scatter)
+                fa.c_base = c_base;
+              } else {
+                compact_rw = 0;  // (12-byte records run on 256 partitions and twice the workgroups: the 16-byte flow as queued)
+              }
             }
           }
           if (headline_shape && !getenv("AMDARROW_GROUPBY_OLD_MERGE"))
@@ -410,7 +423,10 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
         fa.sub_bits = nsub > 1 ? sub_bits : 0; fa.sub_id = static_cast<uint32_t>(sub);
         FastArgs fh = fa;  // the same scatter on the mask k_hot_aggregate wrote
         fh.m_data = hot.alt_mask; fh.m_valid = nullptr; fh.m_off = 0;
-        if (compact) {
+        if (hot_compact) {  // the remainder of a skewed input (the mask k_hot_aggregate_vec wrote), on 8-byte records
+          if (V) hipLaunchKernelGGL((k_part_scatter_compact<true, true, false, 2, 9>), dim3(nblocks), dim3(kBThreads), 0, ctx->stream, fh, cap, records, hist, misc);
+          else hipLaunchKernelGGL((k_part_scatter_compact<true, false, false, 2, 9>), dim3(nblocks), dim3(kBThreads), 0, ctx->stream, fh, cap, records, hist, misc);
+        } else if (compact) {
 #define AA_CBINS4(MM, VV, KK, RR, PP) hipLaunchKernelGGL((k_part_scatter_compact<MM, VV, KK, RR, PP>), dim3(nblocks), dim3(kBThreads), 0, ctx->stream, fa, cap, records, hist, misc)
 #define AA_CBINS3(MM, VV, KK) do { if (compact_rw == 2 && compact_pb == 9) AA_CBINS4(MM, VV, KK, 2, 9); else if (compact_rw == 2) AA_CBINS4(MM, VV, KK, 2, 8); \
           else if (compact_pb == 9) AA_CBINS4(MM, VV, KK, 3, 9); else AA_CBINS4(MM, VV, KK, 3, 8); } while (0)
@@ -440,7 +456,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
                                misc, use_hot, static_cast<const unsigned int*>(nullptr));
         }
         AA_HIP(hipGetLastError());
-        if (compact) {
+        if (compact || hot_compact) {
 #define AA_CAGG(RR, PP) hipLaunchKernelGGL((k_part_aggregate_compact<RR, PP>), dim3(1 << PP), dim3(kPartThreads), 0, ctx->stream, records, hist, nblocks, cap, \
                                acc_double, t, r.bitmap, misc, static_cast<int64_t>(T), c_base, fa.k_flip, static_cast<uint32_t>(rows_per_block))
           if (compact_rw == 2 && compact_pb == 9) AA_CAGG(2, 9); else if (compact_rw == 2) AA_CAGG(2, 8);
@@ -534,6 +550,12 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
       ctx->gb_carry_misses = carry_misses; ctx->gb_carry_off = carry_off;  // (start_over_measured forgets the shape's hints; the retry picks the back-off up here)
       return start_over_measured();
     }
+    if (hot_compact && (overflow & kOverflowCompact)) {  // a row outside the sampled key range / a wide value: the same call on 16-byte records
+      hot_compact = false;
+      compact_rw = 0;
+      path = 4;  // -> 3 after the loop's decrement (no second guess: guess_tried)
+      continue;
+    }
     if (overflow && fast && hinted) {  // the hint (or the guess) was wrong for this input: forget it, start over with the full path 3
       guessed = false;
       guess_tried = true;  // (one compact attempt per call: what broke a hinted call's assumption -- a few far keys, one wide value -- hides from a sample too)
@@ -597,7 +619,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
     }
     *out_num_groups = G;
     ctx->gb_last_path = path == 3 && status[1] != 0 ? 2 : path;
-    ctx->gb_last_words = ctx->gb_last_path == 0 || ctx->gb_last_path == 3 ? 0 : compact ? compact_rw : 4;
+    ctx->gb_last_words = ctx->gb_last_path == 0 || ctx->gb_last_path == 3 ? 0 : (compact || hot_compact) ? compact_rw : 4;
     break;
   }
   // no trailing synchronise: *out_num_groups is final, the output arrays are stream-ordered

@@ -215,13 +215,13 @@ class PendingMerge:
 
 # ---- dense protocol on the device: the HIP kernels of csrc/dist_merge.hip around the two all-reduces ----
 class DenseDeviceState:
-    """Accumulators and outputs of the device merge, allocated once per plan: acc[2][R + 2]
-    (sums | counts; column R = the null key, acc[0][R + 1] = keys outside the range), owner[R + 1],
+    """Accumulators and outputs of the device merge, allocated once per plan: acc[R + 2][2]
+    ({sum, count} per key; column R = the null key, acc[R + 1][0] = keys outside the range), owner[R + 1],
     and the merged table (capacity rows) with its group count in a device word."""
 
     def __init__(self, kmin, R, is_float, key_torch, capacity, device):
         self.kmin, self.R, self.is_float, self.capacity = kmin, R, is_float, capacity
-        self.acc = torch.zeros(2, R + 2, dtype=torch.float64 if is_float else torch.int64, device=device)
+        self.acc = torch.zeros(R + 2, 2, dtype=torch.float64 if is_float else torch.int64, device=device)
         self.owner = torch.zeros(R + 2, dtype=torch.int64, device=device)  # [R + 1]: -(largest local table) after the MIN
         rows = R + 1
         self.rows = rows
@@ -233,7 +233,7 @@ class DenseDeviceState:
 
     @property
     def bad(self):
-        return self.acc[0, self.R + 1:self.R + 2]
+        return self.acc[self.R + 1, 0:1]
 
 
 def merge_dense_device(ctx, key_type, r_keys, r_key_validity, r_sums, r_counts, num_groups, st, rank, world,

@@ -133,7 +133,7 @@ Result<GroupByResult> ShardedGroupBy::DenseStep(const Local& t, bool* left_plan)
   int64_t G = 0;
   uint64_t bad_bits = 0;
   rc = amdarrow_memcpy_d2h(abi, &G, word->data(), 8);
-  if (rc == AMDARROW_OK) rc = amdarrow_memcpy_d2h(abi, &bad_bits, acc_->data() + 8 * (range_ + 1), 8);  // acc[0][R + 1]
+  if (rc == AMDARROW_OK) rc = amdarrow_memcpy_d2h(abi, &bad_bits, acc_->data() + 16 * (range_ + 1), 8);  // acc[R + 1][0]
   if (rc != AMDARROW_OK) return Status::FromAbi(rc);
   double bad_f;
   memcpy(&bad_f, &bad_bits, 8);

@@ -344,8 +344,8 @@ int amdarrow_filter_groupby_multi(amdarrow_ctx* ctx, const amdarrow_array* value
  * merged table is what that GroupBy returns on the concatenated shards, first-appearance order
  * (:391-401) included.  Dense protocol for integer keys of a small global range [kmin, kmin + R):
  *   scatter  this rank's partial table (keys / validity bytes / 8-byte sums / int64 counts, in local
- *            first-appearance order) into acc[2][R + 2] (sums | counts; column R = the null key,
- *            acc[0][R + 1] = keys outside the range) and owner[R + 2]: owner[col] = rank << 32 | local id
+ *            first-appearance order) into acc[R + 2][2] ({sum, count} per key, 16 bytes side by side;
+ *            column R = the null key, acc[R + 1][0] = keys outside the range) and owner[R + 2]: owner[col] = rank << 32 | local id
  *            (INT64_MAX where absent), owner[R + 1] = -(local group count), which the MIN turns into
  *            the stride of the slot array.  The caller then all-reduces acc with SUM and owner with MIN;
  *   order    reads the reduced arrays back out in global order (rank-major, local id minor) into
