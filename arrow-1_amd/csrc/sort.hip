@@ -998,7 +998,9 @@ __global__ __launch_bounds__(kOThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
       // (Measured and dropped: 16 / 32 words per round trip; the first window's loads issued ahead of the staging
       // rounds; two levels -- a tile adds up its predecessors inside its group of sixteen, then walks over group words
       // published by each group's last tile: 526 / 487 -> 601 / 565 us per pass, the extra hop through a tile that is
-      // dispatched last in its group costs more than the shorter walk saves.)
+      // dispatched last in its group costs more than the shorter walk saves; group words that every tile ADDS its count
+      // to with one atomic, no hop: 544 / 500 us, the same as this flat walk.  The wait is not the walk: a tile cannot
+      // finish before the SLOWEST of the ~460 tiles in flight in front of it has counted.)
       int64_t j = int64_t(tile) - 1;
       int spins = 0;
       for (bool done = false; !done;) {
