@@ -30,7 +30,11 @@ namespace amdarrow {
 constexpr int kThreads = 256;
 constexpr int kCTile = 2048;   // classify tile: 256 threads x 8
 constexpr int kRTile = 4096;   // radix tile: 16 keys per lane of a 256-thread block
-constexpr int kOTileRows = 8192;  // one-sweep tile (= kOTile below)
+#ifndef ONESWEEP_TILE
+#define ONESWEEP_TILE 8192
+#define ONESWEEP_THREADS 512
+#endif
+constexpr int kOTileRows = ONESWEEP_TILE;  // one-sweep tile (= kOTile below)
 
 struct SortChunk {
   const void* values; const uint8_t* valid; int64_t off; int64_t length;
@@ -307,7 +311,7 @@ __device__ __forceinline__ int FindChunkO(const SortChunk* chunks, int nchunks, 
 // counted -- counts[class][tile]: sortable | NaN | null -- and the sortable keys' OR / OR-of-complement collected (which
 // bits vary); MODE 1: the histograms of the plan's digits (hs) over the sortable keys.  Loads raw for the whole tile
 // before anything is looked at.
-constexpr int kRcThreads = 512;
+constexpr int kRcThreads = 1024;  // (8 rows per thread: 374 -> 260 us per 100 M float64 against 512 threads x 16 rows)
 template <typename KeyT, int MODE>
 __global__ __launch_bounds__(kRcThreads) void k_rawc_scan(const SortChunk* chunks, int nchunks, int type_id, int64_t notiles, int64_t tile_stride,
                                                           KeyT key_mask, KeyT flip, uint32_t* counts, unsigned long long* orand, HistShifts hs,
@@ -715,10 +719,10 @@ __global__ __launch_bounds__(kThreads) void k_digit_bases(const unsigned int* gh
 
 // 8192 keys per tile and 512 threads: a digit gets a run of 32 keys (256 bytes of keys, 128 of indices) instead of
 // 16 from a 4096-key tile of 256 threads -- 671 -> 595 us per pass; 8192 keys on 256 threads: 705 us.
-constexpr int kOThreads = 512;            // one-sweep block
-constexpr int kOTile = 8192;              // keys per one-sweep tile (<= 2 * kRTile: the look-back array is sized by kRTile tiles)
+constexpr int kOThreads = ONESWEEP_THREADS;  // one-sweep block
+constexpr int kOTile = ONESWEEP_TILE;        // keys per one-sweep tile (<= 2 * kRTile: the look-back array is sized by kRTile tiles)
 static_assert(kOTile >= kRTile, "look-back array");
-static_assert(kOThreads / 64 == 8, "k_radix_onesweep reads eight wave slots of s_tail");
+static_assert(kOThreads >= 256 && kOTile / kOThreads == 16, "digit threads; sixteen keys per thread");
 constexpr int kOWaves = kOThreads / 64;
 
 // ARANK: a key's rank among the keys of its wave with the same digit is what the LDS atomic that
@@ -866,8 +870,10 @@ __global__ __launch_bounds__(kOThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
   __syncthreads();
   OPH(0);  // loads + counting atomics
   if constexpr (RAW == 2) {  // the NaN / null rows go to their final places (tile order, row order inside the tile)
-    if (__builtin_amdgcn_readfirstlane(s_tail[0][0] | s_tail[0][1] | s_tail[0][2] | s_tail[0][3] | s_tail[0][4] | s_tail[0][5] | s_tail[0][6] | s_tail[0][7] |
-                                       s_tail[1][0] | s_tail[1][1] | s_tail[1][2] | s_tail[1][3] | s_tail[1][4] | s_tail[1][5] | s_tail[1][6] | s_tail[1][7])) {
+    uint32_t any_tail = 0;
+#pragma unroll
+    for (int w = 0; w < kOWaves; ++w) any_tail |= s_tail[0][w] | s_tail[1][w];
+    if (__builtin_amdgcn_readfirstlane(any_tail)) {
       uint32_t woff[2] = {0, 0};
       for (int w = 0; w < wave; ++w) { woff[0] += s_tail[0][w]; woff[1] += s_tail[1][w]; }
       const uint32_t tail_base[2] = {rc.offsets[1 * rc.notiles + tile], rc.offsets[2 * rc.notiles + tile]};
