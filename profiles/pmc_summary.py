@@ -6,7 +6,7 @@ The number of steps is the dispatch count of the op's first kernel of every step
 import collections, csv, glob, sys
 
 STEP_MARKERS = ("amdarrow::k_prepare", "amdarrow::k_filter_tile_counts", "amdarrow::k_sort_count", "amdarrow::k_validity",
-                "amdarrow::k_boolean", "amdarrow::k_aggregate<", "amdarrow::k_take", "amdarrow::k_rawc_scan<unsigned long, 1>")
+                "amdarrow::k_boolean", "amdarrow::k_aggregate<", "amdarrow::k_take", "amdarrow::k_rawc_scan<unsigned long, 1>", "amdarrow::k_sort_hist")
 for d in sys.argv[1:]:
     acc = collections.defaultdict(list)
     for f in glob.glob(d + "/*/*counter_collection.csv"):
