@@ -71,6 +71,7 @@ struct amdarrow_ctx {
   GroupByHint gb_hints[kGroupByHints];
   uint64_t gb_hint_clock = 0;
   int gb_last_path = -1, gb_last_words = 0;  // amdarrow_groupby_last_path
+  int gb_hot_guess_off = 0;  // calls that stay off the guessed compact records for skewed input (set when such a guess missed: a skewed shape keeps no hint that could remember it)
   // amdarrow_filter_groupby_multi: the key columns' ranges as the last call of this shape found them (32-bit columns
   // without nulls): the next call packs with them -- the pack kernel checks every value -- instead of a min / max pass
   // per column first

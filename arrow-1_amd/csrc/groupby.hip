@@ -386,6 +386,8 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
               hinted = true;
               path = 3;  // -> 2 after the loop's decrement: the partition path on compact records, from the top
               continue;
+            } else if (probe_host[0] == 1 && probe_host[1] != 0 && probe_host[2] != 0 && ctx->gb_hot_guess_off > 0) {
+              --ctx->gb_hot_guess_off;  // (such a guess missed not long ago: the 16-byte flow as queued)
             } else if (probe_host[0] == 1 && probe_host[1] != 0 && probe_host[2] != 0 && nsub == 1 && m_valid == nullptr &&
                        !getenv("AMDARROW_GROUPBY_OLD_HOT") &&
                        plan_compact(uint64_t(probe_host[3]) + k_bias, uint64_t(probe_host[4]) + k_bias, probe_host[5] == 0)) {
@@ -553,6 +555,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
     if (hot_compact && (overflow & kOverflowCompact)) {  // a row outside the sampled key range / a wide value: the same call on 16-byte records
       hot_compact = false;
       compact_rw = 0;
+      ctx->gb_hot_guess_off = 16;  // the next calls on skewed input do not guess
       path = 4;  // -> 3 after the loop's decrement (no second guess: guess_tried)
       continue;
     }

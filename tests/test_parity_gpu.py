@@ -1547,6 +1547,32 @@ def test_filter_groupby_compact_records(gpu, oracle, shape, monkeypatch):
         assert _last_groupby_path(gpu) == (2, want_words), (shape, step, kind)
 
 
+@pytest.mark.parametrize("case", ["far-keys", "wide-value", "hot+wide-value", "hot+far-keys"])
+def test_filter_groupby_guessed_records_miss(oracle, case):
+    """A call without a predecessor plans compact records from what the pre-aggregation SAMPLED (the first ~2048 distinct
+    keys of each of 256 row ranges); what the sample cannot see -- sixteen keys far outside the sampled range, sixteen
+    values that are not int32, late in the row ranges -- breaks the plan on the device, and the call starts over on
+    16-byte records (with the heavy hitters taken out again where there are any).  The reference's rows every time."""
+    import gpu_api
+    gpu = gpu_api.GpuApi()  # nothing to take over
+    rng = np.random.default_rng(0x0ff1ce + 91)
+    n = 1_500_000
+    base = rng.integers(0, 300_000, n) + 1000
+    vals = rng.integers(-2**31, 2**31 - 1, n)
+    if case.startswith("hot"):
+        base[rng.random(n) < 0.2] = 4242
+    late = np.flatnonzero(np.arange(n) % 8192 >= 7000)  # rows at the end of every 8192-row range: the sample never gets there
+    pick = rng.choice(late, 16, replace=False)
+    if "far-keys" in case:
+        base[pick] += 5_000_000
+    else:
+        vals[pick] = 2**40
+    v, k, m = Arr(INT64, vals.astype(np.int64)), Arr(INT32, base.astype(np.int32)), R(rng, BOOL, n, 0.0, 0, hi=0.9)
+    _check_groupby(oracle, gpu, v, k, m, case)
+    assert _last_groupby_path(gpu) == (2, 4), case     # ended on 16-byte records
+    _check_groupby(oracle, gpu, v, k, m, (case, "again"))
+
+
 def test_filter_groupby_compact_records_knob(gpu, oracle, monkeypatch):
     """AMDARROW_GROUPBY_NO_COMPACT keeps hinted calls on 16-byte records; AMDARROW_GROUPBY_COMPACT_WORDS=3 keeps a
     narrow-valued call on 12-byte records."""
