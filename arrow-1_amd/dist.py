@@ -37,6 +37,27 @@ class Partial:
         return int(self.keys.shape[0])
 
 
+class LazyPartial:
+    """A Partial that is built when somebody looks at it: a step of the dense protocol needs its local table as
+    tensors only if the step has to be redone (the first step's plan, a key outside the plan), and unpacking the key
+    validity bitmap of a million groups is four launches of host time between two steps -- the fused call returns only
+    when its kernels are all but done, so host work behind it leaves the GPU idle (0.69 -> 0.63 ms per merged step)."""
+
+    def __init__(self, make):
+        self._make, self._p = make, None
+
+    def _get(self):
+        if self._p is None:
+            self._p = self._make()
+        return self._p
+
+    keys = property(lambda self: self._get().keys)
+    key_valid = property(lambda self: self._get().key_valid)
+    sums = property(lambda self: self._get().sums)
+    counts = property(lambda self: self._get().counts)
+    num_groups = property(lambda self: self._get().num_groups)
+
+
 # ---- general protocol: all-gather + re-aggregate ---------------------------------------------------
 def merge_partials(part, local_merge, world=None, group=None):
     """All-gather the per-rank partial tables and re-aggregate them.
@@ -188,6 +209,7 @@ class ShardedMerge:
 class PendingMerge:
     def __init__(self, owner, part, merged, n_present, bad, event=None):
         self.owner, self.part, self.merged, self.n_present, self.bad, self.event = owner, part, merged, n_present, bad, event
+        self.bad_host = None  # (GroupByMerger: `bad` copied to pinned host memory on the merge's stream, in front of `event`)
         self.done = False
 
     def wait(self):
@@ -195,7 +217,11 @@ class PendingMerge:
             return self
         if self.event is not None:
             self.event.synchronize()
-        if self.bad is not None and int(self.bad.item()) != 0:
+        if self.bad_host is not None:  # no second round trip to the device: the flag arrived with the event
+            left = float(self.bad_host[0]) != 0
+        else:
+            left = self.bad is not None and int(self.bad.item()) != 0
+        if left:
             self.merged, self.n_present = self.owner._left_the_plan(self.part), None
         self.done = True
         return self
@@ -432,6 +458,7 @@ class GroupByMerger:
         self._slot = 0
         self._bufs = None
         self._pending = [None, None]
+        self._bad_host, self._bad_used = None, None
 
     def _partial_of(self, r):
         G = r.num_groups
@@ -499,13 +526,18 @@ class GroupByMerger:
                 self._side.wait_event(done_local)
                 mpart, n_present = merge_dense_device(self._side_ctx, self.key_type, r.keys, r.key_validity, r.sums, r.counts, r.num_groups,
                                                       state, self.rank, self.world)
+                if self._bad_host is None:
+                    self._bad_host = [torch.zeros(1, dtype=state.bad.dtype).pin_memory() for _ in range(2)]
+                self._bad_host[slot].copy_(state.bad, non_blocking=True)
+                self._bad_used = self._bad_host[slot]
                 self._event = torch.cuda.Event()
                 self._event.record(self._side)
             return mpart, n_present, state.bad
 
-        self._event = None
-        res = self._sm.step(self._partial_of(r), slot, run_dense)
+        self._event, self._bad_used = None, None
+        res = self._sm.step(LazyPartial(lambda: self._partial_of(r)), slot, run_dense)
         res.event = self._event
+        res.bad_host = self._bad_used
         self._pending[slot] = res
         return res
 
