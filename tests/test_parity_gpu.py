@@ -963,6 +963,19 @@ def test_sort_hybrid_windows_match_oracle(gpu, oracle, t, monkeypatch):
                 assert np.array_equal(gpu.sort_indices(a, order), oracle.sort_indices(a, order)), (t, n, shape, order)
         chunks = [R(rng, t, m, .05, k) for k, m in enumerate([n // 2, 0, n // 3, 7])]
         assert np.array_equal(gpu.sort_indices(chunks, ASC), oracle.sort_indices(chunks, ASC))
+    if t in (INT64, UINT64):
+        # the window kernel ranks the keys of a shared bucket by one packed word (20 key bits below the bucket's | window
+        # position); words that tie in those bits compare by the keys themselves: every value twice or three times
+        # (equal keys: the earlier row first), and pairs that differ only in their LOW 16 bits (different keys, equal words)
+        for n in (40_000, 300_000):
+            base = rng.integers(info.min, info.max, n // 3 + 1, endpoint=True, dtype=orc.NP_OF[t])
+            twice = np.concatenate([base, base, base[: n - 2 * len(base)] if n > 2 * len(base) else base[:0]])[:n]
+            near = twice.copy()
+            near[len(base):2 * len(base)] ^= rng.integers(1, 1 << 16, min(len(base), n - len(base))).astype(orc.NP_OF[t])
+            for d in (twice, near):
+                a = Arr(t, rng.permutation(d))
+                for order in (ASC, DESC):
+                    assert np.array_equal(gpu.sort_indices(a, order), oracle.sort_indices(a, order)), (t, n, "pairs", order)
     if t in (INT64, DOUBLE):  # two keys: the second stage visits the rows through the first stage's permutation
         k1 = Arr(INT32, rng.integers(-2**31, 2**31, 60_000))
         k2 = Arr(t, rng.integers(0, 5, 60_000).astype(orc.NP_OF[t]))
