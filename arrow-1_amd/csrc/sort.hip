@@ -325,12 +325,21 @@ __global__ __launch_bounds__(kRcThreads) void k_rawc_scan(const SortChunk* chunk
   if (kHist) { for (int i = threadIdx.x; i < 4 * 256; i += kRcThreads) s_h[i] = 0; }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   KeyT k_or = 0, k_orn = 0;
-  int parity = 0;
-  for (int64_t tile = int64_t(blockIdx.x) * tile_stride; tile < notiles; tile += int64_t(gridDim.x) * tile_stride, parity ^= 1) {
-    const SortChunk c = chunks[FindChunkO(chunks, nchunks, tile)];
+  // Two tiles' loads in flight: the next tile's keys and validity bytes are requested before this tile is classified
+  // (a tile at a time, every tile began with the round trips of its chunk record and its keys in a row).  The chunk
+  // record is looked up again only when a tile leaves the chunk of the tile before it.
+  SortChunk c_a{}, c_b{};
+  KeyT key_a[kIters], key_b[kIters];
+  uint32_t vb_a[kIters], vb_b[kIters];
+  int chunk_at = -1;
+  SortChunk chunk_now{};
+  auto load = [&](int64_t tile, SortChunk& c, KeyT (&key)[kIters], uint32_t (&vb)[kIters]) {
+    if (chunk_at < 0 || tile < chunk_now.otile_start || (chunk_at + 1 < nchunks && tile >= chunks[chunk_at + 1].otile_start)) {
+      chunk_at = FindChunkO(chunks, nchunks, tile);
+      chunk_now = chunks[chunk_at];
+    }
+    c = chunk_now;
     const int64_t r0 = (tile - c.otile_start) * kOTileRows;
-    KeyT key[kIters];
-    uint32_t vb[kIters];
     int64_t ri[kIters];
 #pragma unroll
     for (int j = 0; j < kIters; ++j) {
@@ -343,14 +352,18 @@ __global__ __launch_bounds__(kRcThreads) void k_rawc_scan(const SortChunk* chunk
 #pragma unroll
       for (int j = 0; j < kIters; ++j) vb[j] = c.valid[ri[j] >> 3];
     }
+  };
+  auto process = [&](int64_t tile, const SortChunk& c, const KeyT (&key)[kIters], const uint32_t (&vb)[kIters], int parity) {
+    const int64_t r0 = (tile - c.otile_start) * kOTileRows;
     uint32_t tot[3] = {0, 0, 0};  // (per thread; reduced once per tile)
 #pragma unroll
     for (int j = 0; j < kIters; ++j) {
       const int64_t r = r0 + j * kRcThreads + threadIdx.x;
+      const int64_t ri = c.off + (r < c.length ? r : c.length - 1);
       int cls = 3;
       KeyT k = 0;
       if (r < c.length) {
-        if (!((vb[j] >> (ri[j] & 7)) & 1u)) cls = 2;
+        if (!((vb[j] >> (ri & 7)) & 1u)) cls = 2;
         else {
           bool is_nan;
           k = (KeyFromRaw<KeyT>(type_id, key[j], &is_nan) ^ flip) & key_mask;
@@ -375,6 +388,23 @@ __global__ __launch_bounds__(kRcThreads) void k_rawc_scan(const SortChunk* chunk
         uint32_t t = 0;
         for (int w = 0; w < kWaves; ++w) t += s_cls[parity][threadIdx.x][w];
         counts[threadIdx.x * notiles + tile] = t;
+      }
+    }
+  };
+  {
+    const int64_t step = int64_t(gridDim.x) * tile_stride;
+    int64_t t0 = int64_t(blockIdx.x) * tile_stride;
+    if (t0 < notiles) {
+      load(t0, c_a, key_a, vb_a);
+      for (;;) {
+        const int64_t t1 = t0 + step;
+        if (t1 < notiles) load(t1, c_b, key_b, vb_b);
+        process(t0, c_a, key_a, vb_a, 0);
+        if (t1 >= notiles) break;
+        t0 = t1 + step;
+        if (t0 < notiles) load(t0, c_a, key_a, vb_a);
+        process(t1, c_b, key_b, vb_b, 1);
+        if (t0 >= notiles) break;
       }
     }
   }
