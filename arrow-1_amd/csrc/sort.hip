@@ -1134,32 +1134,55 @@ __device__ unsigned long long g_ws_phase[64][16];
 #define WPH(i)
 #define WPH_FLUSH()
 #endif
-// The key of the lane below (lane 0: `carry`), without touching LDS: a DPP wave shift per 32-bit half.
+// Where the windows begin.  Boundary t (t = 0 .. windows): the first run head at or after position t * kWTile -- the
+// keys are sorted by their top part, so "the first position whose top part differs from that of the key in front of the
+// tile" is a binary search over at most kWSpan - kWTile positions, twelve dependent loads per thread and fifty thousand
+// threads: ~20 us per 100 M keys, after which a window knows its keys without looking at a single candidate (it used
+// to load 4096 of them, compare every one with its neighbour and reduce the heads over the workgroup: a third of the
+// window kernel).  A boundary travels as two 64-bit words, position << 48 | the part of a key above the window's own
+// digits: x = of the key AT the boundary (the window's first key), y = of the key in front of it (the last key of the
+// window before).  A run that does not end within kWSpan - kWTile positions leaves the position at kWNoBound: the
+// window before reports it.
+constexpr uint32_t kWNoBound = 0xFFFFu;
 template <typename KeyT>
-__device__ __forceinline__ KeyT KeyOfLaneBelow(KeyT k, KeyT carry, int lane) {
-  constexpr int kShr1 = 0x138;  // wave_shr:1
-  uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(static_cast<uint32_t>(k)), kShr1, 0xf, 0xf, false));
-  KeyT r = lo;
-  if (sizeof(KeyT) == 8) {
-    const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(static_cast<uint32_t>(static_cast<uint64_t>(k) >> 32)), kShr1, 0xf, 0xf, false));
-    r = static_cast<KeyT>(static_cast<uint64_t>(hi) << 32 | lo);
+__global__ __launch_bounds__(256) void k_window_bounds(const KeyT* keys, int64_t n, KeyT top_mask, int64_t nwin, ulonglong2* bounds) {
+  const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (t > nwin) return;
+  const int low_bits = sizeof(KeyT) == 8 ? __ffsll(static_cast<long long>(top_mask)) - 1 : __ffs(static_cast<int>(top_mask)) - 1;
+  const int64_t p = t * kWTile;
+  if (p >= n) {  // the input's end (boundary `windows`, and any boundary past it)
+    const unsigned long long before = n > 0 ? static_cast<unsigned long long>(keys[n - 1]) >> low_bits : 0ull;
+    const unsigned long long rel = static_cast<unsigned long long>(n - (t - 1) * kWTile);  // relative to the window BEFORE (what reads y)
+    bounds[t] = make_ulonglong2(0ull, (rel <= kWSpan ? rel : kWNoBound) << 48 | before);
+    return;
   }
-  return lane == 0 ? carry : r;
-}
-template <typename KeyT>
-__device__ __forceinline__ KeyT KeyOfLane63(KeyT k) {
-  uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(k)), 63));
-  if (sizeof(KeyT) == 8) {
-    const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(static_cast<uint64_t>(k) >> 32)), 63));
-    return static_cast<KeyT>(static_cast<uint64_t>(hi) << 32 | lo);
+  if (p == 0) {
+    bounds[0] = make_ulonglong2(static_cast<unsigned long long>(keys[0]) >> low_bits, 0ull);
+    return;
   }
-  return static_cast<KeyT>(lo);
+  const KeyT v = keys[p - 1] & top_mask;
+  // first position q in [p, lim] with a top part other than v (lim = where the search gives up, or the input's end)
+  const int64_t reach = p + (kWSpan - kWTile);
+  const int64_t lim = reach < n ? reach : n;
+  int64_t lo = p, hi = lim;  // answer in [lo, hi]; keys[hi] differs (or hi == lim: unknown / the end)
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((keys[mid] & top_mask) != v) hi = mid; else lo = mid + 1;
+  }
+  // lo == lim: no head inside the reach -- the run ends exactly at the input's end (lim == n) or is too long
+  const bool found = lo < lim || (lim < n && (keys[lim] & top_mask) != v) || lim == n;
+  const unsigned long long before = static_cast<unsigned long long>(keys[lo - 1]) >> low_bits;
+  const unsigned long long at = lo < n ? static_cast<unsigned long long>(keys[lo]) >> low_bits : 0ull;
+  // x: relative to this boundary's own window (t), y: relative to the window before (t - 1)
+  const unsigned long long relx = static_cast<unsigned long long>(lo - p), rely = static_cast<unsigned long long>(lo - (p - kWTile));
+  bounds[t] = make_ulonglong2((found ? relx : kWNoBound) << 48 | at, (found && rely <= kWSpan ? rely : kWNoBound) << 48 | before);
 }
+
 // 128 registers: four workgroups per CU (32 KB of LDS each) instead of three -- 904 -> 712 us per 100 M uint64
 template <typename KeyT>
 __global__ __launch_bounds__(kWThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_window_sort(
     const KeyT* keys, const uint32_t* idx_in, int64_t n, KeyT top_mask, unsigned int* error, unsigned int* crowded /* [windows], zeroed */,
-    uint64_t* out64) {
+    uint64_t* out64, const ulonglong2* bounds /* [windows + 1], k_window_bounds */) {
   constexpr int kIters = kWSpan / kWThreads;  // 16: step j takes the candidates [j * 256, (j + 1) * 256), a wave 64 consecutive ones
   // What bounds this kernel is instruction issue (four workgroups share a CU: a wave gets a quarter of its SIMD) and
   // the LDS traffic of lanes that go to unrelated addresses (64 lanes over 32 banks: an 8-byte access of a wave takes
@@ -1171,7 +1194,6 @@ __global__ __launch_bounds__(kWThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
   __shared__ uint32_t s_sub[kWSpan];     // by bucket: sub-bucket bits << 12 | window position; later the row indices in sorted order
   __shared__ uint32_t s_scan[16];
   __shared__ uint32_t s_big;
-  __shared__ unsigned long long s_heads[2][kWWaves];  // per wave: its first head inside the tile / at or after the tile's end (packed, see below)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t win = WindowOfBlock();
@@ -1184,89 +1206,40 @@ __global__ __launch_bounds__(kWThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
   unsigned long long wph_last = __builtin_readcyclecounter();
 #endif
 
-  // The keys of every candidate in one round of loads (the row indices follow once the window is known, for its keys
-  // only).  The heads of the runs are found by comparing a key with the lane below (DPP), lane 0 with the key in front
-  // of the wave's 64 (a scalar load).
-  KeyT key[kIters], front[kIters];
+  // The window: runs that START in this tile, [lo, hi) in candidate positions.  k_window_bounds has found both ends and
+  // the upper parts of the window's first and last key (which is all the bucket pass needs to know about its key range):
+  // no candidate is loaded to find them, and only the window's keys and row indices are loaded at all.
+  const ulonglong2 b0 = bounds[win], b1 = bounds[win + 1];
+  const unsigned long long plo = b0.x, phi = b1.y;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(plo >> 48));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(phi >> 48));
+  if (lo >= static_cast<uint32_t>(kWTile)) return;  // no segment starts here: an earlier tile owns these keys
+  if (hi > static_cast<uint32_t>(kWSpan)) {          // the last segment runs past the window
+    if (tid == 0) __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  const uint32_t count = hi - lo;
+  const int low_bits = sizeof(KeyT) == 8 ? __ffsll(static_cast<long long>(top_mask)) - 1 : __ffs(static_cast<int>(top_mask)) - 1;
+  // does step j hold a key of the window in this wave?  (scalar: whole steps are skipped)
+#define WS_STEP_LIVE(j) (static_cast<uint32_t>((j) * kWThreads + wave * 64 + 64) > lo && static_cast<uint32_t>((j) * kWThreads + wave * 64) < hi)
+  KeyT key[kIters];
+  uint32_t idx[kIters];
 #pragma unroll
   for (int j = 0; j < kIters; ++j) {
-    const uint32_t li = j * kWThreads + tid;
-    key[j] = li < cand ? keys[p0 + li] : KeyT(0);
-    const uint32_t b0 = j * kWThreads + wave * 64;  // (wave-uniform: a scalar load)
-    front[j] = b0 < cand && p0 + b0 > 0 ? keys[p0 + b0 - 1] : KeyT(0);
+    key[j] = 0; idx[j] = 0;
+    if (WS_STEP_LIVE(j)) {
+      const uint32_t li = j * kWThreads + tid;
+      const int64_t at = p0 + (li < cand ? li : cand - 1);
+      key[j] = keys[at];
+      idx[j] = idx_in[at];
+    }
   }
   {
     uint4* z = reinterpret_cast<uint4*>(s_cnt);
     for (int i = tid; i < kWBuckets / 4; i += kWThreads) z[i] = make_uint4(0, 0, 0, 0);
   }
-  // segment heads: lo = first head inside the tile, hi = first head at or after the tile's end.  A head travels as ONE
-  // 64-bit word, position << 48 | the part of a key above the window's own digits (the host plans at least two digits
-  // for the window: that part has at most 48 bits) -- for lo the head's own key, for hi the key in FRONT of the head:
-  // the minimum over the workgroup (wave reduction, one word per wave, one barrier) names the window AND its first
-  // and last key, which is all the bucket pass needs to know about the window's key range.
-  const int low_bits = sizeof(KeyT) == 8 ? __ffsll(static_cast<long long>(top_mask)) - 1 : __ffs(static_cast<int>(top_mask)) - 1;
-  constexpr uint32_t kNone = kWSpan + 1;  // (a position no head can have; the input's end may sit at kWSpan itself)
-  constexpr unsigned long long kNoHead = static_cast<unsigned long long>(kNone) << 48;
-  unsigned long long plo = kNoHead, phi = kNoHead;
-#pragma unroll
-  for (int j = 0; j < kIters; ++j) {
-    const uint32_t li = j * kWThreads + tid;
-    const KeyT prev = KeyOfLaneBelow<KeyT>(key[j], front[j], lane);
-    const bool head = li < cand && ((p0 + li == 0) || ((prev ^ key[j]) & top_mask) != 0);
-    if (head) {  // (rare: most steps no lane gets here)
-      if (li < kWTile) {
-        const unsigned long long mine = static_cast<unsigned long long>(li) << 48 | static_cast<unsigned long long>(key[j]) >> low_bits;
-        plo = mine < plo ? mine : plo;
-      } else {
-        const unsigned long long ahead = static_cast<unsigned long long>(li) << 48 | static_cast<unsigned long long>(prev) >> low_bits;
-        phi = ahead < phi ? ahead : phi;
-      }
-    }
-  }
-  if (p0 + cand == n) {  // the input ends inside the window: its end is the last run's end
-#pragma unroll
-    for (int j = 0; j < kIters; ++j) {
-      const uint32_t li = j * kWThreads + tid;
-      if (li + 1 == cand) {
-        const unsigned long long end = static_cast<unsigned long long>(cand) << 48 | static_cast<unsigned long long>(key[j]) >> low_bits;
-        phi = end < phi ? end : phi;
-      }
-    }
-  }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    const unsigned long long ol = __shfl_xor(plo, d, 64), oh = __shfl_xor(phi, d, 64);
-    plo = ol < plo ? ol : plo;
-    phi = oh < phi ? oh : phi;
-  }
-  if (lane == 0) { s_heads[0][wave] = plo; s_heads[1][wave] = phi; }
   __syncthreads();
-#pragma unroll
-  for (int w = 0; w < kWWaves; ++w) {
-    const unsigned long long ol = s_heads[0][w], oh = s_heads[1][w];
-    plo = ol < plo ? ol : plo;
-    phi = oh < phi ? oh : phi;
-  }
   WPH(0);
-  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(plo >> 48));
-  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(phi >> 48));
-  if (lo == kNone) return;  // no segment starts here: an earlier tile owns these keys
-  if (hi == kNone) {        // the last segment runs past the window
-    if (tid == 0) __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
-  }
-  const uint32_t count = hi - lo;
-  // does step j hold a key of the window in this wave?  (scalar: whole steps are skipped)
-#define WS_STEP_LIVE(j) (static_cast<uint32_t>((j) * kWThreads + wave * 64 + 64) > lo && static_cast<uint32_t>((j) * kWThreads + wave * 64) < hi)
-  uint32_t idx[kIters];  // the window's row indices: on their way while the keys are ranked
-#pragma unroll
-  for (int j = 0; j < kIters; ++j) {
-    idx[j] = 0;
-    if (WS_STEP_LIVE(j)) {
-      const uint32_t li = j * kWThreads + tid;
-      idx[j] = idx_in[p0 + (li < cand ? li : cand - 1)];
-    }
-  }
 
   // ---- bucket pass: ONE counting pass instead of one LSD pass per varying digit ----------------------
   // bucket = (key - base) >> shift, monotone in the key: keys of different buckets are in order once every bucket knows
@@ -1829,6 +1802,7 @@ static int SortRawClassified(amdarrow_ctx* ctx, const std::vector<SortChunk>& hc
   const size_t lb_words = 256 * static_cast<size_t>(nb_max);  // per pass: a word per tile and digit
   const size_t o_lookback = cv.Take(4 * lb_words * 4);
   const size_t o_crowded = cv.Take(4 * static_cast<size_t>(nwin));
+  const size_t o_bounds = cv.Take(16 * static_cast<size_t>(nwin + 1));  // k_window_bounds
   void* base;
   AA_TRY(Scratch(ctx, cv.off, &base));
   char* b = static_cast<char*>(base);
@@ -1929,7 +1903,9 @@ static int SortRawClassified(amdarrow_ctx* ctx, const std::vector<SortChunk>& hc
   std::reverse(wd.shift, wd.shift + wd.n);
   const unsigned nw = static_cast<unsigned>((n0 + kWTile - 1) / kWTile);
   AA_HIP(hipMemsetAsync(crowded, 0, 4 * static_cast<size_t>(nw), ctx->stream));
-  hipLaunchKernelGGL((k_window_sort<KeyT>), dim3(nw), dim3(kWThreads), 0, ctx->stream, keys_a, idx_a, n0, top_mask, ctl + 14, crowded, out);
+  auto* wbounds = reinterpret_cast<ulonglong2*>(b + o_bounds);
+  hipLaunchKernelGGL((k_window_bounds<KeyT>), dim3((nw + 1 + 255) / 256), dim3(256), 0, ctx->stream, keys_a, n0, top_mask, int64_t(nw), wbounds);
+  hipLaunchKernelGGL((k_window_sort<KeyT>), dim3(nw), dim3(kWThreads), 0, ctx->stream, keys_a, idx_a, n0, top_mask, ctl + 14, crowded, out, wbounds);
   AA_HIP(hipGetLastError());
   unsigned int err[4] = {0, 0, 0, 0};
   AA_TRY(ReadBack(ctx, ctl + 14, 16, err));
@@ -1995,6 +1971,7 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
   const size_t o_ctl = cv.Take(256);  // [13] duplicate-sample flag, [14] error word of the window sort, [15] of the one-sweep passes
   const size_t lb_words = static_cast<size_t>(hist_n);  // per pass: a word per tile and digit
   const size_t o_lookback = cv.Take(4 * lb_words * kPasses);
+  const size_t o_bounds = cv.Take(16 * static_cast<size_t>((n + kWTile - 1) / kWTile + 1));  // k_window_bounds
   void* base;
   AA_TRY(Scratch(ctx, cv.off, &base));
   char* b = static_cast<char*>(base);
@@ -2266,7 +2243,9 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
     const unsigned nwin = static_cast<unsigned>((n0 + kWTile - 1) / kWTile);
     auto* crowded = reinterpret_cast<unsigned int*>(bhist);  // (the three-kernel passes' block histograms: unused on this path, 256 words per 4096 keys)
     AA_HIP(hipMemsetAsync(crowded, 0, 4 * static_cast<size_t>(nwin), ctx->stream));
-    hipLaunchKernelGGL((k_window_sort<KeyT>), dim3(nwin), dim3(kWThreads), 0, ctx->stream, keys_a, idx_a, n0, top_mask, ctl + 14, crowded, out);
+    auto* wbounds = reinterpret_cast<ulonglong2*>(b + o_bounds);
+    hipLaunchKernelGGL((k_window_bounds<KeyT>), dim3((nwin + 1 + 255) / 256), dim3(256), 0, ctx->stream, keys_a, n0, top_mask, int64_t(nwin), wbounds);
+    hipLaunchKernelGGL((k_window_sort<KeyT>), dim3(nwin), dim3(kWThreads), 0, ctx->stream, keys_a, idx_a, n0, top_mask, ctl + 14, crowded, out, wbounds);
     AA_HIP(hipGetLastError());
     window_keys = keys_a; window_idx = idx_a; window_n = nwin;
   }
