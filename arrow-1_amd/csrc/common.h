@@ -61,6 +61,7 @@ struct amdarrow_ctx {
     // through), and how many calls stay on 16-byte records once it reached four (interleaved data sets of one shape
     // would otherwise pay for two attempts every other call)
     int compact_misses = 0, compact_off = 0;
+    int no_bins = 0;  // calls of this shape that stay off the bin scatters (their bins overflowed: clustered keys), see FilterGroupByImpl
     uint64_t last_used = 0;
   };
   int gb_caller = 0;  // set by the entry point around FilterGroupByImpl (under `mu`)

@@ -180,10 +180,18 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
   // then reads the first bytes of the key buffer where it would read values, and marks no record as carrying one)
   const bool bins_shape = ks.total_bits == 32 && (k_load_bits == 32 || k_load_bits == 64) && !keys->validity && !m_valid &&
                           (values ? BitWidth(values->type_id) == 64 : (!mask && n >= 64));
-  const bool use_bins = bins_shape && !getenv("AMDARROW_GROUPBY_NO_BINS") &&
+  bool use_bins = bins_shape && !getenv("AMDARROW_GROUPBY_NO_BINS") &&
                         (reinterpret_cast<uintptr_t>(keys->values) + (k_load_bits / 8) * static_cast<uintptr_t>(keys->offset)) % 16 == 0 &&
                         (values ? (reinterpret_cast<uintptr_t>(values->values) + 8 * static_cast<uintptr_t>(values->offset)) % 16 == 0
                                 : reinterpret_cast<uintptr_t>(keys->values) % 16 == 0);
+  // Clustered keys (sorted input, time-ordered ids: a tile's 4096 rows hold a few dozen keys) defeat the bins -- a tile's
+  // records meet in a few of the 512 bins, dozens each where a bin takes sixteen, and the records that find their bin full
+  // overflow the room at the region tops --: an attempt that ends that way is repeated with the staged scatter, which ranks a
+  // tile's records by partition whatever their spread, and the shape's hint keeps the next calls off the bins for a while.
+  bool bins_overflowed = false;
+  const int no_bins_before = shape_known ? hint.no_bins : 0;
+  const bool bins_off_by_hint = use_bins && no_bins_before > 0;
+  if (bins_off_by_hint) use_bins = false;
   // (key_lo / key_hi: the selected keys' range in the scatter's key order plus the bias; narrow: the selected values were all int32)
   auto plan_compact = [&](uint64_t key_lo, uint64_t key_hi, bool narrow) -> bool {
     if (!(use_bins && compact_allowed && key_lo <= key_hi && key_lo >= k_bias && key_hi - k_bias <= 0xFFFFFFFFull) ||
@@ -536,6 +544,10 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
 #endif
     memcpy(&G, status + 6, 8);
     const unsigned int overflow = status[0];
+    if (getenv("AMDARROW_GROUPBY_TRACE"))  // (diagnostics: one line per attempt of a call)
+      fprintf(stderr, "group-by attempt: path %d sub_bits %d hinted %d guessed %d compact %d(%d words) hot_compact %d local_only %d -> overflow %u gave_up %u hot %u groups %lld key range [%u, %u]\n",
+              path, sub_bits, int(hinted), int(guessed), int(compact), compact_rw, int(hot_compact), int(local_only), overflow, status[1], status[5],
+              static_cast<long long>(G), status[8], status[9]);
     if (local_only && path == 3 && status[1] != 0) {  // the pre-aggregation gave up after all: everything, from the start
       local_only = false;
       hint.n = -1;
@@ -565,6 +577,13 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
       hinted = false;
       hint.n = -1;
       path = 4;  // -> 3 after the loop's decrement
+      continue;
+    }
+    if ((overflow & kOverflowRegion) && fast && path >= 2 && use_bins) {  // clustered keys? the same path once more, on the staged scatter
+      use_bins = false;
+      bins_overflowed = true;
+      hot_compact = false;
+      path += 1;  // (the loop's decrement brings it back)
       continue;
     }
     if (overflow && fast) {  // capacity assumption failed: next (more general) path
@@ -615,6 +634,9 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
     if (hinted && use_bins && hint.n == shape.n && status[8] <= status[9]) {
       if (!compact) { hint.stats = 1; hint.key_lo = status[8] + k_bias; hint.key_hi = status[9] + k_bias; hint.k_bias = k_bias; }
       if (fa_val_wide && !(compact && compact_rw == 2)) hint.values_narrow = status[10] == 0 ? 1 : 0;
+    }
+    if (hint.n == shape.n) {  // (how long the shape stays off the bins: sixteen calls after an overflow, then the bins get another try)
+      hint.no_bins = bins_overflowed ? 16 : bins_off_by_hint ? no_bins_before - 1 : no_bins_before;
     }
     if (hint.n == shape.n) {  // the back-off state stays with the shape; a compact call that went through ends a run of misses
       hint.compact_misses = compact && carry_misses > 0 ? carry_misses - 1 : carry_misses;

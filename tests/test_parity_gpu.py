@@ -415,6 +415,36 @@ def test_full_size_groupby_compact_records_exact(full, shape, monkeypatch):
         assert torch.equal(first, exp_first[k]) and bool((first[1:] > first[:-1]).all()), (shape, step)
 
 
+def test_full_size_groupby_sorted_keys(full):
+    """100 M rows whose keys are SORTED (1 M groups, a hundred rows each): a tile's records meet in a few dozen bins, the
+    bin scatters' attempt overflows and is repeated with the staged scatter; the next calls of the shape start there
+    (1.2 ms -- the overflowing attempts used to end on the exact two-pass path, 45-75 ms).  Sums, counts and first rows
+    against torch's scatter reductions."""
+    import torch
+    import gpu_api
+    from arrow1_amd import compute, device
+    gpu = gpu_api.GpuApi()
+    keys = torch.sort(full["keys"])[0].contiguous()
+    keys_arr = device.DeviceArray(orc.INT32, keys.view(torch.uint8), None, N_FULL)
+    vals, sel = full["vals"], _bits(full["mask"], N_FULL)
+    ok = sel & _bits(full["valid"], N_FULL)
+    rows = torch.arange(N_FULL, device="cuda")
+    exp_sum = torch.zeros(1_000_000, dtype=torch.int64, device="cuda").index_add_(0, keys[ok].long(), vals[ok])
+    exp_cnt = torch.zeros(1_000_000, dtype=torch.int64, device="cuda").index_add_(0, keys[ok].long(), torch.ones_like(vals[ok]))
+    exp_first = torch.full((1_000_000,), N_FULL, dtype=torch.int64, device="cuda").scatter_reduce_(0, keys[sel].long(), rows[sel], "amin")
+    present = exp_first < N_FULL
+    for step in range(3):
+        r = compute.filter_groupby(gpu.ctx, full["values"], keys_arr, full["mask_arr"], group_capacity=1 << 21)
+        G = r.num_groups
+        assert G == int(present.sum())
+        assert _last_groupby_path(gpu) == (2, 4), step  # the one-pass partition path on the staged scatter's 16-byte records
+        k = r.keys[:G * 4].view(torch.int32).long()
+        assert torch.equal(r.sums[:G * 8].view(torch.int64), exp_sum[k]), step
+        assert torch.equal(r.counts[:G * 8].view(torch.int64), exp_cnt[k]), step
+        first = r.first_rows[:G * 4].view(torch.int32).to(torch.int64)
+        assert torch.equal(first, exp_first[k]) and bool((first[1:] > first[:-1]).all()), step
+
+
 def test_full_size_sort_is_sorted_stable_permutation(gpu, full):
     import torch
     from arrow1_amd import compute, device
@@ -1558,6 +1588,25 @@ def test_filter_groupby_compact_records(gpu, oracle, shape, monkeypatch):
             else:
                 assert np.array_equal(x, y), (shape, step, kind)
         assert _last_groupby_path(gpu) == (2, want_words), (shape, step, kind)
+
+
+def test_filter_groupby_clustered_keys_leave_the_bins(oracle, monkeypatch):
+    """Sorted keys, a hundred rows each: a 4096-row tile holds forty keys, so its records meet in forty of the 512 bins,
+    fifty each where a bin takes sixteen, and the room at the region tops overflows -- the attempt is repeated with the
+    staged scatter (same path), and the shape's hint keeps the next calls off the bins.  The partition path is forced
+    (the per-workgroup pre-aggregation would hold these few keys per row range at this size)."""
+    import gpu_api
+    monkeypatch.setenv("AMDARROW_GROUPBY_PATH", "2")
+    gpu = gpu_api.GpuApi()
+    rng = np.random.default_rng(0x0ff1ce + 123)
+    n = 3_000_000
+    keys = np.sort(rng.integers(0, 30_000, n)).astype(np.int32)
+    v, k, m = R(rng, INT64, n, 0.02, 0), Arr(INT32, keys), R(rng, BOOL, n, 0.0, 0)
+    for step in range(3):
+        _check_groupby(oracle, gpu, v, k, m, step)
+        # (at this size the staged scatter's regions -- sized for keys that spread -- may overflow as well, and the exact
+        # two-pass path takes the call; test_full_size_groupby_sorted_keys runs the shape where the staged scatter holds)
+        assert _last_groupby_path(gpu) in ((2, 4), (1, 4)), step
 
 
 @pytest.mark.parametrize("case", ["far-keys", "wide-value", "hot+wide-value", "hot+far-keys"])
