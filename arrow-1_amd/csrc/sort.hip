@@ -246,6 +246,36 @@ __global__ __launch_bounds__(kThreads) void k_sort_count_all_sortable(const Sort
   counts[2 * ntiles + tile] = 0;
 }
 
+// One more key for bucket `d` of an LDS histogram -- for every lane of the wave for which `active` holds.  The lanes
+// that agree with the wave's first active lane are counted with ONE atomic when there are many of them: 64 lanes adding
+// to one LDS word are served one after the other, and that is what the high digits of small integers, of sorted or of
+// clustered keys are -- the same value in every lane (k_sort_hist took 2.1 ms instead of 0.16 for int64 values in
+// [0, 1000], the counting phase of a one-sweep pass 0.69 ms instead of 0.50 for sorted keys).  Returns, where the
+// caller ranks with the atomic's return value (RANK), the number of keys of bucket d counted before this one: the
+// agreeing lanes are numbered in lane order behind their common base, which is the order the ranks have to have.
+template <bool RANK>
+__device__ __forceinline__ uint32_t WaveHistAdd(uint32_t* h, uint32_t d, bool active) {
+  const uint64_t act = __ballot(active);
+  uint32_t rank = 0;
+  if (act == 0) return rank;  // (wave-uniform)
+  const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(d), __builtin_ctzll(act)));
+  const bool same = active && d == first;
+  const uint64_t m = __ballot(same);
+  const uint32_t agree = static_cast<uint32_t>(__popcll(m));
+  if (agree >= 16) {  // (wave-uniform)
+    uint32_t base = 0;
+    if (LaneId() == __builtin_ctzll(m)) base = atomicAdd(&h[first], agree);
+    if (RANK) {
+      base = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(base), __builtin_ctzll(m)));
+      if (same) rank = base + static_cast<uint32_t>(RankBelowLane(m));
+    }
+    if (active && !same) rank = atomicAdd(&h[d], 1u);
+  } else if (active) {
+    rank = atomicAdd(&h[d], 1u);
+  }
+  return rank;
+}
+
 // The digit histograms of a column without nulls or NaNs, straight from its values: what k_sort_partition builds on
 // the way, without its copy of the keys and indices -- the first radix pass then reads the column itself (RAW in
 // k_radix_onesweep) and numbers the rows as it goes.
@@ -277,10 +307,27 @@ __global__ __launch_bounds__(kThreads) void k_sort_hist(const void* values, int6
     for (int j = 0; j < kIters; ++j) key[j] = (key[j] ^ flip) & key_mask;  // (flip: sign bit and order, see the caller)
 #pragma unroll
     for (int j = 0; j < kIters; ++j) {
-      if (!in[j]) continue;
-      k_or |= key[j]; k_and &= key[j];
+      if (in[j]) { k_or |= key[j]; k_and &= key[j]; }
+      if (tile + 1 < ntiles) {  // a whole tile (wave-uniform): every lane holds a key
+        // Where most lanes of the wave hold the same digit value -- the high digits of small integers, of sorted or of
+        // clustered keys: all 64 -- they are counted with ONE atomic: 64 lanes adding to one LDS word are served one
+        // after the other (int64 values in [0, 1000]: 2.1 ms for this kernel instead of 0.16).
 #pragma unroll
-      for (int q = kFirst; q < kPasses; ++q) atomicAdd(&s_h[q * 256 + ((key[j] >> (8 * q)) & 255)], 1u);
+        for (int q = kFirst; q < kPasses; ++q) {
+          const uint32_t d = static_cast<uint32_t>((key[j] >> (8 * q)) & 255);
+          const uint32_t f = __builtin_amdgcn_readfirstlane(d);
+          const uint64_t m = __ballot(d == f);
+          if (__popcll(m) >= 32) {  // (wave-uniform)
+            if (LaneId() == 0) atomicAdd(&s_h[q * 256 + f], static_cast<unsigned int>(__popcll(m)));
+            if (d != f) atomicAdd(&s_h[q * 256 + d], 1u);
+          } else {
+            atomicAdd(&s_h[q * 256 + d], 1u);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = kFirst; q < kPasses; ++q) WaveHistAdd<false>(&s_h[q * 256], static_cast<uint32_t>((key[j] >> (8 * q)) & 255), in[j]);
+      }
     }
   }
 #pragma unroll
@@ -444,9 +491,8 @@ __global__ __launch_bounds__(kThreads) void k_hist_shifts(const KeyT* keys, int6
     }
 #pragma unroll
     for (int j = 0; j < kIters; ++j) {
-      if (!in[j]) continue;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) if (q < hs.n) atomicAdd(&s_h[q * 256 + ((key[j] >> hs.shift[q]) & 255)], 1u);
+      for (int q = 0; q < 4; ++q) if (q < hs.n) WaveHistAdd<false>(&s_h[q * 256], static_cast<uint32_t>((key[j] >> hs.shift[q]) & 255), in[j]);
     }
   }
   __syncthreads();
@@ -562,13 +608,13 @@ __global__ __launch_bounds__(kThreads) void k_sort_partition(const SortChunk* ch
         const int64_t p = base[0] + RankBelowLane(m0);
         keys[p] = key[j];
         idx[p] = static_cast<uint32_t>(gidx);
-#pragma unroll
-        for (int q = 0; q < kPasses; ++q) atomicAdd(&s_h[q * 256 + ((key[j] >> (8 * q)) & 255)], 1u);
       } else if (cls[j] == 1) {
         out_indices[base[1] + RankBelowLane(m1)] = gidx;
       } else if (cls[j] == 2) {
         out_indices[base[2] + RankBelowLane(m2)] = gidx;
       }
+#pragma unroll
+      for (int q = 0; q < kPasses; ++q) WaveHistAdd<false>(&s_h[q * 256], static_cast<uint32_t>((key[j] >> (8 * q)) & 255), cls[j] == 0);
       base[0] += __popcll(m0); base[1] += __popcll(m1); base[2] += __popcll(m2);
     }
     __syncthreads();
@@ -892,6 +938,8 @@ __global__ __launch_bounds__(kOThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
   uint32_t rk[ARANK ? kIters : 1];
 #pragma unroll
   for (int j = 0; j < kIters; ++j) {
+    // (one atomic per lane also where most lanes agree -- sorted input: 0.69 ms per pass instead of 0.50 --: the wave-wide
+    // variant, WaveHistAdd<true>, cost this kernel its registers and every input 0.1 ms per pass)
     if ((alive >> j) & 1u) {
       const uint32_t r = atomicAdd(&s_whist[wave][(key[j] >> shift) & 255], 1u);
       if (ARANK) rk[ARANK ? j : 0] = r;
