@@ -189,7 +189,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
   // overflow the room at the region tops --: an attempt that ends that way is repeated with the staged scatter, which ranks a
   // tile's records by partition whatever their spread, and the shape's hint keeps the next calls off the bins for a while.
   bool bins_overflowed = false;
-  const int no_bins_before = shape_known ? hint.no_bins : 0;
+  const int no_bins_before = shape_known ? hint.no_bins : 0, no_bins_next_before = shape_known ? hint.no_bins_next : 16;
   const bool bins_off_by_hint = use_bins && no_bins_before > 0;
   if (bins_off_by_hint) use_bins = false;
   // (key_lo / key_hi: the selected keys' range in the scatter's key order plus the bias; narrow: the selected values were all int32)
@@ -635,8 +635,18 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
       if (!compact) { hint.stats = 1; hint.key_lo = status[8] + k_bias; hint.key_hi = status[9] + k_bias; hint.k_bias = k_bias; }
       if (fa_val_wide && !(compact && compact_rw == 2)) hint.values_narrow = status[10] == 0 ? 1 : 0;
     }
-    if (hint.n == shape.n) {  // (how long the shape stays off the bins: sixteen calls after an overflow, then the bins get another try)
-      hint.no_bins = bins_overflowed ? 16 : bins_off_by_hint ? no_bins_before - 1 : no_bins_before;
+    if (hint.n == shape.n) {  // (how long the shape stays off the bins: sixteen calls after an overflow, twice as many after the next, ...; then the bins get another try)
+      const int next_before = shape_known ? no_bins_next_before : 16;
+      if (bins_overflowed) {
+        hint.no_bins = next_before;
+        hint.no_bins_next = next_before < 1024 ? 2 * next_before : 1024;
+      } else if (bins_off_by_hint) {
+        hint.no_bins = no_bins_before - 1;
+        hint.no_bins_next = next_before;
+      } else {
+        hint.no_bins = no_bins_before;
+        hint.no_bins_next = use_bins ? 16 : next_before;  // (the bins held this call)
+      }
     }
     if (hint.n == shape.n) {  // the back-off state stays with the shape; a compact call that went through ends a run of misses
       hint.compact_misses = compact && carry_misses > 0 ? carry_misses - 1 : carry_misses;

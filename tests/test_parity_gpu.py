@@ -1602,8 +1602,10 @@ def test_filter_groupby_clustered_keys_leave_the_bins(oracle, monkeypatch):
     n = 3_000_000
     keys = np.sort(rng.integers(0, 30_000, n)).astype(np.int32)
     v, k, m = R(rng, INT64, n, 0.02, 0), Arr(INT32, keys), R(rng, BOOL, n, 0.0, 0)
-    for step in range(3):
-        _check_groupby(oracle, gpu, v, k, m, step)
+    want = oracle.filter_groupby_sum(v, k, m)
+    for step in range(20):  # (past the sixteen calls the shape's hint stays off the bins: they get another try, and overflow again)
+        for x, y in zip(want, gpu.filter_groupby_sum(v, k, m)):
+            assert np.array_equal(x, y), step
         # (at this size the staged scatter's regions -- sized for keys that spread -- may overflow as well, and the exact
         # two-pass path takes the call; test_full_size_groupby_sorted_keys runs the shape where the staged scatter holds)
         assert _last_groupby_path(gpu) in ((2, 4), (1, 4)), step
