@@ -406,7 +406,22 @@ struct TakeArgs {
   void* out_values; uint8_t* out_validity;
   unsigned long long* valid_count;  // device, slotted counters (common.h), counter 0
   unsigned long long* err_pos;      // device, initialised to ~0
+  const uint8_t* v_summary;         // nullable: bit B set = byte (v_off >> 3) + B of v_valid is 0xFF (k_validity_summary)
 };
+
+// One bit per validity BYTE: is it 0xFF?  A uniformly random take is bound by the number of lines it asks the fabric
+// for, not by bytes (100 M rows: 50 M value gathers 1.0 ms; the same plus 50 M validity-byte gathers 1.72 ms -- the
+// 12.5 MB bitmap does not fit an XCD's L2).  The summary of the same bitmap is 1.5 MB and does: a row whose
+// validity byte is full (92 % of them at 1 % nulls) is served from L2 and only the rest ask for the byte itself.
+__global__ __launch_bounds__(kThreads) void k_validity_summary(const uint8_t* valid, int64_t nbytes, uint8_t* summary) {
+  const int64_t s = int64_t(blockIdx.x) * kThreads + threadIdx.x;  // summary byte s <- validity bytes [8 s, 8 s + 8)
+  if (8 * s >= nbytes) return;
+  uint32_t m = 0;
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+    if (8 * s + b < nbytes && valid[8 * s + b] == 0xFFu) m |= 1u << b;
+  summary[s] = static_cast<uint8_t>(m);
+}
 
 template <typename IdxT> struct IndexLoad {
   __device__ static bool Load(const void* p, int64_t k, int64_t upper, int64_t* out) {
@@ -469,14 +484,25 @@ __global__ __launch_bounds__(kThreads) void k_take(TakeArgs a) {
     T v[kU];
     uint32_t vvb[kU], bvb[kU];
     const bool need_vbits = a.v_may_null && have_values;
+    const bool summarised = need_vbits && a.v_summary != nullptr;
 #pragma unroll
     for (int u = 0; u < kU; ++u) {  // gathers, all in flight together
       // values' validity is consulted only when values.null_count != 0 (:306, :338)
-      vvb[u] = need_vbits ? a.v_valid[(a.v_off + j[u]) >> 3] : 0xFFu;
+      if (summarised) vvb[u] = a.v_summary[(((a.v_off + j[u]) >> 3) - (a.v_off >> 3)) >> 3];
+      else vvb[u] = need_vbits ? a.v_valid[(a.v_off + j[u]) >> 3] : 0xFFu;
       v[u] = 0; bvb[u] = 0;
       if (have_values) {
         if (kBits) bvb[u] = reinterpret_cast<const uint8_t*>(a.v_data)[(a.v_off + j[u]) >> 3];
         else v[u] = reinterpret_cast<const T*>(a.v_data)[a.v_off + j[u]];
+      }
+    }
+    if (summarised) {  // (wave-uniform) the validity byte itself only where the summary does not call it full
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int64_t vbyte = (a.v_off + j[u]) >> 3;
+        const bool full = (vvb[u] >> ((vbyte - (a.v_off >> 3)) & 7)) & 1u;
+        vvb[u] = 0xFFu;
+        if (!full) vvb[u] = a.v_valid[vbyte];
       }
     }
 #pragma unroll
@@ -906,15 +932,29 @@ int amdarrow_take(amdarrow_ctx* ctx, const amdarrow_array* values, const amdarro
   if (!out_validity || !out_values) return SetError(AMDARROW_INVALID, "take: output buffers required");
 
   std::lock_guard<std::mutex> lock(ctx->mu);
+  // The summary of the values' validity (k_validity_summary) pays where the bitmap is larger than an XCD's L2, the take is
+  // long enough to repay a pass over the bitmap, and most validity bytes are full.
+  const int64_t v_nulls = ArgNullCount(values);
+  const int64_t v_first_byte = values->offset >> 3;
+  const int64_t v_nbytes = ((values->offset + values->length + 7) >> 3) - v_first_byte;
+  const bool summarise = v_nulls != 0 && values->length > 0 && v_nbytes > (int64_t(2) << 20) && indices->length >= (int64_t(1) << 20) &&
+                         (v_nulls < 0 || v_nulls * 16 <= values->length) && !getenv("AMDARROW_TAKE_NO_SUMMARY");
+  const int64_t summary_bytes = summarise ? (v_nbytes + 7) / 8 : 0;
   void* base;
-  AA_TRY(Scratch(ctx, kCounterBytes + 256, &base));
+  AA_TRY(Scratch(ctx, kCounterBytes + 256 + summary_bytes, &base));
   auto* counters = static_cast<unsigned long long*>(base);                    // valid rows, slotted
   auto* err_pos = counters + kCounterSlots * kCounterStride;                  // first out-of-bounds position (atomicMin: rare)
   AA_TRY(ClearCounters(ctx, counters));
   AA_HIP(hipMemsetAsync(err_pos, 0xFF, 8, ctx->stream));
   TakeArgs a{};
   a.v_data = values->values; a.v_valid = values->validity; a.v_off = values->offset; a.v_len = values->length;
-  a.v_may_null = ArgNullCount(values) != 0;
+  a.v_may_null = v_nulls != 0;
+  if (summarise) {
+    auto* summary = reinterpret_cast<uint8_t*>(base) + kCounterBytes + 256;
+    hipLaunchKernelGGL(k_validity_summary, dim3(static_cast<unsigned>((summary_bytes + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       ctx->stream, values->validity + v_first_byte, v_nbytes, summary);
+    a.v_summary = summary;
+  }
   a.i_data = indices->values; a.i_valid = indices->validity; a.i_off = indices->offset; a.n = indices->length;
   a.boundscheck = boundscheck;
   a.out_values = out_values; a.out_validity = out_validity;

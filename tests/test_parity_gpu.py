@@ -110,6 +110,30 @@ def test_take_random(gpu, oracle, t):
                 assert gpu.take(v, i).same(oracle.take(v, i)), (t, it, vnp, inp)
 
 
+def test_take_random_large_validity_summary(gpu, oracle, monkeypatch):
+    """A long random Take from a column whose validity bitmap is larger than an XCD's L2 consults a summary of the
+    bitmap first (one bit per validity byte: is it 0xFF?) and the byte itself only where that bit is clear: sliced
+    values (the summary is built over bytes, the slice starts mid-byte), null indices, runs of nulls and dense nulls
+    at the edges; the same call without the summary."""
+    rng = np.random.default_rng(77)
+    nv = 20_000_000
+    v = R(rng, INT64, nv, 0.03, 5, lo=-2**60, hi=2**60)
+    off = v.offset
+    valid = v.valid.copy()
+    valid[off:off + 4096] = False                        # a run of nulls at the slice's start
+    valid[off + nv - 70:off + nv] = False                # and at its end (the last, partial byte)
+    valid[off + 1_000_000:off + 1_000_064] = True
+    v = Arr(INT64, v.data, valid, off, nv, -1)
+    i = R(rng, UINT32, (1 << 20) + 77, 0.01, 3, lo=0, hi=nv - 1)
+    i.data[i.offset:i.offset + 3000] = np.arange(3000)   # the null run
+    i.data[i.offset + 3000:i.offset + 3070] = nv - 1 - np.arange(70)
+    i = Arr(UINT32, i.data, i.valid, i.offset, i.length)
+    want = oracle.take(v, i)
+    assert gpu.take(v, i).same(want)
+    monkeypatch.setenv("AMDARROW_TAKE_NO_SUMMARY", "1")
+    assert gpu.take(v, i).same(want)
+
+
 def test_take_bounds_errors(gpu, oracle):
     v = Arr(INT32, np.arange(10))
     for it, val in [(INT8, -1), (INT64, 10), (UINT64, 10), (INT16, 11), (UINT8, 200)]:
