@@ -34,6 +34,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 SEED = 0x0ff1ce         # kRandomSeed, compute/kernels/test_util.h:123
 
 VALUE_RANGE = "small"
+VALUE_RANGE_GIVEN = False
 NUM_GROUPS = 1_000_000  # --groups
 NUM_CHUNKS = 1  # --chunks (sort workloads)
 HOT_FRAC = 0.0  # --hot-frac (headline workload: this share of the rows carries ONE key)
@@ -129,7 +130,10 @@ def make_inputs(workload, n, dev, rank, sel):
         d["_keep"] = (off, data)
         d["_mean_len"] = total / n
     elif workload == "sort_2key":
-        vals = torch.randint(-2**62, 2**62, (n,), dtype=torch.int64, device=dev, generator=gen)
+        if VALUE_RANGE_GIVEN and VALUE_RANGE == "small":  # (--value-range small: the two keys fit one word together, the composite-key sort)
+            vals = torch.randint(-100, 101, (n,), dtype=torch.int64, device=dev, generator=gen)
+        else:
+            vals = torch.randint(-2**62, 2**62, (n,), dtype=torch.int64, device=dev, generator=gen)
         keys = torch.randint(0, NUM_GROUPS, (n,), dtype=torch.int32, device=dev, generator=gen)
         d["values"] = device.DeviceArray(_abi.INT64, vals.view(torch.uint8), device_bitmap(n, 0.99, gen, dev), n, 0, -1)
         d["keys"] = device.DeviceArray(_abi.INT32, keys.view(torch.uint8), None, n)
@@ -492,13 +496,15 @@ def main():
     ap.add_argument("--key-bits", type=int, default=32, choices=[32, 64], help="headline workload: width of the key column")
     ap.add_argument("--wide-keys", action="store_true", help="distinct keys spread over the whole range of the key type (64-bit: the wide-key path; 32-bit: hashed partition tables)")
     ap.add_argument("--chunks", type=int, default=1, help="sort workloads: present the rows as this many equal chunks")
-    ap.add_argument("--value-range", default="small", choices=["small", "full"],
-                    help="headline workload: int64 values uniform in [-100, 100] (SURVEY 8d) or over the whole 64-bit range")
+    ap.add_argument("--value-range", default=None, choices=["small", "full"],
+                    help="headline workload: int64 values uniform in [-100, 100] (SURVEY 8d; the default) or over the whole 64-bit range; "
+                         "sort_2key: 'small' makes the two keys fit one 64-bit word together (default: values over 63 bits)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the cold / wide-value legs and the H2D / D2H line (profiling runs)")
     args = ap.parse_args()
-    global NUM_GROUPS, NUM_CHUNKS, KEY_BITS, HOT_FRAC, WIDE_KEYS, VALUE_RANGE
-    VALUE_RANGE = args.value_range
+    global NUM_GROUPS, NUM_CHUNKS, KEY_BITS, HOT_FRAC, WIDE_KEYS, VALUE_RANGE, VALUE_RANGE_GIVEN
+    VALUE_RANGE_GIVEN = args.value_range is not None
+    VALUE_RANGE = args.value_range or "small"
     WIDE_KEYS = args.wide_keys
     HOT_FRAC = args.hot_frac
     KEY_BITS = args.key_bits

@@ -881,6 +881,57 @@ def test_sort_indices_multi_key_random(gpu, oracle, nkeys):
 
 
 @pytest.mark.gpu
+def test_sort_indices_multi_key_composite(gpu, oracle, monkeypatch):
+    """Integer key columns whose ranges fit one 64-bit word together sort as ONE composite key (field = value - min or
+    max - value, nulls behind the largest value): 2-4 keys of every integer width, both orders, nulls, chunked tables
+    with unaligned boundaries, a constant and an all-null column, fields that fill 32 / 64 bits exactly and one bit
+    more (the key-by-key sort takes over), against the oracle; and the same calls key by key."""
+    rng = np.random.default_rng(901)
+    ints = [INT8, orc.UINT8, orc.INT16, UINT16, INT32, orc.UINT32, INT64, orc.UINT64]
+
+    def check(keys, orders, tag):
+        want = oracle.sort_indices_multi(keys, orders)
+        assert np.array_equal(gpu.sort_indices_multi(keys, orders), want), tag
+        monkeypatch.setenv("AMDARROW_SORT_NO_COMPOSITE", "1")
+        assert np.array_equal(gpu.sort_indices_multi(keys, orders), want), (tag, "key by key")
+        monkeypatch.delenv("AMDARROW_SORT_NO_COMPOSITE")
+
+    for n in (1, 257, 60_000):
+        for trial in range(6):
+            nk = int(rng.integers(2, 5))
+            ts = [ints[int(rng.integers(0, len(ints)))] for _ in range(nk)]
+            orders = [int(rng.integers(0, 2)) for _ in range(nk)]
+            spans = [int(rng.choice([1, 3, 40, 1000])) for _ in range(nk)]
+            lows = [0 if t in (orc.UINT8, UINT16, orc.UINT32, orc.UINT64) else -int(rng.integers(0, 50)) for t in ts]
+            p = float(rng.choice([0, .1, .5]))
+            keys = [R(rng, t, n, p, k % 4, lo=lo, hi=lo + sp) for k, (t, lo, sp) in enumerate(zip(ts, lows, spans))]
+            check(keys, orders, (n, trial, ts, "batch"))
+            lay = [[n], [n // 3, 0, n - n // 3], [1, n - 1] if n > 1 else [1], [n - n // 2, n // 2]]
+            tab = [[R(rng, t, m, p, (k + j) % 3, lo=lo, hi=lo + sp) for j, m in enumerate(lay[(k + trial) % 4])]
+                   for k, (t, lo, sp) in enumerate(zip(ts, lows, spans))]
+            check(tab, orders, (n, trial, ts, "table"))
+    n = 50_000
+    full32 = Arr(orc.UINT32, rng.integers(0, 2**32, n, dtype=np.uint64))
+    full32.data[:2] = [0, 2**32 - 1]
+    full32 = Arr(orc.UINT32, full32.data)
+    coarse = R(rng, INT32, n, 0, 1, lo=-2, hi=1)
+    i32 = Arr(INT32, np.concatenate([[-2**31, 2**31 - 1], rng.integers(-2**31, 2**31, n - 2)]))
+    i64 = Arr(INT64, np.concatenate([[-2**63, 2**63 - 1], rng.integers(-2**63, 2**63, n - 2)]))
+    few = Arr(orc.UINT8, rng.integers(0, 3, n))
+    const = Arr(INT64, np.full(n, -7))
+    nulls = Arr(INT32, np.zeros(n, np.int32), np.zeros(n, bool))
+    with_null = R(rng, orc.UINT32, n, .05, 3, lo=0, hi=2**32 - 1)
+    with_null.data[with_null.offset:with_null.offset + 2] = [0, 2**32 - 1]
+    with_null.valid[with_null.offset:with_null.offset + 2] = True
+    with_null = Arr(orc.UINT32, with_null.data, with_null.valid, with_null.offset, n)
+    for keys, tag in [([coarse, full32], "2 + 32 bits"), ([few, coarse, const, nulls], "constant and all-null columns"),
+                      ([full32, i32], "32 + 32 bits"), ([i32, with_null], "32 + 33 bits: key by key"),
+                      ([few, i64], "2 + 64 bits: key by key"), ([const, i64], "0 + 64 bits"), ([nulls, few], "all-null first key")]:
+        for orders in ([ASC] * len(keys), [DESC] * len(keys), [DESC, ASC] * (len(keys) // 2) + [DESC] * (len(keys) % 2)):
+            check(keys, orders, (tag, orders))
+
+
+@pytest.mark.gpu
 def test_sort_indices_multi_key_errors(gpu, oracle):
     a, b = Arr(INT32, [1, 2, 3]), Arr(INT32, [1, 2])
     for api in (oracle, gpu):
