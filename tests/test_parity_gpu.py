@@ -1178,6 +1178,37 @@ def test_binary_take_and_filter_random(gpu, oracle):
 
 
 @pytest.mark.gpu
+def test_binary_take_staged_copy(gpu, oracle, monkeypatch):
+    """The bytes of a Filter / Take of strings move through LDS when a step's rows (4 runs of 64 output rows) come from
+    a narrow source range: dense and sparse selections (all four runs at once, halves, single runs, none), locally
+    shuffled and repeated indices, rows longer than the staged limit and longer than the buffers between short ones,
+    empty strings, nulls on both sides, a data buffer that starts mid-vector; against the oracle, with the staged
+    path and without."""
+    rng = np.random.default_rng(311)
+    n = 40_000
+    items = []
+    for r in range(n):
+        u = rng.random()
+        ln = 0 if u < .1 else 300 if u < .101 else 9000 if u < .1012 else int(rng.integers(0, 17))
+        items.append(None if rng.random() < .05 else bytes(rng.integers(97, 123, ln).astype(np.uint8)))
+    v = orc.BinArr(items, 3, n - 3, pad=5)
+    local = np.arange(n - 3)
+    for lo in range(0, n - 3, 97):
+        rng.shuffle(local[lo:lo + 97])
+    takes = [Arr(INT32, local), Arr(orc.UINT32, np.repeat(np.arange(0, 9000), 3)),
+             R(rng, INT64, 30_000, .1, 1, lo=0, hi=n - 4), Arr(INT32, np.sort(rng.integers(0, n - 3, 25_000)))]
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("AMDARROW_BINARY_TAKE_NO_STAGING", env)
+        for sel in (.95, .5, .33, .12, .01):
+            f = R(rng, BOOL, n - 3, .02, 5, hi=sel)
+            for ns in (DROP, EMIT_NULL):
+                assert gpu.binary_filter(v, f, ns).same(oracle.binary_filter(v, f, ns)), (sel, ns, env)
+        for k, i in enumerate(takes):
+            assert gpu.binary_take(v, i).same(oracle.binary_take(v, i)), (k, env)
+
+
+@pytest.mark.gpu
 def test_binary_concatenate_random(gpu, oracle):
     rng = np.random.default_rng(301)
     for sizes in ([(5, 0, 0), (0, 0, 1), (200, .2, 3), (64, 0, 2), (77, 1.0, 1)], [(3, 0, 0)], [(0, 0, 0)], [(10, .5, 2), (10, 0, 0)],
