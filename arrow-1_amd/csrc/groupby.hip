@@ -88,9 +88,21 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
         }
       }
     }
+    // a shape whose last call found keys spread over more than 2^32 values (ids, hashes) goes the wide-key way without
+    // looking: that path assumes nothing about the keys
+    bool wide_from_hint = false;
+    if (!bias_from_hint && !(keys->validity && keys->null_count != 0) && !getenv("AMDARROW_GROUPBY_PATH") && !getenv("AMDARROW_GROUPBY_NO_HINT") &&
+        !getenv("AMDARROW_GROUPBY_NO_WIDE")) {
+      int every = kHintProbeEvery;
+      if (const char* env = getenv("AMDARROW_GROUPBY_PROBE_EVERY")) every = std::max(2, atoi(env));
+      for (auto& h : ctx->gb_hints)
+        if (h.n == n && h.caller == ctx->gb_caller && h.key_type == keys->type_id && h.value_type == (values ? values->type_id : 0) && h.has_mask == (mask != nullptr) &&
+            h.has_value_validity == (values && values->validity != nullptr) && h.wide_keys)
+          wide_from_hint = (++h.wide_uses % every) != 0;
+    }
     amdarrow_agg kr{};
-    if (!bias_from_hint) AA_TRY(AggregateLocked(ctx, keys, &kr));
-    if (bias_from_hint || (kr.valid_count > 0 && kr.max - kr.min < 0xFFFFFFFFull)) {  // (wrap-around difference: exact for both signednesses)
+    if (!bias_from_hint && !wide_from_hint) AA_TRY(AggregateLocked(ctx, keys, &kr));
+    if (bias_from_hint || (!wide_from_hint && kr.valid_count > 0 && kr.max - kr.min < 0xFFFFFFFFull)) {  // (wrap-around difference: exact for both signednesses)
       if (!bias_from_hint) k_bias = kr.min;
       ks.total_bits = 32;
       ks.col[0].bits = 32;
@@ -123,6 +135,9 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
   const bool wide = !fast_ok && ks.total_bits == 64 && !(keys->validity && keys->null_count != 0) &&
                     n >= (int64_t(1) << 18) && n < (int64_t(1) << 30) && !getenv("AMDARROW_GROUPBY_NO_WIDE");
   if (wide) path = 1;
+  // wide keys, first attempt: ONE pass -- the bin scatter on five-word records {row, key, value} (no histogram pass, no
+  // scan) and the stream aggregate over them; regions that overflow (skewed keys) fall back to the exact two-pass variant
+  bool wide_onepass = wide && !getenv("AMDARROW_GROUPBY_WIDE_TWO_PASS");
   if (const char* env = getenv("AMDARROW_GROUPBY_PATH")) path = std::min(path, atoi(env));
   // Path 3 first tries to pre-aggregate every row range in LDS and looks for heavy hitters; with many
   // evenly spread groups both give up (~60 us of kernels and launches for nothing).  A call of the
@@ -276,20 +291,31 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
       if (bias_from_hint && !compact) return start_over_measured();
       if (use_bins) cap += kCSpillUnits;  // room at the top of every region for the records that found their bin full
       hist_n = int64_t(kP) * (nblocks + (use_bins ? 1 : 0));  // bins: one more (always empty) segment per partition, where the spill list was
+    } else if (path == 1 && wide_onepass) {
+      const int64_t tile = kBThreads * 4;
+      nblocks = static_cast<int>(std::min<int64_t>(ctx->num_cus, (n + tile - 1) / tile));
+      rows_per_block = (((n + nblocks - 1) / nblocks + tile - 1) / tile) * tile;
+      // (every row may be selected: the mask's density is not known here)
+      const double mean = static_cast<double>(rows_per_block) / kP * (m_data ? 0.75 : 1.0);
+      cap = static_cast<int64_t>(mean * 1.5 + 8.0 * std::sqrt(mean) + 32.0);       // records
+      cap = (((cap * 5 + 3) / 4 + 7) & ~int64_t(7)) + 2 * kWSpillRecs;             // 16-byte units, whole lines, room for the spilled records
+      hist_n = int64_t(kP) * (nblocks + 1);
     } else if (path == 1) {
       nblocks = static_cast<int>(std::min<int64_t>(ctx->num_cus, (n + kPartRows - 1) / kPartRows));
       rows_per_block = (((n + nblocks - 1) / nblocks + kPartRows - 1) / kPartRows) * kPartRows;
       hist_n = int64_t(kP) * nblocks + 1;
     }
+    const bool w1 = path == 1 && wide_onepass;
     const int64_t scan_nb = (hist_n + 2047) / 2048;
     const size_t off_hist = c.Take(4 * hist_n);
     const size_t off_sums = c.Take(4 * scan_nb);
     const size_t off_sumoff = c.Take(8 * (scan_nb + 1));
     const int nseg = nblocks + (path >= 2 && use_bins ? 1 : 0);  // segments per partition the aggregate walks
     const size_t rec_bytes = path >= 2 ? std::max(16 * static_cast<size_t>(cap) * (compact ? size_t(1) << compact_pb : size_t(kP)) * nseg, LocalStageBytes(nblocks_local))
+                           : w1 ? 16 * static_cast<size_t>(cap) * kP * (nblocks + 1)
                            : path == 1 ? 16 * static_cast<size_t>(n) : 0;
     const size_t off_rec = c.Take(rec_bytes);
-    const size_t off_hi = c.Take(path == 1 && wide ? 4 * static_cast<size_t>(n) : 0);
+    const size_t off_hi = c.Take(path == 1 && wide && !w1 ? 4 * static_cast<size_t>(n) : 0);
     // heavy-hitter scratch (path 3 only)
     const int nwg_hot = path == 3 ? nblocks_local : 0;
     const size_t off_hot_cand = c.Take(4 * size_t(nwg_hot) * kHotPerWg);
@@ -323,8 +349,8 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
     hipLaunchKernelGGL(k_prepare, dim3(GridFor(r.nwords, kThreads, ctx->num_cus * 4)), dim3(kThreads), 0, ctx->stream, r.bitmap,
                        r.nwords, misc, wg_flags, nblocks_local > nblocks ? nblocks_local : nblocks,
                        path == 3 ? hot.cand_n : static_cast<unsigned int*>(nullptr),
-                       path >= 2 && use_bins ? reinterpret_cast<uint32_t*>(b + off_hist) : static_cast<uint32_t*>(nullptr), nseg,
-                       path >= 2 && use_bins ? misc + 8 : static_cast<unsigned int*>(nullptr));
+                       (path >= 2 && use_bins) || w1 ? reinterpret_cast<uint32_t*>(b + off_hist) : static_cast<uint32_t*>(nullptr), w1 ? nblocks + 1 : nseg,
+                       (path >= 2 && use_bins) || w1 ? misc + 8 : static_cast<unsigned int*>(nullptr));
     AA_HIP(hipGetLastError());
 
     if (fast) {
@@ -482,6 +508,15 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
                            sub == 0 ? static_cast<int64_t>(T) : int64_t(0));
         AA_HIP(hipGetLastError());
         }  // sub-problems
+      } else if (w1) {
+        const bool M = m_data != nullptr, V = values && values->validity != nullptr;
+        if (!values) fa.v = ValueCol{keys->values, nullptr, 0, AMDARROW_INT64};  // (never used as values: see BinLoadTile)
+#define AA_WBINS(MM, VV) hipLaunchKernelGGL((k_part_scatter_compact<MM, VV, true, 5, 9>), dim3(nblocks), dim3(kBThreads), 0, ctx->stream, fa, cap, records, hist, misc)
+        if (M && V) AA_WBINS(true, true); else if (M) AA_WBINS(true, false); else if (V) AA_WBINS(false, true); else AA_WBINS(false, false);
+#undef AA_WBINS
+        hipLaunchKernelGGL(k_part_aggregate_wide, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nblocks, cap, acc_double, t, misc,
+                           static_cast<uint32_t>(rows_per_block));
+        AA_HIP(hipGetLastError());
       } else {
         AA_HIP(hipMemsetAsync(hist + hist_n - 1, 0, 4, ctx->stream));
         hipLaunchKernelGGL(k_part_hist, dim3(nblocks), dim3(kPartThreads), 0, ctx->stream, fa, hist);
@@ -545,8 +580,8 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
     memcpy(&G, status + 6, 8);
     const unsigned int overflow = status[0];
     if (getenv("AMDARROW_GROUPBY_TRACE"))  // (diagnostics: one line per attempt of a call)
-      fprintf(stderr, "group-by attempt: path %d sub_bits %d hinted %d guessed %d compact %d(%d words) hot_compact %d local_only %d -> overflow %u gave_up %u hot %u groups %lld key range [%u, %u]\n",
-              path, sub_bits, int(hinted), int(guessed), int(compact), compact_rw, int(hot_compact), int(local_only), overflow, status[1], status[5],
+      fprintf(stderr, "group-by attempt: path %d sub_bits %d hinted %d guessed %d compact %d(%d words) hot_compact %d local_only %d wide_onepass %d -> overflow %u gave_up %u hot %u groups %lld key range [%u, %u]\n",
+              path, sub_bits, int(hinted), int(guessed), int(compact), compact_rw, int(hot_compact), int(local_only), int(w1), overflow, status[1], status[5],
               static_cast<long long>(G), status[8], status[9]);
     if (local_only && path == 3 && status[1] != 0) {  // the pre-aggregation gave up after all: everything, from the start
       local_only = false;
@@ -577,6 +612,11 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
       hinted = false;
       hint.n = -1;
       path = 4;  // -> 3 after the loop's decrement
+      continue;
+    }
+    if (overflow && w1) {  // a region or a table too small for these keys: the exact two-pass variant
+      wide_onepass = false;
+      path += 1;  // (the loop's decrement brings it back)
       continue;
     }
     if ((overflow & kOverflowRegion) && fast && path >= 2 && use_bins) {  // clustered keys? the same path once more, on the staged scatter
@@ -652,9 +692,15 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
       hint.compact_misses = compact && carry_misses > 0 ? carry_misses - 1 : carry_misses;
       hint.compact_off = carry_off;
     }
+    if (wide && path == 1) {  // the next calls of this shape skip the min / max pass
+      if (hint.n != shape.n) { shape.last_used = hint.last_used; hint = shape; }
+      hint.wide_keys = 1;
+    } else if (hint.n == shape.n) {
+      hint.wide_keys = 0;
+    }
     *out_num_groups = G;
     ctx->gb_last_path = path == 3 && status[1] != 0 ? 2 : path;
-    ctx->gb_last_words = ctx->gb_last_path == 0 || ctx->gb_last_path == 3 ? 0 : (compact || hot_compact) ? compact_rw : 4;
+    ctx->gb_last_words = ctx->gb_last_path == 0 || ctx->gb_last_path == 3 ? 0 : w1 ? 5 : (compact || hot_compact) ? compact_rw : 4;
     break;
   }
   // no trailing synchronise: *out_num_groups is final, the output arrays are stream-ordered
