@@ -469,6 +469,47 @@ def test_full_size_groupby_sorted_keys(full):
         assert torch.equal(first, exp_first[k]) and bool((first[1:] > first[:-1]).all()), step
 
 
+def test_full_size_groupby_wide_keys(full):
+    """100 M rows grouped by 1 M int64 ids spread over the whole 64-bit range (a bijection of the fixture's int32 keys):
+    ONE pass over five-word records, with the fixture's 50 % mask and without one; sums, counts, first rows and the
+    first-appearance order against torch's scatter reductions; three calls of the shape (the later ones skip the
+    min / max pass)."""
+    import torch
+    import gpu_api
+    from arrow1_amd import compute, device
+    gpu = gpu_api.GpuApi()
+    small = full["keys"].long()
+    wide = small * (0x9E3779B97F4A7C15 - (1 << 64)) + 0x632BE59BD9B4E019  # (odd multiplier, wraps: a bijection of the 64-bit integers)
+    lut = torch.empty(1_000_000, dtype=torch.int64, device="cuda")
+    lut[small] = wide
+    assert int(torch.unique(lut).numel()) == 1_000_000
+    keys_arr = device.DeviceArray(orc.INT64, wide.view(torch.uint8), None, N_FULL)
+    vals = full["vals"]
+    rows = torch.arange(N_FULL, device="cuda")
+    valid = _bits(full["valid"], N_FULL)
+    order = torch.argsort(lut)
+    slut = lut[order]
+    for mask_arr, sel in ((full["mask_arr"], _bits(full["mask"], N_FULL)), (None, torch.ones(N_FULL, dtype=torch.bool, device="cuda"))):
+        ok = sel & valid
+        exp_sum = torch.zeros(1_000_000, dtype=torch.int64, device="cuda").index_add_(0, small[ok], vals[ok])
+        exp_cnt = torch.zeros(1_000_000, dtype=torch.int64, device="cuda").index_add_(0, small[ok], torch.ones_like(vals[ok]))
+        exp_first = torch.full((1_000_000,), N_FULL, dtype=torch.int64, device="cuda").scatter_reduce_(0, small[sel], rows[sel], "amin")
+        present = exp_first < N_FULL
+        for step in range(3):
+            r = compute.filter_groupby(gpu.ctx, full["values"], keys_arr, mask_arr, group_capacity=1 << 21)
+            G = r.num_groups
+            assert G == int(present.sum())
+            assert _last_groupby_path(gpu) == (1, 5), step
+            got = r.keys[:G * 8].view(torch.int64)
+            k = order[torch.searchsorted(slut, got)]  # the small key of every group
+            assert torch.equal(lut[k], got), step
+            assert torch.equal(r.sums[:G * 8].view(torch.int64), exp_sum[k]), step
+            assert torch.equal(r.counts[:G * 8].view(torch.int64), exp_cnt[k]), step
+            first = r.first_rows[:G * 4].view(torch.int32).to(torch.int64)
+            assert torch.equal(first, exp_first[k]) and bool((first[1:] > first[:-1]).all()), step
+        del exp_sum, exp_cnt, exp_first, ok
+
+
 def test_full_size_sort_is_sorted_stable_permutation(gpu, full):
     import torch
     from arrow1_amd import compute, device
@@ -1304,6 +1345,54 @@ def test_filter_groupby_multi_key_refusals(gpu):
                                                              None, 16)
     assert G == 3 and sums.values_numpy().tolist() == [40, 60, 50] and counts.values_numpy().tolist() == [2, 2, 1]
     assert okeys[0].values_numpy().tolist() == [3, 1, 2] and okeys[1].validity_numpy().tolist() == [True, True, False]
+
+
+@pytest.mark.gpu
+def test_filter_groupby_wide_keys_one_pass(oracle, monkeypatch):
+    """64-bit keys that do not range-compress go through ONE pass (five-word records {row, key, value} through the
+    bins, stream aggregate into the hashed tables): with and without a mask, dense and sparse masks, value nulls,
+    float64 values, sliced inputs, a tail that is no whole tile; the records that find their bin full (a dense mask on
+    half-size tiles); one key on a quarter of the rows (its region overflows: the exact two-pass variant takes over);
+    calls of one shape in a row (the second and third skip the min / max pass), then keys of the same shape that DO
+    range-compress (the wide way takes them as they are, the probing call finds the fast path again)."""
+    import gpu_api
+    gpu = gpu_api.GpuApi()  # a context of its own: this test is about what calls of one shape hand on
+    rng = np.random.default_rng(611)
+    n = 1_300_007
+    pool = rng.integers(-2**63, 2**63 - 1, 60_000)
+
+    def check(v, k, m, tag, want_words=None):
+        om = m if m is not None else Arr(BOOL, np.ones(k.length, bool))  # (the oracle's GroupBy takes a mask)
+        want = oracle.filter_groupby_sum(v, k, om)
+        got = gpu.filter_groupby_sum(v, k, m)
+        for x, y in zip(want, got):
+            if x.dtype == np.float64:
+                assert _within(x, y, _f64_bound(oracle, v, k, om) if v.type_id == DOUBLE else 0), tag
+            else:
+                assert np.array_equal(x, y), tag
+        if want_words is not None:
+            assert _last_groupby_path(gpu) == want_words, tag
+
+    keys = Arr(INT64, pool[rng.integers(0, len(pool), n + 5)], None, 5, n)
+    for sel in (.5, .97, .03):
+        check(R(rng, INT64, n, .02, 3, lo=-2**40, hi=2**40), keys, R(rng, BOOL, n, 0, 2, hi=sel), ("mask", sel), (1, 5))
+    check(R(rng, INT64, n, 0, 0), keys, None, "no mask", (1, 5))
+    check(R(rng, DOUBLE, n, .1, 1), Arr(orc.UINT64, pool[rng.integers(0, len(pool), n)].view(np.uint64)), R(rng, BOOL, n, 0, 0), "float64 values, uint64 keys", (1, 5))
+    hot = pool[rng.integers(0, len(pool), n)]
+    hot[rng.random(n) < .25] = pool[7]
+    check(R(rng, INT64, n, .02, 0), Arr(INT64, hot), R(rng, BOOL, n, 0, 0), "one key on a quarter of the rows", (1, 4))
+    # one shape, call after call
+    v, m = R(rng, INT64, n, .02, 0), R(rng, BOOL, n, 0, 0)
+    for step in range(3):
+        check(v, Arr(INT64, pool[rng.integers(0, len(pool), n)]), m, ("hinted", step), (1, 5))
+    narrow = Arr(INT64, rng.integers(10**12, 10**12 + 50_000, n))
+    check(v, narrow, m, "keys that range-compress, on the wide hint", (1, 5))
+    monkeypatch.setenv("AMDARROW_GROUPBY_PROBE_EVERY", "2")
+    check(v, narrow, m, "the probing call")
+    assert _last_groupby_path(gpu)[0] >= 2
+    monkeypatch.delenv("AMDARROW_GROUPBY_PROBE_EVERY")
+    monkeypatch.setenv("AMDARROW_GROUPBY_WIDE_TWO_PASS", "1")
+    check(v, Arr(INT64, pool[rng.integers(0, len(pool), n)]), m, "two-pass variant", (1, 4))
 
 
 @pytest.mark.gpu
