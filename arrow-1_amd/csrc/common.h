@@ -63,6 +63,7 @@ struct amdarrow_ctx {
     int compact_misses = 0, compact_off = 0;
     int no_bins = 0;  // calls of this shape that stay off the bin scatters (their bins overflowed: clustered keys), see FilterGroupByImpl
     int no_bins_next = 16;  // ... and how many it will be after the next overflow (doubles up to 1024; back to 16 once the bins hold)
+    int sub_bits = 0;  // that call needed 4 / 16 rounds per partition (more groups than 512 LDS tables hold): the next calls start there
     int wide_keys = 0, wide_uses = 0;  // that call's 64-bit keys did not range-compress: the next calls skip the min / max pass and go the wide-key way (all but every 64th)
     uint64_t last_used = 0;
   };

@@ -175,12 +175,13 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
   // few groups per row range last time: the pre-aggregation alone is queued (no gated scatter / aggregate launches
   // behind it, ~5 us each); if it gives up this time the call starts over with everything
   bool local_only = false;
+  int hinted_sub_bits = 0;
   if (path == 3 && shape_known &&
       !getenv("AMDARROW_GROUPBY_PATH") && !getenv("AMDARROW_GROUPBY_NO_HINT")) {
     int every = kHintProbeEvery;
     if (const char* env = getenv("AMDARROW_GROUPBY_PROBE_EVERY")) every = std::max(2, atoi(env));
     if (hint.local_ok) local_only = true;
-    else if (++hint.uses % every != 0) { path = 2; hinted = true; }
+    else if (++hint.uses % every != 0) { path = 2; hinted = true; hinted_sub_bits = hint.sub_bits; }
   }
   // Compact records (k_part_scatter_compact): a hinted call whose predecessor's selected keys spanned few enough
   // values carries 12-byte records, 8-byte ones if that call's (integer) values were all int32; the kernel checks
@@ -243,7 +244,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
   unsigned long long* gx = nullptr;
   unsigned int* misc = nullptr;  // status words, see RankFirstRows; [64..] one flag per workgroup of the local path
   constexpr int kMaxFlags = 1024;
-  int sub_bits = 0;  // 2 after a partition's LDS table overflowed: four sub-problems, up to ~7 M groups
+  int sub_bits = hinted_sub_bits;  // 2 after a partition's LDS table overflowed: four sub-problems, up to ~7 M groups; then 4 (bin scatter: rounds of the aggregate)
   bool fa_val_wide = false;  // the last attempt's scatter reported whether the values were all int32 (status[10])
   for (;; --path) {
     fa_val_wide = false;
@@ -269,7 +270,9 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
       rows_per_block = (((n + nblocks - 1) / nblocks + tile - 1) / tile) * tile;
       nblocks_local = static_cast<int>(std::min<int64_t>(ctx->num_cus, (n + kDRows - 1) / kDRows));
       rows_per_block_local = (((n + nblocks_local - 1) / nblocks_local + kDRows - 1) / kDRows) * kDRows;
-      const double mean = static_cast<double>(rows_per_block) / kP / nsub;
+      // (sub-problems behind the bin scatter: ONE scatter of every selected row, the aggregate folds each partition in nsub rounds)
+      const bool sub_rounds_sizing = nsub > 1 && use_bins && !getenv("AMDARROW_GROUPBY_SUB_PASSES");
+      const double mean = static_cast<double>(rows_per_block) / kP / (sub_rounds_sizing ? 1 : nsub);
       // room for a key of up to ~0.25 % of the rows next to the uniform share (hotter keys are taken out before the scatter)
       cap = (static_cast<int64_t>(mean * 2.0 + 8.0 * std::sqrt(mean) + 32.0) + 7) & ~int64_t(7);  // whole 128-byte lines
       if (compact_rw != 0 && hinted && path == 2 && nsub == 1) {
@@ -455,8 +458,9 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
           run_if = abort_flag;
         }
         const unsigned int* use_hot = path == 3 ? misc + 5 : nullptr;
-        for (int sub = 0; sub < (local_only && path == 3 ? 0 : nsub); ++sub) {  // one pass per sub-problem (nsub == 1 unless a table overflowed before)
-        fa.sub_bits = nsub > 1 ? sub_bits : 0; fa.sub_id = static_cast<uint32_t>(sub);
+        const bool sub_rounds = nsub > 1 && use_bins && !getenv("AMDARROW_GROUPBY_SUB_PASSES");
+        for (int sub = 0; sub < (local_only && path == 3 ? 0 : sub_rounds ? 1 : nsub); ++sub) {  // one pass per sub-problem (nsub == 1 unless a table overflowed before)
+        fa.sub_bits = nsub > 1 && !sub_rounds ? sub_bits : 0; fa.sub_id = static_cast<uint32_t>(sub);
         FastArgs fh = fa;  // the same scatter on the mask k_hot_aggregate wrote
         fh.m_data = hot.alt_mask; fh.m_valid = nullptr; fh.m_off = 0;
         if (hot_compact) {  // the remainder of a skewed input (the mask k_hot_aggregate_vec wrote), on 8-byte records
@@ -499,9 +503,9 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
           else if (compact_pb == 9) AA_CAGG(3, 9); else AA_CAGG(3, 8);
 #undef AA_CAGG
         } else if (use_bins)
-          hipLaunchKernelGGL(k_part_aggregate_piped, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nseg,
+          hipLaunchKernelGGL(k_part_aggregate_piped, dim3(kP, sub_rounds ? nsub : 1), dim3(kPartThreads), 0, ctx->stream, records, hist, nseg,
                              cap, ks.total_bits, acc_double, t, r.bitmap, misc, run_if, int64_t(sub) * kP * kSlots,
-                             sub == 0 ? static_cast<int64_t>(T) : int64_t(0), fa.key_minmax, fa.k_flip, use_hot);
+                             sub == 0 ? static_cast<int64_t>(T) : int64_t(0), fa.key_minmax, fa.k_flip, use_hot, sub_rounds ? sub_bits : 0);
         else
         hipLaunchKernelGGL(k_part_aggregate_direct, dim3(kP), dim3(kPartThreads), 0, ctx->stream, records, hist, nseg,
                            cap, ks.total_bits, acc_double, t, r.bitmap, misc, run_if, int64_t(sub) * kP * kSlots,
@@ -611,6 +615,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
       guess_tried = true;  // (one compact attempt per call: what broke a hinted call's assumption -- a few far keys, one wide value -- hides from a sample too)
       hinted = false;
       hint.n = -1;
+      sub_bits = 0;
       path = 4;  // -> 3 after the loop's decrement
       continue;
     }
@@ -633,6 +638,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
         // more with four sub-problems (four passes over the input, 2048 partitions in effect),
         // then the generic global-atomic table
         if (sub_bits == 0) { sub_bits = 2; path = 3; }  // -> 2 after the loop's decrement
+        else if (sub_bits >= 2 && sub_bits < 4 && use_bins && !getenv("AMDARROW_GROUPBY_SUB_PASSES")) { ++sub_bits; path = 3; }  // eight, then sixteen rounds over the records: up to ~14 M / ~28 M groups
         else path = 1;
       }
       continue;
@@ -658,6 +664,11 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
         hint = shape;
       }
       else hint.n = -1;
+    }
+    if (path == 2 && !hinted && sub_bits > 0 && use_bins && status[5] == 0) {  // the next calls of this shape start with as many rounds
+      shape.uses = 0; shape.stats = 0; shape.sub_bits = sub_bits;
+      shape.last_used = hint.last_used;
+      hint = shape;
     }
     if (guessed) {  // the guess held: the next call of this shape takes over what this one's scatter measured, like after any unhinted call
       shape.uses = shape_known ? hint.uses : 0;
