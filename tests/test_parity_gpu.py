@@ -1361,6 +1361,52 @@ def test_filter_groupby_multi_key_refusals(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kt", [INT32, orc.UINT16, INT8, FLOAT])
+def test_filter_groupby_null_keys_split_off(gpu, oracle, kt, monkeypatch):
+    """Rows with a null key are one group: aggregated by a kernel of their own while the group-by proper runs on
+    mask AND key validity with keys that carry none, the null group joining the finished table before the numbering.
+    Key types of 8-32 bits, sliced bitmaps, a nullable mask, value nulls, int64 and float64 values, few and many null
+    keys, the null group as the very first and the very last group, no selected row with a null key (no null group),
+    every key null; against the oracle, and the same calls with the nulls carried through the scatters."""
+    rng = np.random.default_rng(650 + kt)
+    n = 600_011
+    hi = {INT32: 150_000, orc.UINT16: 40_000, INT8: 100, FLOAT: 30_000}[kt]
+
+    def check(v, k, m, tag):
+        want = oracle.filter_groupby_sum(v, k, m)
+        for env in (None, "1"):
+            if env:
+                monkeypatch.setenv("AMDARROW_GROUPBY_NO_NULL_SPLIT", env)
+            got = gpu.filter_groupby_sum(v, k, m)
+            if env:
+                monkeypatch.delenv("AMDARROW_GROUPBY_NO_NULL_SPLIT")
+            for x, y in zip(want, got):
+                if x.dtype == np.float64 and v.type_id == DOUBLE:
+                    assert _within(x, y, _f64_bound(oracle, v, k, m)), (tag, env)
+                else:
+                    assert np.array_equal(x, y, equal_nan=True), (tag, env)
+
+    def keys(p_null, off=0):
+        k = R(rng, kt, n, p_null, off, lo=0, hi=hi)
+        if kt == FLOAT:
+            k = Arr(FLOAT, np.floor(k.data), k.valid, off, n)
+        return k
+    check(R(rng, INT64, n, .02, 3), keys(.3, 5), R(rng, BOOL, n, .05, 7), "30 % null keys, nullable mask")
+    check(R(rng, DOUBLE, n, .1, 0), keys(.01, 1), R(rng, BOOL, n, 0, 0), "1 % null keys, float64 values")
+    k = keys(.2)
+    valid = k.valid.copy(); valid[0] = False
+    check(R(rng, INT64, n, 0, 0), Arr(kt, k.data, valid), Arr(BOOL, np.ones(n, bool)), "the null group first")
+    valid = np.ones(n, bool); valid[-1] = False
+    check(R(rng, INT64, n, 0, 0), Arr(kt, k.data, valid), Arr(BOOL, np.ones(n, bool)), "the null group last, one row")
+    m = R(rng, BOOL, n, 0, 0)
+    valid = k.valid | ~m.data  # null keys only where the mask drops the row
+    check(R(rng, INT64, n, .02, 0), Arr(kt, k.data, valid), m, "no selected row with a null key")
+    check(R(rng, INT64, n, .5, 0), Arr(kt, k.data, np.zeros(n, bool)), m, "every key null")
+    vn = R(rng, INT64, n, 0, 0)
+    check(Arr(INT64, vn.data, k.valid), k, m, "the null group's values all null")
+
+
+@pytest.mark.gpu
 def test_filter_groupby_wide_keys_one_pass(oracle, monkeypatch):
     """64-bit keys that do not range-compress go through ONE pass (five-word records {row, key, value} through the
     bins, stream aggregate into the hashed tables): with and without a mask, dense and sparse masks, value nulls,
