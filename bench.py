@@ -171,10 +171,15 @@ def bytes_per_row(workload, sel):
             "mask_and_kleene": 0.75, "agg_f64": 8.125}[workload]  # 2 x (data + validity) bits in, data + validity bits out
 
 
+def group_capacity():
+    """Room for --groups groups (2 M at the default)."""
+    return max(1 << 21, 1 << (NUM_GROUPS + 1).bit_length())
+
+
 def make_step(workload, ctx, inp, sel, world, rank):
     """Returns a zero-argument callable running ONE step on this rank's shard."""
     if workload == "filter_groupby_sum_i64":
-        bufs = compute.GroupByBuffers(ctx.device, 1 << 21, _abi.INT64 if KEY_BITS == 64 else _abi.INT32)
+        bufs = compute.GroupByBuffers(ctx.device, group_capacity(), _abi.INT64 if KEY_BITS == 64 else _abi.INT32)
         if world == 1:
             return lambda: compute.filter_groupby(ctx, inp["values"], inp["keys"], inp["mask"], buffers=bufs)
         from arrow1_amd import dist as adist
@@ -183,7 +188,7 @@ def make_step(workload, ctx, inp, sel, world, rank):
         step.finish = merger.finish  # merges of the last steps still in flight on the side stream
         return step
     if workload == "hash_agg_f64":
-        bufs = compute.GroupByBuffers(ctx.device, 1 << 21, _abi.INT32)
+        bufs = compute.GroupByBuffers(ctx.device, group_capacity(), _abi.INT32)
         return lambda: compute.filter_groupby(ctx, inp["values"], inp["keys"], None, buffers=bufs)
     if workload == "filter_i64":
         return lambda: compute.filter(ctx, inp["values"], inp["mask"])
@@ -396,7 +401,7 @@ def headline_extras(ctx, inp, n, dev, sel):
                                first call of a shape, or a caller whose data change shape every call, sees)
       wide_values_ms_per_step  int64 values over the whole 64-bit range (12-byte records instead of 8-byte ones), steady state"""
     out = {}
-    bufs = compute.GroupByBuffers(ctx.device, 1 << 21, _abi.INT32)
+    bufs = compute.GroupByBuffers(ctx.device, group_capacity(), _abi.INT32)
     call = lambda: compute.filter_groupby(ctx, inp["values"], inp["keys"], inp["mask"], buffers=bufs)  # noqa: E731
     os.environ["AMDARROW_GROUPBY_NO_HINT"] = "1"
     try:
