@@ -67,6 +67,9 @@ struct amdarrow_ctx {
     int wide_keys = 0, wide_uses = 0;  // that call's 64-bit keys did not range-compress: the next calls skip the min / max pass and go the wide-key way (all but every 64th)
     uint64_t last_used = 0;
   };
+  // multi-key sorts on the leading 64 bits of a wider composite key: the window kernels of the hybrid sort mark every row
+  // whose key equals another row's (bit 63 of its output index; rows < 2^31) and report that they ran
+  bool sort_mark_ties = false, sort_ties_marked = false;
   int gb_caller = 0;  // set by the entry point around FilterGroupByImpl (under `mu`)
   int gb_carry_misses = -1, gb_carry_off = 0;  // back-off state handed to the retry of a call whose hinted bias did not hold (-1: none)
   bool gb_no_bias_hint = false;  // set around the retry of a call whose hinted bias did not hold

@@ -1228,7 +1228,9 @@ __global__ __launch_bounds__(256) void k_window_bounds(const KeyT* keys, int64_t
 }
 
 // 128 registers: four workgroups per CU (32 KB of LDS each) instead of three -- 904 -> 712 us per 100 M uint64
-template <typename KeyT>
+// MARK (rows < 2^31): bit 63 of a row's output = another row of the window carries the same key (k_fix_ties).  A template
+// parameter: the flag as a run-time argument cost the kernel its register budget (spills, 0.5 -> 4.6 ms).
+template <typename KeyT, bool MARK = false>
 __global__ __launch_bounds__(kWThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_window_sort(
     const KeyT* keys, const uint32_t* idx_in, int64_t n, KeyT top_mask, unsigned int* error, unsigned int* crowded /* [windows], zeroed */,
     uint64_t* out64, const ulonglong2* bounds /* [windows + 1], k_window_bounds */) {
@@ -1387,11 +1389,13 @@ __global__ __launch_bounds__(kWThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
         for (uint32_t q = 0; q < kFlat; ++q) other[q] = s_sub[q < lim ? bs + q : static_cast<uint32_t>(tid)];
         uint32_t before_me = 0;
         bool slow = lim > kFlat;
+        bool tie = false;
 #pragma unroll
         for (uint32_t q = 0; q < kFlat; ++q) {
           const uint32_t x = other[q] ^ sub[j];
           before_me += q < lim && other[q] < sub[j] ? 1u : 0u;
           slow = slow || (q < lim && !sub_exact && x != 0 && (x >> 12) == 0);  // another key with the same staged bits
+          if constexpr (MARK) tie = tie || (q < lim && sub_exact && x != 0 && (x >> 12) == 0);  // (all the bits below the bucket: the same key)
         }
         if (slow) {  // everything again, ties by the keys themselves (both from global memory), then by the position
           before_me = 0;
@@ -1401,12 +1405,15 @@ __global__ __launch_bounds__(kWThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
             if (!sub_exact && ((o ^ sub[j]) >> 12) == 0) {
               const KeyT ok = keys[p0 + lo + (o & 0xFFFu)], mk = keys[p0 + lo + (sub[j] & 0xFFFu)];
               before_me += (ok < mk || (ok == mk && o < sub[j])) ? 1u : 0u;
+              if constexpr (MARK) tie = tie || ok == mk;
             } else {
               before_me += o < sub[j] ? 1u : 0u;
+              if constexpr (MARK) tie = tie || ((o ^ sub[j]) >> 12) == 0;
             }
           }
         }
-        sc[j] = bs + before_me;  // (dead candidates: never used)
+        if constexpr (MARK) sc[j] = (bs + before_me) | (tie ? 0x80000000u : 0u);
+        else sc[j] = bs + before_me;  // (dead candidates: never used)
       }
       __syncthreads();
       WPH(6);
@@ -1416,10 +1423,17 @@ __global__ __launch_bounds__(kWThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
       for (int j = 0; j < kIters; ++j) {
         if (!WS_STEP_LIVE(j)) continue;
         const uint32_t li = j * kWThreads + tid;
-        if (li >= lo && li < hi) s_rows[sc[j]] = idx[j];
+        if constexpr (MARK) { if (li >= lo && li < hi) s_rows[sc[j] & 0x7FFFFFFFu] = idx[j] | (sc[j] & 0x80000000u); }
+        else if (li >= lo && li < hi) s_rows[sc[j]] = idx[j];
       }
       __syncthreads();
       WPH(7);
+      if constexpr (MARK) {
+        for (uint32_t i = tid; i < count; i += kWThreads) {
+          const uint32_t v = s_rows[i];
+          out64[p0 + lo + i] = static_cast<uint64_t>(v & 0x7FFFFFFFu) | (static_cast<uint64_t>(v >> 31) << 63);
+        }
+      } else
       for (uint32_t i = tid; i < count; i += kWThreads) out64[p0 + lo + i] = s_rows[i];
       WPH(8);
       WPH_FLUSH();
@@ -1438,7 +1452,8 @@ __global__ __launch_bounds__(kWThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
 // LDS atomics hand out their return values.  Same window geometry; a workgroup whose flag is down returns at once.
 template <typename KeyT>
 __global__ __launch_bounds__(kWThreads) void k_window_lsd(const KeyT* keys, const uint32_t* idx_in, int64_t n, KeyT top_mask,
-                                                         WindowDigits digits, const unsigned int* crowded, uint64_t* out64) {
+                                                         WindowDigits digits, const unsigned int* crowded, uint64_t* out64,
+                                                         int mark_ties = 0) {
   constexpr bool ARANK = false;
   constexpr int kIters = kWSpan / kWThreads;
   __shared__ KeyT s_keys[kWSpan];
@@ -1592,7 +1607,11 @@ __global__ __launch_bounds__(kWThreads) void k_window_lsd(const KeyT* keys, cons
 #pragma unroll
   for (int j = 0; j < kIters; ++j) {
     const uint32_t li = wave * (kIters * 64) + j * 64 + lane;
-    if (li < count) out64[p0 + lo + li] = idx[j];
+    if (li >= count) continue;
+    uint64_t v = idx[j];
+    // (s_keys holds the window's keys in sorted order since the last pass: a key with an equal neighbour is tied)
+    if (mark_ties && ((li > 0 && s_keys[li - 1] == key[j]) || (li + 1 < count && s_keys[li + 1] == key[j]))) v |= uint64_t(1) << 63;
+    out64[p0 + lo + li] = v;
   }
 }
 
@@ -1954,16 +1973,18 @@ static int SortRawClassified(amdarrow_ctx* ctx, const std::vector<SortChunk>& hc
   AA_HIP(hipMemsetAsync(crowded, 0, 4 * static_cast<size_t>(nw), ctx->stream));
   auto* wbounds = reinterpret_cast<ulonglong2*>(b + o_bounds);
   hipLaunchKernelGGL((k_window_bounds<KeyT>), dim3((nw + 1 + 255) / 256), dim3(256), 0, ctx->stream, keys_a, n0, top_mask, int64_t(nw), wbounds);
-  hipLaunchKernelGGL((k_window_sort<KeyT>), dim3(nw), dim3(kWThreads), 0, ctx->stream, keys_a, idx_a, n0, top_mask, ctl + 14, crowded, out, wbounds);
+  if (ctx->sort_mark_ties) hipLaunchKernelGGL((k_window_sort<KeyT, true>), dim3(nw), dim3(kWThreads), 0, ctx->stream, keys_a, idx_a, n0, top_mask, ctl + 14, crowded, out, wbounds);
+  else hipLaunchKernelGGL((k_window_sort<KeyT>), dim3(nw), dim3(kWThreads), 0, ctx->stream, keys_a, idx_a, n0, top_mask, ctl + 14, crowded, out, wbounds);
   AA_HIP(hipGetLastError());
   unsigned int err[4] = {0, 0, 0, 0};
   AA_TRY(ReadBack(ctx, ctl + 14, 16, err));
   if (err[2]) { ctx->lds_rank_ordered = 0; return AMDARROW_OK; }  // (SortImpl redoes everything with the ballot ranking)
   if (err[0] || err[1]) return AMDARROW_OK;                       // a run too long for the windows / a pass gave up: the usual way
   if (err[3]) {
-    hipLaunchKernelGGL((k_window_lsd<KeyT>), dim3(nw), dim3(kWThreads), 0, ctx->stream, keys_a, idx_a, n0, top_mask, wd, crowded, out);
+    hipLaunchKernelGGL((k_window_lsd<KeyT>), dim3(nw), dim3(kWThreads), 0, ctx->stream, keys_a, idx_a, n0, top_mask, wd, crowded, out, ctx->sort_mark_ties ? 1 : 0);
     AA_HIP(hipGetLastError());
   }
+  if (ctx->sort_mark_ties) ctx->sort_ties_marked = true;
   *done = true;
   return AMDARROW_OK;
 }
@@ -2294,7 +2315,8 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
     AA_HIP(hipMemsetAsync(crowded, 0, 4 * static_cast<size_t>(nwin), ctx->stream));
     auto* wbounds = reinterpret_cast<ulonglong2*>(b + o_bounds);
     hipLaunchKernelGGL((k_window_bounds<KeyT>), dim3((nwin + 1 + 255) / 256), dim3(256), 0, ctx->stream, keys_a, n0, top_mask, int64_t(nwin), wbounds);
-    hipLaunchKernelGGL((k_window_sort<KeyT>), dim3(nwin), dim3(kWThreads), 0, ctx->stream, keys_a, idx_a, n0, top_mask, ctl + 14, crowded, out, wbounds);
+    if (ctx->sort_mark_ties) hipLaunchKernelGGL((k_window_sort<KeyT, true>), dim3(nwin), dim3(kWThreads), 0, ctx->stream, keys_a, idx_a, n0, top_mask, ctl + 14, crowded, out, wbounds);
+    else hipLaunchKernelGGL((k_window_sort<KeyT>), dim3(nwin), dim3(kWThreads), 0, ctx->stream, keys_a, idx_a, n0, top_mask, ctl + 14, crowded, out, wbounds);
     AA_HIP(hipGetLastError());
     window_keys = keys_a; window_idx = idx_a; window_n = nwin;
   }
@@ -2304,7 +2326,7 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
     AA_TRY(ReadBack(ctx, ctl + 14, 16, err));
     if (err[3] && !err[0] && !err[1] && !err[2]) {
       hipLaunchKernelGGL((k_window_lsd<KeyT>), dim3(window_n), dim3(kWThreads), 0, ctx->stream, window_keys, window_idx, n0, top_mask, wd,
-                         reinterpret_cast<const unsigned int*>(bhist), out);
+                         reinterpret_cast<const unsigned int*>(bhist), out, ctx->sort_mark_ties ? 1 : 0);
       AA_HIP(hipGetLastError());
     }
     if (err[2]) {  // never seen on gfx950; the device then ranks with ballots from here on
@@ -2314,6 +2336,7 @@ static int SortImpl(amdarrow_ctx* ctx, const amdarrow_array* chunks, int nchunks
     if (err[1]) return SortImpl<KeyT>(ctx, chunks, nchunks, type_id, order, n, out, perm, /*allow_onesweep=*/false, false);
     if (err[0]) return SortImpl<KeyT>(ctx, chunks, nchunks, type_id, order, n, out, perm, /*allow_onesweep=*/true, /*allow_hybrid=*/false);
   }
+  if (top && ctx->sort_mark_ties) ctx->sort_ties_marked = true;  // (the window kernels wrote `out`, and nothing sent the sort another way)
   return AMDARROW_OK;
 }
 
@@ -2377,6 +2400,7 @@ struct CompositePiece {  // one key's rows of one segment (a run of rows that no
   const void* data; const uint8_t* valid; int64_t off;  // element / bit offset of the segment's first row
   uint64_t lo, hi;     // the column's range over its valid rows, in the orderable form below
   uint32_t width_bytes, is_signed, descending, shift;
+  uint32_t rshift;     // leading-bits composites: the field's low bits that do not fit (>= 64: the whole field)
   uint64_t null_code;  // the field of a null row
 };
 struct CompositeArgs { CompositePiece key[kMaxCompositeKeys]; int nkeys; int64_t len; int64_t step; };  // (step > 1: the range kernel looks at every step-th row only)
@@ -2481,7 +2505,7 @@ __global__ __launch_bounds__(256) void k_composite_build(CompositeArgs a, OutT* 
       for (int j = 0; j < kU; ++j) {
         const bool ok = (vb[j] >> ((key.off + idx[j]) & 7)) & 1u;
         const uint64_t field = !ok ? key.null_code : key.descending ? key.hi - u[j] : u[j] - key.lo;
-        word[j] |= field << key.shift;
+        if (key.rshift < 64) word[j] |= (field >> key.rshift) << key.shift;  // (uniform)
       }
     }
 #pragma unroll
@@ -2489,6 +2513,59 @@ __global__ __launch_bounds__(256) void k_composite_build(CompositeArgs a, OutT* 
       const int64_t i = base + 64 * j + lane;
       if (i < a.len) out[i] = static_cast<OutT>(word[j]);
     }
+  }
+}
+// ---- tuples wider than 64 bits: the leading 64 bits sorted, the ties on them put right -------------------------
+// The composite of (int32 over 1 M values, int64 over 63 bits) needs 83 bits.  Sorting key by key gathers the earlier key
+// through the later key's permutation (2 ms per 100 M rows).  Instead the LEADING 64 bits of the tuple are sorted as one key
+// -- the hybrid sort's window kernels mark every row whose 64 bits equal another row's (bit 63 of its index) -- and
+// k_fix_ties sorts every run of consecutive marked rows by the whole tuple (read from the columns: a few rows), then by
+// row number.  The marked rows of a run are in the order of their leading bits already, which the whole tuple's order
+// refines; a run longer than kMaxTieRun (heavily duplicated tuples) gives the call back to the key-by-key sort.
+constexpr int kMaxTieRun = 64;
+__device__ __forceinline__ uint64_t CompositeField(const CompositePiece& k, uint32_t row) {
+  const int64_t i = k.off + row;
+  if (k.valid && !((k.valid[i >> 3] >> (i & 7)) & 1u)) return k.null_code;
+  uint64_t u;
+  switch (k.width_bytes) {
+    case 1: u = k.is_signed ? static_cast<uint64_t>(static_cast<int64_t>(static_cast<const int8_t*>(k.data)[i])) : static_cast<const uint8_t*>(k.data)[i]; break;
+    case 2: u = k.is_signed ? static_cast<uint64_t>(static_cast<int64_t>(static_cast<const int16_t*>(k.data)[i])) : static_cast<const uint16_t*>(k.data)[i]; break;
+    case 4: u = k.is_signed ? static_cast<uint64_t>(static_cast<int64_t>(static_cast<const int32_t*>(k.data)[i])) : static_cast<const uint32_t*>(k.data)[i]; break;
+    default: u = static_cast<const uint64_t*>(k.data)[i]; break;
+  }
+  if (k.is_signed) u ^= 1ull << 63;
+  return k.descending ? k.hi - u : u - k.lo;
+}
+__global__ __launch_bounds__(256) void k_fix_ties(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int64_t n, CompositeArgs a,
+                                                  unsigned int* fail) {
+  for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) {
+    const uint64_t v = in[i];
+    if (!(v >> 63)) { out[i] = v; continue; }
+    if (i > 0 && (in[i - 1] >> 63)) continue;  // inside a run: its first row's thread writes it
+    uint32_t rows[kMaxTieRun];
+    int len = 0;
+    bool too_long = false;
+    for (int64_t j = i; j < n; ++j) {
+      const uint64_t w = in[j];
+      if (!(w >> 63)) break;
+      if (len == kMaxTieRun) { too_long = true; break; }
+      rows[len++] = static_cast<uint32_t>(w);
+    }
+    if (too_long) { __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); continue; }
+    auto less = [&](uint32_t x, uint32_t y) {
+      for (int k = 0; k < a.nkeys; ++k) {
+        const uint64_t fx = CompositeField(a.key[k], x), fy = CompositeField(a.key[k], y);
+        if (fx != fy) return fx < fy;
+      }
+      return x < y;
+    };
+    for (int t = 1; t < len; ++t) {  // insertion sort: runs are a handful of rows
+      const uint32_t x = rows[t];
+      int q = t;
+      while (q > 0 && less(x, rows[q - 1])) { rows[q] = rows[q - 1]; --q; }
+      rows[q] = x;
+    }
+    for (int t = 0; t < len; ++t) out[i + t] = rows[t];
   }
 }
 }  // namespace amdarrow
@@ -2558,7 +2635,7 @@ extern "C" int amdarrow_sort_indices_multi(amdarrow_ctx* ctx, const amdarrow_arr
     unsigned long long got[3 * kMaxCompositeKeys];
     // A sample first (every step-th row, 64 K rows of the longest segment): its ranges are lower bounds, and columns
     // that are plainly too wide together are found without a pass over them.
-    bool fits = true;
+    bool fits = true, lead = false;
     if (n >= (int64_t(1) << 22)) {
       const CompositeArgs* longest = &segs[0];
       for (const CompositeArgs& a : segs) if (a.len > longest->len) longest = &a;
@@ -2572,8 +2649,10 @@ extern "C" int amdarrow_sort_indices_multi(amdarrow_ctx* ctx, const amdarrow_arr
       for (int k = 0; k < nkeys; ++k)
         if (got[3 * k] < got[3 * k + 1]) bits += 64 - __builtin_clzll(got[3 * k + 1] - got[3 * k]);
       fits = bits <= 64;  // (the sample's minima and maxima stay in `ranges`: they are the column's own values)
+      // wider tuples: their leading 64 bits as one key, the ties put right afterwards (k_fix_ties); one chunk per key
+      lead = !fits && bits <= 128 && segs.size() == 1 && n < (int64_t(1) << 31) && !getenv("AMDARROW_SORT_NO_LEADING_BITS");
     }
-    if (fits) {
+    if (fits || lead) {
       for (const CompositeArgs& a : segs)
         hipLaunchKernelGGL(k_composite_range, dim3(GridFor(a.len, 256 * 8, ctx->num_cus * 4)), dim3(256), 0, ctx->stream, a, ranges);
       AA_HIP(hipGetLastError());
@@ -2581,16 +2660,18 @@ extern "C" int amdarrow_sort_indices_multi(amdarrow_ctx* ctx, const amdarrow_arr
     }
     int total_bits = 0;
     int width[kMaxCompositeKeys];
-    for (int k = 0; k < nkeys && fits; ++k) {
+    for (int k = 0; k < nkeys && (fits || lead); ++k) {
       const bool any_valid = got[3 * k] <= got[3 * k + 1];
       const uint64_t span = any_valid ? got[3 * k + 1] - got[3 * k] : 0;  // the largest value field
       const bool nulls = got[3 * k + 2] != 0;
-      if (nulls && span == ~0ull) { fits = false; break; }
+      if (nulls && span == ~0ull) { fits = lead = false; break; }
       const uint64_t top = span + (nulls ? 1 : 0);                      // the largest field
       width[k] = top == 0 ? 0 : 64 - __builtin_clzll(top);
       total_bits += width[k];
-      fits = total_bits <= 64;
+      if (total_bits > 64) { if (fits) lead = segs.size() == 1 && n >= (int64_t(1) << 22) && n < (int64_t(1) << 31) && !getenv("AMDARROW_SORT_NO_LEADING_BITS"); fits = false; }
+      if (total_bits > 128) lead = false;
       for (CompositeArgs& a : segs) {
+        a.key[k].rshift = 0;
         a.key[k].lo = any_valid ? got[3 * k] : 0; a.key[k].hi = any_valid ? got[3 * k + 1] : 0;
         a.key[k].null_code = span + 1;  // (only ever used when nulls exist)
       }
@@ -2623,6 +2704,51 @@ extern "C" int amdarrow_sort_indices_multi(amdarrow_ctx* ctx, const amdarrow_arr
       AA_TRY(rc);
       AA_HIP(e);
       return AMDARROW_OK;
+    }
+    if (lead && total_bits > 64 && total_bits <= 128) {
+      const int drop = total_bits - 64;  // the tuple's low bits the sorted key leaves out
+      CompositeArgs cut = segs[0];       // the fields cut to the leading 64 bits; segs[0] keeps the whole fields for k_fix_ties
+      int below = total_bits;
+      for (int k = 0; k < nkeys; ++k) {
+        below -= width[k];               // bits of the tuple below field k
+        segs[0].key[k].shift = 0;
+        if (below >= drop) { cut.key[k].shift = static_cast<uint32_t>(below - drop); cut.key[k].rshift = 0; }
+        else if (below + width[k] > drop) { cut.key[k].shift = 0; cut.key[k].rshift = static_cast<uint32_t>(drop - below); }
+        else { cut.key[k].shift = 0; cut.key[k].rshift = 64; }
+      }
+      void* comp = nullptr;
+      uint64_t* marked = nullptr;
+      AA_TRY(amdarrow_malloc(ctx, 8 * n + 64, &comp));
+      int rc = amdarrow_malloc(ctx, 8 * n, reinterpret_cast<void**>(&marked));
+      auto* fail = reinterpret_cast<unsigned int*>(static_cast<char*>(comp) + 8 * n);
+      if (rc == AMDARROW_OK) {
+        if (hipMemsetAsync(fail, 0, 64, ctx->stream) != hipSuccess) rc = SetError(AMDARROW_UNKNOWN_ERROR, "sort_indices: composite key setup failed");
+        hipLaunchKernelGGL(k_composite_build<uint64_t>, dim3(GridFor(n, 256 * 8, ctx->num_cus * 8)), dim3(256), 0, ctx->stream, cut, static_cast<uint64_t*>(comp));
+        if (hipGetLastError() != hipSuccess) rc = SetError(AMDARROW_UNKNOWN_ERROR, "sort_indices: composite key launch failed");
+      }
+      bool done = false;
+      if (rc == AMDARROW_OK) {
+        amdarrow_array arr{};
+        arr.values = comp; arr.validity = nullptr; arr.length = n; arr.offset = 0; arr.null_count = 0; arr.type_id = AMDARROW_UINT64;
+        ctx->sort_mark_ties = true; ctx->sort_ties_marked = false;
+        rc = SortImpl<uint64_t>(ctx, &arr, 1, arr.type_id, AMDARROW_ASCENDING, n, marked);
+        ctx->sort_mark_ties = false;
+        if (rc == AMDARROW_OK && ctx->sort_ties_marked) {
+          hipLaunchKernelGGL(k_fix_ties, dim3(GridFor(n, 256, ctx->num_cus * 16)), dim3(256), 0, ctx->stream, marked, out_indices, n, segs[0], fail);
+          unsigned int failed = 1;
+          if (hipGetLastError() != hipSuccess) rc = SetError(AMDARROW_UNKNOWN_ERROR, "sort_indices: tie fix-up launch failed");
+          else rc = ReadBack(ctx, fail, 4, &failed);
+          done = rc == AMDARROW_OK && failed == 0;
+        }
+      }
+      const hipError_t e = hipStreamSynchronize(ctx->stream);
+      if (marked) (void)amdarrow_free(ctx, marked);
+      (void)amdarrow_free(ctx, comp);
+      AA_TRY(rc);
+      AA_HIP(e);
+      if (getenv("AMDARROW_SORT_TRACE"))  // (diagnostics)
+        fprintf(stderr, "sort_indices_multi: %d bits, leading 64 sorted, ties marked %d, fixed up %d\n", total_bits, int(ctx->sort_ties_marked), int(done));
+      if (done) return AMDARROW_OK;  // (else: no hybrid sort for these keys, or a run of ties too long -- key by key)
     }
   }
   // the stages ping-pong between `out_indices` and one temporary so that the last lands in out_indices

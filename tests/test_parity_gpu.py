@@ -986,6 +986,39 @@ def test_sort_indices_multi_key_composite(gpu, oracle, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_sort_indices_multi_key_leading_bits(gpu, oracle, monkeypatch):
+    """Integer key tuples of 65-128 bits: the leading 64 bits sort as one key, the window kernels mark the rows that tie
+    on them and a fix-up sorts every run of marked rows by the whole tuple.  4.2 M rows (the path needs the hybrid
+    sort): (int32 over 1 M values, int64 over 63 bits + nulls) with rows planted that share the leading bits and differ
+    below them, and exact duplicates (index order); both orders; tuples duplicated a thousand times each (no hybrid sort,
+    or runs too long: key by key) and a tuple of 136 bits (key by key); against the oracle and the key-by-key sort."""
+    rng = np.random.default_rng(902)
+    n = 4_200_000
+    k1 = rng.integers(0, 1_000_000, n).astype(np.int32)
+    v = rng.integers(-2**62, 2**62, n)
+    src = rng.integers(0, n, 40_000)
+    dst = rng.integers(0, n, 40_000)
+    k1[dst] = k1[src]
+    v[dst[:20_000]] = v[src[:20_000]] + rng.integers(-1000, 1000, 20_000)   # same leading bits (mostly), another tuple
+    v[dst[20_000:]] = v[src[20_000:]]                                         # the same tuple: index order
+    a = Arr(INT32, k1)
+    b = Arr(INT64, v, rng.random(n) > .01)
+
+    def check(keys, orders, tag):
+        want = oracle.sort_indices_multi(keys, orders)
+        assert np.array_equal(gpu.sort_indices_multi(keys, orders), want), tag
+        monkeypatch.setenv("AMDARROW_SORT_NO_LEADING_BITS", "1")
+        assert np.array_equal(gpu.sort_indices_multi(keys, orders), want), (tag, "key by key")
+        monkeypatch.delenv("AMDARROW_SORT_NO_LEADING_BITS")
+    check([a, b], [ASC, DESC], "83 bits")
+    check([b, a], [DESC, ASC], "83 bits, the wide key first")
+    pool = rng.integers(-2**62, 2**62, 1000)
+    check([Arr(INT8, rng.integers(0, 4, n)), Arr(INT64, pool[rng.integers(0, 1000, n)])], [ASC, ASC], "4000 tuples, a thousand rows each")
+    c = Arr(orc.UINT64, rng.integers(0, 2**64, n, dtype=np.uint64))
+    check([Arr(INT8, rng.integers(0, 100, n)), b, c], [DESC, ASC, ASC], "136 bits")
+
+
+@pytest.mark.gpu
 def test_sort_indices_multi_key_errors(gpu, oracle):
     a, b = Arr(INT32, [1, 2, 3]), Arr(INT32, [1, 2])
     for api in (oracle, gpu):
