@@ -935,6 +935,37 @@ def test_sort_indices_multi_key_random(gpu, oracle, nkeys):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["float64-around-zero", "float64-magnitudes", "int64-around-zero", "float64-two-clusters"])
+def test_sort_indices_crowded_windows_of_several_runs(gpu, oracle, shape):
+    """3 M rows (the hybrid sort) whose keys make a window of the LDS tail hold SEVERAL runs of the global passes' digits
+    with its keys clustered at the ends of its range -- a float column on either side of zero: the largest negative
+    keys and the smallest positive ones are neighbours in order and far apart as bit patterns.  Such a window is
+    crowded (dozens of keys per bucket) and goes to the LSD fallback, which used to pass over the digits BELOW the
+    global passes only and so lost the order of the runs (2048 rows out of place; found in round 3 through a
+    multi-key test, the full-size float64 test's values being all positive).  Both orders, NaNs, nulls."""
+    rng = np.random.default_rng(903)
+    n = 3_000_000
+    if shape == "float64-around-zero":
+        d = rng.random(n) * 1000 - 300
+    elif shape == "float64-magnitudes":
+        d = np.where(rng.random(n) < .5, -1.0, 1.0) * 10.0 ** rng.uniform(-300, 300, n)
+    elif shape == "float64-two-clusters":
+        d = np.where(rng.random(n) < .5, -1e-200, 1e-200) * (1 + rng.random(n))
+    else:
+        d = rng.integers(-2**40, 2**40, n)
+    t = INT64 if shape.startswith("int64") else DOUBLE
+    cases = [Arr(t, d)]
+    if t == DOUBLE:
+        dn = d.copy(); dn[rng.random(n) < .001] = np.nan
+        cases.append(Arr(DOUBLE, dn, rng.random(n) > .01))
+    else:
+        cases.append(Arr(INT64, d, rng.random(n) > .01))
+    for a in cases:
+        for order in (ASC, DESC):
+            assert np.array_equal(gpu.sort_indices(a, order), oracle.sort_indices(a, order)), (shape, order, a.valid is not None)
+
+
+@pytest.mark.gpu
 def test_sort_indices_multi_key_composite(gpu, oracle, monkeypatch):
     """Integer key columns whose ranges fit one 64-bit word together sort as ONE composite key (field = value - min or
     max - value, nulls behind the largest value): 2-4 keys of every integer width, both orders, nulls, chunked tables
@@ -964,6 +995,15 @@ def test_sort_indices_multi_key_composite(gpu, oracle, monkeypatch):
             tab = [[R(rng, t, m, p, (k + j) % 3, lo=lo, hi=lo + sp) for j, m in enumerate(lay[(k + trial) % 4])]
                    for k, (t, lo, sp) in enumerate(zip(ts, lows, spans))]
             check(tab, orders, (n, trial, ts, "table"))
+    # float keys: -0.0 ties with +0.0, NaNs behind the values and nulls behind the NaNs in both orders
+    n = 30_000
+    special = np.array([0.0, -0.0, 1.5, -2.5, np.nan, np.inf, -np.inf, 3e38, 1e-40, -1e-40], np.float32)
+    f1 = Arr(FLOAT, special[rng.integers(0, len(special), n)], rng.random(n) > .1)
+    f2 = R(rng, FLOAT, n, .05, 2, lo=-3, hi=40)
+    i16 = R(rng, orc.INT16, n, .1, 1, lo=-5, hi=5)
+    for keys, tag in [([f1, i16], "float32 specials + int16"), ([i16, f1, f2], "int16 + two float32"), ([f2, f1], "two float32")]:
+        for orders in ([ASC] * len(keys), [DESC] * len(keys), [DESC, ASC] * (len(keys) // 2) + [DESC] * (len(keys) % 2)):
+            check(keys, orders, (tag, orders))
     n = 50_000
     full32 = Arr(orc.UINT32, rng.integers(0, 2**32, n, dtype=np.uint64))
     full32.data[:2] = [0, 2**32 - 1]
@@ -1016,6 +1056,12 @@ def test_sort_indices_multi_key_leading_bits(gpu, oracle, monkeypatch):
     check([Arr(INT8, rng.integers(0, 4, n)), Arr(INT64, pool[rng.integers(0, 1000, n)])], [ASC, ASC], "4000 tuples, a thousand rows each")
     c = Arr(orc.UINT64, rng.integers(0, 2**64, n, dtype=np.uint64))
     check([Arr(INT8, rng.integers(0, 100, n)), b, c], [DESC, ASC, ASC], "136 bits")
+    d = rng.random(n) * 1000 - 300
+    d[dst[:20_000]] = d[src[:20_000]]                  # ties on the float key: the int32 key decides
+    d[rng.integers(0, n, 3000)] = np.array([0.0, -0.0, np.inf])[rng.integers(0, 3, 3000)]
+    check([Arr(DOUBLE, d), a], [DESC, ASC], "float64 + int32")
+    dn = d.copy(); dn[rng.random(n) < .001] = np.nan
+    check([a, Arr(DOUBLE, dn, rng.random(n) > .01)], [ASC, DESC], "int32 + float64 with NaNs and nulls")
 
 
 @pytest.mark.gpu
