@@ -272,7 +272,9 @@ static int FilterGroupByCore(amdarrow_ctx* ctx, const amdarrow_array* values, co
   if (wide) path = 1;
   // wide keys, first attempt: ONE pass -- the bin scatter on five-word records {row, key, value} (no histogram pass, no
   // scan) and the stream aggregate over them; regions that overflow (skewed keys) fall back to the exact two-pass variant
-  bool wide_onepass = wide && !getenv("AMDARROW_GROUPBY_WIDE_TWO_PASS");
+  // (the bin scatter's loaders: 8-byte values as 16-byte vectors, a mask without validity; a call without values reads the key
+  // buffer where it would read values and must not have a mask either -- as for the 32-bit keys' bins)
+  bool wide_onepass = wide && !m_valid && (values ? BitWidth(values->type_id) == 64 : (!mask && n >= 64)) && !getenv("AMDARROW_GROUPBY_WIDE_TWO_PASS");
   if (const char* env = getenv("AMDARROW_GROUPBY_PATH")) path = std::min(path, atoi(env));
   // Path 3 first tries to pre-aggregate every row range in LDS and looks for heavy hitters; with many
   // evenly spread groups both give up (~60 us of kernels and launches for nothing).  A call of the

@@ -1516,6 +1516,10 @@ def test_filter_groupby_wide_keys_one_pass(oracle, monkeypatch):
         check(R(rng, INT64, n, .02, 3, lo=-2**40, hi=2**40), keys, R(rng, BOOL, n, 0, 2, hi=sel), ("mask", sel), (1, 5))
     check(R(rng, INT64, n, 0, 0), keys, None, "no mask", (1, 5))
     check(R(rng, DOUBLE, n, .1, 1), Arr(orc.UINT64, pool[rng.integers(0, len(pool), n)].view(np.uint64)), R(rng, BOOL, n, 0, 0), "float64 values, uint64 keys", (1, 5))
+    # values narrower than 64 bits and a nullable mask are not the bin scatter's: the two-pass variant
+    for vt in (INT32, orc.UINT8, FLOAT):
+        check(R(rng, vt, n, .02, 1, lo=0, hi=100), keys, R(rng, BOOL, n, 0, 2), ("narrow values", vt), (1, 4))
+    check(R(rng, INT64, n, .02, 0), keys, R(rng, BOOL, n, .05, 3), "nullable mask", (1, 4))
     hot = pool[rng.integers(0, len(pool), n)]
     hot[rng.random(n) < .25] = pool[7]
     check(R(rng, INT64, n, .02, 0), Arr(INT64, hot), R(rng, BOOL, n, 0, 0), "one key on a quarter of the rows", (1, 4))
@@ -1526,7 +1530,8 @@ def test_filter_groupby_wide_keys_one_pass(oracle, monkeypatch):
     narrow = Arr(INT64, rng.integers(10**12, 10**12 + 50_000, n))
     check(v, narrow, m, "keys that range-compress, on the wide hint", (1, 5))
     monkeypatch.setenv("AMDARROW_GROUPBY_PROBE_EVERY", "2")
-    check(v, narrow, m, "the probing call")
+    check(v, narrow, m, "the probing call, or the one before it")
+    check(v, narrow, m, "the probing call at the latest")
     assert _last_groupby_path(gpu)[0] >= 2
     monkeypatch.delenv("AMDARROW_GROUPBY_PROBE_EVERY")
     monkeypatch.setenv("AMDARROW_GROUPBY_WIDE_TWO_PASS", "1")
