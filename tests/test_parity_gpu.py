@@ -469,6 +469,43 @@ def test_full_size_groupby_sorted_keys(full):
         assert torch.equal(first, exp_first[k]) and bool((first[1:] > first[:-1]).all()), step
 
 
+def test_full_size_groupby_null_keys(full):
+    """100 M rows, the fixture's keys with 30 % of them null: the null group split off in front (k_null_split), the
+    group-by proper on mask AND key validity.  Sums, counts, first rows and the order against torch's scatter reductions,
+    the null group (key validity 0) at its place in first-appearance order."""
+    import torch
+    import bench
+    import gpu_api
+    from arrow1_amd import compute, device
+    gpu = gpu_api.GpuApi()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x0ff1ce + 31)
+    kvalid_buf = bench.device_bitmap(N_FULL, 0.7, g, "cuda")
+    kvalid = _bits(kvalid_buf, N_FULL)
+    keys = full["keys"].long()
+    keys_arr = device.DeviceArray(orc.INT32, full["keys"].view(torch.uint8), kvalid_buf, N_FULL, 0, -1)
+    vals, sel = full["vals"], _bits(full["mask"], N_FULL)
+    vvalid = _bits(full["valid"], N_FULL)
+    rows = torch.arange(N_FULL, device="cuda")
+    slot = torch.where(kvalid, keys, torch.full_like(keys, 1_000_000))  # the null group as key 1 000 000
+    ok = sel & vvalid
+    exp_sum = torch.zeros(1_000_001, dtype=torch.int64, device="cuda").index_add_(0, slot[ok], vals[ok])
+    exp_cnt = torch.zeros(1_000_001, dtype=torch.int64, device="cuda").index_add_(0, slot[ok], torch.ones_like(vals[ok]))
+    exp_first = torch.full((1_000_001,), N_FULL, dtype=torch.int64, device="cuda").scatter_reduce_(0, slot[sel], rows[sel], "amin")
+    present = exp_first < N_FULL
+    for step in range(2):
+        r = compute.filter_groupby(gpu.ctx, full["values"], keys_arr, full["mask_arr"], group_capacity=1 << 21)
+        G = r.num_groups
+        assert G == int(present.sum())
+        kv = _bits(r.key_validity, G)
+        assert int((~kv).sum()) == 1
+        k = torch.where(kv, r.keys[:G * 4].view(torch.int32).long(), torch.full((G,), 1_000_000, dtype=torch.int64, device="cuda"))
+        assert torch.equal(r.sums[:G * 8].view(torch.int64), exp_sum[k]), step
+        assert torch.equal(r.counts[:G * 8].view(torch.int64), exp_cnt[k]), step
+        first = r.first_rows[:G * 4].view(torch.int32).to(torch.int64)
+        assert torch.equal(first, exp_first[k]) and bool((first[1:] > first[:-1]).all()), step
+
+
 def test_full_size_groupby_wide_keys(full):
     """100 M rows grouped by 1 M int64 ids spread over the whole 64-bit range (a bijection of the fixture's int32 keys):
     ONE pass over five-word records, with the fixture's 50 % mask and without one; sums, counts, first rows and the
