@@ -386,7 +386,11 @@ static int FilterGroupByCore(amdarrow_ctx* ctx, const amdarrow_array* values, co
   for (;; --path) {
     fa_val_wide = false;
     const bool fast = path > 0;
-    const int nsub = (fast && path == 2) ? 1 << sub_bits : 1;
+    // (sub-problems: the partition attempt of path 2 -- and of path 3 where the aggregate does them as rounds over one scatter:
+    // a table overflow with heavy hitters taken out goes through the heavy-hitter pass again, not through a scatter that
+    // would send a third of the rows to one region)
+    const bool rounds_on_path3 = path == 3 && sub_bits > 0 && use_bins && !getenv("AMDARROW_GROUPBY_SUB_PASSES");
+    const int nsub = (fast && (path == 2 || rounds_on_path3)) ? 1 << sub_bits : 1;
     const uint64_t T = fast ? uint64_t(nsub) * kP * kSlots
                             : NextPow2(2 * static_cast<uint64_t>(group_capacity < n ? group_capacity : n));
     Carver c;
@@ -778,8 +782,9 @@ static int FilterGroupByCore(amdarrow_ctx* ctx, const amdarrow_array* values, co
         // the two-pass variant has the same LDS tables.  More groups than 512 partitions hold: once
         // more with four sub-problems (four passes over the input, 2048 partitions in effect),
         // then the generic global-atomic table
-        if (sub_bits == 0) { sub_bits = 2; path = 3; }  // -> 2 after the loop's decrement
-        else if (sub_bits >= 2 && sub_bits < 4 && use_bins && !getenv("AMDARROW_GROUPBY_SUB_PASSES")) { ++sub_bits; path = 3; }  // eight, then sixteen rounds over the records: up to ~14 M / ~28 M groups
+        const bool had_hot = status[5] != 0 && use_bins && !getenv("AMDARROW_GROUPBY_SUB_PASSES");  // heavy hitters were taken out: path 3 again (-> 3 after the loop's decrement)
+        if (sub_bits == 0) { sub_bits = 2; path = had_hot ? 4 : 3; }  // -> 2 after the loop's decrement
+        else if (sub_bits >= 2 && sub_bits < 4 && use_bins && !getenv("AMDARROW_GROUPBY_SUB_PASSES")) { ++sub_bits; path = had_hot ? 4 : 3; }  // eight, then sixteen rounds over the records: up to ~14 M / ~28 M groups
         else path = 1;
       }
       continue;

@@ -2490,6 +2490,25 @@ def test_sort_indices_fuzz_mid_size(gpu, oracle, t):
 
 
 @pytest.mark.gpu
+def test_filter_groupby_heavy_hitters_and_many_groups(oracle):
+    """A key on a third of the rows AND more groups than 512 LDS tables hold: the table overflow sends the call through the
+    heavy-hitter pass again, with the aggregate folding every partition in rounds (it used to drop to the scatter without
+    that pass, whose regions the hot key overflowed, and on down to the global-atomic table)."""
+    import gpu_api
+    gpu = gpu_api.GpuApi()
+    rng = np.random.default_rng(904)
+    n = 7_000_000
+    for keys in (np.where(rng.random(n) < .3, 7, rng.integers(0, 4_000_000, n)),
+                 np.where(rng.random(n) < .5, np.minimum(rng.zipf(1.2, n), 1000), rng.integers(0, 5_000_000, n))):
+        k, v, m = Arr(INT32, keys.astype(np.int32)), R(rng, INT64, n, .02, 0), R(rng, BOOL, n, 0, 0, hi=.8)
+        want = oracle.filter_groupby_sum(v, k, m)
+        for call in range(2):
+            for x, y in zip(want, gpu.filter_groupby_sum(v, k, m)):
+                assert np.array_equal(x, y), call
+            assert _last_groupby_path(gpu)[0] >= 2, call  # (3: the pre-aggregation's path; not the generic table)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", [1, 2])
 def test_filter_groupby_fuzz_mid_size(oracle, seed):
     """Key types x key distributions x value types x null keys x masks x slice offsets, 0.3-2.5 M rows, some calls
