@@ -484,7 +484,15 @@ __global__ __launch_bounds__(kThreads) void k_take(TakeArgs a) {
     T v[kU];
     uint32_t vvb[kU], bvb[kU];
     const bool need_vbits = a.v_may_null && have_values;
-    const bool summarised = need_vbits && a.v_summary != nullptr;
+    // (the summary is for scattered indices: where every lane's four rows lie close together -- monotonic indices, a Filter's
+    // -- the validity bytes themselves are neighbours in the cache and the summary only adds a dependent stage, +10 %)
+    bool summarised = need_vbits && a.v_summary != nullptr;
+    if (summarised) {
+      int64_t far = 0;
+#pragma unroll
+      for (int u = 1; u < kU; ++u) { const int64_t d = j[u] - j[0]; far |= (d < 0 ? -d : d) >> 16; }
+      summarised = __ballot(far != 0) != 0;  // (wave-uniform)
+    }
 #pragma unroll
     for (int u = 0; u < kU; ++u) {  // gathers, all in flight together
       // values' validity is consulted only when values.null_count != 0 (:306, :338)
