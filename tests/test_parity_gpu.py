@@ -1127,11 +1127,19 @@ def test_concatenate_random(gpu, oracle, t):
 
 
 @pytest.mark.gpu
-def test_full_size_two_key_sort_is_lexicographic_stable_permutation(gpu, full):
+@pytest.mark.parametrize("values", ["in [-100, 100]: a 28-bit composite key", "over 63 bits: the tuple's leading 64 bits + the tie fix-up"])
+def test_full_size_two_key_sort_is_lexicographic_stable_permutation(gpu, full, values):
     """100 M rows, keys (int32 group key ascending, int64 value descending): sorted
     lexicographically, ties in index order, and a permutation."""
     import torch
-    from arrow1_amd import compute
+    from arrow1_amd import compute, device
+    if values.startswith("over"):
+        g = torch.Generator(device="cuda")
+        g.manual_seed(0x0ff1ce + 77)
+        wide = torch.randint(-2**62, 2**62, (N_FULL,), dtype=torch.int64, device="cuda", generator=g)
+        wide[1::3] = wide[0::3][:wide[1::3].numel()] // 1024 * 1024 + 5  # neighbours that share their leading bits, and exact repeats below
+        wide[2::30] = wide[0::30][:wide[2::30].numel()]
+        full = dict(full, vals=wide, values=device.DeviceArray(orc.INT64, wide.view(torch.uint8), full["valid"], N_FULL, 0, -1))
     idx = compute.sort_indices_multi(gpu.ctx, [full["keys_arr"], full["values"]], [ASC, DESC]).values[:N_FULL * 8].view(torch.int64)
     k = full["keys"][idx]
     assert bool((k[1:] >= k[:-1]).all())
