@@ -112,11 +112,18 @@ __global__ __launch_bounds__(kThreads) void k_null_split(const uint8_t* m_data, 
 }
 // One wave: the null group into the first free slot of the finished table, its first row marked for the numbering.
 __global__ __launch_bounds__(64) void k_inject_null(GroupTable t, unsigned long long* first_bitmap, const NullAcc* acc,
-                                                    unsigned long long hkey, unsigned int* overflow) {
+                                                    unsigned long long hkey, unsigned int* overflow, int wide_slot) {
   const uint32_t first = acc->first;
   if (first == kNoRow) return;  // no selected row has a null key
   const int lane = threadIdx.x;
   const uint64_t T = t.mask + 1;
+  if (wide_slot) {  // a single 64-bit key that did not range-compress: its null lives in the special slot behind the table
+    if (lane == 0) {
+      t.hkeys[T] = 0; t.first[T] = first; t.sums[T] = acc->sum; t.counts[T] = acc->count;
+      atomicOr(&first_bitmap[first >> 6], 1ull << (first & 63));
+    }
+    return;
+  }
   for (uint64_t base = 0; base < T; base += 64) {
     const bool free_slot = base + lane < T && t.hkeys[base + lane] == kEmpty && t.first[base + lane] == kNoRow;
     const uint64_t found = __ballot(free_slot);
@@ -140,7 +147,7 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
                              int64_t* out_num_groups, bool locked, ulonglong4** packed_out, uint64_t* bias_out) {
   const int64_t n = keys->length;
   const int kbw = BitWidth(keys->type_id);
-  const bool null_split = keys->validity && keys->null_count != 0 && kbw >= 8 && kbw <= 32 && n >= (int64_t(1) << 18) &&
+  const bool null_split = keys->validity && keys->null_count != 0 && kbw >= 8 && kbw <= 64 && n >= (int64_t(1) << 18) &&
                           n < (int64_t(1) << 32) - 1 && (!values || values->length == n) && (!mask || (mask->type_id == AMDARROW_BOOL && mask->length == n)) &&
                           !getenv("AMDARROW_GROUPBY_NO_NULL_SPLIT");
   if (!null_split)
@@ -686,7 +693,9 @@ static int FilterGroupByCore(amdarrow_ctx* ctx, const amdarrow_array* values, co
       AA_HIP(hipGetLastError());
     }
     if (null_inject) {  // the null group (k_null_split) joins the finished table
-      hipLaunchKernelGGL(k_inject_null, dim3(1), dim3(64), 0, ctx->stream, t, r.bitmap, null_inject, Fmix64(uint64_t(1) << ks.total_bits), misc);
+      const KeySpec& kinj = fast ? ks : ks_generic;  // (how this attempt's table spells its keys: the generic path takes a 64-bit column as it is)
+      hipLaunchKernelGGL(k_inject_null, dim3(1), dim3(64), 0, ctx->stream, t, r.bitmap, null_inject, Fmix64(uint64_t(1) << (kinj.total_bits & 63)), misc,
+                         kinj.wide_null_slot ? 1 : 0);
       AA_HIP(hipGetLastError());
     }
     int64_t G = 0;

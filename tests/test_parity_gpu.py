@@ -1485,7 +1485,7 @@ def test_filter_groupby_multi_key_refusals(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kt", [INT32, orc.UINT16, INT8, FLOAT])
+@pytest.mark.parametrize("kt", [INT32, orc.UINT16, INT8, FLOAT, INT64, orc.UINT64, DOUBLE])
 def test_filter_groupby_null_keys_split_off(gpu, oracle, kt, monkeypatch):
     """Rows with a null key are one group: aggregated by a kernel of their own while the group-by proper runs on
     mask AND key validity with keys that carry none, the null group joining the finished table before the numbering.
@@ -1494,7 +1494,7 @@ def test_filter_groupby_null_keys_split_off(gpu, oracle, kt, monkeypatch):
     every key null; against the oracle, and the same calls with the nulls carried through the scatters."""
     rng = np.random.default_rng(650 + kt)
     n = 600_011
-    hi = {INT32: 150_000, orc.UINT16: 40_000, INT8: 100, FLOAT: 30_000}[kt]
+    hi = {INT32: 150_000, orc.UINT16: 40_000, INT8: 100, FLOAT: 30_000, INT64: 120_000, orc.UINT64: 90_000, DOUBLE: 30_000}[kt]
 
     def check(v, k, m, tag):
         want = oracle.filter_groupby_sum(v, k, m)
@@ -1512,8 +1512,10 @@ def test_filter_groupby_null_keys_split_off(gpu, oracle, kt, monkeypatch):
 
     def keys(p_null, off=0):
         k = R(rng, kt, n, p_null, off, lo=0, hi=hi)
-        if kt == FLOAT:
-            k = Arr(FLOAT, np.floor(k.data), k.valid, off, n)
+        if kt in (FLOAT, DOUBLE):
+            k = Arr(kt, np.floor(k.data), k.valid, off, n)
+        if kt == orc.UINT64:  # ids over the whole 64-bit range: the wide-key path behind the split
+            k = Arr(kt, (k.data.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)), k.valid, off, n)
         return k
     check(R(rng, INT64, n, .02, 3), keys(.3, 5), R(rng, BOOL, n, .05, 7), "30 % null keys, nullable mask")
     check(R(rng, DOUBLE, n, .1, 0), keys(.01, 1), R(rng, BOOL, n, 0, 0), "1 % null keys, float64 values")
