@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kThreads) void k_null_split(const uint8_t* m_data, 
     const int nbits = n - 64 * w >= 64 ? 64 : static_cast<int>(n - 64 * w);
     uint64_t sel = LoadBitsOrOnes(m_data, m_off + 64 * w, nbits);
     if (m_valid) sel &= LoadBits64(m_valid, m_off + 64 * w, nbits);
-    const uint64_t kv = LoadBits64(k_valid, k_off + 64 * w, nbits);
+    const uint64_t kv = LoadBitsOrOnes(k_valid, k_off + 64 * w, nbits);  // (no key validity: the kernel only folds the mask's validity into the mask)
     out_mask[w] = sel & kv;
     uint64_t nulls = sel & ~kv;
     if (nulls && first == kNoRow) first = static_cast<uint32_t>(64 * w + __builtin_ctzll(nulls));  // (a thread's words ascend)
@@ -147,7 +147,11 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
                              int64_t* out_num_groups, bool locked, ulonglong4** packed_out, uint64_t* bias_out) {
   const int64_t n = keys->length;
   const int kbw = BitWidth(keys->type_id);
-  const bool null_split = keys->validity && keys->null_count != 0 && kbw >= 8 && kbw <= 64 && n >= (int64_t(1) << 18) &&
+  // (the same pass folds a NULLABLE MASK's validity into the mask -- what a comparison over a nullable column yields: the bin
+  // scatters take a mask without validity, and such a call ran on the generic scatter, 1.43 ms per 100 M rows instead of 0.55)
+  const bool keys_nullable = keys->validity && keys->null_count != 0 && kbw >= 8 && kbw <= 64;
+  const bool mask_nullable = mask && mask->validity && mask->null_count != 0;
+  const bool null_split = (keys_nullable || mask_nullable) && n >= (int64_t(1) << 18) &&
                           n < (int64_t(1) << 32) - 1 && (!values || values->length == n) && (!mask || (mask->type_id == AMDARROW_BOOL && mask->length == n)) &&
                           !getenv("AMDARROW_GROUPBY_NO_NULL_SPLIT");
   if (!null_split)
@@ -171,16 +175,16 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
     if (values) v = ValueCol{values->values, values->validity, values->offset, values->type_id};
     hipLaunchKernelGGL(k_null_split, dim3(GridFor(nwords, kThreads, ctx->num_cus * 4)), dim3(kThreads), 0, ctx->stream,
                        mask ? static_cast<const uint8_t*>(mask->values) : nullptr, mask ? mask->validity : nullptr, mask ? mask->offset : 0,
-                       keys->validity, keys->offset, v, values ? 1 : 0, n, mask2, acc);
+                       keys_nullable ? keys->validity : nullptr, keys->offset, v, values ? 1 : 0, n, mask2, acc);
     if (hipGetLastError() != hipSuccess) rc = SetError(AMDARROW_UNKNOWN_ERROR, "group-by: null split launch failed");
   }
   if (rc == AMDARROW_OK) {
     amdarrow_array keys_nn = *keys;
-    keys_nn.validity = nullptr; keys_nn.null_count = 0;
+    if (keys_nullable) { keys_nn.validity = nullptr; keys_nn.null_count = 0; }
     amdarrow_array mask_nn{};
     mask_nn.type_id = AMDARROW_BOOL; mask_nn.values = mask2; mask_nn.validity = nullptr; mask_nn.length = n; mask_nn.offset = 0; mask_nn.null_count = 0;
     rc = FilterGroupByCore(ctx, values, &keys_nn, &mask_nn, group_capacity, out_sums, out_counts, out_keys, out_key_validity, out_first_rows,
-                           out_num_groups, /*locked=*/true, packed_out, bias_out, acc);
+                           out_num_groups, /*locked=*/true, packed_out, bias_out, keys_nullable ? acc : nullptr);
   }
   (void)hipStreamSynchronize(ctx->stream);  // (the block goes back to the pool: nothing queued may still read it)
   (void)amdarrow_free(ctx, block);

@@ -1530,6 +1530,8 @@ def test_filter_groupby_null_keys_split_off(gpu, oracle, kt, monkeypatch):
     check(R(rng, INT64, n, .5, 0), Arr(kt, k.data, np.zeros(n, bool)), m, "every key null")
     vn = R(rng, INT64, n, 0, 0)
     check(Arr(INT64, vn.data, k.valid), k, m, "the null group's values all null")
+    # a nullable mask alone (keys without nulls): its validity folded into the mask by the same pass
+    check(R(rng, INT64, n, .02, 2), Arr(kt, k.data), R(rng, BOOL, n, .1, 3), "nullable mask, keys without nulls")
 
 
 @pytest.mark.gpu
@@ -1563,10 +1565,10 @@ def test_filter_groupby_wide_keys_one_pass(oracle, monkeypatch):
         check(R(rng, INT64, n, .02, 3, lo=-2**40, hi=2**40), keys, R(rng, BOOL, n, 0, 2, hi=sel), ("mask", sel), (1, 5))
     check(R(rng, INT64, n, 0, 0), keys, None, "no mask", (1, 5))
     check(R(rng, DOUBLE, n, .1, 1), Arr(orc.UINT64, pool[rng.integers(0, len(pool), n)].view(np.uint64)), R(rng, BOOL, n, 0, 0), "float64 values, uint64 keys", (1, 5))
-    # values narrower than 64 bits and a nullable mask are not the bin scatter's: the two-pass variant
+    # values narrower than 64 bits are not the bin scatter's: the two-pass variant
     for vt in (INT32, orc.UINT8, FLOAT):
         check(R(rng, vt, n, .02, 1, lo=0, hi=100), keys, R(rng, BOOL, n, 0, 2), ("narrow values", vt), (1, 4))
-    check(R(rng, INT64, n, .02, 0), keys, R(rng, BOOL, n, .05, 3), "nullable mask", (1, 4))
+    check(R(rng, INT64, n, .02, 0), keys, R(rng, BOOL, n, .05, 3), "nullable mask (its validity folded into the mask in front)", (1, 5))
     hot = pool[rng.integers(0, len(pool), n)]
     hot[rng.random(n) < .25] = pool[7]
     check(R(rng, INT64, n, .02, 0), Arr(INT64, hot), R(rng, BOOL, n, 0, 0), "one key on a quarter of the rows", (1, 4))
