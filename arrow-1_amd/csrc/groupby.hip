@@ -141,6 +141,29 @@ static int FilterGroupByCore(amdarrow_ctx* ctx, const amdarrow_array* values, co
                              const amdarrow_array* mask, int64_t group_capacity, void* out_sums, int64_t* out_counts,
                              void* out_keys, uint8_t* out_key_validity, uint32_t* out_first_rows,
                              int64_t* out_num_groups, bool locked, ulonglong4** packed_out, uint64_t* bias_out, const NullAcc* null_inject);
+// Values narrower than 64 bits as their accumulator type (FindAccumulatorType: signed -> int64, unsigned / boolean -> uint64,
+// float -> double), element i at the same offset: the specialised loaders take 8-byte values as 16-byte vectors, and an
+// int32 or float32 value column sent the call to the generic kernels (1.18 ms per 100 M rows against 0.52).  The copy is 4 + 8
+// bytes per row, 0.25 ms.
+__global__ __launch_bounds__(kThreads) void k_widen_values(ValueCol v, int64_t n, unsigned long long* out /* element 0 = row -v.off */) {
+  constexpr int kU = 4;
+  const int64_t stride = int64_t(gridDim.x) * kThreads;
+  for (int64_t i0 = int64_t(blockIdx.x) * kThreads + threadIdx.x; i0 < n; i0 += kU * stride) {
+    uint64_t w[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t i = i0 + u * stride;
+      bool is_double;
+      w[u] = LoadAccum(v, i < n ? i : n - 1, &is_double);
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t i = i0 + u * stride;
+      if (i < n) out[v.off + i] = w[u];
+    }
+  }
+}
+
 static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, const amdarrow_array* keys,
                              const amdarrow_array* mask, int64_t group_capacity, void* out_sums, int64_t* out_counts,
                              void* out_keys, uint8_t* out_key_validity, uint32_t* out_first_rows,
@@ -151,43 +174,67 @@ static int FilterGroupByImpl(amdarrow_ctx* ctx, const amdarrow_array* values, co
   // scatters take a mask without validity, and such a call ran on the generic scatter, 1.43 ms per 100 M rows instead of 0.55)
   const bool keys_nullable = keys->validity && keys->null_count != 0 && kbw >= 8 && kbw <= 64;
   const bool mask_nullable = mask && mask->validity && mask->null_count != 0;
-  const bool null_split = (keys_nullable || mask_nullable) && n >= (int64_t(1) << 18) &&
-                          n < (int64_t(1) << 32) - 1 && (!values || values->length == n) && (!mask || (mask->type_id == AMDARROW_BOOL && mask->length == n)) &&
-                          !getenv("AMDARROW_GROUPBY_NO_NULL_SPLIT");
-  if (!null_split)
+  const bool shapes_ok = n >= (int64_t(1) << 18) && n < (int64_t(1) << 32) - 1 && (!values || values->length == n) &&
+                         (!mask || (mask->type_id == AMDARROW_BOOL && mask->length == n));
+  const bool null_split = (keys_nullable || mask_nullable) && shapes_ok && !getenv("AMDARROW_GROUPBY_NO_NULL_SPLIT");
+  const int vbw = values ? BitWidth(values->type_id) : 64;
+  const bool widen = values && vbw >= 1 && vbw < 64 && (kbw == 32 || kbw == 64) && shapes_ok && !getenv("AMDARROW_GROUPBY_NO_WIDEN");
+  if (!null_split && !widen)
     return FilterGroupByCore(ctx, values, keys, mask, group_capacity, out_sums, out_counts, out_keys, out_key_validity, out_first_rows,
                              out_num_groups, locked, packed_out, bias_out, nullptr);
   std::unique_lock<std::mutex> lock(ctx->mu, std::defer_lock);
   if (!locked) lock.lock();
   const int64_t nwords = (n + 63) >> 6;
   void* block = nullptr;
-  AA_TRY(amdarrow_malloc(ctx, 64 + 8 * (nwords + 2), &block));
-  auto* acc = static_cast<NullAcc*>(block);
-  auto* mask2 = reinterpret_cast<unsigned long long*>(static_cast<char*>(block) + 64);
-  const NullAcc init{0, 0, kNoRow, 0};
-  memcpy(static_cast<char*>(ctx->pinned) + kStatusOffset + 192, &init, sizeof init);
+  void* wblock = nullptr;
+  if (null_split) AA_TRY(amdarrow_malloc(ctx, 64 + 8 * (nwords + 2), &block));
   int rc = AMDARROW_OK;
-  if (hipMemcpyAsync(acc, static_cast<char*>(ctx->pinned) + kStatusOffset + 192, sizeof init, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-      hipMemsetAsync(mask2 + nwords, 0, 16, ctx->stream) != hipSuccess)
-    rc = SetError(AMDARROW_UNKNOWN_ERROR, "group-by: null split setup failed");
-  if (rc == AMDARROW_OK) {
-    ValueCol v{};
-    if (values) v = ValueCol{values->values, values->validity, values->offset, values->type_id};
-    hipLaunchKernelGGL(k_null_split, dim3(GridFor(nwords, kThreads, ctx->num_cus * 4)), dim3(kThreads), 0, ctx->stream,
-                       mask ? static_cast<const uint8_t*>(mask->values) : nullptr, mask ? mask->validity : nullptr, mask ? mask->offset : 0,
-                       keys_nullable ? keys->validity : nullptr, keys->offset, v, values ? 1 : 0, n, mask2, acc);
-    if (hipGetLastError() != hipSuccess) rc = SetError(AMDARROW_UNKNOWN_ERROR, "group-by: null split launch failed");
+  amdarrow_array values_w{};
+  if (widen) {
+    rc = amdarrow_malloc(ctx, 8 * (values->offset + n) + 64, &wblock);
+    if (rc == AMDARROW_OK) {
+      // (row 0 of the slice on a 16-byte boundary: the bin scatters' condition)
+      auto* wide = reinterpret_cast<unsigned long long*>(static_cast<char*>(wblock) + ((values->offset & 1) ? 8 : 0));
+      const ValueCol v{values->values, values->validity, values->offset, values->type_id};
+      hipLaunchKernelGGL(k_widen_values, dim3(GridFor(n, kThreads * 4, ctx->num_cus * 8)), dim3(kThreads), 0, ctx->stream, v, n, wide);
+      if (hipGetLastError() != hipSuccess) rc = SetError(AMDARROW_UNKNOWN_ERROR, "group-by: value widening launch failed");
+      values_w = *values;
+      values_w.values = wide;
+      values_w.type_id = IsFloat(values->type_id) ? AMDARROW_DOUBLE : IsSignedInt(values->type_id) ? AMDARROW_INT64 : AMDARROW_UINT64;
+      values = &values_w;
+    }
   }
-  if (rc == AMDARROW_OK) {
-    amdarrow_array keys_nn = *keys;
-    if (keys_nullable) { keys_nn.validity = nullptr; keys_nn.null_count = 0; }
-    amdarrow_array mask_nn{};
-    mask_nn.type_id = AMDARROW_BOOL; mask_nn.values = mask2; mask_nn.validity = nullptr; mask_nn.length = n; mask_nn.offset = 0; mask_nn.null_count = 0;
-    rc = FilterGroupByCore(ctx, values, &keys_nn, &mask_nn, group_capacity, out_sums, out_counts, out_keys, out_key_validity, out_first_rows,
-                           out_num_groups, /*locked=*/true, packed_out, bias_out, keys_nullable ? acc : nullptr);
+  if (rc == AMDARROW_OK && !null_split)
+    rc = FilterGroupByCore(ctx, values, keys, mask, group_capacity, out_sums, out_counts, out_keys, out_key_validity, out_first_rows,
+                           out_num_groups, /*locked=*/true, packed_out, bias_out, nullptr);
+  if (rc == AMDARROW_OK && null_split) {
+    auto* acc = static_cast<NullAcc*>(block);
+    auto* mask2 = reinterpret_cast<unsigned long long*>(static_cast<char*>(block) + 64);
+    const NullAcc init{0, 0, kNoRow, 0};
+    memcpy(static_cast<char*>(ctx->pinned) + kStatusOffset + 192, &init, sizeof init);
+    if (hipMemcpyAsync(acc, static_cast<char*>(ctx->pinned) + kStatusOffset + 192, sizeof init, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemsetAsync(mask2 + nwords, 0, 16, ctx->stream) != hipSuccess)
+      rc = SetError(AMDARROW_UNKNOWN_ERROR, "group-by: null split setup failed");
+    if (rc == AMDARROW_OK) {
+      ValueCol v{};
+      if (values) v = ValueCol{values->values, values->validity, values->offset, values->type_id};
+      hipLaunchKernelGGL(k_null_split, dim3(GridFor(nwords, kThreads, ctx->num_cus * 4)), dim3(kThreads), 0, ctx->stream,
+                         mask ? static_cast<const uint8_t*>(mask->values) : nullptr, mask ? mask->validity : nullptr, mask ? mask->offset : 0,
+                         keys_nullable ? keys->validity : nullptr, keys->offset, v, values ? 1 : 0, n, mask2, acc);
+      if (hipGetLastError() != hipSuccess) rc = SetError(AMDARROW_UNKNOWN_ERROR, "group-by: null split launch failed");
+    }
+    if (rc == AMDARROW_OK) {
+      amdarrow_array keys_nn = *keys;
+      if (keys_nullable) { keys_nn.validity = nullptr; keys_nn.null_count = 0; }
+      amdarrow_array mask_nn{};
+      mask_nn.type_id = AMDARROW_BOOL; mask_nn.values = mask2; mask_nn.validity = nullptr; mask_nn.length = n; mask_nn.offset = 0; mask_nn.null_count = 0;
+      rc = FilterGroupByCore(ctx, values, &keys_nn, &mask_nn, group_capacity, out_sums, out_counts, out_keys, out_key_validity, out_first_rows,
+                             out_num_groups, /*locked=*/true, packed_out, bias_out, keys_nullable ? acc : nullptr);
+    }
   }
-  (void)hipStreamSynchronize(ctx->stream);  // (the block goes back to the pool: nothing queued may still read it)
-  (void)amdarrow_free(ctx, block);
+  (void)hipStreamSynchronize(ctx->stream);  // (the blocks go back to the pool: nothing queued may still read them)
+  if (block) (void)amdarrow_free(ctx, block);
+  if (wblock) (void)amdarrow_free(ctx, wblock);
   return rc;
 }
 

@@ -1565,9 +1565,9 @@ def test_filter_groupby_wide_keys_one_pass(oracle, monkeypatch):
         check(R(rng, INT64, n, .02, 3, lo=-2**40, hi=2**40), keys, R(rng, BOOL, n, 0, 2, hi=sel), ("mask", sel), (1, 5))
     check(R(rng, INT64, n, 0, 0), keys, None, "no mask", (1, 5))
     check(R(rng, DOUBLE, n, .1, 1), Arr(orc.UINT64, pool[rng.integers(0, len(pool), n)].view(np.uint64)), R(rng, BOOL, n, 0, 0), "float64 values, uint64 keys", (1, 5))
-    # values narrower than 64 bits are not the bin scatter's: the two-pass variant
+    # values narrower than 64 bits are widened to their accumulator type in front (the bin scatters load 8-byte values)
     for vt in (INT32, orc.UINT8, FLOAT):
-        check(R(rng, vt, n, .02, 1, lo=0, hi=100), keys, R(rng, BOOL, n, 0, 2), ("narrow values", vt), (1, 4))
+        check(R(rng, vt, n, .02, 1, lo=0, hi=100), keys, R(rng, BOOL, n, 0, 2), ("narrow values", vt), (1, 5))
     check(R(rng, INT64, n, .02, 0), keys, R(rng, BOOL, n, .05, 3), "nullable mask (its validity folded into the mask in front)", (1, 5))
     hot = pool[rng.integers(0, len(pool), n)]
     hot[rng.random(n) < .25] = pool[7]
