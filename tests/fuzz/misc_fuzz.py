@@ -37,11 +37,16 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 20):
     t0 = time.time()
     def same_groups(w, r):
         (io, ngo, uo), (ig, ngg, ug) = w, r
-        if ngo != ngg or not all(np.array_equal(x, y) for x, y in zip(io, ig)): return False
-        for (va, vb, nca), (vc, vd, ncb) in zip(uo, ug):
-            a1 = va.view(np.uint8) if va.dtype != bool else va
-            c1 = vc.view(np.uint8) if vc.dtype != bool else vc
-            if not (np.array_equal(vb, vd) and nca == ncb and np.array_equal(a1[np.repeat(vb, a1.size // max(len(vb), 1))] if False else a1, c1)): return False
+        if ngo != ngg or not all(np.array_equal(x, y) for x, y in zip(io, ig)):
+            print("  ids / group count differ:", ngo, ngg, [bool(np.array_equal(x, y)) for x, y in zip(io, ig)])
+            return False
+        for c, ((va, vb, nca), (vc, vd, ncb)) in enumerate(zip(uo, ug)):
+            ok_v = np.array_equal(vb, vd) and nca == ncb
+            m = vb.astype(bool)[:len(va)] if len(vb) >= len(va) else None
+            ok_d = ok_v and (np.array_equal(va[m], vc[m], equal_nan=va.dtype.kind == "f") if m is not None else np.array_equal(va, vc))
+            if not ok_d:
+                print("  uniques of column", c, "differ: validity", ok_v, "null counts", nca, ncb)
+                return False
         return True
     try:
         w = o.group_ids(batches)

@@ -2502,6 +2502,29 @@ def test_sort_indices_fuzz_mid_size(gpu, oracle, t):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kt", [orc.UINT64, INT64])
+def test_grouper_64bit_keys_null_group_and_the_key_zero(gpu, oracle, kt):
+    """A grouper over one 64-bit key column: a batch with nulls (general path: the null group's key word is 0), then large
+    batches without nulls that hold the key 0 -- the batch-grouped path's directly indexed id table used to hand the null
+    group's id to the rows of the key 0 (found by tests/fuzz/misc_fuzz.py through a three-column grouper's uniques)."""
+    rng = np.random.default_rng(905)
+    n = 400_000
+    b1 = Arr(kt, rng.integers(0, 5000, n).astype(orc.NP_OF[kt]), rng.random(n) > .05)
+    b2 = Arr(kt, rng.integers(0, 9000, n).astype(orc.NP_OF[kt]))
+    b3 = Arr(kt, np.concatenate([[0, 0, 7], rng.integers(0, 12000, n - 3)]).astype(orc.NP_OF[kt]))
+    for batches in ([[b1], [b2], [b3]], [[b2], [b1], [b3]]):
+        io, ngo, uo = oracle.group_ids(batches)
+        ig, ngg, ug = gpu.group_ids(batches)
+        assert ngo == ngg
+        for x, y in zip(io, ig):
+            assert np.array_equal(x, y)
+        (va, vb, nca), (vc, vd, ncb) = uo[0], ug[0]
+        assert np.array_equal(vb, vd) and nca == ncb
+        ok = np.unpackbits(vb, bitorder="little")[:len(va)].astype(bool) if vb.dtype == np.uint8 and len(vb) != len(va) else vb.astype(bool)
+        assert np.array_equal(va[ok], vc[ok])
+
+
+@pytest.mark.gpu
 def test_filter_groupby_heavy_hitters_and_many_groups(oracle):
     """A key on a third of the rows AND more groups than 512 LDS tables hold: the table overflow sends the call through the
     heavy-hitter pass again, with the aggregate folding every partition in rounds (it used to drop to the scatter without
